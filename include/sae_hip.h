@@ -1,0 +1,135 @@
+/*
+ * sae_hip.h — C-ABI of the MI355X (gfx950) hot-path library for the Swapping-Autoencoder
+ * GAN training step.
+ *
+ * This is the drop-in boundary.  Every entry point replaces one native
+ * interface of the reference (paths relative to the reference checkout):
+ *
+ *   sae_upfirdn2d_f32        <- upfirdn2d_op.upfirdn2d(...)   models/networks/stylegan2_op/upfirdn2d.cpp:12-19
+ *                               (kernel: upfirdn2d_kernel.cu:52-137, host: :140-272)
+ *   sae_bias_act_f32         <- fused.fused_bias_act(...)      models/networks/stylegan2_op/fused_bias_act.cpp:11-17
+ *                               (kernel: fused_bias_act_kernel.cu:18-49, host: :52-99)
+ *   sae_bias_act_bwd_f32     <- fused_bias_act(grad=1) followed by grad_input.sum(dim)
+ *                               models/networks/stylegan2_op/fused_act.py:32-41 (one fused pass here)
+ *   sae_conv2d_{fwd,dgrad,wgrad}_f32
+ *                            <- F.conv2d / F.conv_transpose2d and their ATen backward
+ *                               models/networks/stylegan2_layers.py:136,175,182,306,315,321
+ *   sae_gemm_f32             <- F.linear and its backward       models/networks/stylegan2_layers.py:177,186
+ *
+ * Conventions (what the reference's pybind layer did implicitly is explicit here):
+ *   - plain pointers and sizes only, no torch types; all tensors are dense fp32 in device memory
+ *     of ONE device, the one `stream` belongs to;
+ *   - the caller owns every buffer, including outputs and workspaces (no hidden allocation, so a
+ *     caching allocator and stream ordering stay intact); workspace sizes come from the
+ *     *_workspace() queries, which are pure host functions;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *     nothing here synchronises the device;
+ *   - return value: 0 on success, a negative SAE_E* code otherwise; sae_last_error() returns a
+ *     thread-local human-readable message for the last failing call on this thread.  Nothing
+ *     throws, nothing exits;
+ *   - no global mutable state besides that thread-local message: calls are re-entrant.
+ */
+#ifndef SAE_HIP_H
+#define SAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAE_ABI_VERSION 1
+
+#define SAE_OK 0
+#define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
+#define SAE_ELAUNCH (-2)   /* the HIP runtime reported a launch error */
+#define SAE_EWORKSPACE (-3)/* workspace missing or too small */
+
+typedef void* sae_stream_t; /* hipStream_t */
+
+int sae_abi_version(void);
+const char* sae_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * upfirdn2d: zero-insertion upsample -> pad/crop -> 2-D FIR (true convolution) -> decimate.
+ * x: [major, in_h, in_w, minor]   k: [kh, kw] (row-major, as passed by the caller, NOT flipped)
+ * y: [major, out_h, out_w, minor] with out = (in*up + pad0 + pad1 - k + down) / down  (C division,
+ * upfirdn2d_kernel.cu:167-168).  Negative pads crop.  Unlike the reference (which launches nothing
+ * and returns uninitialised memory when no template matches, upfirdn2d_kernel.cu:172-268) every
+ * (up, down, kh, kw) >= 1 is supported; kh*kw <= 1024.
+ * ------------------------------------------------------------------------------------------ */
+int sae_upfirdn2d_f32(const float* x, const float* k, float* y,
+                      int64_t major, int64_t in_h, int64_t in_w, int64_t minor,
+                      int32_t kh, int32_t kw,
+                      int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
+                      int32_t pad_x0, int32_t pad_x1, int32_t pad_y0, int32_t pad_y1,
+                      sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * bias_act: y[i] = act'(x[i] + b[(i / step_b) % size_b]) * scale       fused_bias_act_kernel.cu:18-49
+ *   act: 1 = linear, 3 = leaky-ReLU(alpha);  grad: 0 = value, 1 = first derivative applied to x
+ *   using sign(ref), 2 = second derivative (identically 0 for both activations).
+ *   b may be NULL (no bias), ref may be NULL only when grad == 0.
+ * ------------------------------------------------------------------------------------------ */
+int sae_bias_act_f32(const float* x, const float* b, const float* ref, float* y,
+                     int64_t numel, int64_t step_b, int64_t size_b,
+                     int32_t act, int32_t grad, float alpha, float scale,
+                     sae_stream_t stream);
+
+/* Fused backward of the leaky-ReLU form: gx = (y_ref > 0 ? gy : alpha*gy) * scale and
+ * gb[c] = sum over everything but the channel axis of gx (deterministic two-stage reduction,
+ * no atomics).  workspace: sae_bias_act_bwd_workspace() floats. */
+int64_t sae_bias_act_bwd_workspace(int64_t numel, int64_t step_b, int64_t size_b);
+int sae_bias_act_bwd_f32(const float* gy, const float* y_ref, float* gx, float* gb,
+                         float* workspace, int64_t workspace_floats,
+                         int64_t numel, int64_t step_b, int64_t size_b,
+                         float alpha, float scale, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense 2-D convolution family on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), NCHW.
+ * One descriptor describes the forward problem
+ *     y[n,m,oy,ox] = alpha * sum_{c,ky,kx} w[m,c,ky,kx] * x[n,c,oy*stride+ky-pad, ox*stride+kx-pad]
+ * (cross-correlation, zero padding), and the same descriptor is passed to dgrad / wgrad:
+ *     dgrad: gx[n,c,iy,ix]   = alpha * sum_{m,ky,kx} w[m,c,ky,kx] * gy[n,m,oy,ox],  iy = oy*stride+ky-pad
+ *     wgrad: gw[m,c,ky,kx]   = alpha * sum_{n,oy,ox} gy[n,m,oy,ox] * x[n,c,oy*stride+ky-pad, ...]
+ * A stride-2 transposed convolution (F.conv_transpose2d, stylegan2_layers.py:306) is dgrad with
+ * the roles of x and y exchanged.  Weight element (m,c,ky,kx) lives at
+ *     w[m*w_stride_m + c*w_stride_c + ky*kw + kx]
+ * so both [M,C,kh,kw] and [C,M,kh,kw] parameter layouts are addressed without a copy.
+ * Supported: kh == kw in {1,3}; stride in {1,2}; 0 <= pad < kh.  oh/ow must equal
+ * (h + 2*pad - kh)/stride + 1 (floor).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sae_conv2d_desc {
+    int64_t n;              /* batch */
+    int64_t c, h, w;        /* x side: channels, height, width */
+    int64_t m, oh, ow;      /* y side: channels, height, width */
+    int32_t kh, kw, stride, pad;
+    int64_t w_stride_m, w_stride_c;
+} sae_conv2d_desc;
+
+#define SAE_CONV_FWD 0
+#define SAE_CONV_DGRAD 1
+#define SAE_CONV_WGRAD 2
+/* floats of workspace needed by the given operation (op = SAE_CONV_*) */
+int64_t sae_conv2d_workspace(const sae_conv2d_desc* d, int32_t op);
+
+int sae_conv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d,
+                       float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+int sae_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
+                         float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
+                         float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Strided GEMM on the fp32 matrix cores:  C[i*ldc + j] = alpha * sum_k A[i*a_si + k*a_sk] * B[k*b_sk + j*b_sj]
+ * (+ bias[j] when bias != NULL).  Serves F.linear forward (A = x, B = W^T), its dgrad and wgrad.
+ * ------------------------------------------------------------------------------------------ */
+int sae_gemm_f32(const float* a, const float* b, const float* bias, float* c,
+                 int64_t m, int64_t n, int64_t k,
+                 int64_t a_si, int64_t a_sk, int64_t b_sk, int64_t b_sj, int64_t ldc,
+                 float alpha, sae_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAE_HIP_H */

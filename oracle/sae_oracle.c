@@ -1,0 +1,300 @@
+/*
+ * sae_oracle.c — CPU restatement of the reference's algorithms for the hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library, and only as the checker / reported baseline — never as the thing
+ * shipped or measured as the product.  The product path (swapping_autoencoder_pytorch_amd)
+ * must fail loudly when the HIP library is missing; it never falls back to this file.
+ *
+ * Parity pin: the reference ships no tests or golden vectors.  This
+ * restatement is pinned against outputs of the reference's own Python modules run in the build
+ * container (native-fallback path, upfirdn2d.py:162-222, fused_act.py:93-96,
+ * stylegan2_layers.py) — fixtures under tests/golden/, generator tests/golden/make_golden.py —
+ * and checked in tests/test_oracle_golden.py.
+ *
+ * Each function carries the same signature as its sae_* counterpart in include/sae_hip.h
+ * (host pointers; the stream argument is ignored) and cites the reference lines it follows.
+ * Accumulation is in double so the oracle is a strictly better approximation of the real-number
+ * result than either fp32 implementation (the reference's or ours).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+
+#define SAE_OK 0
+#define SAE_EINVAL (-1)
+#define SAE_EWORKSPACE (-3)
+
+typedef void* sae_stream_t;
+
+typedef struct sae_conv2d_desc {
+    int64_t n;
+    int64_t c, h, w;
+    int64_t m, oh, ow;
+    int32_t kh, kw, stride, pad;
+    int64_t w_stride_m, w_stride_c;
+} sae_conv2d_desc;
+
+static __thread char g_err[256];
+
+int oracle_abi_version(void) { return 1; }
+const char* oracle_last_error(void) { return g_err; }
+
+/* upfirdn2d_kernel.cu:18-26 */
+static inline int64_t floor_div(int64_t a, int64_t b) {
+    int64_t c = a / b;
+    if (c * b > a) c--;
+    return c;
+}
+
+/*
+ * upfirdn2d_kernel.cu:52-137 (per-output arithmetic :114-129, flipped taps :71-81, zero reads
+ * outside the input :98-104) with the output size of :167-168.  The CUDA kernel bounds its tap
+ * loops by the template size kernel_h/up and relies on zero-padded taps; here the loop simply
+ * stops when the tap index leaves [0,kh) — the same sum.
+ */
+int oracle_upfirdn2d_f32(const float* x, const float* k, float* y,
+                         int64_t major, int64_t in_h, int64_t in_w, int64_t minor,
+                         int32_t kh, int32_t kw,
+                         int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
+                         int32_t pad_x0, int32_t pad_x1, int32_t pad_y0, int32_t pad_y1,
+                         sae_stream_t stream) {
+    (void)stream;
+    if (!x || !k || !y || up_x < 1 || up_y < 1 || down_x < 1 || down_y < 1 || kh < 1 || kw < 1) {
+        snprintf(g_err, sizeof g_err, "oracle_upfirdn2d_f32: bad argument");
+        return SAE_EINVAL;
+    }
+    int64_t out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
+    int64_t out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
+    if (out_h <= 0 || out_w <= 0) return SAE_OK;
+#pragma omp parallel for schedule(static)
+    for (int64_t mj = 0; mj < major; ++mj)
+        for (int64_t oy = 0; oy < out_h; ++oy)
+            for (int64_t ox = 0; ox < out_w; ++ox) {
+                int64_t mid_x = ox * down_x + up_x - 1 - pad_x0;
+                int64_t mid_y = oy * down_y + up_y - 1 - pad_y0;
+                int64_t in_x = floor_div(mid_x, up_x);
+                int64_t in_y = floor_div(mid_y, up_y);
+                int64_t kx0 = (in_x + 1) * up_x - mid_x - 1;
+                int64_t ky0 = (in_y + 1) * up_y - mid_y - 1;
+                for (int64_t mn = 0; mn < minor; ++mn) {
+                    double v = 0.0;
+                    for (int64_t yy = 0; ky0 + yy * up_y < kh; ++yy) {
+                        int64_t iy = in_y + yy;
+                        if (iy < 0 || iy >= in_h) continue;
+                        int64_t ky = ky0 + yy * up_y;
+                        for (int64_t xx = 0; kx0 + xx * up_x < kw; ++xx) {
+                            int64_t ix = in_x + xx;
+                            if (ix < 0 || ix >= in_w) continue;
+                            int64_t kx = kx0 + xx * up_x;
+                            /* sk[ky][kx] = kernel[kh-1-ky][kw-1-kx]   (:71-81) */
+                            double tap = k[(kh - 1 - ky) * kw + (kw - 1 - kx)];
+                            v += (double)x[((mj * in_h + iy) * in_w + ix) * minor + mn] * tap;
+                        }
+                    }
+                    y[((mj * out_h + oy) * out_w + ox) * minor + mn] = (float)v;
+                }
+            }
+    return SAE_OK;
+}
+
+/* fused_bias_act_kernel.cu:18-49; the arithmetic is done in float exactly as the CUDA kernel
+ * does for scalar_t = float (one add, one select/multiply, one multiply). */
+int oracle_bias_act_f32(const float* x, const float* b, const float* ref, float* y,
+                        int64_t numel, int64_t step_b, int64_t size_b,
+                        int32_t act, int32_t grad, float alpha, float scale,
+                        sae_stream_t stream) {
+    (void)stream;
+    if (!x || !y || numel < 0 || (b && (step_b < 1 || size_b < 1)) || (grad == 1 && !ref) ||
+        (act != 1 && act != 3) || grad < 0 || grad > 2) {
+        snprintf(g_err, sizeof g_err, "oracle_bias_act_f32: bad argument");
+        return SAE_EINVAL;
+    }
+    for (int64_t i = 0; i < numel; ++i) {
+        float v = x[i];
+        if (b) v += b[(i / step_b) % size_b];
+        float r = ref ? ref[i] : 0.0f;
+        float o;
+        switch (act * 10 + grad) {
+            default:
+            case 10: o = v; break;
+            case 11: o = v; break;
+            case 12: o = 0.0f; break;
+            case 30: o = (v > 0.0f) ? v : v * alpha; break;
+            case 31: o = (r > 0.0f) ? v : v * alpha; break;
+            case 32: o = 0.0f; break;
+        }
+        y[i] = o * scale;
+    }
+    return SAE_OK;
+}
+
+int64_t oracle_bias_act_bwd_workspace(int64_t numel, int64_t step_b, int64_t size_b) {
+    (void)numel; (void)step_b; (void)size_b;
+    return 0;
+}
+
+/* fused_act.py:32-41: grad_input = fused_bias_act(grad_output, empty, out, 3, 1, a, s);
+ * grad_bias = grad_input.sum(all dims but 1).  The sum is accumulated in double. */
+int oracle_bias_act_bwd_f32(const float* gy, const float* y_ref, float* gx, float* gb,
+                            float* workspace, int64_t workspace_floats,
+                            int64_t numel, int64_t step_b, int64_t size_b,
+                            float alpha, float scale, sae_stream_t stream) {
+    (void)stream; (void)workspace; (void)workspace_floats;
+    if (!gy || !y_ref || !gx || !gb || step_b < 1 || size_b < 1) {
+        snprintf(g_err, sizeof g_err, "oracle_bias_act_bwd_f32: bad argument");
+        return SAE_EINVAL;
+    }
+    double* acc = (double*)calloc((size_t)size_b, sizeof(double));
+    if (!acc) return SAE_EWORKSPACE;
+    for (int64_t i = 0; i < numel; ++i) {
+        float g = gy[i];
+        float o = (y_ref[i] > 0.0f) ? g : g * alpha;
+        o *= scale;
+        gx[i] = o;
+        acc[(i / step_b) % size_b] += (double)o;
+    }
+    for (int64_t c = 0; c < size_b; ++c) gb[c] = (float)acc[c];
+    free(acc);
+    return SAE_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense conv family.  The reference delegates these to PyTorch ATen (un-vendored, unpinned
+ * dependency: README.md:29 "PyTorch 1.7.1"); call sites stylegan2_layers.py:136 (EqualConv2d),
+ * :175,:182 (EqualLinear on 4-D input), :306 (conv_transpose2d), :315,:321 (ModulatedConv2d).
+ * What is restated here is the published definition of torch.nn.functional.conv2d
+ * (cross-correlation, zero padding, floor output size) and its two adjoints.
+ * ------------------------------------------------------------------------------------------- */
+static int conv_desc_ok(const sae_conv2d_desc* d) {
+    if (!d || d->n < 0 || d->c < 1 || d->m < 1 || d->h < 1 || d->w < 1 || d->kh < 1 || d->kw < 1 ||
+        d->stride < 1 || d->pad < 0)
+        return 0;
+    if (d->oh != (d->h + 2 * d->pad - d->kh) / d->stride + 1) return 0;
+    if (d->ow != (d->w + 2 * d->pad - d->kw) / d->stride + 1) return 0;
+    return d->oh >= 1 && d->ow >= 1;
+}
+
+int64_t oracle_conv2d_workspace(const sae_conv2d_desc* d, int32_t op) {
+    (void)d; (void)op;
+    return 0;
+}
+
+int oracle_conv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d,
+                          float alpha, float* workspace, int64_t workspace_floats,
+                          sae_stream_t stream) {
+    (void)workspace; (void)workspace_floats; (void)stream;
+    if (!x || !w || !y || !conv_desc_ok(d)) {
+        snprintf(g_err, sizeof g_err, "oracle_conv2d_fwd_f32: bad argument");
+        return SAE_EINVAL;
+    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t n = 0; n < d->n; ++n)
+        for (int64_t m = 0; m < d->m; ++m)
+            for (int64_t oy = 0; oy < d->oh; ++oy)
+                for (int64_t ox = 0; ox < d->ow; ++ox) {
+                    double acc = 0.0;
+                    for (int64_t c = 0; c < d->c; ++c)
+                        for (int ky = 0; ky < d->kh; ++ky) {
+                            int64_t iy = oy * d->stride + ky - d->pad;
+                            if (iy < 0 || iy >= d->h) continue;
+                            for (int kx = 0; kx < d->kw; ++kx) {
+                                int64_t ix = ox * d->stride + kx - d->pad;
+                                if (ix < 0 || ix >= d->w) continue;
+                                acc += (double)w[m * d->w_stride_m + c * d->w_stride_c + ky * d->kw + kx] *
+                                       (double)x[((n * d->c + c) * d->h + iy) * d->w + ix];
+                            }
+                        }
+                    y[((n * d->m + m) * d->oh + oy) * d->ow + ox] = (float)(acc * (double)alpha);
+                }
+    return SAE_OK;
+}
+
+int oracle_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
+                            float alpha, float* workspace, int64_t workspace_floats,
+                            sae_stream_t stream) {
+    (void)workspace; (void)workspace_floats; (void)stream;
+    if (!gy || !w || !gx || !conv_desc_ok(d)) {
+        snprintf(g_err, sizeof g_err, "oracle_conv2d_dgrad_f32: bad argument");
+        return SAE_EINVAL;
+    }
+    int64_t plane = d->h * d->w;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t n = 0; n < d->n; ++n)
+        for (int64_t c = 0; c < d->c; ++c) {
+            double* acc = (double*)calloc((size_t)plane, sizeof(double));
+            for (int64_t m = 0; m < d->m; ++m)
+                for (int ky = 0; ky < d->kh; ++ky)
+                    for (int kx = 0; kx < d->kw; ++kx) {
+                        double wv = w[m * d->w_stride_m + c * d->w_stride_c + ky * d->kw + kx];
+                        for (int64_t oy = 0; oy < d->oh; ++oy) {
+                            int64_t iy = oy * d->stride + ky - d->pad;
+                            if (iy < 0 || iy >= d->h) continue;
+                            for (int64_t ox = 0; ox < d->ow; ++ox) {
+                                int64_t ix = ox * d->stride + kx - d->pad;
+                                if (ix < 0 || ix >= d->w) continue;
+                                acc[iy * d->w + ix] +=
+                                    wv * (double)gy[((n * d->m + m) * d->oh + oy) * d->ow + ox];
+                            }
+                        }
+                    }
+            for (int64_t i = 0; i < plane; ++i)
+                gx[(n * d->c + c) * plane + i] = (float)(acc[i] * (double)alpha);
+            free(acc);
+        }
+    return SAE_OK;
+}
+
+int oracle_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
+                            float alpha, float* workspace, int64_t workspace_floats,
+                            sae_stream_t stream) {
+    (void)workspace; (void)workspace_floats; (void)stream;
+    if (!x || !gy || !gw || !conv_desc_ok(d)) {
+        snprintf(g_err, sizeof g_err, "oracle_conv2d_wgrad_f32: bad argument");
+        return SAE_EINVAL;
+    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int64_t m = 0; m < d->m; ++m)
+        for (int64_t c = 0; c < d->c; ++c)
+            for (int ky = 0; ky < d->kh; ++ky)
+                for (int kx = 0; kx < d->kw; ++kx) {
+                    double acc = 0.0;
+                    for (int64_t n = 0; n < d->n; ++n)
+                        for (int64_t oy = 0; oy < d->oh; ++oy) {
+                            int64_t iy = oy * d->stride + ky - d->pad;
+                            if (iy < 0 || iy >= d->h) continue;
+                            for (int64_t ox = 0; ox < d->ow; ++ox) {
+                                int64_t ix = ox * d->stride + kx - d->pad;
+                                if (ix < 0 || ix >= d->w) continue;
+                                acc += (double)gy[((n * d->m + m) * d->oh + oy) * d->ow + ox] *
+                                       (double)x[((n * d->c + c) * d->h + iy) * d->w + ix];
+                            }
+                        }
+                    gw[m * d->w_stride_m + c * d->w_stride_c + ky * d->kw + kx] =
+                        (float)(acc * (double)alpha);
+                }
+    return SAE_OK;
+}
+
+/* F.linear (stylegan2_layers.py:177,186) and its adjoints as one strided product. */
+int oracle_gemm_f32(const float* a, const float* b, const float* bias, float* c,
+                    int64_t m, int64_t n, int64_t k,
+                    int64_t a_si, int64_t a_sk, int64_t b_sk, int64_t b_sj, int64_t ldc,
+                    float alpha, sae_stream_t stream) {
+    (void)stream;
+    if (!a || !b || !c || m < 0 || n < 0 || k < 0) {
+        snprintf(g_err, sizeof g_err, "oracle_gemm_f32: bad argument");
+        return SAE_EINVAL;
+    }
+    for (int64_t i = 0; i < m; ++i)
+        for (int64_t j = 0; j < n; ++j) {
+            double acc = 0.0;
+            for (int64_t kk = 0; kk < k; ++kk)
+                acc += (double)a[i * a_si + kk * a_sk] * (double)b[kk * b_sk + j * b_sj];
+            acc *= (double)alpha;
+            if (bias) acc += (double)bias[j];
+            c[i * ldc + j] = (float)acc;
+        }
+    return SAE_OK;
+}

@@ -1,0 +1,44 @@
+"""Build csrc/libsae_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OUT = os.path.join(HERE, "libsae_hip.so")
+ARCH = "gfx950"
+
+
+def sources():
+    return sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hip"))
+
+
+def deps():
+    return sources() + [os.path.join(HERE, "sae_common.h"), os.path.join(ROOT, "include", "sae_hip.h")]
+
+
+def up_to_date():
+    return os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps())
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: cannot build the gfx950 hot-path library")
+
+
+def build(force=False, verbose=False):
+    if not force and up_to_date():
+        return OUT
+    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-I", os.path.join(ROOT, "include"), "-I", HERE] + sources() + ["-o", OUT]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

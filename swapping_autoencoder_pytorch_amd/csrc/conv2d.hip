@@ -1,0 +1,907 @@
+// Dense conv2d family (forward / dgrad / wgrad, incl. the stride-2 transposed form) as implicit
+// GEMMs on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s peak).
+//
+// Replaces the ATen calls F.conv2d / F.conv_transpose2d and their backward at
+// models/networks/stylegan2_layers.py:136,175,182,306,315,321 (EqualConv2d, EqualLinear on 4-D
+// input, ModulatedConv2d).  The reference's "modulated conv" is a dense conv with batch-shared
+// weights, so batch folds into the GEMM N dimension here instead of a
+// groups = batch grouped conv.
+//
+// GEMM view (NCHW, W contiguous):  D[m][pixel] = sum_{c,tap} A[m][(c,tap)] * B[(c,tap)][pixel]
+//   A = weights, re-laid once per call by conv_wprep_kernel into wp[tap][c][m] (m contiguous,
+//       zero padded to the tile, equalised-lr scale `alpha` and the dgrad flip/transposition
+//       folded in), staged to LDS as As[tap][c][m] with 16-byte global loads;
+//   B = never materialised: for a tile of 32*NI*WN output pixels the input PATCH (tile + halo,
+//       zero filled outside the image) of CK channels is staged to LDS once and each of the
+//       KS*KS taps reads it at a shifted offset, so every staged input element feeds 9 MFMAs
+//       rows (3x3) and HBM/L2 traffic for B is the bare input, not 9x im2col;
+//   MFMA operands (one fp32 VGPR each): lane l supplies A[i = l&31][k = l>>5] and
+//       B[k = l>>5][j = l&31]; the two k of one instruction are two input channels at the same
+//       tap, so the 32 lanes of a half-wave read 32 consecutive pixels (conflict-free
+//       ds_read_b32; for stride 2 the patch columns are stored de-interleaved even|odd so the
+//       stride-2 pixel walk is still unit-stride in LDS).
+// A workgroup is 4 waves (one per SIMD); a wave owns MI x NI 32x32 accumulator tiles.  The next
+// K-chunk's global loads are issued before the current chunk's MFMAs (register staging, write
+// after the barrier) so HBM/L2 latency hides under the matrix pipe.
+//
+// Stride-2 dgrad / transposed conv ("tr" kernel): output pixels are split by parity class
+// (oy&1, ox&1); class (ey,ex) only receives taps with ky = ey, kx = ex (mod 2) -> 4/2/2/1 taps,
+// no multiplications by inserted zeros.  A wave's four N-tiles are the four classes of the
+// same 32 half-resolution positions, so every tap issues exactly one useful MFMA per M-tile.
+//
+// wgrad: D[m][(c,tap)] = sum_pixels gy[m][pixel] * x[c][pixel shifted by tap]; K = pixels is
+// huge and M x C*taps small, so the pixel range is split over workgroups (split-K), each
+// leaving an fp32 slab; a fixed-order second kernel sums the slabs, applies alpha and scatters
+// to the parameter layout (deterministic, no atomics).
+#include "sae_common.h"
+
+namespace sae {
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// weight re-layout
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void conv_wprep_kernel(const float* __restrict__ w,
+                                                            float* __restrict__ wp, int M, int C, int Mp,
+                                                            int Cp, int taps, int64_t sm, int64_t sc,
+                                                            int flip, float alpha) {
+    const int64_t total = (int64_t)taps * Cp * Mp;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * kBlock) {
+        const int m = (int)(i % Mp);
+        const int64_t t = i / Mp;
+        const int c = (int)(t % Cp);
+        const int tap = (int)(t / Cp);
+        float v = 0.0f;
+        if (m < M && c < C) v = alpha * w[m * sm + c * sc + (flip ? taps - 1 - tap : tap)];
+        wp[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward-type implicit GEMM (stride 1 or 2 gather)
+// ------------------------------------------------------------------------------------------
+struct IgemmParams {
+    int N, C, H, W;       // input tensor; C = contraction channels
+    int M, OH, OW;        // logical output grid, M = output channels
+    int YH, YW;           // allocated output plane
+    int oys, oxs;         // output scatter multipliers (2 for the 1x1 stride-2 dgrad)
+    int Cp, Mp;           // padded dims of wp
+    int pad;              // iy = oy*S + ky - pad
+    int tw_log2, th_log2; // pixel tile = TN images x TH rows x TW cols
+    int tiles_x, tiles_y, tiles_n;
+};
+
+template <int KS, int S, int BN>
+struct PatchCap {
+    // worst case over TW,TH >= 4 (smallest tiles have the largest halo share)
+    static constexpr int value = (KS == 1) ? BN : (S == 1 ? (9 * BN) / 4 : (41 * BN) / 8);
+};
+
+template <int KS, int S, int MI, int NI, int WM, int WN, int CK>
+__global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ wp,
+                                                            float* __restrict__ y, const IgemmParams p) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int T = KS * KS;
+    constexpr int BM = 32 * MI * WM;
+    constexpr int BN = 32 * NI * WN;
+    constexpr int XCAP = PatchCap<KS, S, BN>::value;
+    constexpr int PPT = (XCAP + kBlock - 1) / kBlock;      // patch slots per thread per channel
+    constexpr int A_VEC = T * CK * BM / 4;                  // float4 per A chunk
+    constexpr int APT = (A_VEC + kBlock - 1) / kBlock;
+    __shared__ float As[T * CK * BM];
+    __shared__ float Xs[CK * XCAP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+
+    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
+    const int TN = BN >> (p.tw_log2 + p.th_log2);
+    int bt = blockIdx.x;
+    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
+    const int tiy = bt % p.tiles_y;
+    const int tin = bt / p.tiles_y;
+    const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
+    const int m0 = blockIdx.y * BM;
+
+    const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
+    const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
+    const int HALFW = (PW + 1) >> 1;
+    const int RS = PW;
+    const int IP = PH * RS;
+    const int CP = TN * IP;           // staged floats per channel (<= XCAP, checked on the host)
+    const int HW = p.H * p.W;
+
+    // per-thread patch slots: global offset relative to (image n0, channel 0) or -1
+    int poff[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int e = tid + kBlock * s;
+        int off = -1;
+        if (e < CP) {
+            const int pn = e / IP;
+            const int rem = e - pn * IP;
+            const int r = rem / RS;
+            const int cl = rem - r * RS;
+            int c = cl;
+            if (KS != 1 && S == 2) c = (cl < HALFW) ? 2 * cl : 2 * (cl - HALFW) + 1;
+            int iy, ix;
+            if (KS == 1) { iy = (oy0 + r) * S - p.pad; ix = (ox0 + c) * S - p.pad; }
+            else { iy = oy0 * S - p.pad + r; ix = ox0 * S - p.pad + c; }
+            if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                off = pn * p.C * HW + iy * p.W + ix;
+        }
+        poff[s] = off;
+    }
+
+    // per-lane LDS base of each N-tile pixel, and per-tap offsets
+    int pixbase[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int pp = (wn * NI + ni) * 32 + l31;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> p.tw_log2) & (TH - 1);
+        const int pn = pp >> (p.tw_log2 + p.th_log2);
+        pixbase[ni] = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px;
+    }
+    int tapoff[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ky = t / KS, kx = t % KS;
+        tapoff[t] = (KS == 1) ? 0 : ky * RS + ((S == 2) ? (kx & 1) * HALFW + (kx >> 1) : kx);
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    const float* xb = x + (int64_t)n0 * p.C * HW;
+    float xv[CK][PPT];
+    f32x4 av[APT];
+
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch) {
+            const bool ch_ok = (c0 + ch) < p.C;
+            const float* xc = xb + (int64_t)(c0 + ch) * HW;
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) xv[ch][s] = (ch_ok && poff[s] >= 0) ? xc[poff[s]] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e4 = tid + kBlock * i;
+            if (e4 < A_VEC) {
+                const int row = e4 / (BM / 4);       // tap*CK + ch
+                const int col4 = e4 - row * (BM / 4);
+                const int tap = row / CK, ch = row - tap * CK;
+                av[i] = *reinterpret_cast<const f32x4*>(
+                    wp + ((int64_t)tap * p.Cp + c0 + ch) * p.Mp + m0 + col4 * 4);
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch)
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                const int e = tid + kBlock * s;
+                if (e < CP) Xs[ch * XCAP + e] = xv[ch][s];
+            }
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e4 = tid + kBlock * i;
+            if (e4 < A_VEC) *reinterpret_cast<f32x4*>(As + e4 * 4) = av[i];
+        }
+    };
+
+    load_chunk(0);
+    for (int c0 = 0; c0 < p.Cp; c0 += CK) {
+        __syncthreads();   // everyone finished reading the previous chunk
+        store_chunk();
+        __syncthreads();
+        if (c0 + CK < p.Cp) load_chunk(c0 + CK);   // in flight under the MFMAs below
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int kk = 0; kk < CK / 2; ++kk) {
+                const int ch = 2 * kk + half;
+                float a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[mi] = As[(t * CK + ch) * BM + (wm * MI + mi) * 32 + l31];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[ni] = Xs[ch * XCAP + pixbase[ni] + tapoff[t]];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+    }
+
+    // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int pp = (wn * NI + ni) * 32 + l31;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> p.tw_log2) & (TH - 1);
+        const int pn = pp >> (p.tw_log2 + p.th_log2);
+        const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
+        if (n < p.N && oy < p.OH && ox < p.OW) {
+            float* yb = y + ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < p.M) yb[(int64_t)m * p.YH * p.YW] = acc[mi][ni][r];
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// stride-2 transposed gather ("tr"): out[m][o] = sum_{c,k : o + pad = 2 i + k} wp[k][c][m] * in[c][i]
+// 3x3 taps only.  N-tiles of a wave = the 4 parity classes of the same 32 q positions.
+// ------------------------------------------------------------------------------------------
+struct TrParams {
+    int N, C, IH, IW;     // input tensor (the small, "y side" image)
+    int M, OH, OW;        // output tensor (the large, "x side" image)
+    int QH, QW;           // half-resolution grid covered
+    int Cp, Mp;
+    int pad;
+    int tw_log2, th_log2; // q tile = TN images x TH x TW
+    int tiles_x, tiles_y, tiles_n;
+};
+
+template <int MI, int WM, int WN, int CK>
+__global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ wp,
+                                                               float* __restrict__ y, const TrParams p) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int T = 9;
+    constexpr int BM = 32 * MI * WM;
+    constexpr int BQ = 32 * WN;                  // q positions per workgroup
+    constexpr int XCAP = (25 * BQ) / 16;         // (TW+1)(TH+1)/(TW*TH) <= 25/16 for TW,TH >= 4
+    constexpr int PPT = (XCAP + kBlock - 1) / kBlock;
+    constexpr int A_VEC = T * CK * BM / 4;
+    constexpr int APT = (A_VEC + kBlock - 1) / kBlock;
+    __shared__ float As[T * CK * BM];
+    __shared__ float Xs[CK * XCAP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+
+    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
+    const int TN = BQ >> (p.tw_log2 + p.th_log2);
+    int bt = blockIdx.x;
+    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
+    const int tiy = bt % p.tiles_y;
+    const int tin = bt / p.tiles_y;
+    const int qx0 = tix * TW, qy0 = tiy * TH, n0 = tin * TN;
+    const int m0 = blockIdx.y * BM;
+
+    const int PH = TH + 1, PW = TW + 1;          // patch row r <-> input row qy0 - 1 + r
+    const int RS = PW;
+    const int IP = PH * RS;
+    const int CP = TN * IP;
+    const int HW = p.IH * p.IW;
+
+    int poff[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int e = tid + kBlock * s;
+        int off = -1;
+        if (e < CP) {
+            const int pn = e / IP;
+            const int rem = e - pn * IP;
+            const int r = rem / RS;
+            const int c = rem - r * RS;
+            const int iy = qy0 - 1 + r, ix = qx0 - 1 + c;
+            if (n0 + pn < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+                off = pn * p.C * HW + iy * p.IW + ix;
+        }
+        poff[s] = off;
+    }
+
+    const int pp = wn * 32 + l31;
+    const int px = pp & (TW - 1);
+    const int py = (pp >> p.tw_log2) & (TH - 1);
+    const int pn = pp >> (p.tw_log2 + p.th_log2);
+    const int pixbase = pn * IP + py * RS + px;
+    int tapoff[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ky = t / 3, kx = t % 3;
+        // tap k contributes from input index q - (k == 2 ? 1 : 0); patch row of input q is q - q0 + 1
+        tapoff[t] = ((ky == 2) ? 0 : 1) * RS + ((kx == 2) ? 0 : 1);
+    }
+
+    f32x16 acc[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][cl][r] = 0.0f;
+
+    const float* xb = x + (int64_t)n0 * p.C * HW;
+    float xv[CK][PPT];
+    f32x4 av[APT];
+
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch) {
+            const bool ch_ok = (c0 + ch) < p.C;
+            const float* xc = xb + (int64_t)(c0 + ch) * HW;
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) xv[ch][s] = (ch_ok && poff[s] >= 0) ? xc[poff[s]] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e4 = tid + kBlock * i;
+            if (e4 < A_VEC) {
+                const int row = e4 / (BM / 4);
+                const int col4 = e4 - row * (BM / 4);
+                const int tap = row / CK, ch = row - tap * CK;
+                av[i] = *reinterpret_cast<const f32x4*>(
+                    wp + ((int64_t)tap * p.Cp + c0 + ch) * p.Mp + m0 + col4 * 4);
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch)
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                const int e = tid + kBlock * s;
+                if (e < CP) Xs[ch * XCAP + e] = xv[ch][s];
+            }
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e4 = tid + kBlock * i;
+            if (e4 < A_VEC) *reinterpret_cast<f32x4*>(As + e4 * 4) = av[i];
+        }
+    };
+
+    load_chunk(0);
+    for (int c0 = 0; c0 < p.Cp; c0 += CK) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (c0 + CK < p.Cp) load_chunk(c0 + CK);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int cls = ((t / 3) & 1) * 2 + ((t % 3) & 1);   // parity class fed by this tap
+#pragma unroll
+            for (int kk = 0; kk < CK / 2; ++kk) {
+                const int ch = 2 * kk + half;
+                const float b = Xs[ch * XCAP + pixbase + tapoff[t]];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float a = As[(t * CK + ch) * BM + (wm * MI + mi) * 32 + l31];
+                    // cls is a compile-time constant after unrolling t
+                    if (cls == 0) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][0], 0, 0, 0);
+                    else if (cls == 1) acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][1], 0, 0, 0);
+                    else if (cls == 2) acc[mi][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][2], 0, 0, 0);
+                    else acc[mi][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][3], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int n = n0 + pn, qy = qy0 + py, qx = qx0 + px;
+    if (n < p.N) {
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) {
+            const int oy = 2 * qy + (cl >> 1) - p.pad;
+            const int ox = 2 * qx + (cl & 1) - p.pad;
+            if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
+                float* yb = y + ((int64_t)n * p.M * p.OH + oy) * p.OW + ox;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (m < p.M) yb[(int64_t)m * p.OH * p.OW] = acc[mi][cl][r];
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad: slab[slice][tap][a][b] = sum over the slice's pixels of  S[a][pix] * L[b][pix*stride + tap - pad]
+//   S = gy (a = y-side channel m), L = x (b = x-side channel c)
+// ------------------------------------------------------------------------------------------
+struct WgradParams {
+    int N, C, H, W;       // L tensor (x side)
+    int M, OH, OW;        // S tensor (y side)
+    int pad;
+    int tw_log2, th_log2; // pixel chunk = TN x TH x TW = 64 pixels of the y side
+    int tiles_x, tiles_y, tiles_n;
+    int chunks, chunks_per_slice;
+    int Ap, Bp;           // slab dims (padded M, C)
+};
+
+constexpr int kWgPix = 64;
+
+template <int KS, int S>
+struct WgPatchCap {
+    static constexpr int value = (KS == 1) ? 65 : (S == 1 ? 145 : 325);   // odd strides
+};
+
+template <int KS, int S, int TA, int TB, int WA, int WB>
+__global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restrict__ xl,
+                                                            const float* __restrict__ gs,
+                                                            float* __restrict__ slab, const WgradParams p) {
+    static_assert(WA * WB == 4, "4 waves per workgroup");
+    constexpr int T = KS * KS;
+    constexpr int BA = 32 * TA * WA, BB = 32 * TB * WB;
+    constexpr int PK = kWgPix;
+    constexpr int SLD = PK + 1;
+    constexpr int LP = WgPatchCap<KS, S>::value;
+    constexpr int PPT = (LP + kBlock - 1) / kBlock;
+    __shared__ float Ss[BA * SLD];
+    __shared__ float Ls[BB * LP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wa = wid / WB, wb = wid % WB;
+    const int b0 = blockIdx.x * BB, a0 = blockIdx.y * BA, slice = blockIdx.z;
+
+    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
+    const int TN = PK >> (p.tw_log2 + p.th_log2);
+    const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
+    const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
+    const int HALFW = (PW + 1) >> 1;
+    const int RS = PW;
+    const int IP = PH * RS;
+    const int CPs = TN * IP;
+    const int HWl = p.H * p.W, HWs = p.OH * p.OW;
+
+    int tapoff[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ky = t / KS, kx = t % KS;
+        tapoff[t] = (KS == 1) ? 0 : ky * RS + ((S == 2) ? (kx & 1) * HALFW + (kx >> 1) : kx);
+    }
+
+    f32x16 acc[TA][TB][T];
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ta][tb][t][r] = 0.0f;
+
+    const int ch_begin = slice * p.chunks_per_slice;
+    int ch_end = ch_begin + p.chunks_per_slice;
+    if (ch_end > p.chunks) ch_end = p.chunks;
+
+    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
+        int bt = chunk;
+        const int tix = bt % p.tiles_x; bt /= p.tiles_x;
+        const int tiy = bt % p.tiles_y;
+        const int tin = bt / p.tiles_y;
+        const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
+
+        __syncthreads();   // previous chunk fully consumed
+        // ---- stage S: Ss[a][pix], pix = tid & 63 fixed per thread
+        {
+            const int pix = tid & (PK - 1);
+            const int px = pix & (TW - 1);
+            const int py = (pix >> p.tw_log2) & (TH - 1);
+            const int pn = pix >> (p.tw_log2 + p.th_log2);
+            const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
+            const bool ok = n < p.N && oy < p.OH && ox < p.OW;
+            const float* sb = gs + ((int64_t)n * p.M) * HWs + (int64_t)oy * p.OW + ox;
+#pragma unroll 4
+            for (int a = tid >> 6; a < BA; a += kBlock / PK) {
+                float v = 0.0f;
+                if (ok && a0 + a < p.M) v = sb[(int64_t)(a0 + a) * HWs];
+                Ss[a * SLD + pix] = v;
+            }
+        }
+        // ---- stage L: Ls[b][patch]
+        {
+            int poff[PPT];
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) {
+                const int e = tid + kBlock * s;
+                int off = -1;
+                if (e < CPs) {
+                    const int pn = e / IP;
+                    const int rem = e - pn * IP;
+                    const int r = rem / RS;
+                    const int cl = rem - r * RS;
+                    int c = cl;
+                    if (KS != 1 && S == 2) c = (cl < HALFW) ? 2 * cl : 2 * (cl - HALFW) + 1;
+                    int iy, ix;
+                    if (KS == 1) { iy = (oy0 + r) * S - p.pad; ix = (ox0 + c) * S - p.pad; }
+                    else { iy = oy0 * S - p.pad + r; ix = ox0 * S - p.pad + c; }
+                    if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                        off = pn * p.C * HWl + iy * p.W + ix;
+                }
+                poff[s] = off;
+            }
+            const float* lb = xl + (int64_t)n0 * p.C * HWl;
+#pragma unroll 4
+            for (int b = 0; b < BB; ++b) {
+                const bool ch_ok = (b0 + b) < p.C;
+                const float* lc = lb + (int64_t)(b0 + b) * HWl;
+#pragma unroll
+                for (int s = 0; s < PPT; ++s) {
+                    const int e = tid + kBlock * s;
+                    if (e < CPs) Ls[b * LP + e] = (ch_ok && poff[s] >= 0) ? lc[poff[s]] : 0.0f;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- MFMA over the 64 pixels, two per instruction
+#pragma unroll 2
+        for (int kp = 0; kp < PK / 2; ++kp) {
+            const int pk = 2 * kp + half;
+            const int px = pk & (TW - 1);
+            const int py = (pk >> p.tw_log2) & (TH - 1);
+            const int pn = pk >> (p.tw_log2 + p.th_log2);
+            const int pbase = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px;
+            float a[TA];
+#pragma unroll
+            for (int ta = 0; ta < TA; ++ta) a[ta] = Ss[((wa * TA + ta) * 32 + l31) * SLD + pk];
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb) {
+                const float* lrow = Ls + ((wb * TB + tb) * 32 + l31) * LP + pbase;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float b = lrow[tapoff[t]];
+#pragma unroll
+                    for (int ta = 0; ta < TA; ++ta)
+                        acc[ta][tb][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b, acc[ta][tb][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- slab store: rows = a (m), cols = b (c)
+#pragma unroll
+    for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int bcol = b0 + (wb * TB + tb) * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int arow = a0 + (wa * TA + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    slab[(((int64_t)slice * T + t) * p.Ap + arow) * p.Bp + bcol] = acc[ta][tb][t][r];
+                }
+            }
+}
+
+__global__ __launch_bounds__(kBlock) void conv_wgrad_reduce_kernel(const float* __restrict__ slab,
+                                                                   float* __restrict__ gw, int M, int C,
+                                                                   int Ap, int Bp, int taps, int slices,
+                                                                   int64_t sm, int64_t sc, float alpha) {
+    const int64_t total = (int64_t)taps * M * C;
+    const int64_t slice_stride = (int64_t)taps * Ap * Bp;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * kBlock) {
+        const int c = (int)(i % C);
+        const int64_t t = i / C;
+        const int m = (int)(t % M);
+        const int tap = (int)(t / M);
+        const float* s = slab + ((int64_t)tap * Ap + m) * Bp + c;
+        float acc = 0.0f;
+        for (int sl = 0; sl < slices; ++sl) acc += s[sl * slice_stride];
+        gw[m * sm + c * sc + tap] = alpha * acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: planning and dispatch
+// ------------------------------------------------------------------------------------------
+bool desc_ok(const sae_conv2d_desc* d, const char* who) {
+    if (!d) { fail(SAE_EINVAL, "%s: null descriptor", who); return false; }
+    if (d->n < 0 || d->c < 1 || d->m < 1 || d->h < 1 || d->w < 1) {
+        fail(SAE_EINVAL, "%s: bad tensor dims", who); return false;
+    }
+    if (d->kh != d->kw || (d->kh != 1 && d->kh != 3) || (d->stride != 1 && d->stride != 2) || d->pad < 0 ||
+        d->pad >= d->kh) {
+        fail(SAE_EINVAL, "%s: unsupported geometry k=%dx%d stride=%d pad=%d (k in {1,3}, stride in {1,2}, pad < k)",
+             who, d->kh, d->kw, d->stride, d->pad);
+        return false;
+    }
+    if (d->oh != (d->h + 2 * d->pad - d->kh) / d->stride + 1 || d->ow != (d->w + 2 * d->pad - d->kw) / d->stride + 1 ||
+        d->oh < 1 || d->ow < 1) {
+        fail(SAE_EINVAL, "%s: oh/ow do not match the conv formula", who); return false;
+    }
+    const int64_t lim = (int64_t)1 << 31;
+    if (d->n * d->c * d->h * d->w >= lim * 4 || d->n * d->m * d->oh * d->ow >= lim * 4 || d->c * d->h * d->w >= lim ||
+        d->m * d->oh * d->ow >= lim || d->n >= (1 << 24) || d->c >= (1 << 24) || d->m >= (1 << 24)) {
+        fail(SAE_EINVAL, "%s: tensor too large for 32-bit tile arithmetic", who); return false;
+    }
+    return true;
+}
+
+inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
+
+// tile shape of a forward-type launch producing `mout` channels
+struct FwdShape { int cfg; int bm, bn; int ck; };   // cfg 0: 128x128, 1: 64x256, 2: 32x512
+FwdShape fwd_shape(int mout, int ks, int stride) {
+    FwdShape s{};
+    if (mout > 64) { s.cfg = 0; s.bm = 128; s.bn = 128; }
+    else if (mout > 32 || stride == 2) { s.cfg = 1; s.bm = 64; s.bn = 256; }
+    else { s.cfg = 2; s.bm = 32; s.bn = 512; }
+    // channels per K-chunk: 3x3 -> 8 (72 k per chunk); 1x1 -> 32, 16 for the 512-pixel tile (LDS)
+    s.ck = (ks == 1) ? (s.cfg == 2 ? 16 : 32) : 8;
+    return s;
+}
+
+// choose TW/TH (powers of two >= 4) for a tile of `bn` pixels over an oh x ow grid
+void pick_tile(int bn, int oh, int ow, int max_tw, int* tw_log2, int* th_log2) {
+    int tw = 1 << ilog2_ceil(ow);
+    if (tw < 4) tw = 4;
+    if (tw > max_tw) tw = max_tw;
+    int th = 1 << ilog2_ceil(oh);
+    if (th < 4) th = 4;
+    while (tw * th > bn) th >>= 1;
+    if (th < 1) th = 1;
+    *tw_log2 = ilog2_ceil(tw);
+    *th_log2 = ilog2_ceil(th);
+}
+
+struct TrShape { int cfg; int bm, bq; };   // cfg 0: 128 x 64q, 1: 64 x 128q, 2: 32 x 128q
+TrShape tr_shape(int mout) {
+    TrShape s{};
+    if (mout > 64) { s.cfg = 0; s.bm = 128; s.bq = 64; }
+    else if (mout > 32) { s.cfg = 1; s.bm = 64; s.bq = 128; }
+    else { s.cfg = 2; s.bm = 32; s.bq = 128; }
+    return s;
+}
+
+struct WgShape { int ba, bb; };
+WgShape wg_shape(int ks, int stride) {
+    if (ks == 1) return {128, 128};
+    if (stride == 1) return {64, 64};
+    return {128, 32};
+}
+
+struct WgPlan {
+    WgShape sh; int tw_log2, th_log2; int tiles_x, tiles_y, tiles_n; int chunks, cps, slices; int Ap, Bp; int taps;
+};
+WgPlan wg_plan(const sae_conv2d_desc* d) {
+    WgPlan w{};
+    w.sh = wg_shape(d->kh, d->stride);
+    w.taps = d->kh * d->kw;
+    pick_tile(kWgPix, (int)d->oh, (int)d->ow, 32, &w.tw_log2, &w.th_log2);
+    const int tw = 1 << w.tw_log2, th = 1 << w.th_log2, tn = kWgPix / (tw * th);
+    w.tiles_x = ceil_div((int)d->ow, tw);
+    w.tiles_y = ceil_div((int)d->oh, th);
+    w.tiles_n = ceil_div((int)d->n, tn);
+    w.chunks = w.tiles_x * w.tiles_y * w.tiles_n;
+    w.Ap = round_up((int)d->m, w.sh.ba);
+    w.Bp = round_up((int)d->c, w.sh.bb);
+    const int mn_tiles = (w.Ap / w.sh.ba) * (w.Bp / w.sh.bb);
+    int slices = ceil_div(1024, mn_tiles);
+    if (slices > w.chunks) slices = w.chunks;
+    if (slices < 1) slices = 1;
+    w.cps = ceil_div(w.chunks, slices);
+    w.slices = ceil_div(w.chunks, w.cps);
+    return w;
+}
+
+// ---- forward-type launch (regular gather) ------------------------------------------------------
+template <int KS, int S>
+int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const FwdShape& sh, hipStream_t s) {
+    pick_tile(sh.bn, p.OH, p.OW, 32, &p.tw_log2, &p.th_log2);
+    const int tw = 1 << p.tw_log2, th = 1 << p.th_log2, tn = sh.bn / (tw * th);
+    p.tiles_x = ceil_div(p.OW, tw);
+    p.tiles_y = ceil_div(p.OH, th);
+    p.tiles_n = ceil_div(p.N, tn);
+    const int ph = (KS == 1) ? th : (th - 1) * S + KS, pw = (KS == 1) ? tw : (tw - 1) * S + KS;
+    const int cap = (KS == 1) ? sh.bn : (S == 1 ? (9 * sh.bn) / 4 : (41 * sh.bn) / 8);
+    if (tn * ph * pw > cap) return fail(SAE_EINVAL, "conv igemm: patch %d exceeds LDS cap %d", tn * ph * pw, cap);
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(p.Mp / sh.bm));
+    constexpr int CK = (KS == 1) ? 32 : 8;
+    constexpr int CK2 = (KS == 1) ? 16 : 8;
+    switch (sh.cfg) {
+        case 0: hipLaunchKernelGGL((conv_igemm_kernel<KS, S, 2, 2, 2, 2, CK>), grid, dim3(kBlock), 0, s, x, wp, y, p); break;
+        case 1: hipLaunchKernelGGL((conv_igemm_kernel<KS, S, 2, 2, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, wp, y, p); break;
+        default:
+            if constexpr (S == 1)
+                hipLaunchKernelGGL((conv_igemm_kernel<KS, 1, 1, 4, 1, 4, CK2>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+            else
+                return fail(SAE_EINVAL, "conv igemm: 32x512 tile is stride-1 only");
+            break;
+    }
+    return SAE_OK;
+}
+
+int run_wprep(const float* w, float* wp, int M, int C, int Mp, int Cp, int taps, int64_t sm, int64_t sc, int flip,
+              float alpha, hipStream_t s) {
+    const int64_t total = (int64_t)taps * Cp * Mp;
+    int64_t blocks = ceil_div64(total, kBlock);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_wprep_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, w, wp, M, C, Mp, Cp, taps, sm,
+                       sc, flip, alpha);
+    return SAE_OK;
+}
+
+// forward-type gather producing `mout` channels from `cin` channels
+int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int H, int W,
+               int mout, int OH, int OW, int YH, int YW, int oys, int oxs, int ks, int stride, int pad, int64_t sm,
+               int64_t sc, int flip, float alpha, hipStream_t s) {
+    const FwdShape sh = fwd_shape(mout, ks, stride);
+    const int Mp = round_up(mout, sh.bm), Cp = round_up(cin, sh.ck), taps = ks * ks;
+    const int64_t need = (int64_t)taps * Cp * Mp;
+    if (!ws || ws_floats < need)
+        return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
+    run_wprep(w, ws, mout, cin, Mp, Cp, taps, sm, sc, flip, alpha, s);
+    IgemmParams p{};
+    p.N = N; p.C = cin; p.H = H; p.W = W; p.M = mout; p.OH = OH; p.OW = OW; p.YH = YH; p.YW = YW;
+    p.oys = oys; p.oxs = oxs; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
+    int rc;
+    if (ks == 3 && stride == 1) rc = launch_igemm<3, 1>(x, ws, y, p, sh, s);
+    else if (ks == 3) rc = launch_igemm<3, 2>(x, ws, y, p, sh, s);
+    else if (stride == 1) rc = launch_igemm<1, 1>(x, ws, y, p, sh, s);
+    else rc = launch_igemm<1, 2>(x, ws, y, p, sh, s);
+    return rc;
+}
+
+int64_t gather_ws(int cin, int mout, int ks, int stride) {
+    const FwdShape sh = fwd_shape(mout, ks, stride);
+    return (int64_t)ks * ks * round_up(cin, sh.ck) * round_up(mout, sh.bm);
+}
+
+// stride-2 3x3 transposed gather producing `mout` channels (the large image) from `cin` channels
+int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int IH, int IW,
+           int mout, int OH, int OW, int pad, int64_t sm, int64_t sc, float alpha, hipStream_t s) {
+    const TrShape sh = tr_shape(mout);
+    constexpr int CK = 8;
+    const int Mp = round_up(mout, sh.bm), Cp = round_up(cin, CK);
+    const int64_t need = (int64_t)9 * Cp * Mp;
+    if (!ws || ws_floats < need)
+        return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
+    run_wprep(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s);
+    TrParams p{};
+    p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
+    p.QH = (OH + pad - 1) / 2 + 1;
+    p.QW = (OW + pad - 1) / 2 + 1;
+    pick_tile(sh.bq, p.QH, p.QW, 32, &p.tw_log2, &p.th_log2);
+    const int tw = 1 << p.tw_log2, th = 1 << p.th_log2, tn = sh.bq / (tw * th);
+    p.tiles_x = ceil_div(p.QW, tw);
+    p.tiles_y = ceil_div(p.QH, th);
+    p.tiles_n = ceil_div(N, tn);
+    if (tn * (th + 1) * (tw + 1) > (25 * sh.bq) / 16)
+        return fail(SAE_EINVAL, "conv tr: patch exceeds LDS cap");
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(Mp / sh.bm));
+    switch (sh.cfg) {
+        case 0: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 2, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
+        case 1: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
+        default: hipLaunchKernelGGL((conv_igemm_tr_kernel<1, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
+    }
+    return SAE_OK;
+}
+
+int64_t tr_ws(int cin, int mout) {
+    const TrShape sh = tr_shape(mout);
+    return (int64_t)9 * round_up(cin, 8) * round_up(mout, sh.bm);
+}
+
+template <int KS, int S, int TA, int TB, int WA, int WB>
+void launch_wgrad(const float* x, const float* gy, float* slab, const WgradParams& p, const WgPlan& w, hipStream_t s) {
+    const dim3 grid((unsigned)(w.Bp / w.sh.bb), (unsigned)(w.Ap / w.sh.ba), (unsigned)w.slices);
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, TA, TB, WA, WB>), grid, dim3(kBlock), 0, s, x, gy, slab, p);
+}
+
+}  // namespace
+}  // namespace sae
+
+using namespace sae;
+
+extern "C" int64_t sae_conv2d_workspace(const sae_conv2d_desc* d, int32_t op) {
+    if (!desc_ok(d, "sae_conv2d_workspace")) return 0;
+    switch (op) {
+        case SAE_CONV_FWD: return gather_ws((int)d->c, (int)d->m, d->kh, d->stride);
+        case SAE_CONV_DGRAD:
+            if (d->stride == 1) return gather_ws((int)d->m, (int)d->c, d->kh, 1);
+            if (d->kh == 1) return gather_ws((int)d->m, (int)d->c, 1, 1);
+            return tr_ws((int)d->m, (int)d->c);
+        case SAE_CONV_WGRAD: {
+            const WgPlan w = wg_plan(d);
+            return (int64_t)w.slices * w.taps * w.Ap * w.Bp;
+        }
+        default: return 0;
+    }
+}
+
+extern "C" int sae_conv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d, float alpha,
+                                  float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    if (!desc_ok(d, "sae_conv2d_fwd_f32")) return SAE_EINVAL;
+    if (d->n == 0) return SAE_OK;
+    if (!x || !w || !y) return fail(SAE_EINVAL, "sae_conv2d_fwd_f32: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = run_gather(x, w, y, workspace, workspace_floats, (int)d->n, (int)d->c, (int)d->h, (int)d->w, (int)d->m,
+                        (int)d->oh, (int)d->ow, (int)d->oh, (int)d->ow, 1, 1, d->kh, d->stride, d->pad,
+                        d->w_stride_m, d->w_stride_c, 0, alpha, s);
+    if (rc != SAE_OK) return rc;
+    return check_launch("sae_conv2d_fwd_f32");
+}
+
+extern "C" int sae_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
+                                    float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    if (!desc_ok(d, "sae_conv2d_dgrad_f32")) return SAE_EINVAL;
+    if (d->n == 0) return SAE_OK;
+    if (!gy || !w || !gx) return fail(SAE_EINVAL, "sae_conv2d_dgrad_f32: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (d->stride == 1) {
+        // gx = full correlation of gy with the flipped, channel-transposed taps: pad' = k - 1 - pad
+        rc = run_gather(gy, w, gx, workspace, workspace_floats, (int)d->n, (int)d->m, (int)d->oh, (int)d->ow,
+                        (int)d->c, (int)d->h, (int)d->w, (int)d->h, (int)d->w, 1, 1, d->kh, 1, d->kh - 1 - d->pad,
+                        d->w_stride_c, d->w_stride_m, 1, alpha, s);
+    } else if (d->kh == 1) {
+        // 1x1 stride 2 (pad 0): gx[2oy][2ox] = W^T gy, every other position is zero
+        hipMemsetAsync(gx, 0, sizeof(float) * (size_t)(d->n * d->c * d->h * d->w), s);
+        rc = run_gather(gy, w, gx, workspace, workspace_floats, (int)d->n, (int)d->m, (int)d->oh, (int)d->ow,
+                        (int)d->c, (int)d->oh, (int)d->ow, (int)d->h, (int)d->w, 2, 2, 1, 1, 0, d->w_stride_c,
+                        d->w_stride_m, 0, alpha, s);
+    } else {
+        rc = run_tr(gy, w, gx, workspace, workspace_floats, (int)d->n, (int)d->m, (int)d->oh, (int)d->ow, (int)d->c,
+                    (int)d->h, (int)d->w, d->pad, d->w_stride_c, d->w_stride_m, alpha, s);
+    }
+    if (rc != SAE_OK) return rc;
+    return check_launch("sae_conv2d_dgrad_f32");
+}
+
+extern "C" int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
+                                    float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    if (!desc_ok(d, "sae_conv2d_wgrad_f32")) return SAE_EINVAL;
+    if (!gw) return fail(SAE_EINVAL, "sae_conv2d_wgrad_f32: null gw");
+    if (d->n > 0 && (!x || !gy)) return fail(SAE_EINVAL, "sae_conv2d_wgrad_f32: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const WgPlan w = wg_plan(d);
+    const int64_t need = (int64_t)w.slices * w.taps * w.Ap * w.Bp;
+    if (!workspace || workspace_floats < need)
+        return fail(SAE_EWORKSPACE, "sae_conv2d_wgrad_f32: workspace %lld < %lld floats", (long long)workspace_floats,
+                    (long long)need);
+    WgradParams p{};
+    p.N = (int)d->n; p.C = (int)d->c; p.H = (int)d->h; p.W = (int)d->w; p.M = (int)d->m; p.OH = (int)d->oh;
+    p.OW = (int)d->ow; p.pad = d->pad; p.tw_log2 = w.tw_log2; p.th_log2 = w.th_log2; p.tiles_x = w.tiles_x;
+    p.tiles_y = w.tiles_y; p.tiles_n = w.tiles_n; p.chunks = w.chunks; p.chunks_per_slice = w.cps; p.Ap = w.Ap;
+    p.Bp = w.Bp;
+    {
+        const int tw = 1 << w.tw_log2, th = 1 << w.th_log2, tn = kWgPix / (tw * th);
+        const int ph = (d->kh == 1) ? th : (th - 1) * d->stride + d->kh;
+        const int pw = (d->kh == 1) ? tw : (tw - 1) * d->stride + d->kh;
+        const int cap = (d->kh == 1) ? 65 : (d->stride == 1 ? 145 : 325);
+        if (tn * ph * pw > cap) return fail(SAE_EINVAL, "sae_conv2d_wgrad_f32: patch exceeds LDS cap");
+    }
+    if (d->n > 0) {
+        if (d->kh == 3 && d->stride == 1) launch_wgrad<3, 1, 1, 1, 2, 2>(x, gy, workspace, p, w, s);
+        else if (d->kh == 3) launch_wgrad<3, 2, 1, 1, 4, 1>(x, gy, workspace, p, w, s);
+        else if (d->stride == 1) launch_wgrad<1, 1, 2, 2, 2, 2>(x, gy, workspace, p, w, s);
+        else launch_wgrad<1, 2, 2, 2, 2, 2>(x, gy, workspace, p, w, s);
+    }
+    const int64_t total = (int64_t)w.taps * d->m * d->c;
+    int64_t blocks = ceil_div64(total, kBlock);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const float*)workspace,
+                       gw, (int)d->m, (int)d->c, w.Ap, w.Bp, w.taps, d->n > 0 ? w.slices : 0, d->w_stride_m,
+                       d->w_stride_c, alpha);
+    return check_launch("sae_conv2d_wgrad_f32");
+}

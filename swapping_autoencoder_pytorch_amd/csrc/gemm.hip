@@ -1,0 +1,151 @@
+// Strided fp32 GEMM on the matrix cores for the EqualLinear layers
+// (reference: F.linear at models/networks/stylegan2_layers.py:177,186 and its ATen backward).
+//
+//   C[i*ldc + j] = alpha * sum_k A[i*a_si + k*a_sk] * B[k*b_sk + j*b_sj]  (+ bias[j])
+//
+// One kernel serves forward (A = x, B = W^T), dgrad (A = gy, B = W) and wgrad (A = gy^T, B = x)
+// through the strides.  These layers are < 1 % of the step's FLOPs and are
+// weight-bandwidth / launch bound: the design goal is "no pathologies", not peak MFMA rate.
+//   * 64x64 workgroup tile, 4 waves of 32x32 (v_mfma_f32_32x32x2_f32), K chunks of 32 staged
+//     through LDS with whichever of (row, k) is unit-stride in memory mapped onto the lanes;
+//   * skinny problems (few 64x64 tiles, long K - the batch-16 style/modulation projections) split
+//     K across the 4 waves of a workgroup on a 32x32 tile and reduce through LDS, so a
+//     [16 x 2048] x [2048 x 512] product still spreads over 16 workgroups x 4 waves.
+#include "sae_common.h"
+
+namespace sae {
+namespace {
+
+constexpr int kKc = 32;   // K chunk
+
+struct GemmParams {
+    int64_t m, n, k;
+    int64_t a_si, a_sk, b_sk, b_sj, ldc;
+    float alpha;
+};
+
+// stage a [rows x kKc] panel of a strided matrix into LDS as dst[kk][row] (row stride LD)
+template <int ROWS, int LD, int NTHREADS>
+__device__ __forceinline__ void stage_panel(float* dst, const float* __restrict__ src, int64_t row0, int64_t rows,
+                                            int64_t k0, int64_t kmax, int64_t s_row, int64_t s_k, int t) {
+    if (s_k == 1) {   // k contiguous in memory: lanes walk k
+#pragma unroll 4
+        for (int e = t; e < ROWS * kKc; e += NTHREADS) {
+            const int r = e / kKc, kk = e - r * kKc;
+            float v = 0.0f;
+            if (row0 + r < rows && k0 + kk < kmax) v = src[(row0 + r) * s_row + (k0 + kk)];
+            dst[kk * LD + r] = v;
+        }
+    } else {          // rows contiguous (or generic): lanes walk rows
+#pragma unroll 4
+        for (int e = t; e < ROWS * kKc; e += NTHREADS) {
+            const int kk = e / ROWS, r = e - kk * ROWS;
+            float v = 0.0f;
+            if (row0 + r < rows && k0 + kk < kmax) v = src[(row0 + r) * s_row + (k0 + kk) * s_k];
+            dst[kk * LD + r] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ bias, float* __restrict__ c,
+                                                        const GemmParams p) {
+    constexpr int BT = 64, LD = BT + 1;
+    __shared__ float As[kKc * LD];
+    __shared__ float Bs[kKc * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int64_t i0 = (int64_t)blockIdx.y * BT, j0 = (int64_t)blockIdx.x * BT;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int64_t k0 = 0; k0 < p.k; k0 += kKc) {
+        __syncthreads();
+        stage_panel<BT, LD, kBlock>(As, a, i0, p.m, k0, p.k, p.a_si, p.a_sk, tid);
+        stage_panel<BT, LD, kBlock>(Bs, b, j0, p.n, k0, p.k, p.b_sj, p.b_sk, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kp = 0; kp < kKc / 2; ++kp) {
+            const float av = As[(2 * kp + half) * LD + wm * 32 + l31];
+            const float bv = Bs[(2 * kp + half) * LD + wn * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+    }
+    const int64_t j = j0 + wn * 32 + l31;
+    if (j < p.n) {
+        const float bj = bias ? bias[j] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t i = i0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (i < p.m) c[i * p.ldc + j] = p.alpha * acc[r] + bj;
+        }
+    }
+}
+
+// 32x32 output tile per workgroup; the 4 waves take K chunks round-robin and reduce through LDS.
+__global__ __launch_bounds__(kBlock) void gemm32_splitk_kernel(const float* __restrict__ a,
+                                                               const float* __restrict__ b,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ c, const GemmParams p) {
+    constexpr int BT = 32, LD = BT + 1;
+    __shared__ float As[4][kKc * LD];
+    __shared__ float Bs[4][kKc * LD];
+    __shared__ float red[4][32 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.y * BT, j0 = (int64_t)blockIdx.x * BT;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int64_t nchunks = ceil_div64(p.k, kKc);
+    // every wave runs the same number of iterations so the (wave-private) staging never diverges
+    const int64_t iters = ceil_div64(nchunks, 4);
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t k0 = (it * 4 + wid) * kKc;   // may be >= k: stages zeros
+        stage_panel<BT, LD, kWave>(As[wid], a, i0, p.m, k0, p.k, p.a_si, p.a_sk, lane);
+        stage_panel<BT, LD, kWave>(Bs[wid], b, j0, p.n, k0, p.k, p.b_sj, p.b_sk, lane);
+        __syncthreads();
+#pragma unroll
+        for (int kp = 0; kp < kKc / 2; ++kp) {
+            const float av = As[wid][(2 * kp + half) * LD + l31];
+            const float bv = Bs[wid][(2 * kp + half) * LD + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wid][((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l31] = acc[r];
+    __syncthreads();
+    for (int e = tid; e < 32 * 32; e += kBlock) {
+        const int i = e >> 5, j = e & 31;
+        const float v = (red[0][i * 33 + j] + red[1][i * 33 + j]) + (red[2][i * 33 + j] + red[3][i * 33 + j]);
+        if (i0 + i < p.m && j0 + j < p.n)
+            c[(i0 + i) * p.ldc + (j0 + j)] = p.alpha * v + (bias ? bias[j0 + j] : 0.0f);
+    }
+}
+
+}  // namespace
+}  // namespace sae
+
+using namespace sae;
+
+extern "C" int sae_gemm_f32(const float* a, const float* b, const float* bias, float* c, int64_t m, int64_t n,
+                            int64_t k, int64_t a_si, int64_t a_sk, int64_t b_sk, int64_t b_sj, int64_t ldc,
+                            float alpha, sae_stream_t stream) {
+    if (m < 0 || n < 0 || k < 0) return fail(SAE_EINVAL, "sae_gemm_f32: negative size");
+    if (m == 0 || n == 0) return SAE_OK;
+    if (!c || (k > 0 && (!a || !b))) return fail(SAE_EINVAL, "sae_gemm_f32: null matrix");
+    if (ldc < n) return fail(SAE_EINVAL, "sae_gemm_f32: ldc < n");
+    GemmParams p{m, n, k, a_si, a_sk, b_sk, b_sj, ldc, alpha};
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t tiles64 = ceil_div64(m, 64) * ceil_div64(n, 64);
+    if (tiles64 < 128 && k >= 256) {
+        const dim3 grid((unsigned)ceil_div64(n, 32), (unsigned)ceil_div64(m, 32));
+        hipLaunchKernelGGL(gemm32_splitk_kernel, grid, dim3(kBlock), 0, s, a, b, bias, c, p);
+    } else {
+        const dim3 grid((unsigned)ceil_div64(n, 64), (unsigned)ceil_div64(m, 64));
+        hipLaunchKernelGGL(gemm64_kernel, grid, dim3(kBlock), 0, s, a, b, bias, c, p);
+    }
+    return check_launch("sae_gemm_f32");
+}

@@ -1,0 +1,40 @@
+// Shared host/device helpers for the gfx950 hot-path library (see include/sae_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "sae_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace sae {
+
+constexpr int kWave = 64;       // CDNA wavefront
+constexpr int kBlock = 256;     // 4 waves, one per SIMD of a CU
+
+char* err_buf();                // thread-local message buffer (sae_api.hip)
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(SAE_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return SAE_OK;
+}
+
+__host__ __device__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+__host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+inline int ilog2_ceil(int64_t v) {  // smallest e with (1 << e) >= v, v >= 1
+    int e = 0;
+    while (((int64_t)1 << e) < v) ++e;
+    return e;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace sae

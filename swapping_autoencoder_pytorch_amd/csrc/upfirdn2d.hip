@@ -1,0 +1,238 @@
+// K1 — upfirdn2d: zero-insertion upsample -> pad/crop -> 2-D FIR -> decimate.
+//
+// Replaces upfirdn2d_op.upfirdn2d (reference: models/networks/stylegan2_op/upfirdn2d.cpp:12-19,
+// upfirdn2d_kernel.cu:52-272).  The arithmetic per output follows upfirdn2d_kernel.cu:114-129
+// (taps flipped as in :71-81, out-of-range input reads as zero :98-104, output size :167-168),
+// with the same accumulation order (tap rows outer, tap columns inner, one fp32 chain).
+//
+// Two kernels:
+//  * blur_kernel<KH,KW,TW,RB> — the train path.  Every upfirdn2d call issued by train.py has
+//    up = down = 1: a pure FIR blur with <= 4x4 taps, HBM-bound at
+//    4*(numel_in + numel_out) bytes.  Design for gfx950: a wave's 64 lanes own 64 CONSECUTIVE
+//    output columns, so every global load/store instruction of a wave is one contiguous
+//    256-byte run regardless of the odd row lengths (257, 255, 129 ...) the blurs produce, which
+//    rule out 16-byte accesses; each thread register-blocks RB consecutive output rows of its
+//    column, so one LDS read feeds up to KH outputs ((RB+KH-1)*KW reads per RB outputs, 4.75 per
+//    output at RB = 16 instead of 16).  The input strip of every thread row (RB+KH-1 rows by
+//    TW+KW-1 columns, zero-filled outside the image) is staged through LDS once.  Small planes
+//    (the 4x4 ... 32x32 tails of D / Dpatch with up to 49152 planes) are packed many
+//    strips-per-block (TW = 8/16/32) instead of one mostly idle block per plane as in the CUDA
+//    kernel (fixed 16x64 tile, upfirdn2d_kernel.cu:177-222).
+//  * upfirdn2d_generic_kernel — any up/down/taps/minor (API parity: Upsample/Downsample,
+//    stylegan2_layers.py:38-87).  The reference returns uninitialised memory when no template
+//    matches (upfirdn2d_kernel.cu:172-268); here every valid argument set computes.
+#include "sae_common.h"
+
+namespace sae {
+namespace {
+
+struct BlurParams {
+    int64_t planes;
+    int in_h, in_w, out_h, out_w;
+    int pad_x0, pad_y0;
+    int kh, kw;          // actual tap counts (<= template KH/KW); taps beyond read as zero
+    int groups_per_plane;  // ceil(out_h / RB)
+    int x_tiles;           // ceil(out_w / TW)
+    int64_t groups;        // planes * groups_per_plane
+};
+
+template <int KH, int KW, int TW, int RB>
+__global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ k,
+                                                      float* __restrict__ y, const BlurParams p) {
+    constexpr int NR = kBlock / TW;          // thread rows per block
+    constexpr int SR = RB + KH - 1;          // staged rows per strip
+    constexpr int SW = TW + KW - 1;          // staged columns per strip
+    constexpr int SWP = SW | 1;              // odd row stride
+    __shared__ float strip[NR][SR * SWP];
+    __shared__ float taps[KH * KW];
+
+    const int tx = threadIdx.x % TW;
+    const int tr = threadIdx.x / TW;
+
+    // flipped taps, zero padded to the template size (upfirdn2d_kernel.cu:71-81)
+    if (threadIdx.x < KH * KW) {
+        const int ky = threadIdx.x / KW, kx = threadIdx.x % KW;
+        float v = 0.0f;
+        if (ky < p.kh && kx < p.kw) v = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+        taps[threadIdx.x] = v;
+    }
+
+    const int64_t bid = blockIdx.x;
+    const int xt = (int)(bid % p.x_tiles);
+    const int64_t g = (bid / p.x_tiles) * NR + tr;  // strip (row group) handled by this thread row
+    const bool live = g < p.groups;
+    const int64_t plane = live ? g / p.groups_per_plane : 0;
+    const int oy0 = live ? (int)(g - plane * p.groups_per_plane) * RB : 0;
+    const int ox0 = xt * TW;
+    const int iy0 = oy0 - p.pad_y0;  // input row of staged row 0
+    const int ix0 = ox0 - p.pad_x0;  // input column of staged column 0
+
+    const float* xp = x + plane * (int64_t)p.in_h * p.in_w;
+    float* sp = strip[tr];
+    if (live) {
+        for (int e = tx; e < SR * SW; e += TW) {
+            const int r = e / SW, c = e - r * SW;
+            const int iy = iy0 + r, ix = ix0 + c;
+            float v = 0.0f;
+            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = xp[(int64_t)iy * p.in_w + ix];
+            sp[r * SWP + c] = v;
+        }
+    }
+    __syncthreads();
+
+    float tap[KH][KW];
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+        for (int b = 0; b < KW; ++b) tap[a][b] = taps[a * KW + b];
+
+    float acc[RB];
+#pragma unroll
+    for (int o = 0; o < RB; ++o) acc[o] = 0.0f;
+
+#pragma unroll
+    for (int r = 0; r < SR; ++r) {
+        float v[KW];
+#pragma unroll
+        for (int c = 0; c < KW; ++c) v[c] = sp[r * SWP + tx + c];
+#pragma unroll
+        for (int ky = 0; ky < KH; ++ky) {
+            const int o = r - ky;  // output row fed by staged row r through tap row ky
+            if (o >= 0 && o < RB) {
+#pragma unroll
+                for (int c = 0; c < KW; ++c) acc[o] = fmaf(v[c], tap[ky][c], acc[o]);
+            }
+        }
+    }
+
+    const int ox = ox0 + tx;
+    if (live && ox < p.out_w) {
+        float* yp = y + plane * (int64_t)p.out_h * p.out_w;
+#pragma unroll
+        for (int o = 0; o < RB; ++o) {
+            const int oy = oy0 + o;
+            if (oy < p.out_h) yp[(int64_t)oy * p.out_w + ox] = acc[o];
+        }
+    }
+}
+
+struct GenericParams {
+    int64_t major, minor;
+    int in_h, in_w, out_h, out_w;
+    int kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0;
+    int64_t total;  // major * out_h * out_w * minor
+};
+
+__device__ __forceinline__ int floor_div_i(int a, int b) {  // upfirdn2d_kernel.cu:18-26
+    int c = a / b;
+    if (c * b > a) c--;
+    return c;
+}
+
+__global__ __launch_bounds__(kBlock) void upfirdn2d_generic_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ k,
+                                                                   float* __restrict__ y,
+                                                                   const GenericParams p) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.total;
+         i += (int64_t)gridDim.x * kBlock) {
+        int64_t t = i;
+        const int64_t mn = t % p.minor; t /= p.minor;
+        const int ox = (int)(t % p.out_w); t /= p.out_w;
+        const int oy = (int)(t % p.out_h);
+        const int64_t mj = t / p.out_h;
+        const int mid_x = ox * p.down_x + p.up_x - 1 - p.pad_x0;
+        const int mid_y = oy * p.down_y + p.up_y - 1 - p.pad_y0;
+        const int in_x = floor_div_i(mid_x, p.up_x);
+        const int in_y = floor_div_i(mid_y, p.up_y);
+        const int kx0 = (in_x + 1) * p.up_x - mid_x - 1;
+        const int ky0 = (in_y + 1) * p.up_y - mid_y - 1;
+        float v = 0.0f;
+        for (int yy = 0; ky0 + yy * p.up_y < p.kh; ++yy) {
+            const int iy = in_y + yy;
+            if (iy < 0 || iy >= p.in_h) continue;
+            const int ky = ky0 + yy * p.up_y;
+            for (int xx = 0; kx0 + xx * p.up_x < p.kw; ++xx) {
+                const int ix = in_x + xx;
+                if (ix < 0 || ix >= p.in_w) continue;
+                const int kx = kx0 + xx * p.up_x;
+                const float tapv = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+                v = fmaf(x[((mj * p.in_h + iy) * p.in_w + ix) * p.minor + mn], tapv, v);
+            }
+        }
+        y[i] = v;
+    }
+}
+
+template <int KH, int KW, int TW, int RB>
+void launch_blur(const float* x, const float* k, float* y, BlurParams p, hipStream_t s) {
+    constexpr int NR = kBlock / TW;
+    p.groups_per_plane = ceil_div(p.out_h, RB);
+    p.x_tiles = ceil_div(p.out_w, TW);
+    p.groups = p.planes * p.groups_per_plane;
+    const int64_t blocks = ceil_div64(p.groups, NR) * p.x_tiles;
+    hipLaunchKernelGGL((blur_kernel<KH, KW, TW, RB>), dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, p);
+}
+
+template <int KH, int KW>
+void dispatch_blur(const float* x, const float* k, float* y, const BlurParams& p, hipStream_t s) {
+    // tile width from the output width, rows-per-thread from the output height
+    if (p.out_w > 32) {
+        if (p.out_h >= 16) launch_blur<KH, KW, 64, 16>(x, k, y, p, s);
+        else launch_blur<KH, KW, 64, 4>(x, k, y, p, s);
+    } else if (p.out_w > 16) {
+        if (p.out_h >= 16) launch_blur<KH, KW, 32, 16>(x, k, y, p, s);
+        else launch_blur<KH, KW, 32, 4>(x, k, y, p, s);
+    } else if (p.out_w > 8) {
+        if (p.out_h >= 16) launch_blur<KH, KW, 16, 16>(x, k, y, p, s);
+        else launch_blur<KH, KW, 16, 4>(x, k, y, p, s);
+    } else {
+        launch_blur<KH, KW, 8, 4>(x, k, y, p, s);
+    }
+}
+
+}  // namespace
+}  // namespace sae
+
+using namespace sae;
+
+extern "C" int sae_upfirdn2d_f32(const float* x, const float* k, float* y, int64_t major, int64_t in_h,
+                                 int64_t in_w, int64_t minor, int32_t kh, int32_t kw, int32_t up_x,
+                                 int32_t up_y, int32_t down_x, int32_t down_y, int32_t pad_x0,
+                                 int32_t pad_x1, int32_t pad_y0, int32_t pad_y1, sae_stream_t stream) {
+    if (up_x < 1 || up_y < 1 || down_x < 1 || down_y < 1 || kh < 1 || kw < 1 || (int64_t)kh * kw > 1024)
+        return fail(SAE_EINVAL, "sae_upfirdn2d_f32: bad up/down/taps (%d,%d,%d,%d,%dx%d)", up_x, up_y, down_x,
+                    down_y, kh, kw);
+    if (major < 0 || minor < 1 || in_h < 1 || in_w < 1)
+        return fail(SAE_EINVAL, "sae_upfirdn2d_f32: bad tensor size");
+    if (in_h > (1 << 24) || in_w > (1 << 24)) return fail(SAE_EINVAL, "sae_upfirdn2d_f32: plane too large");
+    const int64_t out_h = (in_h * up_y + pad_y0 + pad_y1 - kh + down_y) / down_y;
+    const int64_t out_w = (in_w * up_x + pad_x0 + pad_x1 - kw + down_x) / down_x;
+    if (out_h < 1 || out_w < 1)
+        return fail(SAE_EINVAL, "sae_upfirdn2d_f32: empty output (%lld x %lld)", (long long)out_h, (long long)out_w);
+    if (major == 0) return SAE_OK;
+    if (!x || !k || !y) return fail(SAE_EINVAL, "sae_upfirdn2d_f32: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+
+    const bool is_blur = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && minor == 1 && kh <= 4 && kw <= 4;
+    if (is_blur) {
+        BlurParams p{};
+        p.planes = major;
+        p.in_h = (int)in_h; p.in_w = (int)in_w; p.out_h = (int)out_h; p.out_w = (int)out_w;
+        p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
+        if (kh == 1 && kw == 1) dispatch_blur<1, 1>(x, k, y, p, s);
+        else if (kh <= 3 && kw <= 3) dispatch_blur<3, 3>(x, k, y, p, s);
+        else dispatch_blur<4, 4>(x, k, y, p, s);
+        return check_launch("sae_upfirdn2d_f32(blur)");
+    }
+    GenericParams g{};
+    g.major = major; g.minor = minor;
+    g.in_h = (int)in_h; g.in_w = (int)in_w; g.out_h = (int)out_h; g.out_w = (int)out_w;
+    g.kh = kh; g.kw = kw; g.up_x = up_x; g.up_y = up_y; g.down_x = down_x; g.down_y = down_y;
+    g.pad_x0 = pad_x0; g.pad_y0 = pad_y0;
+    g.total = major * out_h * out_w * minor;
+    int64_t blocks = ceil_div64(g.total, kBlock);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(upfirdn2d_generic_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, g);
+    return check_launch("sae_upfirdn2d_f32(generic)");
+}

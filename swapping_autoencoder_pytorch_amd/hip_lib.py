@@ -1,0 +1,128 @@
+"""ctypes binding of the C-ABI hot-path library (include/sae_hip.h).
+
+The product loads exactly one shared object: ``csrc/libsae_hip.so`` built for gfx950 by
+``csrc/build.py`` (``__graft_entry__.build()``).  There is no CPU implementation behind this
+module: if the library is missing, or a tensor handed to an op is not resident on a GPU, the
+call raises.  (The reference decided native-vs-fallback with ``util.is_custom_kernel_supported``,
+util/util.py:432-436, which raises on ROCm; that gate is not consulted here.)
+
+``SaeLibrary`` is parametrised by path and symbol prefix only so that the test-suite can bind the
+same signatures of the CPU oracle (``oracle_*``) and of the emulator build of the kernels
+(tests/emu) for checking; the product never does.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, "csrc", "libsae_hip.so")
+
+SAE_CONV_FWD, SAE_CONV_DGRAD, SAE_CONV_WGRAD = 0, 1, 2
+
+_f32p = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_f32 = C.c_float
+_stream = C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    """Mirror of ``sae_conv2d_desc``."""
+    _fields_ = [("n", _i64), ("c", _i64), ("h", _i64), ("w", _i64),
+                ("m", _i64), ("oh", _i64), ("ow", _i64),
+                ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
+                ("w_stride_m", _i64), ("w_stride_c", _i64)]
+
+    def key(self):
+        return tuple(getattr(self, f) for f, _ in self._fields_)
+
+
+_SIGNATURES = {
+    "abi_version": (C.c_int, []),
+    "last_error": (C.c_char_p, []),
+    "upfirdn2d_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i32, _i32,
+                                _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _stream]),
+    "bias_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _stream]),
+    "bias_act_bwd_workspace": (_i64, [_i64, _i64, _i64]),
+    "bias_act_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _f32, _f32, _stream]),
+    "conv2d_workspace": (_i64, [C.POINTER(ConvDesc), _i32]),
+    "conv2d_fwd_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
+    "conv2d_dgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
+    "conv2d_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
+    "gemm_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _stream]),
+}
+
+EXPORTED_SYMBOLS = tuple("sae_" + name for name in _SIGNATURES)
+
+
+class SaeError(RuntimeError):
+    pass
+
+
+class SaeLibrary:
+    def __init__(self, path=DEFAULT_LIBRARY, prefix="sae_", device_only=True):
+        if not os.path.exists(path):
+            raise SaeError(
+                "HIP hot-path library not found at %s - build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback." % path)
+        self.path = path
+        self.prefix = prefix
+        self.device_only = device_only
+        self._dll = C.CDLL(path)
+        self._fn = {}
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(self._dll, prefix + name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+            self._fn[name] = fn
+        if self._fn["abi_version"]() != 1:
+            raise SaeError("ABI version mismatch in %s" % path)
+
+    def last_error(self):
+        msg = self._fn["last_error"]()
+        return msg.decode("utf-8", "replace") if msg else ""
+
+    def query(self, name, *args):
+        return self._fn[name](*args)
+
+    def call(self, name, *args):
+        rc = self._fn[name](*args)
+        if rc != 0:
+            raise SaeError("%s%s failed (%d): %s" % (self.prefix, name, rc, self.last_error()))
+
+    # -- tensor plumbing --------------------------------------------------------------------
+    def check(self, *tensors):
+        """Every tensor handed to a kernel must be fp32, contiguous and (product) on a GPU."""
+        import torch
+        for t in tensors:
+            if t is None:
+                continue
+            if t.dtype != torch.float32:
+                raise SaeError("hot-path kernels are fp32 only, got %s" % t.dtype)
+            if not t.is_contiguous():
+                raise SaeError("internal error: non-contiguous tensor reached the C-ABI")
+            if self.device_only and not t.is_cuda:
+                raise SaeError(
+                    "tensor on %s: the MI355X hot path has no CPU implementation (move the model "
+                    "and data to a GPU)" % t.device)
+
+    def stream(self, t):
+        if t.is_cuda:
+            import torch
+            return torch.cuda.current_stream(t.device).cuda_stream
+        return None
+
+
+_LIB = None
+
+
+def get():
+    """The product's library instance (loaded on first use; raises if it is not built)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = SaeLibrary()
+    return _LIB
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()

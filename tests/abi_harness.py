@@ -1,0 +1,107 @@
+"""Drive the C-ABI (include/sae_hip.h) of any bound library on numpy data.
+
+`lib` is a SaeLibrary: the oracle (host pointers), the emulator build of the kernels (host
+pointers) or the real HIP library (device="cuda": buffers are staged through torch tensors on
+the GPU and the call goes through exactly the pointers/stream the product passes)."""
+import ctypes as C
+
+import numpy as np
+
+from swapping_autoencoder_pytorch_amd.hip_lib import ConvDesc
+
+OPS = ("conv2d_fwd_f32", "conv2d_dgrad_f32", "conv2d_wgrad_f32")
+
+
+class _Buf:
+    def __init__(self, arr, device):
+        self.device = device
+        if device is None:
+            self.np = np.ascontiguousarray(arr, dtype=np.float32)
+            self.ptr = self.np.ctypes.data
+        else:
+            import torch
+            self.t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(device)
+            self.ptr = self.t.data_ptr()
+
+    def numpy(self):
+        if self.device is None:
+            return self.np
+        return self.t.cpu().numpy()
+
+
+def _stream(device):
+    if device is None:
+        return None
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _out(shape, device):
+    return _Buf(np.full(shape, np.nan, np.float32), device)
+
+
+def upfirdn2d(lib, x, k, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0), device=None):
+    major, ih, iw, minor = x.shape
+    kh, kw = k.shape
+    oh = (ih * up[1] + pad[2] + pad[3] - kh + down[1]) // down[1]
+    ow = (iw * up[0] + pad[0] + pad[1] - kw + down[0]) // down[0]
+    bx, bk, by = _Buf(x, device), _Buf(k, device), _out((major, oh, ow, minor), device)
+    lib.call("upfirdn2d_f32", bx.ptr, bk.ptr, by.ptr, major, ih, iw, minor, kh, kw, up[0], up[1], down[0], down[1],
+             pad[0], pad[1], pad[2], pad[3], _stream(device))
+    return by.numpy()
+
+
+def bias_act(lib, x, b, ref, act=3, grad=0, alpha=0.2, scale=2 ** 0.5, device=None):
+    step_b = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+    bx = _Buf(x, device)
+    bb = _Buf(b, device) if b is not None else None
+    br = _Buf(ref, device) if ref is not None else None
+    by = _out(x.shape, device)
+    lib.call("bias_act_f32", bx.ptr, bb.ptr if bb else None, br.ptr if br else None, by.ptr, x.size, step_b,
+             b.size if b is not None else 1, act, grad, alpha, scale, _stream(device))
+    return by.numpy()
+
+
+def bias_act_bwd(lib, gy, y, alpha=0.2, scale=2 ** 0.5, device=None):
+    step_b = int(np.prod(gy.shape[2:])) if gy.ndim > 2 else 1
+    size_b = gy.shape[1]
+    n = lib.query("bias_act_bwd_workspace", gy.size, step_b, size_b)
+    bg, by = _Buf(gy, device), _Buf(y, device)
+    bgx, bgb, ws = _out(gy.shape, device), _out((size_b,), device), _out((max(n, 1),), device)
+    lib.call("bias_act_bwd_f32", bg.ptr, by.ptr, bgx.ptr, bgb.ptr, ws.ptr, n, gy.size, step_b, size_b, alpha, scale,
+             _stream(device))
+    return bgx.numpy(), bgb.numpy()
+
+
+def conv_desc(n, c, h, w, m, k, stride, pad, w_cm_layout=False):
+    d = ConvDesc()
+    d.n, d.c, d.h, d.w, d.m = n, c, h, w, m
+    d.kh = d.kw = k
+    d.stride, d.pad = stride, pad
+    d.oh = (h + 2 * pad - k) // stride + 1
+    d.ow = (w + 2 * pad - k) // stride + 1
+    if w_cm_layout:   # parameter stored [C, M, k, k]
+        d.w_stride_m, d.w_stride_c = k * k, m * k * k
+    else:             # parameter stored [M, C, k, k]
+        d.w_stride_m, d.w_stride_c = c * k * k, k * k
+    return d
+
+
+def conv(lib, op, d, a, b, out_shape, alpha=1.0, device=None):
+    n = lib.query("conv2d_workspace", C.byref(d), op)
+    ba, bb, bo, ws = _Buf(a, device), _Buf(b, device), _out(out_shape, device), _out((max(n, 1),), device)
+    lib.call(OPS[op], ba.ptr, bb.ptr, bo.ptr, C.byref(d), alpha, ws.ptr, n, _stream(device))
+    return bo.numpy()
+
+
+def gemm(lib, a, b, bias, m, n, k, a_si, a_sk, b_sk, b_sj, alpha=1.0, device=None):
+    ba, bb = _Buf(a, device), _Buf(b, device)
+    bbias = _Buf(bias, device) if bias is not None else None
+    bc = _out((m, n), device)
+    lib.call("gemm_f32", ba.ptr, bb.ptr, bbias.ptr if bbias else None, bc.ptr, m, n, k, a_si, a_sk, b_sk, b_sj, n,
+             alpha, _stream(device))
+    return bc.numpy()
+
+
+def rel_err(a, b):
+    return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(float(np.abs(b).max()), 1e-30))

@@ -1,0 +1,50 @@
+"""Shared case tables for the emulator (CPU) and GPU kernel parity tests."""
+
+# (x shape [major,h,w,minor], taps shape, up(x,y), down(x,y), pad(x0,x1,y0,y1))
+UPFIRDN_SMALL = [
+    ((6, 16, 16, 1), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2)),      # D/Dpatch blur before 3x3 s2 conv
+    ((6, 16, 16, 1), (4, 4), (1, 1), (1, 1), (1, 1, 1, 1)),      # blur before the 1x1 s2 skip / after G upsample
+    ((3, 67, 70, 1), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2)),      # non-multiple-of-tile plane
+    ((5, 9, 9, 1), (3, 3), (1, 1), (1, 1), (0, 0, 0, 0)),        # E: [1,2,1] after reflection pad
+    ((5, 8, 8, 1), (3, 3), (1, 1), (1, 1), (1, 0, 1, 0)),        # E skip: pad (1,0)
+    ((4, 7, 7, 1), (1, 1), (1, 1), (1, 1), (0, 0, 0, 0)),        # E global branch blur [1]
+    ((40, 4, 4, 1), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2)),       # tiny planes, many of them
+    ((3, 33, 33, 1), (4, 4), (1, 1), (1, 1), (1, 1, 1, 1)),
+    ((3, 20, 12, 1), (2, 2), (1, 1), (1, 1), (1, 0, 1, 0)),
+    ((3, 8, 8, 1), (4, 4), (2, 2), (1, 1), (2, 1, 2, 1)),        # Upsample (API parity)
+    ((3, 16, 16, 1), (4, 4), (1, 1), (2, 2), (1, 1, 1, 1)),      # Downsample (API parity)
+    ((2, 8, 8, 3), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2)),        # minor > 1
+    ((2, 9, 9, 1), (4, 4), (1, 1), (1, 1), (-1, -1, -1, -1)),    # negative pads crop
+    ((2, 9, 7, 1), (5, 5), (1, 1), (1, 1), (2, 2, 2, 2)),        # > 4 taps (reference: uninitialised)
+    ((2, 9, 7, 1), (3, 4), (2, 1), (1, 3), (2, 0, 1, 1)),        # anisotropic everything
+    ((3, 130, 40, 1), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2)),
+]
+
+BIAS_ACT_SHAPES = [(2, 8, 16, 16), (3, 5, 7, 7), (4, 16), (2, 4, 33, 31), (2, 3, 32, 32), (5, 6, 20, 20)]
+
+# (n, c, h, w, m, k, stride, pad, weights stored [C,M,k,k])
+CONV_SMALL = [
+    (2, 8, 8, 8, 32, 3, 1, 1, False), (1, 5, 16, 16, 40, 3, 1, 1, False), (3, 10, 4, 4, 70, 3, 1, 1, False),
+    (1, 9, 36, 33, 130, 3, 1, 0, False),
+    (2, 8, 9, 9, 32, 3, 2, 0, False), (1, 5, 17, 17, 40, 3, 2, 0, False), (3, 10, 9, 9, 70, 3, 2, 0, False),
+    (1, 6, 33, 33, 130, 3, 2, 0, False), (1, 4, 18, 18, 20, 3, 2, 0, False), (1, 4, 10, 12, 20, 3, 2, 1, False),
+    (2, 40, 8, 8, 32, 1, 1, 0, False), (1, 70, 16, 16, 70, 1, 1, 0, False), (2, 33, 7, 7, 130, 1, 2, 0, False),
+    (1, 20, 15, 15, 36, 1, 2, 0, False),
+    (2, 8, 8, 8, 32, 3, 1, 1, True), (1, 6, 17, 17, 40, 3, 2, 0, True), (2, 8, 4, 4, 130, 3, 1, 0, False),
+    (1, 3, 6, 6, 8, 3, 1, 1, False), (1, 3, 40, 40, 3, 1, 1, 0, False), (2, 6, 4, 4, 12, 3, 2, 0, False),
+]
+
+# larger shapes for the GPU (oracle still finishes in seconds): church-preset layer classes scaled down
+CONV_GPU = CONV_SMALL + [
+    (2, 128, 32, 32, 128, 3, 1, 1, False),     # D 3x3 s1
+    (2, 64, 33, 33, 128, 3, 2, 0, False),      # D 3x3 s2 after blur
+    (2, 64, 31, 31, 128, 1, 2, 0, False),      # D skip 1x1 s2
+    (4, 32, 34, 34, 32, 3, 1, 0, False),       # E valid 3x3 after reflection pad (32-channel tile)
+    (2, 64, 16, 16, 96, 3, 2, 0, True),        # G transposed 3x3 (weights [C,M]) via dgrad
+    (8, 48, 4, 4, 96, 3, 1, 1, False),         # tails: many images per tile
+    (2, 3, 64, 64, 32, 3, 1, 1, False),        # Dpatch stem
+    (2, 128, 16, 16, 3, 1, 1, 0, False),       # ToRGB
+    (3, 96, 4, 4, 48, 3, 1, 0, False),         # Dpatch final valid conv 4x4 -> 2x2
+]
+
+GEMM_CASES = [(16, 40, 300), (128, 70, 64), (5, 3, 1000), (70, 130, 33), (33, 200, 513)]

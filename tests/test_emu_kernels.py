@@ -1,0 +1,89 @@
+"""CPU: the product's kernel sources, compiled for the host against the hipemu header
+(tests/emu), versus the CPU oracle.  Exercises the real tile/index arithmetic, LDS staging,
+barriers and MFMA lane layouts without a GPU."""
+import numpy as np
+import pytest
+
+import abi_harness as H
+from kernel_cases import BIAS_ACT_SHAPES, CONV_SMALL, GEMM_CASES, UPFIRDN_SMALL
+
+TOL = 2e-5   # fp32 kernel vs double-accumulating oracle, relative to the output's max magnitude
+
+
+@pytest.mark.parametrize("case", UPFIRDN_SMALL, ids=lambda c: "x".join(map(str, c[0])) + "_k%dx%d" % c[1])
+def test_upfirdn2d(emu_lib, oracle_lib, case):
+    xs, ks, up, down, pad = case
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(xs).astype(np.float32)
+    k = rng.standard_normal(ks).astype(np.float32)
+    a = H.upfirdn2d(emu_lib, x, k, up, down, pad)
+    o = H.upfirdn2d(oracle_lib, x, k, up, down, pad)
+    assert a.shape == o.shape
+    assert not np.isnan(a).any()
+    assert H.rel_err(a, o) < TOL
+
+
+@pytest.mark.parametrize("shape", BIAS_ACT_SHAPES, ids=str)
+def test_bias_act(emu_lib, oracle_lib, shape):
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape[1]).astype(np.float32)
+    ref = rng.standard_normal(shape).astype(np.float32)
+    for act, grad in [(3, 0), (3, 1), (3, 2), (1, 0), (1, 1)]:
+        r = ref if grad else None
+        a = H.bias_act(emu_lib, x, b, r, act, grad)
+        o = H.bias_act(oracle_lib, x, b, r, act, grad)
+        assert np.array_equal(a, o), (act, grad)      # elementwise fp32: bit exact
+    a = H.bias_act(emu_lib, x, None, None)
+    o = H.bias_act(oracle_lib, x, None, None)
+    assert np.array_equal(a, o)
+    gx_a, gb_a = H.bias_act_bwd(emu_lib, x, ref)
+    gx_o, gb_o = H.bias_act_bwd(oracle_lib, x, ref)
+    assert np.array_equal(gx_a, gx_o)
+    assert np.allclose(gb_a, gb_o, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", CONV_SMALL, ids=lambda c: "n%d_c%d_%dx%d_m%d_k%d_s%d_p%d_%s" % c)
+def test_conv2d(emu_lib, oracle_lib, case):
+    n, c, h, w, m, k, s, p, cm = case
+    d = H.conv_desc(n, c, h, w, m, k, s, p, cm)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = rng.standard_normal((c, m, k, k) if cm else (m, c, k, k)).astype(np.float32)
+    gy = rng.standard_normal((n, m, d.oh, d.ow)).astype(np.float32)
+    for op, (a, b, shape) in enumerate([(x, wt, gy.shape), (gy, wt, x.shape), (x, gy, wt.shape)]):
+        e = H.conv(emu_lib, op, d, a, b, shape, alpha=0.37)
+        o = H.conv(oracle_lib, op, d, a, b, shape, alpha=0.37)
+        assert not np.isnan(e).any(), op
+        assert H.rel_err(e, o) < TOL, (op, H.rel_err(e, o))
+
+
+@pytest.mark.parametrize("mnk", GEMM_CASES, ids=str)
+def test_gemm(emu_lib, oracle_lib, mnk):
+    m, n, k = mnk
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = rng.standard_normal((n, k)).astype(np.float32)
+    gy = rng.standard_normal((m, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    for args in [(x, w, bias, m, n, k, k, 1, 1, k, 0.5),        # y = x W^T + b
+                 (gy, w, None, m, k, n, n, 1, k, 1, 1.0),        # gx = gy W
+                 (gy, x, None, n, k, m, 1, n, k, 1, 1.0)]:       # gW = gy^T x
+        e = H.gemm(emu_lib, *args)
+        o = H.gemm(oracle_lib, *args)
+        assert H.rel_err(e, o) < TOL
+
+
+def test_argument_errors(emu_lib):
+    from swapping_autoencoder_pytorch_amd.hip_lib import SaeError
+    x = np.zeros((1, 4, 4, 1), np.float32)
+    k = np.zeros((4, 4), np.float32)
+    y = np.zeros((1, 4, 4, 1), np.float32)
+    with pytest.raises(SaeError):   # up_x = 0
+        emu_lib.call("upfirdn2d_f32", x.ctypes.data, k.ctypes.data, y.ctypes.data, 1, 4, 4, 1, 4, 4, 0, 1, 1, 1,
+                     2, 1, 2, 1, None)
+    with pytest.raises(SaeError):
+        H.bias_act(emu_lib, x, None, None, act=2)
+    d = H.conv_desc(1, 4, 8, 8, 4, 5, 1, 2)     # 5x5 taps: unsupported, must fail loudly
+    with pytest.raises(SaeError):
+        H.conv(emu_lib, 0, d, np.zeros((1, 4, 8, 8), np.float32), np.zeros((4, 4, 5, 5), np.float32), (1, 4, 8, 8))

@@ -1,0 +1,92 @@
+"""GPU parity: the real gfx950 library, called through the C-ABI with device pointers, versus the
+CPU oracle on the same seeded inputs.  fp32 tolerance 2e-5 relative to the output's max
+magnitude per op (north star: <= 1e-4 relative per op)."""
+import numpy as np
+import pytest
+
+import abi_harness as H
+from kernel_cases import BIAS_ACT_SHAPES, CONV_GPU, GEMM_CASES, UPFIRDN_SMALL
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from swapping_autoencoder_pytorch_amd import hip_lib as L
+    return L.get()
+
+
+UPFIRDN_GPU = UPFIRDN_SMALL + [
+    ((64, 256, 256, 1), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2)),
+    ((64, 257, 257, 1), (4, 4), (1, 1), (1, 1), (1, 1, 1, 1)),
+    ((32, 259, 259, 1), (3, 3), (1, 1), (1, 1), (0, 0, 0, 0)),
+    ((3000, 8, 8, 1), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2)),
+    ((8, 64, 64, 1), (4, 4), (2, 2), (1, 1), (2, 1, 2, 1)),
+    ((8, 64, 64, 1), (4, 4), (1, 1), (2, 2), (1, 1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", UPFIRDN_GPU, ids=lambda c: "x".join(map(str, c[0])) + "_k%dx%d" % c[1])
+def test_upfirdn2d(hip_lib, oracle_lib, case):
+    xs, ks, up, down, pad = case
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(xs).astype(np.float32)
+    k = rng.standard_normal(ks).astype(np.float32)
+    a = H.upfirdn2d(hip_lib, x, k, up, down, pad, device=DEV)
+    o = H.upfirdn2d(oracle_lib, x, k, up, down, pad)
+    assert a.shape == o.shape and not np.isnan(a).any()
+    assert H.rel_err(a, o) < TOL
+
+
+@pytest.mark.parametrize("shape", BIAS_ACT_SHAPES + [(16, 128, 64, 64), (128, 32, 32, 32), (16, 512), (4, 7, 129, 129)], ids=str)
+def test_bias_act(hip_lib, oracle_lib, shape):
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape[1]).astype(np.float32)
+    ref = rng.standard_normal(shape).astype(np.float32)
+    for act, grad in [(3, 0), (3, 1), (3, 2), (1, 0)]:
+        r = ref if grad else None
+        a = H.bias_act(hip_lib, x, b, r, act, grad, device=DEV)
+        o = H.bias_act(oracle_lib, x, b, r, act, grad)
+        # one add, one select/mul, one mul per element: bit exact unless the compiler contracts
+        # the (x + b) * alpha pair differently -> allow 1 ulp
+        assert np.allclose(a, o, rtol=2e-7, atol=0), (act, grad)
+    gx_a, gb_a = H.bias_act_bwd(hip_lib, x, ref, device=DEV)
+    gx_o, gb_o = H.bias_act_bwd(oracle_lib, x, ref)
+    assert np.allclose(gx_a, gx_o, rtol=2e-7, atol=0)
+    scale = np.abs(gx_o).sum() / gb_o.size
+    assert np.abs(gb_a - gb_o).max() <= 1e-5 * max(scale, 1.0)
+
+
+@pytest.mark.parametrize("case", CONV_GPU, ids=lambda c: "n%d_c%d_%dx%d_m%d_k%d_s%d_p%d_%s" % c)
+def test_conv2d(hip_lib, oracle_lib, case):
+    n, c, h, w, m, k, s, p, cm = case
+    d = H.conv_desc(n, c, h, w, m, k, s, p, cm)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = rng.standard_normal((c, m, k, k) if cm else (m, c, k, k)).astype(np.float32)
+    gy = rng.standard_normal((n, m, d.oh, d.ow)).astype(np.float32)
+    for op, (a, b, shape) in enumerate([(x, wt, gy.shape), (gy, wt, x.shape), (x, gy, wt.shape)]):
+        e = H.conv(hip_lib, op, d, a, b, shape, alpha=0.37, device=DEV)
+        o = H.conv(oracle_lib, op, d, a, b, shape, alpha=0.37)
+        assert not np.isnan(e).any(), op
+        assert H.rel_err(e, o) < TOL, (op, H.rel_err(e, o))
+
+
+@pytest.mark.parametrize("mnk", GEMM_CASES + [(128, 2048, 3072), (16, 512, 2048)], ids=str)
+def test_gemm(hip_lib, oracle_lib, mnk):
+    m, n, k = mnk
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((m, k)).astype(np.float32)
+    w = rng.standard_normal((n, k)).astype(np.float32)
+    gy = rng.standard_normal((m, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    for args in [(x, w, bias, m, n, k, k, 1, 1, k, 0.5), (gy, w, None, m, k, n, n, 1, k, 1, 1.0),
+                 (gy, x, None, n, k, m, 1, n, k, 1, 1.0)]:
+        e = H.gemm(hip_lib, *args, device=DEV)
+        o = H.gemm(oracle_lib, *args)
+        assert H.rel_err(e, o) < TOL
