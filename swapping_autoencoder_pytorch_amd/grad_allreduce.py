@@ -1,0 +1,113 @@
+"""Bucketed gradient all-reduce overlapped with backward (one process per GPU, RCCL over xGMI).
+
+Replaces what ``nn.DataParallel`` did implicitly in the reference (models/__init__.py:80-93:
+replicate / scatter / gather / reduce_add through GPU 0 on every call).  Design for MI355X:
+
+* every rank holds a full replica and an equal shard of the batch; losses are per-sample means,
+  so averaging gradients over ranks reproduces the global-batch gradient;
+* the trainable set flips between {E, G} and {D, Dpatch} on every call, so there is one reducer
+  per group (not one static DDP bucket list over the whole model);
+* gradients are packed into ~32 MB fp32 buckets in REVERSE parameter order (the order backward
+  produces them); a post-accumulate-grad hook counts arrivals and launches ``all_reduce`` on
+  the bucket (async, on RCCL's own stream) as soon as its last gradient lands, so the 213-223 MB
+  of a step fly while the early layers' wgrad kernels still run.  xGMI is point-to-point
+  (7 links x ~153 GB/s): a handful of large buckets keeps every ring step bandwidth- rather
+  than latency-bound;
+* ``finish()`` waits, scales by 1/world and scatters the averaged values back into ``.grad``.
+  Parameters that received no gradient in this pass (e.g. R1 touches every D parameter but a
+  frozen branch might not) contribute zeros, keeping the collective shape identical on all ranks.
+
+With world_size == 1 (or torch.distributed not initialised) every method is a no-op."""
+import torch
+import torch.distributed as dist
+
+BUCKET_BYTES = 32 * 1024 * 1024
+
+
+class _Bucket:
+    __slots__ = ("params", "offsets", "numel", "flat", "pending", "work")
+
+    def __init__(self):
+        self.params, self.offsets, self.numel = [], [], 0
+        self.flat, self.pending, self.work = None, 0, None
+
+
+class GradAllReducer:
+    def __init__(self, params, bucket_bytes=BUCKET_BYTES, process_group=None):
+        self.params = [p for p in params]
+        self.group = process_group
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.world = dist.get_world_size(process_group) if self.enabled else 1
+        self.armed = False
+        self.buckets = []
+        self._where = {}
+        if not self.enabled:
+            return
+        cur = _Bucket()
+        for p in reversed(self.params):
+            if cur.numel > 0 and (cur.numel + p.numel()) * 4 > bucket_bytes:
+                self.buckets.append(cur)
+                cur = _Bucket()
+            cur.offsets.append(cur.numel)
+            cur.params.append(p)
+            cur.numel += p.numel()
+            self._where[p] = (len(self.buckets), len(cur.params) - 1)
+        if cur.numel:
+            self.buckets.append(cur)
+        for b in self.buckets:
+            ref = b.params[0]
+            b.flat = torch.zeros(b.numel, dtype=ref.dtype, device=ref.device)
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # called right before loss.backward()
+    def arm(self):
+        if not self.enabled:
+            return
+        self.armed = True
+        for b in self.buckets:
+            b.pending = len(b.params)
+            b.work = None
+            b.flat.zero_()
+
+    def _on_grad(self, p):
+        if not self.armed:
+            return
+        bi, pi = self._where[p]
+        b = self.buckets[bi]
+        off = b.offsets[pi]
+        b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        b.pending -= 1
+        if b.pending == 0:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    # called after loss.backward(), before optimizer.step()
+    def finish(self):
+        if not self.enabled or not self.armed:
+            return
+        self.armed = False
+        inv = 1.0 / self.world
+        for b in self.buckets:
+            if b.work is None:      # some parameter of the bucket got no gradient in this pass
+                for p, off in zip(b.params, b.offsets):
+                    if p.grad is not None and b.pending > 0:
+                        b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self.buckets:
+            b.work.wait()
+            b.flat.mul_(inv)
+            for p, off in zip(b.params, b.offsets):
+                if p.grad is not None:
+                    p.grad.copy_(b.flat[off:off + p.numel()].view_as(p.grad))
+                elif p.requires_grad:
+                    p.grad = b.flat[off:off + p.numel()].view_as(p).clone()
+            b.work = None
+
+
+def broadcast_parameters(module, src=0, process_group=None):
+    """One-time replica synchronisation at start-up (parameters and buffers)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=process_group)

@@ -1,0 +1,107 @@
+"""StyleGAN2ResnetGenerator (reference: models/networks/generator.py:23-161, Fig. 18 of the paper).
+
+Spatial code --(modulated by the global code)--> `netG_num_base_resnet_layers` resolution-
+preserving styled residual blocks --> one upsampling styled residual block per encoder
+downsampling (transposed 3x3 + blur main path, bilinear x2 skip) --> ToRGB."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from .. import util
+from ..stylegan2_layers import ConvLayer, EqualLinear, StyledConv, ToRGB
+from .base_network import BaseNetwork
+
+_INV_SQRT2 = 1.0 / math.sqrt(2)
+
+
+class ResolutionPreservingResnetBlock(torch.nn.Module):
+    """generator.py:23-36"""
+
+    def __init__(self, opt, inch, outch, styledim):
+        super().__init__()
+        self.conv1 = StyledConv(inch, outch, 3, styledim, upsample=False)
+        self.conv2 = StyledConv(outch, outch, 3, styledim, upsample=False)
+        self.skip = ConvLayer(inch, outch, 1, activate=False, bias=False) if inch != outch else torch.nn.Identity()
+
+    def forward(self, x, style):
+        res = self.conv2(self.conv1(x, style), style)
+        return (self.skip(x) + res) / math.sqrt(2)
+
+
+class UpsamplingResnetBlock(torch.nn.Module):
+    """generator.py:39-53"""
+
+    def __init__(self, inch, outch, styledim, blur_kernel=[1, 3, 3, 1], use_noise=False):
+        super().__init__()
+        self.inch, self.outch, self.styledim = inch, outch, styledim
+        self.conv1 = StyledConv(inch, outch, 3, styledim, upsample=True, blur_kernel=blur_kernel, use_noise=use_noise)
+        self.conv2 = StyledConv(outch, outch, 3, styledim, upsample=False, use_noise=use_noise)
+        self.skip = ConvLayer(inch, outch, 1, activate=True, bias=True) if inch != outch else torch.nn.Identity()
+
+    def forward(self, x, style):
+        skip = F.interpolate(self.skip(x), scale_factor=2, mode="bilinear", align_corners=False)
+        res = self.conv2(self.conv1(x, style), style)
+        return (skip + res) / math.sqrt(2)
+
+
+class GeneratorModulation(torch.nn.Module):
+    """x * scale(style) + bias(style) (generator.py:56-67)"""
+
+    def __init__(self, styledim, outch):
+        super().__init__()
+        self.scale = EqualLinear(styledim, outch)
+        self.bias = EqualLinear(styledim, outch)
+
+    def forward(self, x, style):
+        if style.ndimension() <= 2:
+            return x * (1 * self.scale(style)[:, :, None, None]) + self.bias(style)[:, :, None, None]
+        style = F.interpolate(style, size=(x.size(2), x.size(3)), mode="bilinear", align_corners=False)
+        return x * (1 * self.scale(style)) + self.bias(style)
+
+
+class StyleGAN2ResnetGenerator(BaseNetwork):
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        parser.add_argument("--netG_scale_capacity", default=1.0, type=float)
+        parser.add_argument("--netG_num_base_resnet_layers", default=2, type=int)
+        parser.add_argument("--netG_use_noise", type=util.str2bool, nargs="?", const=True, default=True)
+        parser.add_argument("--netG_resnet_ch", type=int, default=256)
+        return parser
+
+    def __init__(self, opt):
+        super().__init__(opt)
+        blur_kernel = [1, 3, 3, 1] if opt.use_antialias else [1]
+        self.global_code_ch = opt.global_code_ch + opt.num_classes
+        self.add_module("SpatialCodeModulation", GeneratorModulation(self.global_code_ch, opt.spatial_code_ch))
+
+        n_head = opt.netG_num_base_resnet_layers
+        ch = opt.spatial_code_ch
+        for i in range(n_head):   # widen gradually towards nf(0)
+            out_ch = max(opt.spatial_code_ch, round((i + 1) / n_head * self.nf(0)))
+            self.add_module("HeadResnetBlock%d" % i,
+                            ResolutionPreservingResnetBlock(opt, ch, out_ch, self.global_code_ch))
+            ch = out_ch
+
+        for j in range(opt.netE_num_downsampling_sp):
+            out_ch = self.nf(j + 1)
+            self.add_module("UpsamplingResBlock%d" % (2 ** (4 + j)),
+                            UpsamplingResnetBlock(ch, out_ch, self.global_code_ch, blur_kernel, opt.netG_use_noise))
+            ch = out_ch
+
+        self.add_module("ToRGB", ToRGB(ch, self.global_code_ch, blur_kernel=blur_kernel))
+
+    def nf(self, num_up):
+        """generator.py:141-144"""
+        ch = 128 * (2 ** (self.opt.netE_num_downsampling_sp - num_up))
+        return int(min(512, ch) * self.opt.netG_scale_capacity)
+
+    def forward(self, spatial_code, global_code):
+        spatial_code = util.normalize(spatial_code)
+        global_code = util.normalize(global_code)
+        x = self.SpatialCodeModulation(spatial_code, global_code)
+        for i in range(self.opt.netG_num_base_resnet_layers):
+            x = getattr(self, "HeadResnetBlock%d" % i)(x, global_code)
+        for j in range(self.opt.netE_num_downsampling_sp):
+            x = getattr(self, "UpsamplingResBlock%d" % (2 ** (4 + j)))(x, global_code)
+        return self.ToRGB(x, global_code, None)

@@ -1,0 +1,347 @@
+"""Layer library of the Swapping-Autoencoder networks on the MI355X operators.
+
+Drop-in for the reference's ``models.networks.stylegan2_layers`` (itself derived from
+rosinality/stylegan2-pytorch): same class names, constructor signatures, child-module and
+parameter names (they are checkpoint keys) and the same forward semantics, cited
+per class below — but every convolution, linear map, FIR blur and bias+activation runs on the
+hand-written gfx950 kernels of ``stylegan2_op`` instead of ATen/cuDNN + CUDA extensions.
+
+Not carried over (unused by the Swapping-Autoencoder networks): ``PixelNorm``,
+``ConstantInput`` and the original StyleGAN2 ``Generator``.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import rng
+from .stylegan2_op import FusedLeakyReLU, conv2d, conv_transpose2d, fused_leaky_relu, linear, upfirdn2d
+
+
+def make_kernel(k):
+    """Normalised FIR taps; a 1-D list becomes its outer product (stylegan2_layers.py:27-35)."""
+    taps = torch.as_tensor(k, dtype=torch.float32)
+    if taps.dim() == 1:
+        taps = torch.outer(taps, taps)
+    return taps / taps.sum()
+
+
+def _split_pad(total):
+    return (total + 1) // 2, total // 2
+
+
+class Upsample(nn.Module):
+    """Zero-insertion x``factor`` + FIR (stylegan2_layers.py:38-56).  Off the train path (API parity)."""
+
+    def __init__(self, kernel, factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.factor, down=1, pad=self.pad)
+
+
+class Downsample(nn.Module):
+    """FIR + decimation by ``factor`` (stylegan2_layers.py:59-87).  Off the train path (API parity)."""
+
+    def __init__(self, kernel, factor=2, pad=None, reflection_pad=False):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel))
+        self.reflection = reflection_pad
+        self.pad = _split_pad(self.kernel.shape[0] - factor if pad is None else pad)
+
+    def forward(self, input):
+        pad = self.pad
+        if self.reflection:
+            input = F.pad(input, (pad[0], pad[1], pad[0], pad[1]), mode="reflect")
+            pad = (0, 0)
+        return upfirdn2d(input, self.kernel, up=1, down=self.factor, pad=pad)
+
+
+class Blur(nn.Module):
+    """FIR blur with explicit pads, optionally after a reflection pad (stylegan2_layers.py:90-112)."""
+
+    def __init__(self, kernel, pad, upsample_factor=1, reflection_pad=False):
+        super().__init__()
+        taps = make_kernel(kernel)
+        if upsample_factor > 1:
+            taps = taps * (upsample_factor ** 2)
+        self.register_buffer("kernel", taps)
+        self.pad = pad
+        self.reflection = reflection_pad
+        if reflection_pad:
+            self.reflection_pad = nn.ReflectionPad2d((pad[0], pad[1], pad[0], pad[1]))
+            self.pad = (0, 0)
+
+    def forward(self, input):
+        if self.reflection:
+            input = self.reflection_pad(input)
+        return upfirdn2d(input, self.kernel, pad=self.pad)
+
+
+class EqualConv2d(nn.Module):
+    """Equalised-lr conv: conv2d(x, weight * scale) + bias (stylegan2_layers.py:115-150); the scale
+    is applied inside the MFMA kernel's weight staging."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True, lr_mul=1.0):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2) * lr_mul
+        self.stride = stride
+        self.padding = padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input):
+        return conv2d(input, self.weight, bias=self.bias, stride=self.stride, padding=self.padding,
+                      alpha=self.scale)
+
+    def __repr__(self):
+        o, i, k, _ = self.weight.shape
+        return "%s(%d, %d, %d, stride=%d, padding=%d)" % (type(self).__name__, i, o, k, self.stride, self.padding)
+
+
+class EqualLinear(nn.Module):
+    """Equalised-lr linear layer, optionally followed by the fused bias + leaky-ReLU
+    (stylegan2_layers.py:153-195).  4-D input is treated as a 1x1 convolution (:175,:182)."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init)) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def _matmul(self, input, bias):
+        if input.dim() > 2:
+            return conv2d(input, self.weight[:, :, None, None], bias=bias, alpha=self.scale)
+        return linear(input, self.weight, bias=bias, alpha=self.scale)
+
+    def forward(self, input):
+        bias = self.bias * self.lr_mul if self.bias is not None else None
+        if self.activation:
+            return fused_leaky_relu(self._matmul(input, None), bias)
+        return self._matmul(input, bias)
+
+    def __repr__(self):
+        return "%s(%d, %d)" % (type(self).__name__, self.weight.shape[1], self.weight.shape[0])
+
+
+class ScaledLeakyReLU(nn.Module):
+    """leaky_relu(x) * sqrt(2) (stylegan2_layers.py:198-207): the K2 kernel without a bias."""
+
+    def __init__(self, negative_slope=0.2):
+        super().__init__()
+        self.negative_slope = negative_slope
+
+    def forward(self, input):
+        return fused_leaky_relu(input, None, self.negative_slope, math.sqrt(2))
+
+
+class ModulatedConv2d(nn.Module):
+    """Style-modulated conv (stylegan2_layers.py:210-325) in its dense-equivalent form.
+
+    With ``new_demodulation`` (always True in the reference, :258) the style scales the INPUT per
+    sample (:280-286) and the demodulation factor is computed from the un-modulated weight
+    (:290-292), so every sample shares one weight: ``conv2d(x * s, W * scale * demod)``.  The
+    reference materialises ``batch`` copies of the weight and runs a groups=batch conv
+    (:287,:299-321); here batch is just more pixels in the GEMM N dimension.  Verified equal to the
+    reference module to fp32 round-off in tests/test_reference_parity.py.
+    """
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        self.eps = 1e-8
+        self.kernel_size = kernel_size
+        self.in_channel = in_channel
+        self.out_channel = out_channel
+        self.upsample = upsample
+        self.downsample = downsample
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        if downsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) + (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=_split_pad(p))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+        self.new_demodulation = True
+
+    def __repr__(self):
+        return "%s(%d, %d, %d, upsample=%s, downsample=%s)" % (
+            type(self).__name__, self.in_channel, self.out_channel, self.kernel_size, self.upsample, self.downsample)
+
+    def _input_scale(self, input, style):
+        if style.dim() > 2:   # spatially varying style (:269-277); off the train path
+            style = F.interpolate(style, size=input.shape[2:], mode="bilinear", align_corners=False)
+            s = self.modulation(style)
+            if self.demodulate:
+                s = s * torch.rsqrt(s.pow(2).mean([1], keepdim=True) + 1e-8)
+            return s
+        s = self.modulation(style.view(input.shape[0], -1))
+        if self.demodulate:
+            s = s * torch.rsqrt(s.pow(2).mean([1], keepdim=True) + 1e-8)
+        return s[:, :, None, None]
+
+    def _weight(self):
+        w = self.weight[0] * self.scale
+        if self.demodulate:
+            w = w * torch.rsqrt(w.pow(2).sum([1, 2, 3], keepdim=True) + 1e-8)
+        return w
+
+    def forward(self, input, style):
+        x = input * self._input_scale(input, style)
+        w = self._weight()
+        if self.upsample:
+            return self.blur(conv_transpose2d(x, w, stride=2))
+        if self.downsample:
+            return conv2d(self.blur(x), w, stride=2, padding=0)
+        return conv2d(x, w, padding=self.padding)
+
+
+class NoiseInjection(nn.Module):
+    """image + weight * noise with a fresh N(0,1) map per call unless a noise is passed or fixed
+    (stylegan2_layers.py:328-351).  ``image_size`` / ``fixed_noise`` are read by
+    BaseNetwork.fix_and_gather_noise_parameters (base_network.py:42-51)."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+        self.fixed_noise = None
+        self.image_size = None
+
+    def forward(self, image, noise=None):
+        if self.image_size is None:
+            self.image_size = image.shape
+        if self.fixed_noise is not None:
+            noise = self.fixed_noise
+            if noise.shape[2:] != image.shape[2:]:
+                noise = F.interpolate(noise, image.shape[2:], mode="nearest")
+        elif noise is None:
+            noise = rng.randn_like_image(image)
+        return image + self.weight * noise
+
+
+class StyledConv(nn.Module):
+    """ModulatedConv2d -> noise -> bias + leaky-ReLU (stylegan2_layers.py:367-405)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1],
+                 demodulate=True, use_noise=True, lr_mul=1.0):
+        super().__init__()
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate)
+        self.use_noise = use_noise
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, noise=None):
+        out = self.conv(input, style)
+        if self.use_noise:
+            out = self.noise(out, noise=noise)
+        return self.activate(out)
+
+
+class ToRGB(nn.Module):
+    """1x1 modulated conv without demodulation + bias (+ upsampled skip) (stylegan2_layers.py:408-427)."""
+
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, input, style, skip=None):
+        out = self.conv(input, style) + self.bias
+        if skip is not None:
+            out = out + self.upsample(skip)
+        return out
+
+
+class ConvLayer(nn.Sequential):
+    """[Blur | RefPad] -> Conv -> [Act] with the reference's child names (stylegan2_layers.py:612-668)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=[1, 3, 3, 1], bias=True,
+                 activate=True, pad=None, reflection_pad=False):
+        layers = []
+        if downsample:
+            factor = 2
+            if pad is None:
+                pad = (len(blur_kernel) - factor) + (kernel_size - 1)
+            layers.append(("Blur", Blur(blur_kernel, pad=_split_pad(pad), reflection_pad=reflection_pad)))
+            stride = 2
+            self.padding = 0
+        else:
+            stride = 1
+            self.padding = kernel_size // 2 if pad is None else pad
+            if reflection_pad:
+                layers.append(("RefPad", nn.ReflectionPad2d(self.padding)))
+                self.padding = 0
+        layers.append(("Conv", EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding, stride=stride,
+                                           bias=bias and not activate)))
+        if activate:
+            layers.append(("Act", FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2)))
+        super().__init__(OrderedDict(layers))
+
+
+class ResBlock(nn.Module):
+    """(conv2(conv1(x)) + skip(x)) / sqrt(2) (stylegan2_layers.py:672-693)."""
+
+    def __init__(self, in_channel, out_channel, blur_kernel=[1, 3, 3, 1], reflection_pad=False, pad=None,
+                 downsample=True):
+        super().__init__()
+        self.conv1 = ConvLayer(in_channel, in_channel, 3, reflection_pad=reflection_pad, pad=pad)
+        self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=downsample, blur_kernel=blur_kernel,
+                               reflection_pad=reflection_pad, pad=pad)
+        self.skip = ConvLayer(in_channel, out_channel, 1, downsample=downsample, blur_kernel=blur_kernel,
+                              activate=False, bias=False)
+
+    def forward(self, input):
+        return (self.conv2(self.conv1(input)) + self.skip(input)) / math.sqrt(2)
+
+
+class Discriminator(nn.Module):
+    """StyleGAN2 residual discriminator without the minibatch-stddev layer, which the reference
+    has commented out (stylegan2_layers.py:696-763)."""
+
+    def __init__(self, size, channel_multiplier=2, blur_kernel=[1, 3, 3, 1]):
+        super().__init__()
+        cm = channel_multiplier
+        channels = {4: 512, 8: 512, 16: min(512, int(512 * cm)), 32: min(512, int(512 * cm)), 64: int(256 * cm),
+                    128: int(128 * cm), 256: int(64 * cm), 512: int(32 * cm), 1024: int(16 * cm)}
+        original_size = size
+        log_size = int(round(math.log(size, 2)))
+        size = 2 ** log_size
+        in_channel = channels[size]
+        convs = [("0", ConvLayer(3, in_channel, 1))]
+        for i in range(log_size, 2, -1):
+            out_channel = channels[2 ** (i - 1)]
+            name = str(9 - i) if i <= 8 else "%dx%d" % (2 ** i, 2 ** i)
+            convs.append((name, ResBlock(in_channel, out_channel, blur_kernel)))
+            in_channel = out_channel
+        self.convs = nn.Sequential(OrderedDict(convs))
+        self.final_conv = ConvLayer(in_channel, channels[4], 3)
+        side = int(4 * original_size / size)
+        self.final_linear = nn.Sequential(
+            EqualLinear(channels[4] * side * side, channels[4], activation="fused_lrelu"),
+            EqualLinear(channels[4], 1),
+        )
+
+    def forward(self, input):
+        out = self.final_conv(self.convs(input))
+        return self.final_linear(out.view(out.shape[0], -1))
+
+    def get_features(self, input):
+        return self.final_conv(self.convs(input))

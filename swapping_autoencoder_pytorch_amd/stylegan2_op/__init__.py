@@ -1,0 +1,8 @@
+"""MI355X replacement of the reference's ``models.networks.stylegan2_op`` package (same public
+names, models/networks/stylegan2_op/__init__.py:1-2) plus the dense conv / linear operators the
+layer library is built on."""
+from .fused_act import FusedLeakyReLU, fused_leaky_relu
+from .upfirdn2d import upfirdn2d
+from .conv2d_gemm import conv2d, conv_transpose2d, linear
+
+__all__ = ["FusedLeakyReLU", "fused_leaky_relu", "upfirdn2d", "conv2d", "conv_transpose2d", "linear"]

@@ -1,0 +1,229 @@
+"""Dense conv2d / conv_transpose2d / linear on the gfx950 fp32-MFMA kernels.
+
+These replace the ATen calls of the reference's layer library — ``F.conv2d``
+(models/networks/stylegan2_layers.py:136,175,182,315,321), ``F.conv_transpose2d`` (:306) and
+``F.linear`` (:177,186) — with the same argument meaning.  The equalised-learning-rate factor
+``weight * scale`` the reference recomputes as a separate elementwise kernel on every call
+(:138,175-187,275,285) is folded into the kernels as ``alpha``.
+
+Differentiation: three primitives (forward, dgrad, wgrad) are closed under differentiation —
+the derivative of each is expressed with the other two — so gradients of any order exist.  D and
+Dpatch need second order for the R1 penalty (swapping_autoencoder_model.py:143-174).
+``ctx.needs_input_grad`` is honoured so the forward-only E/G passes of a D step and the
+dgrad-only D/Dpatch passes of a G step (SURVEY.md §7 "grad-mode awareness") launch nothing they
+do not need.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from .. import hip_lib
+from ..hip_lib import SAE_CONV_DGRAD, SAE_CONV_FWD, SAE_CONV_WGRAD, ConvDesc
+
+
+class _Geom:
+    """Immutable description of one conv problem (forward orientation) + weight layout."""
+    __slots__ = ("n", "c", "h", "w", "m", "k", "stride", "pad", "oh", "ow", "cm_layout", "alpha")
+
+    def __init__(self, n, c, h, w, m, k, stride, pad, cm_layout, alpha):
+        self.n, self.c, self.h, self.w, self.m, self.k = n, c, h, w, m, k
+        self.stride, self.pad, self.cm_layout, self.alpha = stride, pad, cm_layout, float(alpha)
+        self.oh = (h + 2 * pad - k) // stride + 1
+        self.ow = (w + 2 * pad - k) // stride + 1
+        if self.oh < 1 or self.ow < 1:
+            raise hip_lib.SaeError("conv2d: empty output for input %dx%d k=%d stride=%d pad=%d" % (h, w, k, stride, pad))
+
+    def weight_shape(self):
+        return (self.c, self.m, self.k, self.k) if self.cm_layout else (self.m, self.c, self.k, self.k)
+
+    def desc(self):
+        d = ConvDesc()
+        d.n, d.c, d.h, d.w, d.m, d.oh, d.ow = self.n, self.c, self.h, self.w, self.m, self.oh, self.ow
+        d.kh = d.kw = self.k
+        d.stride, d.pad = self.stride, self.pad
+        kk = self.k * self.k
+        if self.cm_layout:
+            d.w_stride_m, d.w_stride_c = kk, self.m * kk
+        else:
+            d.w_stride_m, d.w_stride_c = self.c * kk, kk
+        return d
+
+
+def _launch(name, op, geom, a, b, out_shape):
+    lib = hip_lib.get()
+    a = a.contiguous()
+    b = b.contiguous()
+    lib.check(a, b)
+    d = geom.desc()
+    n_ws = lib.query("conv2d_workspace", C.byref(d), op)
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=a.device)
+    out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
+    lib.call(name, a.data_ptr(), b.data_ptr(), out.data_ptr(), C.byref(d), geom.alpha, ws.data_ptr(), n_ws,
+             lib.stream(a))
+    return out
+
+
+def _fwd(x, w, g):
+    return _launch("conv2d_fwd_f32", SAE_CONV_FWD, g, x, w, (g.n, g.m, g.oh, g.ow))
+
+
+def _dgrad(gy, w, g):
+    return _launch("conv2d_dgrad_f32", SAE_CONV_DGRAD, g, gy, w, (g.n, g.c, g.h, g.w))
+
+
+def _wgrad(x, gy, g):
+    return _launch("conv2d_wgrad_f32", SAE_CONV_WGRAD, g, x, gy, g.weight_shape())
+
+
+class ConvForward(Function):
+    """y = alpha * conv(x, w)"""
+
+    @staticmethod
+    def forward(ctx, x, w, geom):
+        ctx.geom = geom
+        ctx.save_for_backward(x, w)
+        return _fwd(x, w, geom)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = ConvDataGrad.apply(gy, w, ctx.geom) if ctx.needs_input_grad[0] else None
+        gw = ConvWeightGrad.apply(x, gy, ctx.geom) if ctx.needs_input_grad[1] else None
+        return gx, gw, None
+
+
+class ConvDataGrad(Function):
+    """gx = alpha * conv^T(gy, w)   (also the forward of the stride-2 transposed conv)"""
+
+    @staticmethod
+    def forward(ctx, gy, w, geom):
+        ctx.geom = geom
+        ctx.save_for_backward(gy, w)
+        return _dgrad(gy, w, geom)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        g_gy = ConvForward.apply(ggx, w, ctx.geom) if ctx.needs_input_grad[0] else None
+        g_w = ConvWeightGrad.apply(ggx, gy, ctx.geom) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w, None
+
+
+class ConvWeightGrad(Function):
+    """gw = alpha * sum_pixels gy (x) x"""
+
+    @staticmethod
+    def forward(ctx, x, gy, geom):
+        ctx.geom = geom
+        ctx.save_for_backward(x, gy)
+        return _wgrad(x, gy, geom)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        g_x = ConvDataGrad.apply(gy, ggw, ctx.geom) if ctx.needs_input_grad[0] else None
+        g_gy = ConvForward.apply(x, ggw, ctx.geom) if ctx.needs_input_grad[1] else None
+        return g_x, g_gy, None
+
+
+def _check_weight(weight):
+    if weight.dim() != 4 or weight.shape[2] != weight.shape[3]:
+        raise hip_lib.SaeError("conv weight must be [M, C, k, k], got %s" % (tuple(weight.shape),))
+    if weight.shape[2] not in (1, 3):
+        raise hip_lib.SaeError("MI355X conv kernels cover k in {1, 3}; got k=%d" % weight.shape[2])
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, alpha=1.0):
+    """F.conv2d semantics for the shapes of the hot path: weight [M, C, k, k], k in {1, 3},
+    stride in {1, 2}, symmetric zero ``padding`` < k.  Returns alpha * conv(input, weight) + bias."""
+    _check_weight(weight)
+    if stride not in (1, 2):
+        raise hip_lib.SaeError("MI355X conv kernels cover stride in {1, 2}; got %r" % (stride,))
+    n, c, h, w = input.shape
+    m, c2, k, _ = weight.shape
+    if c2 != c:
+        raise hip_lib.SaeError("conv2d: input has %d channels, weight expects %d" % (c, c2))
+    geom = _Geom(n, c, h, w, m, k, stride, padding, False, alpha)
+    out = ConvForward.apply(input, weight, geom)
+    if bias is not None:
+        out = out + bias.view(1, -1, 1, 1)
+    return out
+
+
+def conv_transpose2d(input, weight, stride=2, alpha=1.0):
+    """Stride-2, padding-0 transposed convolution (stylegan2_layers.py:306) with the weight kept in
+    the parameter's own [M_out, C_in, k, k] orientation:
+        out[n, m, 2*i + ky, 2*j + kx] += alpha * weight[m, c, ky, kx] * input[n, c, i, j]
+    i.e. the data gradient of a stride-2 conv that maps M_out -> C_in channels."""
+    _check_weight(weight)
+    if stride != 2:
+        raise hip_lib.SaeError("conv_transpose2d: only stride 2 is on the hot path")
+    n, c_in, h, w = input.shape
+    m_out, c2, k, _ = weight.shape
+    if c2 != c_in:
+        raise hip_lib.SaeError("conv_transpose2d: input has %d channels, weight expects %d" % (c_in, c2))
+    oh, ow = (h - 1) * 2 + k, (w - 1) * 2 + k
+    # forward-orientation problem: x side = the large output (m_out channels), y side = input
+    geom = _Geom(n, m_out, oh, ow, c_in, k, 2, 0, True, alpha)
+    assert (geom.oh, geom.ow) == (h, w)
+    return ConvDataGrad.apply(input, weight, geom)
+
+
+# ------------------------------------------------------------------------------------------------
+# linear
+# ------------------------------------------------------------------------------------------------
+def _gemm(a, b, bias, ta, tb, alpha):
+    """alpha * op(a) @ op(b) (+ bias) for 2-D contiguous a, b; op = transpose when the flag is set."""
+    lib = hip_lib.get()
+    a = a.contiguous()
+    b = b.contiguous()
+    bias = bias.contiguous() if bias is not None else None
+    lib.check(a, b, bias)
+    m, k = (a.shape[1], a.shape[0]) if ta else (a.shape[0], a.shape[1])
+    k2, n = (b.shape[1], b.shape[0]) if tb else (b.shape[0], b.shape[1])
+    if k != k2:
+        raise hip_lib.SaeError("gemm: inner dimensions differ (%d vs %d)" % (k, k2))
+    a_si, a_sk = (1, a.shape[1]) if ta else (a.shape[1], 1)
+    b_sk, b_sj = (1, b.shape[1]) if tb else (b.shape[1], 1)
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    lib.call("gemm_f32", a.data_ptr(), b.data_ptr(), hip_lib.ptr(bias), out.data_ptr(), m, n, k, a_si, a_sk, b_sk,
+             b_sj, n, float(alpha), lib.stream(a))
+    return out
+
+
+class MatMul(Function):
+    """alpha * op(a) @ op(b) + bias, closed under differentiation (each gradient is a MatMul)."""
+
+    @staticmethod
+    def forward(ctx, a, b, bias, ta, tb, alpha):
+        ctx.cfg = (ta, tb, alpha)
+        ctx.save_for_backward(a, b)
+        return _gemm(a, b, bias, ta, tb, alpha)
+
+    @staticmethod
+    def backward(ctx, gc):
+        a, b = ctx.saved_tensors
+        ta, tb, alpha = ctx.cfg
+        ga = gb = gbias = None
+        if ctx.needs_input_grad[0]:
+            if not ta:
+                ga = MatMul.apply(gc, b, None, False, not tb, alpha)     # gc @ op(b)^T
+            else:
+                ga = MatMul.apply(b, gc, None, tb, True, alpha)          # op(b) @ gc^T
+        if ctx.needs_input_grad[1]:
+            if not tb:
+                gb = MatMul.apply(a, gc, None, not ta, False, alpha)     # op(a)^T @ gc
+            else:
+                gb = MatMul.apply(gc, a, None, True, ta, alpha)          # gc^T @ op(a)
+        if ctx.needs_input_grad[2]:
+            gbias = gc.sum(0)
+        return ga, gb, gbias, None, None, None
+
+
+def linear(input, weight, bias=None, alpha=1.0):
+    """F.linear semantics: alpha * input @ weight^T + bias, input [..., in], weight [out, in]."""
+    lead = input.shape[:-1]
+    x2 = input.reshape(-1, input.shape[-1])
+    out = MatMul.apply(x2, weight, bias, False, True, alpha)
+    return out.view(*lead, weight.shape[0])

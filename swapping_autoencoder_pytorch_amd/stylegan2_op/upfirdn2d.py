@@ -1,0 +1,95 @@
+"""``upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0))`` on the gfx950 K1 kernel.
+
+Mirrors the operator interface of the reference (models/networks/stylegan2_op/upfirdn2d.py:150-159:
+same name, argument meaning, NCHW in / NCHW out, same pad on x and y) and its differentiation
+contract: twice differentiable w.r.t. ``input`` (R1 regularisation needs the double backward,
+swapping_autoencoder_model.py:143-148), no gradient for ``kernel``.
+
+The adjoint of an (up, down, pad) call with taps k is an upfirdn2d call with flipped taps,
+(up, down) exchanged and the pads of upfirdn2d.py:116-121; its adjoint is the forward call again,
+so two Function classes close the chain at any order.
+"""
+import torch
+from torch.autograd import Function
+
+from .. import hip_lib
+
+
+def _out_size(size, up, down, pad0, pad1, taps):
+    return (size * up + pad0 + pad1 - taps) // down + 1
+
+
+def _run(x, taps, up, down, pad):
+    """x: [N, C, H, W] -> [N, C, H', W'] through sae_upfirdn2d_f32 (major = N*C, minor = 1)."""
+    lib = hip_lib.get()
+    x = x.contiguous()
+    taps = taps.contiguous()
+    lib.check(x, taps)
+    n, c, h, w = x.shape
+    kh, kw = taps.shape
+    up_x, up_y = up
+    down_x, down_y = down
+    px0, px1, py0, py1 = pad
+    oh = _out_size(h, up_y, down_y, py0, py1, kh)
+    ow = _out_size(w, up_x, down_x, px0, px1, kw)
+    if oh < 1 or ow < 1:
+        raise hip_lib.SaeError("upfirdn2d: empty output %dx%d" % (oh, ow))
+    y = torch.empty((n, c, oh, ow), dtype=x.dtype, device=x.device)
+    lib.call("upfirdn2d_f32", x.data_ptr(), taps.data_ptr(), y.data_ptr(), n * c, h, w, 1, kh, kw,
+             up_x, up_y, down_x, down_y, px0, px1, py0, py1, lib.stream(x))
+    return y
+
+
+def _adjoint_pad(in_hw, out_hw, taps_hw, up, down, pad):
+    """Pads of the adjoint call (reference upfirdn2d.py:116-121)."""
+    (ih, iw), (oh, ow), (kh, kw) = in_hw, out_hw, taps_hw
+    up_x, up_y = up
+    down_x, down_y = down
+    px0, _, py0, _ = pad
+    gx0 = kw - px0 - 1
+    gy0 = kh - py0 - 1
+    gx1 = iw * up_x - ow * down_x + px0 - up_x + 1
+    gy1 = ih * up_y - oh * down_y + py0 - up_y + 1
+    return (gx0, gx1, gy0, gy1)
+
+
+class UpFirDn2d(Function):
+    @staticmethod
+    def forward(ctx, input, kernel, up, down, pad):
+        out = _run(input, kernel, up, down, pad)
+        ctx.save_for_backward(kernel)
+        ctx.cfg = (up, down, pad, tuple(input.shape[2:]), tuple(out.shape[2:]))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        kernel, = ctx.saved_tensors
+        grad_input = None
+        if ctx.needs_input_grad[0]:
+            grad_input = UpFirDn2dBackward.apply(grad_output, kernel, *ctx.cfg)
+        return grad_input, None, None, None, None
+
+
+class UpFirDn2dBackward(Function):
+    @staticmethod
+    def forward(ctx, grad_output, kernel, up, down, pad, in_hw, out_hw):
+        g_pad = _adjoint_pad(in_hw, out_hw, tuple(kernel.shape), up, down, pad)
+        flipped = torch.flip(kernel, [0, 1])
+        grad_input = _run(grad_output, flipped, down, up, g_pad)   # (up, down) exchanged
+        assert tuple(grad_input.shape[2:]) == tuple(in_hw), (grad_input.shape, in_hw)
+        ctx.save_for_backward(kernel)
+        ctx.cfg = (up, down, pad)
+        return grad_input
+
+    @staticmethod
+    def backward(ctx, gradgrad_input):
+        kernel, = ctx.saved_tensors
+        up, down, pad = ctx.cfg
+        gradgrad_out = None
+        if ctx.needs_input_grad[0]:
+            gradgrad_out = UpFirDn2d.apply(gradgrad_input, kernel, up, down, pad)
+        return gradgrad_out, None, None, None, None, None, None
+
+
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
+    return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))

@@ -1,0 +1,114 @@
+"""SwappingAutoencoderOptimizer: the alternating D / G step driver.
+
+Host-side mirror of optimizers/swapping_autoencoder_optimizer.py (cited per method): two Adam
+optimisers (lr 0.002, betas (0, 0.99)), the lazy-regularisation correction c = 16/17 on the
+discriminator's, D and G steps alternating call by call starting with D, the R1 penalty every
+``R1_once_every`` discriminator iterations scaled by that interval.
+
+Multi-GPU: one process per GPU; when torch.distributed is initialised the gradients of the group
+being trained are averaged with RCCL all-reduce, bucketed and launched from grad-ready hooks so
+they overlap the rest of backward (grad_allreduce.GradAllReducer) — the MI355X replacement of the
+reference's nn.DataParallel replicate/scatter/gather/reduce (models/__init__.py:75-93)."""
+import torch
+
+from . import util
+from .grad_allreduce import GradAllReducer
+
+
+class SwappingAutoencoderOptimizer:
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        parser.add_argument("--lr", default=0.002, type=float)
+        parser.add_argument("--beta1", default=0.0, type=float)
+        parser.add_argument("--beta2", default=0.99, type=float)
+        parser.add_argument("--R1_once_every", default=16, type=int,
+                            help="lazy R1 regularization: the R1 loss is computed once every this many D iterations")
+        return parser
+
+    def __init__(self, model, fused_adam=None):
+        self.opt = opt = model.opt
+        self.model = model
+        self.train_mode_counter = 0
+        self.discriminator_iter_counter = 0
+        self.Gparams = model.get_parameters_for_mode("generator")
+        self.Dparams = model.get_parameters_for_mode("discriminator")
+        on_gpu = len(self.Gparams) > 0 and self.Gparams[0].is_cuda
+        adam_kw = {"fused": True} if (fused_adam if fused_adam is not None else on_gpu) else {}
+        self.optimizer_G = torch.optim.Adam(self.Gparams, lr=opt.lr, betas=(opt.beta1, opt.beta2), **adam_kw)
+        # StyleGAN2 appendix B: compensate for regularising only every k-th iteration (:36-42)
+        c = opt.R1_once_every / (1 + opt.R1_once_every)
+        self.optimizer_D = torch.optim.Adam(self.Dparams, lr=opt.lr * c, betas=(opt.beta1 ** c, opt.beta2 ** c), **adam_kw)
+        # one reducer per parameter group: the trainable set flips every call
+        self.reducer_G = GradAllReducer(self.Gparams)
+        self.reducer_D = GradAllReducer(self.Dparams)
+
+    def set_requires_grad(self, params, requires_grad):
+        for p in params:
+            p.requires_grad_(requires_grad)
+
+    def prepare_images(self, data_i):
+        return data_i["real_A"]
+
+    def toggle_training_mode(self):
+        """:54-57 — note the reference's naming: the call that returns "generator" runs the D step."""
+        modes = ["discriminator", "generator"]
+        self.train_mode_counter = (self.train_mode_counter + 1) % len(modes)
+        return modes[self.train_mode_counter]
+
+    def train_one_step(self, data_i, total_steps_so_far):
+        images = self.prepare_images(data_i)
+        if self.toggle_training_mode() == "generator":
+            losses = self.train_discriminator_one_step(images)
+        else:
+            losses = self.train_generator_one_step(images)
+        return util.to_numpy(losses)
+
+    def _backward_and_step(self, total_loss, optimizer, reducer):
+        reducer.arm()
+        total_loss.backward()
+        reducer.finish()          # waits for the in-flight buckets, grads now hold the global mean
+        optimizer.step()
+
+    def train_generator_one_step(self, images):
+        """:67-79"""
+        self.set_requires_grad(self.Dparams, False)
+        self.set_requires_grad(self.Gparams, True)
+        self.optimizer_G.zero_grad()
+        g_losses, g_metrics = self.model(images, None, None, command="compute_generator_losses")
+        g_loss = sum(v.mean() for v in g_losses.values())
+        self._backward_and_step(g_loss, self.optimizer_G, self.reducer_G)
+        g_losses.update(g_metrics)
+        return g_losses
+
+    def train_discriminator_one_step(self, images):
+        """:81-111"""
+        opt = self.opt
+        if opt.lambda_GAN == 0.0 and opt.lambda_PatchGAN == 0.0:
+            return {}
+        self.set_requires_grad(self.Dparams, True)
+        self.set_requires_grad(self.Gparams, False)
+        self.discriminator_iter_counter += 1
+        self.optimizer_D.zero_grad()
+        d_losses, d_metrics, sp, gl = self.model(images, command="compute_discriminator_losses")
+        self.previous_sp, self.previous_gl = sp.detach(), gl.detach()
+        d_loss = sum(v.mean() for v in d_losses.values())
+        self._backward_and_step(d_loss, self.optimizer_D, self.reducer_D)
+
+        needs_R1 = opt.lambda_R1 > 0.0 or opt.lambda_patch_R1 > 0.0
+        if needs_R1 and self.discriminator_iter_counter % opt.R1_once_every == 0:
+            self.optimizer_D.zero_grad()
+            r1_losses = self.model(images, command="compute_R1_loss")
+            d_losses.update(r1_losses)
+            r1_loss = sum(v.mean() for v in r1_losses.values()) * opt.R1_once_every
+            self._backward_and_step(r1_loss, self.optimizer_D, self.reducer_D)
+
+        d_losses["D_total"] = sum(v.mean() for v in d_losses.values())
+        d_losses.update(d_metrics)
+        return d_losses
+
+    def save(self, total_steps_so_far):
+        self.model.save(total_steps_so_far)
+
+
+def create_optimizer(opt, model):
+    return SwappingAutoencoderOptimizer(model)

@@ -1,0 +1,57 @@
+"""The six helpers of the reference's util/util.py that sit on the training hot path
+(SURVEY.md §2 row 18), restated: normalize (:18-22), apply_random_crop (:323-343), to_numpy
+(:423-429), str2bool (:43-51).  ``is_custom_kernel_supported`` (:432-436) is deliberately absent:
+the HIP kernels are the only implementation, there is nothing to gate."""
+import argparse
+
+import torch
+import torch.nn.functional as F
+
+from . import rng
+
+
+def normalize(v):
+    """L2-normalise over dim 1 (epsilon inside the rsqrt, as the reference)."""
+    if isinstance(v, list):
+        return [normalize(x) for x in v]
+    return v * torch.rsqrt(torch.sum(v ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+def str2bool(v):
+    if isinstance(v, bool):
+        return v
+    if v.lower() in ("yes", "true", "t", "y", "1"):
+        return True
+    if v.lower() in ("no", "false", "f", "n", "0"):
+        return False
+    raise argparse.ArgumentTypeError("Boolean value expected.")
+
+
+def apply_random_crop(x, target_size, scale_range, num_crops=1):
+    """``num_crops`` random crops per image, each with a random horizontal flip, independent x/y
+    scale in ``scale_range`` and a random offset that keeps the window inside the image, resampled
+    bilinearly to ``target_size`` (grid_sample, align_corners=False, zero padding).
+
+    Consumes the RNG exactly as the reference does (flip [B,1,1,1], scale [B,1,1,2], offset
+    [B,1,1,2] — SURVEY.md Appendix B) so identical seeds give identical crops."""
+    b = x.size(0) * num_crops
+    dev = x.device
+    flip = torch.round(rng.rand((b, 1, 1, 1), dev)) * 2 - 1.0
+    lin = torch.linspace(-1.0, 1.0, target_size, device=dev)
+    gx = lin.view(1, 1, target_size, 1).expand(b, target_size, target_size, 1)
+    gy = lin.view(1, target_size, 1, 1).expand(b, target_size, target_size, 1)
+    unit_grid = torch.cat([gx * flip, gy], dim=3)
+    x = x.unsqueeze(1).expand(-1, num_crops, -1, -1, -1).flatten(0, 1)
+    scale = rng.rand((b, 1, 1, 2), dev) * (scale_range[1] - scale_range[0]) + scale_range[0]
+    offset = (rng.rand((b, 1, 1, 2), dev) * 2 - 1) * (1 - scale)
+    crop = F.grid_sample(x, unit_grid * scale + offset, align_corners=False)
+    return crop.view(b // num_crops, num_crops, crop.size(1), crop.size(2), crop.size(3))
+
+
+def to_numpy(metric_dict):
+    out = {}
+    for k, v in metric_dict.items():
+        if "numpy" not in str(type(v)):
+            v = v.detach().cpu().mean().numpy()
+        out[k] = v
+    return out

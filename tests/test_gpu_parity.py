@@ -1,0 +1,43 @@
+"""GPU suite: the real gfx950 library behind our host-side mirror vs the reference's golden
+outputs (ops, layers incl. second-order gradients, the four networks, and four optimiser steps of
+the alternating D/G driver).  Tolerances are fp32 relative-to-max per tensor."""
+import pytest
+import torch
+
+import parity_common as P
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _native_lib_loaded():
+    assert torch.cuda.is_available()
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    lib = hip_lib.get()
+    assert lib.prefix == "sae_" and lib.device_only and lib.path.endswith("libsae_hip.so")
+    yield
+
+
+def test_ops():
+    P.check_ops(DEV)
+
+
+@pytest.mark.parametrize("name", sorted(P.layer_specs()))
+def test_layers(name):
+    P.check_layer(name, DEV)
+
+
+def test_micro_networks_forward():
+    P.check_micro_forward(DEV)
+
+
+def test_micro_training_steps():
+    P.check_micro_steps(DEV)
+
+
+def test_cpu_tensor_is_refused():
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import upfirdn2d
+    with pytest.raises(hip_lib.SaeError):
+        upfirdn2d(torch.zeros(1, 2, 4, 4), torch.ones(4, 4) / 16, pad=(2, 2))
