@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the full Swapping-Autoencoder train iteration on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched as  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  (one rank per GPU, RCCL; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
+
+One "step" = one full training iteration of the reference's driver on one synthetic batch:
+a discriminator call and a generator call of SwappingAutoencoderOptimizer.train_one_step
+(optimizers/swapping_autoencoder_optimizer.py:59-65), each with its Adam update, with the lazy R1
+penalty on every 16th discriminator iteration (the default K = 16 contains exactly one).
+value = N * B * K / t   (whole-job images per second; B images per GPU -> weak scaling).
+
+Also reported on the same JSON line:
+  roofline     – dominant kernel (3x3 stride-1 implicit-GEMM conv, conv_igemm_kernel<3,1,2,2,2,2,8>):
+                 algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
+                 launch stream inside the timed region, against the fp32 MFMA peak (157.3 TFLOP/s);
+  cpu_baseline – the CPU oracle (a port, oracle/sae_oracle.c) timed on the host cores on a bounded
+                 sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
+FLOPS_PER_IMAGE = {"church256": 1.815e12, "bedroom256": 1.815e12, "ffhq512": 3.91e12, "ffhq1024": 6.08e12}
+DEFAULT_BATCH = {"church256": 16, "bedroom256": 16, "ffhq512": 8, "ffhq1024": 4, "tiny32": 4}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--preset", default="church256", choices=sorted(DEFAULT_BATCH))
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the preset's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+class DominantKernelTimer:
+    """Brackets every launch of the dominant kernel (3x3 stride-1 gather with > 64 output
+    channels = conv_igemm_kernel<3,1,2,2,2,2,8>, reached from conv2d forward and stride-1 dgrad)
+    with HIP events on the launch stream; durations are read after the final synchronise."""
+
+    def __init__(self):
+        self.records = []
+        self.active = False
+
+    def install(self):
+        import torch
+        from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as cg
+        timer = self
+        orig_launch = cg._launch
+
+        def launch(name, op, geom, a, b, out_shape):
+            hit = timer.active and geom.k == 3 and geom.stride == 1 and (
+                (op == cg.SAE_CONV_FWD and geom.m > 64) or (op == cg.SAE_CONV_DGRAD and geom.c > 64))
+            if not hit:
+                return orig_launch(name, op, geom, a, b, out_shape)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_launch(name, op, geom, a, b, out_shape)
+            e1.record()
+            flops = 2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9
+            timer.records.append((flops, e0, e1))
+            return out
+
+        cg._launch = launch
+
+    def summary(self):
+        if not self.records:
+            return None
+        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self.records)
+        fl = sum(f for f, _, _ in self.records)
+        n = len(self.records)
+        achieved = fl / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": "conv_igemm_kernel<3,1,2,2,2,2,8>", "achieved": round(achieved, 2),
+                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                "traffic": None, "launches": n, "avg_launch_ms": round(ms / n, 4),
+                "avg_launch_gflop": round(fl / n / 1e9, 2),
+                "note": "event bracket includes the <1% weight re-layout launch that precedes each conv"}
+
+
+def cpu_baseline(preset):
+    """Oracle (C port, double accumulation, OpenMP) on a bounded sample: forward + dgrad + wgrad of
+    the discriminator's 128->128 3x3 conv at 256x256 on ONE image, scaled by the FLOPs per image of
+    the full iteration."""
+    import ctypes as C
+    import subprocess
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import abi_harness as H
+    from swapping_autoencoder_pytorch_amd.hip_lib import SaeLibrary
+    so = os.path.join(ROOT, "oracle", "libsae_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
+    ora = SaeLibrary(so, prefix="oracle_", device_only=False)
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    n, c, hw, m = 1, 128, 256, 128
+    d = H.conv_desc(n, c, hw, hw, m, 3, 1, 1)
+    x = rng.standard_normal((n, c, hw, hw)).astype(np.float32)
+    w = rng.standard_normal((m, c, 3, 3)).astype(np.float32)
+    gy = rng.standard_normal((n, m, hw, hw)).astype(np.float32)
+    flops = 3 * 2.0 * n * m * hw * hw * c * 9
+    t0 = time.time()
+    H.conv(ora, 0, d, x, w, gy.shape)
+    H.conv(ora, 1, d, gy, w, x.shape)
+    H.conv(ora, 2, d, x, gy, w.shape)
+    dt = time.time() - t0
+    per_image = FLOPS_PER_IMAGE.get(preset, 1.815e12)
+    return {"value": round(flops / dt / per_image, 6), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "oracle conv2d fwd+dgrad+wgrad, D layer 128->128 3x3 @256x256, 1 image (%.0f GFLOP in %.1f s, "
+                      "%.2f GFLOP/s) scaled by %.3f TFLOP/image of the full iteration" % (flops / 1e9, dt, flops / dt / 1e9,
+                                                                                      per_image / 1e12)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    from swapping_autoencoder_pytorch_amd.grad_allreduce import broadcast_parameters
+    from swapping_autoencoder_pytorch_amd.options import make_options
+    from swapping_autoencoder_pytorch_amd.swapping_autoencoder_model import create_model
+    from swapping_autoencoder_pytorch_amd.swapping_autoencoder_optimizer import create_optimizer
+    hip_lib.get()     # fail loudly here if the HIP library is missing
+
+    batch = args.batch or DEFAULT_BATCH[args.preset]
+    opt = make_options(args.preset, batch_size=batch, num_gpus=1)
+    torch.manual_seed(0)                        # identical replicas
+    model = create_model(opt)
+    broadcast_parameters(model.singlegpu_model)
+    optimizer = create_optimizer(opt, model)
+    torch.manual_seed(1234 + rank)              # per-rank crops / noise / data
+
+    size = opt.crop_size
+    pool = [torch.rand(batch, 3, size, size, device=dev) * 2 - 1 for _ in range(4)]
+
+    timer = DominantKernelTimer()
+    if not args.no_kernel_timing:
+        timer.install()
+
+    def iteration(i):
+        optimizer.train_one_step({"real_A": pool[(2 * i) % 4]}, i)       # discriminator call
+        optimizer.train_one_step({"real_A": pool[(2 * i + 1) % 4]}, i)   # generator call
+
+    for i in range(args.warmup):
+        iteration(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    timer.active = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        iteration(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    timer.active = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        images = world * batch * args.steps
+        value = images / dt
+        per_image = FLOPS_PER_IMAGE.get(args.preset)
+        line = {
+            "metric": "images/sec (G+D+Dpatch train step)", "value": round(value, 3), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s preset, %dx%d, B=%d/GPU: full E/G/D/Dpatch D-step + G-step with Adam, lazy R1 "
+                                   "every 16th D iteration" % (args.preset, size, size, batch),
+                       "global_batch": world * batch, "parallelism": "dp%d" % world},
+        }
+        if per_image:
+            line["model_tflops_per_gpu"] = round(value / world * per_image / 1e12, 2)
+            line["frac_of_mfma_f32_roofline"] = round(value / world * per_image / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+        roof = timer.summary()
+        if roof:
+            line["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.preset)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

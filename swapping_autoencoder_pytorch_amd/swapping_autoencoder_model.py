@@ -32,7 +32,12 @@ class SwappingAutoencoderModel(torch.nn.Module):
     def __init__(self, opt):
         super().__init__()
         self.opt = opt
-        self.device = torch.device("cuda:0") if opt.num_gpus > 0 else torch.device("cpu")
+        # the reference hard-codes "cuda:0" (base_model.py:13); with one process per GPU that is
+        # this rank's current device
+        if opt.num_gpus > 0:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        else:
+            self.device = torch.device("cpu")
 
     def initialize(self):
         """swapping_autoencoder_model.py:26-48"""
