@@ -15,6 +15,8 @@
  *                            <- F.conv2d / F.conv_transpose2d and their ATen backward
  *                               models/networks/stylegan2_layers.py:136,175,182,306,315,321
  *   sae_gemm_f32             <- F.linear and its backward       models/networks/stylegan2_layers.py:177,186
+ *   sae_upsample2x_bilinear_{add,bwd}_f32
+ *                            <- F.interpolate(bilinear x2) + residual   models/networks/generator.py:51-53
  *
  * Conventions (what the reference's pybind layer did implicitly is explicit here):
  *   - plain pointers and sizes only, no torch types; all tensors are dense fp32 in device memory
@@ -128,6 +130,18 @@ int sae_gemm_f32(const float* a, const float* b, const float* bias, float* c,
                  int64_t m, int64_t n, int64_t k,
                  int64_t a_si, int64_t a_sk, int64_t b_sk, int64_t b_sj, int64_t ldc,
                  float alpha, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Generator skip path: bilinear x2 upsampling (align_corners = false) fused with the residual add
+ * and 1/sqrt(2) scale,  y[2h,2w] = alpha * (up2x(x[h,w]) + res[2h,2w])  (res may be NULL), and its
+ * adjoint  gx[h,w] = alpha * up2x^T(gy[2h,2w]).  Replaces F.interpolate(scale_factor=2,
+ * mode='bilinear', align_corners=False) + (skip + res) / sqrt(2), models/networks/generator.py:51-53.
+ * Tensors are [planes, h, w] / [planes, 2h, 2w].
+ * ------------------------------------------------------------------------------------------ */
+int sae_upsample2x_bilinear_add_f32(const float* x, const float* res, float* y, int64_t planes,
+                                    int64_t h, int64_t w, float alpha, sae_stream_t stream);
+int sae_upsample2x_bilinear_bwd_f32(const float* gy, float* gx, int64_t planes, int64_t h, int64_t w,
+                                    float alpha, sae_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -298,3 +298,74 @@ int oracle_gemm_f32(const float* a, const float* b, const float* bias, float* c,
         }
     return SAE_OK;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Bilinear x2 upsampling, align_corners = false (ATen UpSampleBilinear2d, un-vendored dependency;
+ * call site generator.py:51) + the residual add / scale of generator.py:53, and the adjoint.
+ * Published formula: src = max((d + 0.5)/scale - 0.5, 0), i0 = floor(src), l1 = src - i0,
+ * i1 = i0 + (i0 < n-1).
+ * ------------------------------------------------------------------------------------------- */
+static void up2_src(int64_t d, int64_t n, int64_t* i0, int64_t* i1, double* l0, double* l1) {
+    double src = ((double)d + 0.5) * 0.5 - 0.5;
+    if (src < 0.0) src = 0.0;
+    *i0 = (int64_t)src;
+    *l1 = src - (double)*i0;
+    *l0 = 1.0 - *l1;
+    *i1 = *i0 + ((*i0 < n - 1) ? 1 : 0);
+}
+
+int oracle_upsample2x_bilinear_add_f32(const float* x, const float* res, float* y, int64_t planes,
+                                       int64_t h, int64_t w, float alpha, sae_stream_t stream) {
+    (void)stream;
+    if (planes < 0 || h < 1 || w < 1 || (planes > 0 && (!x || !y))) {
+        snprintf(g_err, sizeof g_err, "oracle_upsample2x_bilinear_add_f32: bad argument");
+        return SAE_EINVAL;
+    }
+#pragma omp parallel for schedule(static)
+    for (int64_t pl = 0; pl < planes; ++pl)
+        for (int64_t oy = 0; oy < 2 * h; ++oy) {
+            int64_t y0, y1; double hl0, hl1;
+            up2_src(oy, h, &y0, &y1, &hl0, &hl1);
+            for (int64_t ox = 0; ox < 2 * w; ++ox) {
+                int64_t x0, x1; double wl0, wl1;
+                up2_src(ox, w, &x0, &x1, &wl0, &wl1);
+                const float* xp = x + pl * h * w;
+                double v = hl0 * (wl0 * xp[y0 * w + x0] + wl1 * xp[y0 * w + x1]) +
+                           hl1 * (wl0 * xp[y1 * w + x0] + wl1 * xp[y1 * w + x1]);
+                int64_t o = (pl * 2 * h + oy) * 2 * w + ox;
+                if (res) v += (double)res[o];
+                y[o] = (float)(v * (double)alpha);
+            }
+        }
+    return SAE_OK;
+}
+
+int oracle_upsample2x_bilinear_bwd_f32(const float* gy, float* gx, int64_t planes, int64_t h, int64_t w,
+                                       float alpha, sae_stream_t stream) {
+    (void)stream;
+    if (planes < 0 || h < 1 || w < 1 || (planes > 0 && (!gy || !gx))) {
+        snprintf(g_err, sizeof g_err, "oracle_upsample2x_bilinear_bwd_f32: bad argument");
+        return SAE_EINVAL;
+    }
+    /* scatter form of the adjoint, straight from the forward definition */
+#pragma omp parallel for schedule(static)
+    for (int64_t pl = 0; pl < planes; ++pl) {
+        double* acc = (double*)calloc((size_t)(h * w), sizeof(double));
+        for (int64_t oy = 0; oy < 2 * h; ++oy) {
+            int64_t y0, y1; double hl0, hl1;
+            up2_src(oy, h, &y0, &y1, &hl0, &hl1);
+            for (int64_t ox = 0; ox < 2 * w; ++ox) {
+                int64_t x0, x1; double wl0, wl1;
+                up2_src(ox, w, &x0, &x1, &wl0, &wl1);
+                double g = gy[(pl * 2 * h + oy) * 2 * w + ox];
+                acc[y0 * w + x0] += hl0 * wl0 * g;
+                acc[y0 * w + x1] += hl0 * wl1 * g;
+                acc[y1 * w + x0] += hl1 * wl0 * g;
+                acc[y1 * w + x1] += hl1 * wl1 * g;
+            }
+        }
+        for (int64_t i = 0; i < h * w; ++i) gx[pl * h * w + i] = (float)(acc[i] * (double)alpha);
+        free(acc);
+    }
+    return SAE_OK;
+}

@@ -450,7 +450,6 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     constexpr int PK = kWgPix;
     constexpr int SLD = PK + 1;
     constexpr int LP = WgPatchCap<KS, S>::value;
-    constexpr int PPT = (LP + kBlock - 1) / kBlock;
     __shared__ float Ss[BA * SLD];
     __shared__ float Ls[BB * LP];
 
@@ -491,36 +490,41 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     int ch_end = ch_begin + p.chunks_per_slice;
     if (ch_end > p.chunks) ch_end = p.chunks;
 
-    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
+    // Register prefetch (software pipeline): the global loads of chunk k+1 are issued before the
+    // MFMA loop of chunk k and written to LDS after the barrier that ends it, so HBM/L2 latency
+    // hides under the matrix pipe even at one workgroup per CU.
+    //   S: thread (wave w, lane l) holds pixel l of channels a = w, w+4, ...
+    //   L: wave w holds channels b = w, w+4, ...; lane l holds patch elements l, l+64, ...
+    constexpr int NS = BA / 4;
+    constexpr int NLB = BB / 4;
+    constexpr int LS = (KS == 1) ? 1 : (LP + kWave - 1) / kWave;
+    float sv[NS];
+    float lv[NLB][LS];
+
+    auto load_chunk = [&](int chunk) {
         int bt = chunk;
         const int tix = bt % p.tiles_x; bt /= p.tiles_x;
         const int tiy = bt % p.tiles_y;
         const int tin = bt / p.tiles_y;
         const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
-
-        __syncthreads();   // previous chunk fully consumed
-        // ---- stage S: Ss[a][pix], pix = tid & 63 fixed per thread
         {
-            const int pix = tid & (PK - 1);
-            const int px = pix & (TW - 1);
-            const int py = (pix >> p.tw_log2) & (TH - 1);
-            const int pn = pix >> (p.tw_log2 + p.th_log2);
+            const int px = lane & (TW - 1);
+            const int py = (lane >> p.tw_log2) & (TH - 1);
+            const int pn = lane >> (p.tw_log2 + p.th_log2);
             const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
             const bool ok = n < p.N && oy < p.OH && ox < p.OW;
             const float* sb = gs + ((int64_t)n * p.M) * HWs + (int64_t)oy * p.OW + ox;
-#pragma unroll 4
-            for (int a = tid >> 6; a < BA; a += kBlock / PK) {
-                float v = 0.0f;
-                if (ok && a0 + a < p.M) v = sb[(int64_t)(a0 + a) * HWs];
-                Ss[a * SLD + pix] = v;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int a = wid + 4 * i;
+                sv[i] = (ok && a0 + a < p.M) ? sb[(int64_t)(a0 + a) * HWs] : 0.0f;
             }
         }
-        // ---- stage L: Ls[b][patch]
         {
-            int poff[PPT];
+            int poff[LS];
 #pragma unroll
-            for (int s = 0; s < PPT; ++s) {
-                const int e = tid + kBlock * s;
+            for (int s = 0; s < LS; ++s) {
+                const int e = lane + kWave * s;
                 int off = -1;
                 if (e < CPs) {
                     const int pn = e / IP;
@@ -538,18 +542,34 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
                 poff[s] = off;
             }
             const float* lb = xl + (int64_t)n0 * p.C * HWl;
-#pragma unroll 4
-            for (int b = 0; b < BB; ++b) {
+#pragma unroll
+            for (int j = 0; j < NLB; ++j) {
+                const int b = wid + 4 * j;
                 const bool ch_ok = (b0 + b) < p.C;
                 const float* lc = lb + (int64_t)(b0 + b) * HWl;
 #pragma unroll
-                for (int s = 0; s < PPT; ++s) {
-                    const int e = tid + kBlock * s;
-                    if (e < CPs) Ls[b * LP + e] = (ch_ok && poff[s] >= 0) ? lc[poff[s]] : 0.0f;
-                }
+                for (int s = 0; s < LS; ++s) lv[j][s] = (ch_ok && poff[s] >= 0) ? lc[poff[s]] : 0.0f;
             }
         }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) Ss[(wid + 4 * i) * SLD + lane] = sv[i];
+#pragma unroll
+        for (int j = 0; j < NLB; ++j)
+#pragma unroll
+            for (int s = 0; s < LS; ++s) {
+                const int e = lane + kWave * s;
+                if (e < CPs) Ls[(wid + 4 * j) * LP + e] = lv[j][s];
+            }
+    };
+
+    if (ch_begin < ch_end) load_chunk(ch_begin);
+    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
+        __syncthreads();   // previous chunk fully consumed
+        store_chunk();
         __syncthreads();
+        if (chunk + 1 < ch_end) load_chunk(chunk + 1);   // in flight under the MFMAs below
 
         // ---- MFMA over the 64 pixels, two per instruction
 #pragma unroll 2
@@ -696,7 +716,7 @@ WgPlan wg_plan(const sae_conv2d_desc* d) {
     w.Ap = round_up((int)d->m, w.sh.ba);
     w.Bp = round_up((int)d->c, w.sh.bb);
     const int mn_tiles = (w.Ap / w.sh.ba) * (w.Bp / w.sh.bb);
-    int slices = ceil_div(1024, mn_tiles);
+    int slices = ceil_div(512, mn_tiles);
     if (slices > w.chunks) slices = w.chunks;
     if (slices < 1) slices = 1;
     w.cps = ceil_div(w.chunks, slices);

@@ -28,21 +28,34 @@ struct GemmParams {
 template <int ROWS, int LD, int NTHREADS>
 __device__ __forceinline__ void stage_panel(float* dst, const float* __restrict__ src, int64_t row0, int64_t rows,
                                             int64_t k0, int64_t kmax, int64_t s_row, int64_t s_k, int t) {
+    constexpr int NE = ROWS * kKc / NTHREADS;     // loads per thread, all issued before the LDS writes
+    static_assert(ROWS * kKc % NTHREADS == 0, "panel must divide evenly");
+    float v[NE];
     if (s_k == 1) {   // k contiguous in memory: lanes walk k
-#pragma unroll 4
-        for (int e = t; e < ROWS * kKc; e += NTHREADS) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = t + i * NTHREADS;
             const int r = e / kKc, kk = e - r * kKc;
-            float v = 0.0f;
-            if (row0 + r < rows && k0 + kk < kmax) v = src[(row0 + r) * s_row + (k0 + kk)];
-            dst[kk * LD + r] = v;
+            v[i] = (row0 + r < rows && k0 + kk < kmax) ? src[(row0 + r) * s_row + (k0 + kk)] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = t + i * NTHREADS;
+            const int r = e / kKc, kk = e - r * kKc;
+            dst[kk * LD + r] = v[i];
         }
     } else {          // rows contiguous (or generic): lanes walk rows
-#pragma unroll 4
-        for (int e = t; e < ROWS * kKc; e += NTHREADS) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = t + i * NTHREADS;
             const int kk = e / ROWS, r = e - kk * ROWS;
-            float v = 0.0f;
-            if (row0 + r < rows && k0 + kk < kmax) v = src[(row0 + r) * s_row + (k0 + kk) * s_k];
-            dst[kk * LD + r] = v;
+            v[i] = (row0 + r < rows && k0 + kk < kmax) ? src[(row0 + r) * s_row + (k0 + kk) * s_k] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = t + i * NTHREADS;
+            const int kk = e / ROWS, r = e - kk * ROWS;
+            dst[kk * LD + r] = v[i];
         }
     }
 }

@@ -70,14 +70,25 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
 
     const float* xp = x + plane * (int64_t)p.in_h * p.in_w;
     float* sp = strip[tr];
-    if (live) {
-        for (int e = tx; e < SR * SW; e += TW) {
-            const int r = e / SW, c = e - r * SW;
-            const int iy = iy0 + r, ix = ix0 + c;
-            float v = 0.0f;
-            if (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = xp[(int64_t)iy * p.in_w + ix];
-            sp[r * SWP + c] = v;
-        }
+    // all global loads of the strip are issued back to back into registers (NE per thread),
+    // then written to LDS: one load in flight per wave would leave HBM latency fully exposed
+    constexpr int NE = (SR * SW + TW - 1) / TW;
+    float staged[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tx + i * TW;
+        const int r = e / SW, c = e - r * SW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        float v = 0.0f;
+        if (live && e < SR * SW && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w)
+            v = xp[(int64_t)iy * p.in_w + ix];
+        staged[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tx + i * TW;
+        const int r = e / SW, c = e - r * SW;
+        if (e < SR * SW) sp[r * SWP + c] = staged[i];
     }
     __syncthreads();
 

@@ -1,0 +1,136 @@
+// Bilinear x2 upsampling (align_corners = false) fused with the residual add and scale of the
+// generator's upsampling blocks:  y = alpha * (up2x(x) + res)   and its adjoint.
+//
+// Replaces F.interpolate(scale_factor=2, mode='bilinear', align_corners=False) followed by
+// (skip + res) / sqrt(2) in the reference (models/networks/generator.py:51-53): three elementwise
+// passes over the full-resolution tensor (ATen upsample kernel, add, div) become one.  The
+// per-output arithmetic follows ATen's published bilinear formula: for output index d,
+//   src = max((d + 0.5) / 2 - 0.5, 0),  i0 = floor(src),  l1 = src - i0,  l0 = 1 - l1,
+//   i1 = i0 + (i0 < n - 1),             out = l0 * in[i0] + l1 * in[i1]      (rows, then columns)
+// HBM-bound: reads N + 4N (res), writes 4N floats per plane.  One thread per INPUT pixel produces
+// the 2x2 output quad (8-byte stores, a wave writes 512 contiguous bytes per output row).
+#include "sae_common.h"
+
+namespace sae {
+namespace {
+
+struct Up2Params {
+    int64_t planes;
+    int h, w;
+    float alpha;
+};
+
+__device__ __forceinline__ void src_index(int d, int n, int& i0, int& i1, float& l0, float& l1) {
+    float src = (d + 0.5f) * 0.5f - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    i0 = (int)src;
+    l1 = src - (float)i0;
+    l0 = 1.0f - l1;
+    i1 = i0 + ((i0 < n - 1) ? 1 : 0);
+}
+
+__global__ __launch_bounds__(kBlock) void upsample2x_add_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ res,
+                                                                float* __restrict__ y, const Up2Params p) {
+    const int64_t per_plane = (int64_t)p.h * p.w;
+    const int64_t total = p.planes * per_plane;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * kBlock) {
+        const int64_t plane = idx / per_plane;
+        const int rem = (int)(idx - plane * per_plane);
+        const int i = rem / p.w, j = rem - i * p.w;
+        const float* xp = x + plane * per_plane;
+        const int64_t obase = plane * per_plane * 4;
+        float out[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            int y0, y1; float hl0, hl1;
+            src_index(2 * i + r, p.h, y0, y1, hl0, hl1);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                int x0, x1; float wl0, wl1;
+                src_index(2 * j + c, p.w, x0, x1, wl0, wl1);
+                const float a = xp[y0 * p.w + x0], b = xp[y0 * p.w + x1];
+                const float cc = xp[y1 * p.w + x0], d = xp[y1 * p.w + x1];
+                out[r][c] = hl0 * (wl0 * a + wl1 * b) + hl1 * (wl0 * cc + wl1 * d);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int64_t o = obase + (int64_t)(2 * i + r) * (2 * p.w) + 2 * j;
+            float2 v = make_float2(out[r][0], out[r][1]);
+            if (res) {
+                const float2 q = *reinterpret_cast<const float2*>(res + o);
+                v.x += q.x; v.y += q.y;
+            }
+            v.x *= p.alpha; v.y *= p.alpha;
+            *reinterpret_cast<float2*>(y + o) = v;
+        }
+    }
+}
+
+// adjoint: gx[i][j] = alpha * sum over the 4x4 output neighbourhood rows 2i-1..2i+2, cols
+// 2j-1..2j+2 (clamped to the image) with separable weights (1/4, 3/4, 3/4, 1/4).
+__global__ __launch_bounds__(kBlock) void upsample2x_bwd_kernel(const float* __restrict__ gy,
+                                                                float* __restrict__ gx, const Up2Params p) {
+    const int64_t per_plane = (int64_t)p.h * p.w;
+    const int64_t total = p.planes * per_plane;
+    const int oh = 2 * p.h, ow = 2 * p.w;
+    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * kBlock) {
+        const int64_t plane = idx / per_plane;
+        const int rem = (int)(idx - plane * per_plane);
+        const int i = rem / p.w, j = rem - i * p.w;
+        const float* gp = gy + plane * per_plane * 4;
+        const float wgt[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int yy = 2 * i - 1 + a;
+            yy = yy < 0 ? 0 : (yy > oh - 1 ? oh - 1 : yy);
+            float row = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                int xx = 2 * j - 1 + b;
+                xx = xx < 0 ? 0 : (xx > ow - 1 ? ow - 1 : xx);
+                row = fmaf(wgt[b], gp[(int64_t)yy * ow + xx], row);
+            }
+            acc = fmaf(wgt[a], row, acc);
+        }
+        gx[idx] = p.alpha * acc;
+    }
+}
+
+}  // namespace
+}  // namespace sae
+
+using namespace sae;
+
+static int check_up2(const char* who, const void* a, const void* b, int64_t planes, int64_t h, int64_t w) {
+    if (planes < 0 || h < 1 || w < 1 || h > (1 << 14) || w > (1 << 14))
+        return fail(SAE_EINVAL, "%s: bad plane size", who);
+    if (planes > 0 && (!a || !b)) return fail(SAE_EINVAL, "%s: null tensor", who);
+    return SAE_OK;
+}
+
+extern "C" int sae_upsample2x_bilinear_add_f32(const float* x, const float* res, float* y, int64_t planes,
+                                               int64_t h, int64_t w, float alpha, sae_stream_t stream) {
+    const int rc = check_up2("sae_upsample2x_bilinear_add_f32", x, y, planes, h, w);
+    if (rc != SAE_OK || planes == 0) return rc;
+    Up2Params p{planes, (int)h, (int)w, alpha};
+    int64_t blocks = ceil_div64(planes * h * w, kBlock);
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(upsample2x_add_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, res, y, p);
+    return check_launch("sae_upsample2x_bilinear_add_f32");
+}
+
+extern "C" int sae_upsample2x_bilinear_bwd_f32(const float* gy, float* gx, int64_t planes, int64_t h, int64_t w,
+                                               float alpha, sae_stream_t stream) {
+    const int rc = check_up2("sae_upsample2x_bilinear_bwd_f32", gy, gx, planes, h, w);
+    if (rc != SAE_OK || planes == 0) return rc;
+    Up2Params p{planes, (int)h, (int)w, alpha};
+    int64_t blocks = ceil_div64(planes * h * w, kBlock);
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, gy, gx, p);
+    return check_launch("sae_upsample2x_bilinear_bwd_f32");
+}

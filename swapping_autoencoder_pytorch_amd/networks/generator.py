@@ -2,14 +2,26 @@
 
 Spatial code --(modulated by the global code)--> `netG_num_base_resnet_layers` resolution-
 preserving styled residual blocks --> one upsampling styled residual block per encoder
-downsampling (transposed 3x3 + blur main path, bilinear x2 skip) --> ToRGB."""
+downsampling (transposed 3x3 + blur main path, bilinear x2 skip) --> ToRGB.
+
+Two MI355X-specific restructurings that leave parameters, checkpoint keys and results unchanged:
+
+* every ModulatedConv2d (13 at the church preset) and the SpatialCodeModulation project the SAME
+  global code through its own EqualLinear(global_code_ch -> C_in).  Launched one by one these are
+  ~30 weight-bandwidth-bound [B x 2048] x [2048 x C] products per pass ("launch
+  bound"); here their weights are concatenated per forward and ONE GEMM produces all style
+  vectors (same products and sums per output element, so the values are unchanged);
+* the skip path  F.interpolate(skip, x2, bilinear) -> (skip + res) / sqrt(2)  (:51-53) runs as
+  one fused kernel (stylegan2_op.upsample2x_add).
+"""
 import math
 
 import torch
 import torch.nn.functional as F
 
 from .. import util
-from ..stylegan2_layers import ConvLayer, EqualLinear, StyledConv, ToRGB
+from ..stylegan2_layers import ConvLayer, EqualLinear, ModulatedConv2d, StyledConv, ToRGB
+from ..stylegan2_op import linear, upsample2x_add
 from .base_network import BaseNetwork
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
@@ -40,9 +52,9 @@ class UpsamplingResnetBlock(torch.nn.Module):
         self.skip = ConvLayer(inch, outch, 1, activate=True, bias=True) if inch != outch else torch.nn.Identity()
 
     def forward(self, x, style):
-        skip = F.interpolate(self.skip(x), scale_factor=2, mode="bilinear", align_corners=False)
         res = self.conv2(self.conv1(x, style), style)
-        return (skip + res) / math.sqrt(2)
+        # (bilinear_x2(skip) + res) / sqrt(2) in one pass
+        return upsample2x_add(self.skip(x), res, _INV_SQRT2)
 
 
 class GeneratorModulation(torch.nn.Module):
@@ -52,10 +64,15 @@ class GeneratorModulation(torch.nn.Module):
         super().__init__()
         self.scale = EqualLinear(styledim, outch)
         self.bias = EqualLinear(styledim, outch)
+        self._projected = None       # (scale(style), bias(style)) when the generator batched them
 
     def forward(self, x, style):
         if style.ndimension() <= 2:
-            return x * (1 * self.scale(style)[:, :, None, None]) + self.bias(style)[:, :, None, None]
+            if self._projected is not None:
+                sc, bi = self._projected
+            else:
+                sc, bi = self.scale(style), self.bias(style)
+            return x * (1 * sc[:, :, None, None]) + bi[:, :, None, None]
         style = F.interpolate(style, size=(x.size(2), x.size(3)), mode="bilinear", align_corners=False)
         return x * (1 * self.scale(style)) + self.bias(style)
 
@@ -96,12 +113,41 @@ class StyleGAN2ResnetGenerator(BaseNetwork):
         ch = 128 * (2 ** (self.opt.netE_num_downsampling_sp - num_up))
         return int(min(512, ch) * self.opt.netG_scale_capacity)
 
+    # ---- batched style projections ----------------------------------------------------------------
+    def _style_layers(self):
+        mods = [m for m in self.modules() if isinstance(m, ModulatedConv2d)]
+        lins = [self.SpatialCodeModulation.scale, self.SpatialCodeModulation.bias] + [m.modulation for m in mods]
+        return mods, lins
+
+    def _project_styles(self, global_code):
+        """All EqualLinear(global_code) style projections of this pass as one GEMM."""
+        mods, lins = self._style_layers()
+        scale, lr_mul = lins[0].scale, lins[0].lr_mul
+        if any(l.scale != scale or l.lr_mul != lr_mul or l.bias is None or l.activation for l in lins):
+            return None, mods          # heterogeneous layers: let every module project for itself
+        weight = torch.cat([l.weight for l in lins], dim=0)
+        bias = torch.cat([l.bias for l in lins], dim=0) * lr_mul
+        styles = linear(global_code, weight, bias=bias, alpha=scale)
+        return torch.split(styles, [l.weight.shape[0] for l in lins], dim=1), mods
+
     def forward(self, spatial_code, global_code):
         spatial_code = util.normalize(spatial_code)
         global_code = util.normalize(global_code)
-        x = self.SpatialCodeModulation(spatial_code, global_code)
-        for i in range(self.opt.netG_num_base_resnet_layers):
-            x = getattr(self, "HeadResnetBlock%d" % i)(x, global_code)
-        for j in range(self.opt.netE_num_downsampling_sp):
-            x = getattr(self, "UpsamplingResBlock%d" % (2 ** (4 + j)))(x, global_code)
-        return self.ToRGB(x, global_code, None)
+        pieces, mods = (None, [])
+        if global_code.dim() == 2:
+            pieces, mods = self._project_styles(global_code)
+        try:
+            if pieces is not None:
+                self.SpatialCodeModulation._projected = (pieces[0], pieces[1])
+                for m, s in zip(mods, pieces[2:]):
+                    m._projected_style = s
+            x = self.SpatialCodeModulation(spatial_code, global_code)
+            for i in range(self.opt.netG_num_base_resnet_layers):
+                x = getattr(self, "HeadResnetBlock%d" % i)(x, global_code)
+            for j in range(self.opt.netE_num_downsampling_sp):
+                x = getattr(self, "UpsamplingResBlock%d" % (2 ** (4 + j)))(x, global_code)
+            return self.ToRGB(x, global_code, None)
+        finally:
+            self.SpatialCodeModulation._projected = None
+            for m in mods:
+                m._projected_style = None

@@ -178,6 +178,7 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
         self.demodulate = demodulate
         self.new_demodulation = True
+        self._projected_style = None   # set per pass by StyleGAN2ResnetGenerator (batched projection)
 
     def __repr__(self):
         return "%s(%d, %d, %d, upsample=%s, downsample=%s)" % (
@@ -190,7 +191,10 @@ class ModulatedConv2d(nn.Module):
             if self.demodulate:
                 s = s * torch.rsqrt(s.pow(2).mean([1], keepdim=True) + 1e-8)
             return s
-        s = self.modulation(style.view(input.shape[0], -1))
+        if self._projected_style is not None:     # the generator projected all styles in one GEMM
+            s = self._projected_style
+        else:
+            s = self.modulation(style.view(input.shape[0], -1))
         if self.demodulate:
             s = s * torch.rsqrt(s.pow(2).mean([1], keepdim=True) + 1e-8)
         return s[:, :, None, None]

@@ -4,5 +4,6 @@ layer library is built on."""
 from .fused_act import FusedLeakyReLU, fused_leaky_relu
 from .upfirdn2d import upfirdn2d
 from .conv2d_gemm import conv2d, conv_transpose2d, linear
+from .upsample import upsample2x_add
 
-__all__ = ["FusedLeakyReLU", "fused_leaky_relu", "upfirdn2d", "conv2d", "conv_transpose2d", "linear"]
+__all__ = ["FusedLeakyReLU", "fused_leaky_relu", "upfirdn2d", "conv2d", "conv_transpose2d", "linear", "upsample2x_add"]

@@ -1,0 +1,62 @@
+"""Bilinear x2 upsampling fused with the residual add and scale of the generator's upsampling
+blocks: ``alpha * (F.interpolate(x, scale_factor=2, mode='bilinear', align_corners=False) + res)``
+(reference: models/networks/generator.py:51-53) on one gfx950 kernel instead of three elementwise
+passes over the full-resolution tensor.  The operator is linear, so forward and adjoint close the
+differentiation chain at any order."""
+import torch
+from torch.autograd import Function
+
+from .. import hip_lib
+
+
+def _up(x, res, alpha):
+    lib = hip_lib.get()
+    x = x.contiguous()
+    res = res.contiguous() if res is not None else None
+    lib.check(x, res)
+    n, c, h, w = x.shape
+    if res is not None and tuple(res.shape) != (n, c, 2 * h, 2 * w):
+        raise hip_lib.SaeError("upsample2x_add: residual %s does not match 2x of %s" % (tuple(res.shape), tuple(x.shape)))
+    y = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device)
+    lib.call("upsample2x_bilinear_add_f32", x.data_ptr(), hip_lib.ptr(res), y.data_ptr(), n * c, h, w, float(alpha),
+             lib.stream(x))
+    return y
+
+
+def _down(gy, alpha):
+    lib = hip_lib.get()
+    gy = gy.contiguous()
+    lib.check(gy)
+    n, c, oh, ow = gy.shape
+    gx = torch.empty((n, c, oh // 2, ow // 2), dtype=gy.dtype, device=gy.device)
+    lib.call("upsample2x_bilinear_bwd_f32", gy.data_ptr(), gx.data_ptr(), n * c, oh // 2, ow // 2, float(alpha),
+             lib.stream(gy))
+    return gx
+
+
+class Upsample2xAdd(Function):
+    @staticmethod
+    def forward(ctx, x, res, alpha):
+        ctx.alpha = alpha
+        return _up(x, res, alpha)
+
+    @staticmethod
+    def backward(ctx, gy):
+        gx = Upsample2xAdjoint.apply(gy, ctx.alpha) if ctx.needs_input_grad[0] else None
+        gres = gy * ctx.alpha if ctx.needs_input_grad[1] else None
+        return gx, gres, None
+
+
+class Upsample2xAdjoint(Function):
+    @staticmethod
+    def forward(ctx, gy, alpha):
+        ctx.alpha = alpha
+        return _down(gy, alpha)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        return (Upsample2xAdd.apply(ggx, None, ctx.alpha) if ctx.needs_input_grad[0] else None), None
+
+
+def upsample2x_add(x, res=None, alpha=1.0):
+    return Upsample2xAdd.apply(x, res, alpha)

@@ -103,5 +103,21 @@ def gemm(lib, a, b, bias, m, n, k, a_si, a_sk, b_sk, b_sj, alpha=1.0, device=Non
     return bc.numpy()
 
 
+def upsample2x_add(lib, x, res, alpha=1.0, device=None):
+    planes, h, w = x.shape
+    bx = _Buf(x, device)
+    br = _Buf(res, device) if res is not None else None
+    by = _out((planes, 2 * h, 2 * w), device)
+    lib.call("upsample2x_bilinear_add_f32", bx.ptr, br.ptr if br else None, by.ptr, planes, h, w, alpha, _stream(device))
+    return by.numpy()
+
+
+def upsample2x_bwd(lib, gy, alpha=1.0, device=None):
+    planes, oh, ow = gy.shape
+    bg, bo = _Buf(gy, device), _out((planes, oh // 2, ow // 2), device)
+    lib.call("upsample2x_bilinear_bwd_f32", bg.ptr, bo.ptr, planes, oh // 2, ow // 2, alpha, _stream(device))
+    return bo.numpy()
+
+
 def rel_err(a, b):
     return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(float(np.abs(b).max()), 1e-30))

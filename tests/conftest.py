@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _hip_library_is_current():
+    """Rebuild csrc/libsae_hip.so when a kernel source is newer (hipcc cross-compiles for gfx950
+    without a GPU); a missing hipcc leaves whatever prebuilt library travelled with the snapshot."""
+    import shutil
+    from swapping_autoencoder_pytorch_amd.csrc import build as hip_build
+    if not hip_build.up_to_date() and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        hip_build.build()
+    yield
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     """CPU oracle (oracle/sae_oracle.c) bound with the product's ctypes signatures."""

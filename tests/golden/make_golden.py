@@ -111,7 +111,9 @@ def golden_ops(out):
 
 def golden_layers(out):
     import models.networks.stylegan2_layers as L
+    from models.networks.generator import UpsamplingResnetBlock
     specs = {
+        "g_upblock": (lambda: UpsamplingResnetBlock(6, 10, 16, use_noise=True), (2, 6, 8, 8), True),
         "modconv": (lambda: L.ModulatedConv2d(6, 10, 3, 16), (2, 6, 8, 8), True),
         "modconv_up": (lambda: L.ModulatedConv2d(6, 10, 3, 16, upsample=True), (2, 6, 8, 8), True),
         "modconv_nodemod_1x1": (lambda: L.ModulatedConv2d(6, 3, 1, 16, demodulate=False), (2, 6, 8, 8), True),

@@ -87,3 +87,21 @@ def test_argument_errors(emu_lib):
     d = H.conv_desc(1, 4, 8, 8, 4, 5, 1, 2)     # 5x5 taps: unsupported, must fail loudly
     with pytest.raises(SaeError):
         H.conv(emu_lib, 0, d, np.zeros((1, 4, 8, 8), np.float32), np.zeros((4, 4, 5, 5), np.float32), (1, 4, 8, 8))
+
+
+@pytest.mark.parametrize("shape", [(3, 1, 1), (2, 5, 7), (4, 16, 16), (1, 33, 20)], ids=str)
+def test_upsample2x(emu_lib, oracle_lib, shape):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(shape).astype(np.float32)
+    res = rng.standard_normal((shape[0], 2 * shape[1], 2 * shape[2])).astype(np.float32)
+    for r in (res, None):
+        a = H.upsample2x_add(emu_lib, x, r, 0.7, device=None)
+        o = H.upsample2x_add(oracle_lib, x, r, 0.7)
+        assert H.rel_err(a, o) < 1e-6
+    a = H.upsample2x_bwd(emu_lib, res, 0.7, device=None)
+    o = H.upsample2x_bwd(oracle_lib, res, 0.7)
+    assert H.rel_err(a, o) < 1e-6
+    # adjointness: <up(x), g> == <x, up^T(g)>
+    up = H.upsample2x_add(oracle_lib, x, None, 1.0).astype(np.float64)
+    dn = H.upsample2x_bwd(oracle_lib, res, 1.0).astype(np.float64)
+    assert abs((up * res).sum() - (x * dn).sum()) < 1e-4 * max(1.0, abs((up * res).sum()))

@@ -33,7 +33,7 @@ def test_micro_networks_forward():
 
 
 def test_micro_training_steps():
-    P.check_micro_steps(DEV)
+    P.check_micro_steps(DEV, post_update_tol=5e-3)
 
 
 def test_cpu_tensor_is_refused():
