@@ -70,6 +70,8 @@ struct IgemmParams {
     int pad;              // iy = oy*S + ky - pad
     int tw_log2, th_log2; // pixel tile = TN images x TH rows x TW cols
     int tiles_x, tiles_y, tiles_n;
+    int chunks_per_split;   // split-K over input channels (blockIdx.z) for launches with few tiles
+    int64_t slab_stride;    // floats between the partial outputs of consecutive K slices
 };
 
 template <int KS, int S, int BN>
@@ -201,12 +203,15 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
         }
     };
 
-    load_chunk(0);
-    for (int c0 = 0; c0 < p.Cp; c0 += CK) {
+    const int c_begin = blockIdx.z * p.chunks_per_split * CK;
+    int c_end = c_begin + p.chunks_per_split * CK;
+    if (c_end > p.Cp) c_end = p.Cp;
+    load_chunk(c_begin);
+    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
         __syncthreads();   // everyone finished reading the previous chunk
         store_chunk();
         __syncthreads();
-        if (c0 + CK < p.Cp) load_chunk(c0 + CK);   // in flight under the MFMAs below
+        if (c0 + CK < c_end) load_chunk(c0 + CK);   // in flight under the MFMAs below
 #pragma unroll
         for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -235,7 +240,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
         const int pn = pp >> (p.tw_log2 + p.th_log2);
         const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
         if (n < p.N && oy < p.OH && ox < p.OW) {
-            float* yb = y + ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
+            float* yb = y + (int64_t)blockIdx.z * p.slab_stride +
+                        ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -724,18 +730,67 @@ WgPlan wg_plan(const sae_conv2d_desc* d) {
     return w;
 }
 
+// sum of the K-slice partial outputs (fixed order -> deterministic)
+__global__ __launch_bounds__(kBlock) void conv_splitk_reduce_kernel(const float* __restrict__ slab,
+                                                                    float* __restrict__ y, int64_t numel4,
+                                                                    int64_t slab_stride, int ksplit) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel4; i += (int64_t)gridDim.x * kBlock) {
+        f32x4 acc = *reinterpret_cast<const f32x4*>(slab + i * 4);
+        for (int s = 1; s < ksplit; ++s) acc += *reinterpret_cast<const f32x4*>(slab + s * slab_stride + i * 4);
+        *reinterpret_cast<f32x4*>(y + i * 4) = acc;
+    }
+}
+
+// Launch plan of a forward-type gather: tile shape, K split and workspace layout
+// [ wp : taps*Cp*Mp ][ slabs : ksplit * round4(N*M*OH*OW) ]  (slabs only when ksplit > 1).
+struct GatherPlan {
+    FwdShape sh; int Mp, Cp, taps; int tw_log2, th_log2, tiles_x, tiles_y, tiles_n; int ksplit, cps;
+    int64_t wp_floats, out_floats4, ws_floats;
+};
+GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int stride, bool scatter) {
+    GatherPlan g{};
+    g.sh = fwd_shape(mout, ks, stride);
+    g.Mp = round_up(mout, g.sh.bm);
+    g.Cp = round_up(cin, g.sh.ck);
+    g.taps = ks * ks;
+    pick_tile(g.sh.bn, OH, OW, 32, &g.tw_log2, &g.th_log2);
+    const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tn = g.sh.bn / (tw * th);
+    g.tiles_x = ceil_div(OW, tw);
+    g.tiles_y = ceil_div(OH, th);
+    g.tiles_n = ceil_div(N, tn);
+    const int blocks = g.tiles_x * g.tiles_y * g.tiles_n * (g.Mp / g.sh.bm);
+    const int nchunks = g.Cp / g.sh.ck;
+    g.ksplit = 1;
+    g.cps = nchunks;
+    // few workgroups and a long K loop (the 4x4..16x16 tails of D / Dpatch): split the input
+    // channels over blockIdx.z so the launch still fills the 256 CUs
+    if (!scatter && blocks < 192 && nchunks >= 8 && ((int64_t)N * mout * OH * OW) % 4 == 0) {
+        int k = 512 / blocks;
+        if (k > 8) k = 8;
+        if (k > nchunks / 4) k = nchunks / 4;
+        if (k >= 2) {
+            g.cps = ceil_div(nchunks, k);
+            g.ksplit = ceil_div(nchunks, g.cps);
+        }
+    }
+    g.wp_floats = (int64_t)g.taps * g.Cp * g.Mp;
+    g.out_floats4 = ((int64_t)N * mout * OH * OW + 3) / 4 * 4;
+    g.ws_floats = g.wp_floats + (g.ksplit > 1 ? g.ksplit * g.out_floats4 : 0);
+    return g;
+}
+
 // ---- forward-type launch (regular gather) ------------------------------------------------------
 template <int KS, int S>
-int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const FwdShape& sh, hipStream_t s) {
-    pick_tile(sh.bn, p.OH, p.OW, 32, &p.tw_log2, &p.th_log2);
+int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const GatherPlan& g, hipStream_t s) {
+    const FwdShape& sh = g.sh;
+    p.tw_log2 = g.tw_log2; p.th_log2 = g.th_log2;
+    p.tiles_x = g.tiles_x; p.tiles_y = g.tiles_y; p.tiles_n = g.tiles_n;
+    p.chunks_per_split = g.cps;
     const int tw = 1 << p.tw_log2, th = 1 << p.th_log2, tn = sh.bn / (tw * th);
-    p.tiles_x = ceil_div(p.OW, tw);
-    p.tiles_y = ceil_div(p.OH, th);
-    p.tiles_n = ceil_div(p.N, tn);
     const int ph = (KS == 1) ? th : (th - 1) * S + KS, pw = (KS == 1) ? tw : (tw - 1) * S + KS;
     const int cap = (KS == 1) ? sh.bn : (S == 1 ? (9 * sh.bn) / 4 : (41 * sh.bn) / 8);
     if (tn * ph * pw > cap) return fail(SAE_EINVAL, "conv igemm: patch %d exceeds LDS cap %d", tn * ph * pw, cap);
-    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(p.Mp / sh.bm));
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(p.Mp / sh.bm), (unsigned)g.ksplit);
     constexpr int CK = (KS == 1) ? 32 : 8;
     constexpr int CK2 = (KS == 1) ? 16 : 8;
     switch (sh.cfg) {
@@ -765,26 +820,36 @@ int run_wprep(const float* w, float* wp, int M, int C, int Mp, int Cp, int taps,
 int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int H, int W,
                int mout, int OH, int OW, int YH, int YW, int oys, int oxs, int ks, int stride, int pad, int64_t sm,
                int64_t sc, int flip, float alpha, hipStream_t s) {
-    const FwdShape sh = fwd_shape(mout, ks, stride);
-    const int Mp = round_up(mout, sh.bm), Cp = round_up(cin, sh.ck), taps = ks * ks;
-    const int64_t need = (int64_t)taps * Cp * Mp;
-    if (!ws || ws_floats < need)
-        return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
-    run_wprep(w, ws, mout, cin, Mp, Cp, taps, sm, sc, flip, alpha, s);
+    const GatherPlan g = gather_plan(N, cin, mout, OH, OW, ks, stride, oys != 1 || oxs != 1);
+    if (!ws || ws_floats < g.ws_floats)
+        return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)g.ws_floats);
+    run_wprep(w, ws, mout, cin, g.Mp, g.Cp, g.taps, sm, sc, flip, alpha, s);
     IgemmParams p{};
     p.N = N; p.C = cin; p.H = H; p.W = W; p.M = mout; p.OH = OH; p.OW = OW; p.YH = YH; p.YW = YW;
-    p.oys = oys; p.oxs = oxs; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
+    p.oys = oys; p.oxs = oxs; p.Cp = g.Cp; p.Mp = g.Mp; p.pad = pad;
+    p.slab_stride = g.out_floats4;
+    float* out = (g.ksplit > 1) ? ws + g.wp_floats : y;
     int rc;
-    if (ks == 3 && stride == 1) rc = launch_igemm<3, 1>(x, ws, y, p, sh, s);
-    else if (ks == 3) rc = launch_igemm<3, 2>(x, ws, y, p, sh, s);
-    else if (stride == 1) rc = launch_igemm<1, 1>(x, ws, y, p, sh, s);
-    else rc = launch_igemm<1, 2>(x, ws, y, p, sh, s);
-    return rc;
+    if (ks == 3 && stride == 1) rc = launch_igemm<3, 1>(x, ws, out, p, g, s);
+    else if (ks == 3) rc = launch_igemm<3, 2>(x, ws, out, p, g, s);
+    else if (stride == 1) rc = launch_igemm<1, 1>(x, ws, out, p, g, s);
+    else rc = launch_igemm<1, 2>(x, ws, out, p, g, s);
+    if (rc != SAE_OK) return rc;
+    if (g.ksplit > 1) {
+        // y is exactly N*mout*OH*OW floats; the slabs are padded to a multiple of 4, y may not be
+        const int64_t numel = (int64_t)N * mout * OH * OW;
+        const int64_t n4 = numel / 4;
+        int64_t blocks = ceil_div64(n4 > 0 ? n4 : 1, kBlock);
+        if (blocks > 4096) blocks = 4096;
+        if (n4 > 0)
+            hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s,
+                               (const float*)out, y, n4, g.out_floats4, g.ksplit);
+    }
+    return SAE_OK;
 }
 
-int64_t gather_ws(int cin, int mout, int ks, int stride) {
-    const FwdShape sh = fwd_shape(mout, ks, stride);
-    return (int64_t)ks * ks * round_up(cin, sh.ck) * round_up(mout, sh.bm);
+int64_t gather_ws(int N, int cin, int mout, int OH, int OW, int ks, int stride, bool scatter) {
+    return gather_plan(N, cin, mout, OH, OW, ks, stride, scatter).ws_floats;
 }
 
 // stride-2 3x3 transposed gather producing `mout` channels (the large image) from `cin` channels
@@ -836,10 +901,11 @@ using namespace sae;
 extern "C" int64_t sae_conv2d_workspace(const sae_conv2d_desc* d, int32_t op) {
     if (!desc_ok(d, "sae_conv2d_workspace")) return 0;
     switch (op) {
-        case SAE_CONV_FWD: return gather_ws((int)d->c, (int)d->m, d->kh, d->stride);
+        case SAE_CONV_FWD:
+            return gather_ws((int)d->n, (int)d->c, (int)d->m, (int)d->oh, (int)d->ow, d->kh, d->stride, false);
         case SAE_CONV_DGRAD:
-            if (d->stride == 1) return gather_ws((int)d->m, (int)d->c, d->kh, 1);
-            if (d->kh == 1) return gather_ws((int)d->m, (int)d->c, 1, 1);
+            if (d->stride == 1) return gather_ws((int)d->n, (int)d->m, (int)d->c, (int)d->h, (int)d->w, d->kh, 1, false);
+            if (d->kh == 1) return gather_ws((int)d->n, (int)d->m, (int)d->c, (int)d->oh, (int)d->ow, 1, 1, true);
             return tr_ws((int)d->m, (int)d->c);
         case SAE_CONV_WGRAD: {
             const WgPlan w = wg_plan(d);

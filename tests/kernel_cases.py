@@ -32,6 +32,9 @@ CONV_SMALL = [
     (1, 20, 15, 15, 36, 1, 2, 0, False),
     (2, 8, 8, 8, 32, 3, 1, 1, True), (1, 6, 17, 17, 40, 3, 2, 0, True), (2, 8, 4, 4, 130, 3, 1, 0, False),
     (1, 3, 6, 6, 8, 3, 1, 1, False), (1, 3, 40, 40, 3, 1, 1, 0, False), (2, 6, 4, 4, 12, 3, 2, 0, False),
+    # long K, few tiles: exercises the split-K (blockIdx.z) path of forward and stride-1 dgrad
+    (2, 64, 8, 8, 40, 3, 1, 1, False), (1, 72, 9, 9, 40, 3, 2, 0, False), (1, 256, 4, 4, 40, 1, 1, 0, False),
+    (2, 40, 6, 6, 70, 3, 1, 1, False),
 ]
 
 # larger shapes for the GPU (oracle still finishes in seconds): church-preset layer classes scaled down

@@ -25,7 +25,9 @@ def test_ops():
 
 @pytest.mark.parametrize("name", sorted(P.layer_specs()))
 def test_layers(name):
-    P.check_layer(name, DEV)
+    # 1e-4 relative per tensor (north-star tolerance); scalar parameters such as noise.weight are
+    # long cancelling fp32 sums
+    P.check_layer(name, DEV, tol=1e-4)
 
 
 def test_micro_networks_forward():
