@@ -263,7 +263,8 @@ struct TrParams {
     int QH, QW;           // half-resolution grid covered
     int Cp, Mp;
     int pad;
-    int tw_log2, th_log2; // q tile = TN images x TH x TW
+    int tw, th, tn;       // q tile = TN images x TH x TW positions (any sizes with TN*TH*TW <= BQ: the
+                          // transposed problems have 2^k + 1 wide grids, power-of-two tiles waste 25-90 %)
     int tiles_x, tiles_y, tiles_n;
 };
 
@@ -287,8 +288,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wid / WN, wn = wid % WN;
 
-    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
-    const int TN = BQ >> (p.tw_log2 + p.th_log2);
+    const int TW = p.tw, TH = p.th, TN = p.tn;
     int bt = blockIdx.x;
     const int tix = bt % p.tiles_x; bt /= p.tiles_x;
     const int tiy = bt % p.tiles_y;
@@ -320,10 +320,12 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
     }
 
     const int pp = wn * 32 + l31;
-    const int px = pp & (TW - 1);
-    const int py = (pp >> p.tw_log2) & (TH - 1);
-    const int pn = pp >> (p.tw_log2 + p.th_log2);
-    const int pixbase = pn * IP + py * RS + px;
+    const int pn = pp / (TW * TH);
+    const int prem = pp - pn * (TW * TH);
+    const int py = prem / TW;
+    const int px = prem - py * TW;
+    const bool lane_ok = pn < TN;                 // lanes beyond TN*TH*TW positions idle
+    const int pixbase = lane_ok ? pn * IP + py * RS + px : 0;
     int tapoff[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) {
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
     }
 
     const int n = n0 + pn, qy = qy0 + py, qx = qx0 + px;
-    if (n < p.N) {
+    if (lane_ok && n < p.N) {
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) {
             const int oy = 2 * qy + (cl >> 1) - p.pad;
@@ -446,23 +448,35 @@ struct WgPatchCap {
     static constexpr int value = (KS == 1) ? 65 : (S == 1 ? 145 : 325);   // odd strides
 };
 
-template <int KS, int S, int TA, int TB, int WA, int WB>
+// MODE 0: the 4 waves tile the (a, b) plane WA x WB, every wave walks all 64 pixels of a chunk.
+// MODE 1: narrow layers (M, C <= 32): ONE 32 x 32 x taps tile per workgroup; the 4 waves split the
+//         pixels of a chunk (k-pairs w, w+4, ...) and are summed through LDS before the slab store,
+//         so no wave multiplies padding.
+// MODE 2: MODE 1 with the B-tile lanes enumerating (channel, tap) pairs (C * taps <= 32: the RGB
+//         stems): one MFMA per k-pair instead of one per tap.
+template <int KS, int S, int TA, int TB, int WA, int WB, int MODE>
 __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restrict__ xl,
                                                             const float* __restrict__ gs,
                                                             float* __restrict__ slab, const WgradParams p) {
-    static_assert(WA * WB == 4, "4 waves per workgroup");
+    constexpr bool PIXSPLIT = MODE >= 1;
+    constexpr bool PACKCT = MODE == 2;
+    static_assert(PIXSPLIT ? (WA == 1 && WB == 1 && TA == 1 && TB == 1) : (WA * WB == 4), "wave arrangement");
     constexpr int T = KS * KS;
+    constexpr int TT = PACKCT ? 1 : T;      // accumulator tap-tiles per (ta, tb)
     constexpr int BA = 32 * TA * WA, BB = 32 * TB * WB;
     constexpr int PK = kWgPix;
     constexpr int SLD = PK + 1;
     constexpr int LP = WgPatchCap<KS, S>::value;
     __shared__ float Ss[BA * SLD];
     __shared__ float Ls[BB * LP];
+    __shared__ float red[PIXSPLIT ? 4 * 32 * 33 : 1];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63;
+    // the wave index is wave-uniform: say so, or every per-wave base address lives in VGPRs
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int wa = wid / WB, wb = wid % WB;
+    const int wa = PIXSPLIT ? 0 : wid / WB, wb = PIXSPLIT ? 0 : wid % WB;
     const int b0 = blockIdx.x * BB, a0 = blockIdx.y * BA, slice = blockIdx.z;
 
     const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
@@ -482,15 +496,24 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
         tapoff[t] = (KS == 1) ? 0 : ky * RS + ((S == 2) ? (kx & 1) * HALFW + (kx >> 1) : kx);
     }
 
-    f32x16 acc[TA][TB][T];
+    f32x16 acc[TA][TB][TT];
 #pragma unroll
     for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
         for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
-            for (int t = 0; t < T; ++t)
+            for (int t = 0; t < TT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ta][tb][t][r] = 0.0f;
+
+    // MODE 2: lane j of the B tile stands for (channel j / T, tap j % T)
+    int pk_row = 0, pk_tapoff = 0;
+    if (PACKCT) {
+        const int ch = l31 / T, t = l31 - ch * T;
+        const int ky = t / KS, kx = t % KS;
+        pk_row = (ch < BB ? ch : BB - 1) * LP;
+        pk_tapoff = (KS == 1) ? 0 : ky * RS + ((S == 2) ? (kx & 1) * HALFW + (kx >> 1) : kx);
+    }
 
     const int ch_begin = slice * p.chunks_per_slice;
     int ch_end = ch_begin + p.chunks_per_slice;
@@ -513,17 +536,20 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
         const int tiy = bt % p.tiles_y;
         const int tin = bt / p.tiles_y;
         const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
+        // addressing: one wave-uniform 64-bit base per tensor + 32-bit (lane + channel) offsets,
+        // so loads use the SGPR-base form and no per-channel pointer is kept in registers
         {
             const int px = lane & (TW - 1);
             const int py = (lane >> p.tw_log2) & (TH - 1);
             const int pn = lane >> (p.tw_log2 + p.th_log2);
             const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
             const bool ok = n < p.N && oy < p.OH && ox < p.OW;
-            const float* sb = gs + ((int64_t)n * p.M) * HWs + (int64_t)oy * p.OW + ox;
+            const float* sbase = gs + ((int64_t)n0 * p.M + a0) * HWs;
+            const int lane_off = pn * p.M * HWs + oy * p.OW + ox;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int a = wid + 4 * i;
-                sv[i] = (ok && a0 + a < p.M) ? sb[(int64_t)(a0 + a) * HWs] : 0.0f;
+                sv[i] = (ok && a0 + a < p.M) ? sbase[lane_off + a * HWs] : 0.0f;
             }
         }
         {
@@ -547,14 +573,13 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
                 }
                 poff[s] = off;
             }
-            const float* lb = xl + (int64_t)n0 * p.C * HWl;
+            const float* lbase = xl + ((int64_t)n0 * p.C + b0) * HWl;
 #pragma unroll
             for (int j = 0; j < NLB; ++j) {
                 const int b = wid + 4 * j;
                 const bool ch_ok = (b0 + b) < p.C;
-                const float* lc = lb + (int64_t)(b0 + b) * HWl;
 #pragma unroll
-                for (int s = 0; s < LS; ++s) lv[j][s] = (ch_ok && poff[s] >= 0) ? lc[poff[s]] : 0.0f;
+                for (int s = 0; s < LS; ++s) lv[j][s] = (ch_ok && poff[s] >= 0) ? lbase[poff[s] + b * HWl] : 0.0f;
             }
         }
     };
@@ -577,45 +602,105 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
         __syncthreads();
         if (chunk + 1 < ch_end) load_chunk(chunk + 1);   // in flight under the MFMAs below
 
-        // ---- MFMA over the 64 pixels, two per instruction
-#pragma unroll 2
-        for (int kp = 0; kp < PK / 2; ++kp) {
+        // ---- MFMA over the 64 pixels, two per instruction.  The LDS operands of k-pair i+1 are
+        // fetched into a second register set before the MFMAs of k-pair i issue (explicit
+        // double buffering): with one wave per SIMD nothing else hides the ds_read latency.
+        constexpr int KSTEP = PIXSPLIT ? 4 : 1;
+        constexpr int KITER = (PK / 2) / KSTEP;           // k-pairs per wave per chunk (even)
+        static_assert(KITER % 2 == 0, "k-pair loop is unrolled by two");
+        constexpr int NB = PACKCT ? 1 : TB * T;
+        auto fetch = [&](int kp, float (&a)[TA], float (&b)[NB]) {
             const int pk = 2 * kp + half;
             const int px = pk & (TW - 1);
             const int py = (pk >> p.tw_log2) & (TH - 1);
             const int pn = pk >> (p.tw_log2 + p.th_log2);
             const int pbase = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px;
-            float a[TA];
 #pragma unroll
             for (int ta = 0; ta < TA; ++ta) a[ta] = Ss[((wa * TA + ta) * 32 + l31) * SLD + pk];
+            if constexpr (PACKCT) {
+                b[0] = Ls[pk_row + pbase + pk_tapoff];
+            } else {
 #pragma unroll
-            for (int tb = 0; tb < TB; ++tb) {
-                const float* lrow = Ls + ((wb * TB + tb) * 32 + l31) * LP + pbase;
+                for (int tb = 0; tb < TB; ++tb) {
+                    const float* lrow = Ls + ((wb * TB + tb) * 32 + l31) * LP + pbase;
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const float b = lrow[tapoff[t]];
-#pragma unroll
-                    for (int ta = 0; ta < TA; ++ta)
-                        acc[ta][tb][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b, acc[ta][tb][t], 0, 0, 0);
+                    for (int t = 0; t < T; ++t) b[tb * T + t] = lrow[tapoff[t]];
                 }
+            }
+        };
+        auto mma = [&](const float (&a)[TA], const float (&b)[NB]) {
+            if constexpr (PACKCT) {
+                acc[0][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc[0][0][0], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
+#pragma unroll
+                        for (int ta = 0; ta < TA; ++ta)
+                            acc[ta][tb][t] =
+                                __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb * T + t], acc[ta][tb][t], 0, 0, 0);
+            }
+        };
+        const int kp0 = PIXSPLIT ? wid : 0;
+        // the stride-2 instantiation already sits at the register ceiling (80 prefetch + 144
+        // accumulator registers): it keeps a single operand set
+        constexpr bool DOUBLE_BUFFER = !(KS == 3 && S == 2 && MODE == 0);
+        if constexpr (DOUBLE_BUFFER) {
+            float a_even[TA], b_even[NB], a_odd[TA], b_odd[NB];
+            fetch(kp0, a_even, b_even);
+            for (int it = 0; it < KITER; it += 2) {
+                const int kp = kp0 + it * KSTEP;
+                fetch(kp + KSTEP, a_odd, b_odd);
+                mma(a_even, b_even);
+                if (it + 2 < KITER) fetch(kp + 2 * KSTEP, a_even, b_even);
+                mma(a_odd, b_odd);
+            }
+        } else {
+#pragma unroll 2
+            for (int it = 0; it < KITER; ++it) {
+                float a_cur[TA], b_cur[NB];
+                fetch(kp0 + it * KSTEP, a_cur, b_cur);
+                mma(a_cur, b_cur);
             }
         }
     }
 
     // ---- slab store: rows = a (m), cols = b (c)
+    if constexpr (PIXSPLIT) {
+        // sum the four waves' partial tiles through LDS (fixed order), one tap-tile at a time
 #pragma unroll
-    for (int ta = 0; ta < TA; ++ta)
+        for (int t = 0; t < TT; ++t) {
+            __syncthreads();
 #pragma unroll
-        for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int bcol = b0 + (wb * TB + tb) * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int arow = a0 + (wa * TA + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    slab[(((int64_t)slice * T + t) * p.Ap + arow) * p.Bp + bcol] = acc[ta][tb][t][r];
-                }
+            for (int r = 0; r < 16; ++r)
+                red[(wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l31] = acc[0][0][t][r];
+            __syncthreads();
+            for (int e = tid; e < 32 * 32; e += kBlock) {
+                const int i = e >> 5, j = e & 31;
+                const float v = (red[(0 * 32 + i) * 33 + j] + red[(1 * 32 + i) * 33 + j]) +
+                                (red[(2 * 32 + i) * 33 + j] + red[(3 * 32 + i) * 33 + j]);
+                int tap = t, bcol = b0 + j;
+                if (PACKCT) { bcol = j / T; tap = j - bcol * T; }
+                if (bcol < p.Bp && (!PACKCT || bcol < p.C))
+                    slab[(((int64_t)slice * T + tap) * p.Ap + a0 + i) * p.Bp + bcol] = v;
             }
+        }
+    } else {
+#pragma unroll
+        for (int ta = 0; ta < TA; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < TB; ++tb)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int bcol = b0 + (wb * TB + tb) * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int arow = a0 + (wa * TA + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        slab[(((int64_t)slice * T + t) * p.Ap + arow) * p.Bp + bcol] = acc[ta][tb][t][r];
+                    }
+                }
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void conv_wgrad_reduce_kernel(const float* __restrict__ slab,
@@ -699,11 +784,13 @@ TrShape tr_shape(int mout) {
     return s;
 }
 
-struct WgShape { int ba, bb; };
-WgShape wg_shape(int ks, int stride) {
-    if (ks == 1) return {128, 128};
-    if (stride == 1) return {64, 64};
-    return {128, 32};
+struct WgShape { int ba, bb; int mode; };
+WgShape wg_shape(int m, int c, int ks, int stride) {
+    if (c * ks * ks <= 32) return {32, 32, 2};                       // RGB stems: (channel, tap) packed
+    if (m <= 32 && c <= 32 && ks == 3 && stride == 1) return {32, 32, 1};
+    if (ks == 1) return {128, 128, 0};
+    if (stride == 1) return {64, 64, 0};
+    return {128, 32, 0};
 }
 
 struct WgPlan {
@@ -711,7 +798,7 @@ struct WgPlan {
 };
 WgPlan wg_plan(const sae_conv2d_desc* d) {
     WgPlan w{};
-    w.sh = wg_shape(d->kh, d->stride);
+    w.sh = wg_shape((int)d->m, (int)d->c, d->kh, d->stride);
     w.taps = d->kh * d->kw;
     pick_tile(kWgPix, (int)d->oh, (int)d->ow, 32, &w.tw_log2, &w.th_log2);
     const int tw = 1 << w.tw_log2, th = 1 << w.th_log2, tn = kWgPix / (tw * th);
@@ -866,13 +953,25 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
     p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
     p.QH = (OH + pad - 1) / 2 + 1;
     p.QW = (OW + pad - 1) / 2 + 1;
-    pick_tile(sh.bq, p.QH, p.QW, 32, &p.tw_log2, &p.th_log2);
-    const int tw = 1 << p.tw_log2, th = 1 << p.th_log2, tn = sh.bq / (tw * th);
+    {   // tile = tn x th x tw q-positions minimising the number of workgroups (each costs bq lanes of MFMA work)
+        const int cap = (25 * sh.bq) / 16;
+        int64_t best = -1;
+        for (int tw = 4; tw <= 32; ++tw)
+            for (int th = 1; th * tw <= sh.bq; ++th) {
+                int tn = sh.bq / (tw * th);
+                if (tn > N) tn = N;
+                if (tn * (th + 1) * (tw + 1) > cap) continue;
+                const int64_t cost = (int64_t)ceil_div(p.QW, tw) * ceil_div(p.QH, th) * ceil_div(N, tn);
+                if (best < 0 || cost < best || (cost == best && tw > p.tw)) {
+                    best = cost; p.tw = tw; p.th = th; p.tn = tn;
+                }
+            }
+        if (best < 0) return fail(SAE_EINVAL, "conv tr: no tile fits the LDS patch cap");
+    }
+    const int tw = p.tw, th = p.th, tn = p.tn;
     p.tiles_x = ceil_div(p.QW, tw);
     p.tiles_y = ceil_div(p.QH, th);
     p.tiles_n = ceil_div(N, tn);
-    if (tn * (th + 1) * (tw + 1) > (25 * sh.bq) / 16)
-        return fail(SAE_EINVAL, "conv tr: patch exceeds LDS cap");
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(Mp / sh.bm));
     switch (sh.cfg) {
         case 0: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 2, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
@@ -887,10 +986,10 @@ int64_t tr_ws(int cin, int mout) {
     return (int64_t)9 * round_up(cin, 8) * round_up(mout, sh.bm);
 }
 
-template <int KS, int S, int TA, int TB, int WA, int WB>
+template <int KS, int S, int TA, int TB, int WA, int WB, int MODE>
 void launch_wgrad(const float* x, const float* gy, float* slab, const WgradParams& p, const WgPlan& w, hipStream_t s) {
     const dim3 grid((unsigned)(w.Bp / w.sh.bb), (unsigned)(w.Ap / w.sh.ba), (unsigned)w.slices);
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, TA, TB, WA, WB>), grid, dim3(kBlock), 0, s, x, gy, slab, p);
+    hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, TA, TB, WA, WB, MODE>), grid, dim3(kBlock), 0, s, x, gy, slab, p);
 }
 
 }  // namespace
@@ -978,10 +1077,17 @@ extern "C" int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
         if (tn * ph * pw > cap) return fail(SAE_EINVAL, "sae_conv2d_wgrad_f32: patch exceeds LDS cap");
     }
     if (d->n > 0) {
-        if (d->kh == 3 && d->stride == 1) launch_wgrad<3, 1, 1, 1, 2, 2>(x, gy, workspace, p, w, s);
-        else if (d->kh == 3) launch_wgrad<3, 2, 1, 1, 4, 1>(x, gy, workspace, p, w, s);
-        else if (d->stride == 1) launch_wgrad<1, 1, 2, 2, 2, 2>(x, gy, workspace, p, w, s);
-        else launch_wgrad<1, 2, 2, 2, 2, 2>(x, gy, workspace, p, w, s);
+        if (w.sh.mode == 2) {
+            if (d->kh == 3 && d->stride == 1) launch_wgrad<3, 1, 1, 1, 1, 1, 2>(x, gy, workspace, p, w, s);
+            else if (d->kh == 3) launch_wgrad<3, 2, 1, 1, 1, 1, 2>(x, gy, workspace, p, w, s);
+            else if (d->stride == 1) launch_wgrad<1, 1, 1, 1, 1, 1, 2>(x, gy, workspace, p, w, s);
+            else launch_wgrad<1, 2, 1, 1, 1, 1, 2>(x, gy, workspace, p, w, s);
+        } else if (w.sh.mode == 1) {
+            launch_wgrad<3, 1, 1, 1, 1, 1, 1>(x, gy, workspace, p, w, s);
+        } else if (d->kh == 3 && d->stride == 1) launch_wgrad<3, 1, 1, 1, 2, 2, 0>(x, gy, workspace, p, w, s);
+        else if (d->kh == 3) launch_wgrad<3, 2, 1, 1, 4, 1, 0>(x, gy, workspace, p, w, s);
+        else if (d->stride == 1) launch_wgrad<1, 1, 2, 2, 2, 2, 0>(x, gy, workspace, p, w, s);
+        else launch_wgrad<1, 2, 2, 2, 2, 2, 0>(x, gy, workspace, p, w, s);
     }
     const int64_t total = (int64_t)w.taps * d->m * d->c;
     int64_t blocks = ceil_div64(total, kBlock);

@@ -23,6 +23,8 @@
 //    matches (upfirdn2d_kernel.cu:172-268); here every valid argument set computes.
 #include "sae_common.h"
 
+#include <cstdlib>
+
 namespace sae {
 namespace {
 
@@ -188,8 +190,11 @@ void launch_blur(const float* x, const float* k, float* y, BlurParams p, hipStre
 template <int KH, int KW>
 void dispatch_blur(const float* x, const float* k, float* y, const BlurParams& p, hipStream_t s) {
     // tile width from the output width, rows-per-thread from the output height
+    // tuning knob (benchmarks only): SAE_BLUR_RB=8 selects 8 rows per thread for wide planes
+    static const int rb_knob = [] { const char* e = getenv("SAE_BLUR_RB"); return e ? atoi(e) : 0; }();
     if (p.out_w > 32) {
-        if (p.out_h >= 16) launch_blur<KH, KW, 64, 16>(x, k, y, p, s);
+        if (p.out_h >= 16 && rb_knob == 8) launch_blur<KH, KW, 64, 8>(x, k, y, p, s);
+        else if (p.out_h >= 16) launch_blur<KH, KW, 64, 16>(x, k, y, p, s);
         else launch_blur<KH, KW, 64, 4>(x, k, y, p, s);
     } else if (p.out_w > 16) {
         if (p.out_h >= 16) launch_blur<KH, KW, 32, 16>(x, k, y, p, s);
