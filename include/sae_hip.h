@@ -117,6 +117,11 @@ int64_t sae_conv2d_workspace(const sae_conv2d_desc* d, int32_t op);
 
 int sae_conv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d,
                        float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+/* forward fused with the bias + leaky-ReLU that follows it in ConvLayer (stylegan2_layers.py:642-659):
+ *   y = lrelu_{act_slope}(alpha * conv(x, w) + bias[m]) * act_scale          (bias may be NULL)   */
+int sae_conv2d_fwd_bias_act_f32(const float* x, const float* w, const float* bias, float* y,
+                                const sae_conv2d_desc* d, float alpha, float act_slope, float act_scale,
+                                float* workspace, int64_t workspace_floats, sae_stream_t stream);
 int sae_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
                          float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
 int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,

@@ -369,3 +369,14 @@ int oracle_upsample2x_bilinear_bwd_f32(const float* gy, float* gx, int64_t plane
     }
     return SAE_OK;
 }
+
+/* ConvLayer's Conv -> Act pair (stylegan2_layers.py:642-659) in one call: the conv of
+ * oracle_conv2d_fwd_f32 followed by fused_bias_act_kernel.cu:30,36-47 (act = 3, grad = 0). */
+int oracle_conv2d_fwd_bias_act_f32(const float* x, const float* w, const float* bias, float* y,
+                                   const sae_conv2d_desc* d, float alpha, float act_slope, float act_scale,
+                                   float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    int rc = oracle_conv2d_fwd_f32(x, w, y, d, alpha, workspace, workspace_floats, stream);
+    if (rc != SAE_OK) return rc;
+    int64_t hw = d->oh * d->ow;
+    return oracle_bias_act_f32(y, bias, NULL, y, d->n * d->m * hw, hw, d->m, 3, 0, act_slope, act_scale, stream);
+}

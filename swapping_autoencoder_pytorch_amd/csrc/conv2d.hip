@@ -72,6 +72,10 @@ struct IgemmParams {
     int tiles_x, tiles_y, tiles_n;
     int chunks_per_split;   // split-K over input channels (blockIdx.z) for launches with few tiles
     int64_t slab_stride;    // floats between the partial outputs of consecutive K slices
+    // fused epilogue (forward only): y = lrelu(acc + bias[m]) * act_scale when act != 0
+    const float* bias;
+    float act_slope, act_scale;
+    int act;
 };
 
 template <int KS, int S, int BN>
@@ -247,7 +251,14 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (m < p.M) yb[(int64_t)m * p.YH * p.YW] = acc[mi][ni][r];
+                    if (m < p.M) {
+                        float v = acc[mi][ni][r];
+                        if (p.act) {   // bias + leaky-ReLU of the following FusedLeakyReLU, fused_bias_act_kernel.cu:30,47
+                            if (p.bias) v += p.bias[m];
+                            v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
+                        }
+                        yb[(int64_t)m * p.YH * p.YW] = v;
+                    }
                 }
         }
     }
@@ -817,13 +828,25 @@ WgPlan wg_plan(const sae_conv2d_desc* d) {
     return w;
 }
 
-// sum of the K-slice partial outputs (fixed order -> deterministic)
+// sum of the K-slice partial outputs (fixed order -> deterministic), then the optional fused
+// bias + leaky-ReLU epilogue (hw = OH*OW, channels = M locate the bias of a flat element)
 __global__ __launch_bounds__(kBlock) void conv_splitk_reduce_kernel(const float* __restrict__ slab,
                                                                     float* __restrict__ y, int64_t numel4,
-                                                                    int64_t slab_stride, int ksplit) {
+                                                                    int64_t slab_stride, int ksplit,
+                                                                    const float* __restrict__ bias, int act,
+                                                                    float act_slope, float act_scale, int hw,
+                                                                    int channels) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel4; i += (int64_t)gridDim.x * kBlock) {
         f32x4 acc = *reinterpret_cast<const f32x4*>(slab + i * 4);
         for (int s = 1; s < ksplit; ++s) acc += *reinterpret_cast<const f32x4*>(slab + s * slab_stride + i * 4);
+        if (act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[e];
+                if (bias) v += bias[((i * 4 + e) / hw) % channels];
+                acc[e] = ((v > 0.0f) ? v : v * act_slope) * act_scale;
+            }
+        }
         *reinterpret_cast<f32x4*>(y + i * 4) = acc;
     }
 }
@@ -904,9 +927,11 @@ int run_wprep(const float* w, float* wp, int M, int C, int Mp, int Cp, int taps,
 }
 
 // forward-type gather producing `mout` channels from `cin` channels
+struct Epilogue { const float* bias; int act; float slope, scale; };
+
 int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int H, int W,
                int mout, int OH, int OW, int YH, int YW, int oys, int oxs, int ks, int stride, int pad, int64_t sm,
-               int64_t sc, int flip, float alpha, hipStream_t s) {
+               int64_t sc, int flip, float alpha, hipStream_t s, Epilogue ep = Epilogue{nullptr, 0, 0.0f, 1.0f}) {
     const GatherPlan g = gather_plan(N, cin, mout, OH, OW, ks, stride, oys != 1 || oxs != 1);
     if (!ws || ws_floats < g.ws_floats)
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)g.ws_floats);
@@ -915,6 +940,7 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     p.N = N; p.C = cin; p.H = H; p.W = W; p.M = mout; p.OH = OH; p.OW = OW; p.YH = YH; p.YW = YW;
     p.oys = oys; p.oxs = oxs; p.Cp = g.Cp; p.Mp = g.Mp; p.pad = pad;
     p.slab_stride = g.out_floats4;
+    if (g.ksplit == 1) { p.bias = ep.bias; p.act = ep.act; p.act_slope = ep.slope; p.act_scale = ep.scale; }
     float* out = (g.ksplit > 1) ? ws + g.wp_floats : y;
     int rc;
     if (ks == 3 && stride == 1) rc = launch_igemm<3, 1>(x, ws, out, p, g, s);
@@ -930,7 +956,8 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
         if (blocks > 4096) blocks = 4096;
         if (n4 > 0)
             hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s,
-                               (const float*)out, y, n4, g.out_floats4, g.ksplit);
+                               (const float*)out, y, n4, g.out_floats4, g.ksplit, ep.bias, ep.act, ep.slope, ep.scale,
+                               OH * OW, mout);
     }
     return SAE_OK;
 }
@@ -953,16 +980,18 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
     p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
     p.QH = (OH + pad - 1) / 2 + 1;
     p.QW = (OW + pad - 1) / 2 + 1;
-    {   // tile = tn x th x tw q-positions minimising the number of workgroups (each costs bq lanes of MFMA work)
+    {   // tile = tn x th x tw q-positions: fewest workgroups (each costs bq lanes of MFMA work), with a
+        // penalty for narrow rows (short global-memory runs: a 9-wide tile measured no faster than a
+        // 32-wide one with 12 % more workgroups)
         const int cap = (25 * sh.bq) / 16;
-        int64_t best = -1;
+        double best = -1.0;
         for (int tw = 4; tw <= 32; ++tw)
             for (int th = 1; th * tw <= sh.bq; ++th) {
                 int tn = sh.bq / (tw * th);
                 if (tn > N) tn = N;
                 if (tn * (th + 1) * (tw + 1) > cap) continue;
-                const int64_t cost = (int64_t)ceil_div(p.QW, tw) * ceil_div(p.QH, th) * ceil_div(N, tn);
-                if (best < 0 || cost < best || (cost == best && tw > p.tw)) {
+                const double cost = (double)ceil_div(p.QW, tw) * ceil_div(p.QH, th) * ceil_div(N, tn) * (1.0 + 8.0 / tw);
+                if (best < 0 || cost < best) {
                     best = cost; p.tw = tw; p.th = th; p.tn = tn;
                 }
             }
@@ -1025,6 +1054,20 @@ extern "C" int sae_conv2d_fwd_f32(const float* x, const float* w, float* y, cons
                         d->w_stride_m, d->w_stride_c, 0, alpha, s);
     if (rc != SAE_OK) return rc;
     return check_launch("sae_conv2d_fwd_f32");
+}
+
+extern "C" int sae_conv2d_fwd_bias_act_f32(const float* x, const float* w, const float* bias, float* y,
+                                           const sae_conv2d_desc* d, float alpha, float act_slope, float act_scale,
+                                           float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    if (!desc_ok(d, "sae_conv2d_fwd_bias_act_f32")) return SAE_EINVAL;
+    if (d->n == 0) return SAE_OK;
+    if (!x || !w || !y) return fail(SAE_EINVAL, "sae_conv2d_fwd_bias_act_f32: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = run_gather(x, w, y, workspace, workspace_floats, (int)d->n, (int)d->c, (int)d->h, (int)d->w, (int)d->m,
+                        (int)d->oh, (int)d->ow, (int)d->oh, (int)d->ow, 1, 1, d->kh, d->stride, d->pad,
+                        d->w_stride_m, d->w_stride_c, 0, alpha, s, Epilogue{bias, 1, act_slope, act_scale});
+    if (rc != SAE_OK) return rc;
+    return check_launch("sae_conv2d_fwd_bias_act_f32");
 }
 
 extern "C" int sae_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,

@@ -190,10 +190,12 @@ void launch_blur(const float* x, const float* k, float* y, BlurParams p, hipStre
 template <int KH, int KW>
 void dispatch_blur(const float* x, const float* k, float* y, const BlurParams& p, hipStream_t s) {
     // tile width from the output width, rows-per-thread from the output height
-    // tuning knob (benchmarks only): SAE_BLUR_RB=8 selects 8 rows per thread for wide planes
+    // tuning knob (benchmarks only): SAE_BLUR_RB=16 selects 16 rows per thread for wide planes
     static const int rb_knob = [] { const char* e = getenv("SAE_BLUR_RB"); return e ? atoi(e) : 0; }();
     if (p.out_w > 32) {
-        if (p.out_h >= 16 && rb_knob == 8) launch_blur<KH, KW, 64, 8>(x, k, y, p, s);
+        // 8 rows per thread: 67 VGPRs -> 7 waves/SIMD; measured 3.5-4.0 TB/s vs 2.9-3.5 TB/s with 16 rows
+        // (fewer LDS reads per output but half the waves in flight) on 256x256..257x257 planes
+        if (p.out_h >= 16 && rb_knob != 16) launch_blur<KH, KW, 64, 8>(x, k, y, p, s);
         else if (p.out_h >= 16) launch_blur<KH, KW, 64, 16>(x, k, y, p, s);
         else launch_blur<KH, KW, 64, 4>(x, k, y, p, s);
     } else if (p.out_w > 16) {

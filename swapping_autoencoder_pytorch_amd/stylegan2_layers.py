@@ -17,7 +17,8 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import rng
-from .stylegan2_op import FusedLeakyReLU, conv2d, conv_transpose2d, fused_leaky_relu, linear, upfirdn2d
+from .stylegan2_op import (FusedLeakyReLU, conv2d, conv2d_bias_act, conv_transpose2d, fused_leaky_relu, linear,
+                           upfirdn2d)
 
 
 def make_kernel(k):
@@ -298,6 +299,21 @@ class ConvLayer(nn.Sequential):
         if activate:
             layers.append(("Act", FusedLeakyReLU(out_channel) if bias else ScaledLeakyReLU(0.2)))
         super().__init__(OrderedDict(layers))
+        self._activated = activate
+
+    def forward(self, input):
+        """Same result as running the children in order; the Conv -> Act pair is ONE kernel (the
+        bias + leaky-ReLU sits in the conv's epilogue)."""
+        if not self._activated:
+            return super().forward(input)
+        for name, child in self.named_children():
+            if name in ("Blur", "RefPad"):
+                input = child(input)
+        conv, act = self.Conv, self.Act
+        bias = act.bias if isinstance(act, FusedLeakyReLU) else None
+        act_scale = act.scale if isinstance(act, FusedLeakyReLU) else math.sqrt(2)
+        return conv2d_bias_act(input, conv.weight, bias, stride=conv.stride, padding=conv.padding, alpha=conv.scale,
+                               negative_slope=act.negative_slope, scale=act_scale)
 
 
 class ResBlock(nn.Module):

@@ -127,6 +127,42 @@ class ConvWeightGrad(Function):
         return g_x, g_gy, None
 
 
+class ConvBiasAct(Function):
+    """lrelu(alpha * conv(x, w) + bias) * scale in ONE kernel (the activation rides in the MFMA
+    kernel's epilogue): replaces the Conv -> FusedLeakyReLU pair of ConvLayer
+    (stylegan2_layers.py:642-659) and saves a full read + write of the activation tensor.  The
+    backward is the reference's: the activation gradient from the saved OUTPUT (fused_act.py:23-41),
+    then dgrad / wgrad of the conv — all differentiable again."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, geom, slope, scale):
+        lib = hip_lib.get()
+        x = x.contiguous()
+        w = w.contiguous()
+        bias_c = bias.contiguous() if bias is not None else None
+        lib.check(x, w, bias_c)
+        d = geom.desc()
+        n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)
+        ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
+        out = torch.empty((geom.n, geom.m, geom.oh, geom.ow), dtype=torch.float32, device=x.device)
+        lib.call("conv2d_fwd_bias_act_f32", x.data_ptr(), w.data_ptr(), hip_lib.ptr(bias_c), out.data_ptr(), C.byref(d),
+                 geom.alpha, float(slope), float(scale), ws.data_ptr(), n_ws, lib.stream(x))
+        ctx.cfg = (geom, slope, scale, bias is not None)
+        ctx.save_for_backward(x, w, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from .fused_act import FusedLeakyReLUFunctionBackward
+        x, w, out = ctx.saved_tensors
+        geom, slope, scale, has_bias = ctx.cfg
+        g_pre, g_bias = FusedLeakyReLUFunctionBackward.apply(gout, out, slope, scale)
+        gx = ConvDataGrad.apply(g_pre, w, geom) if ctx.needs_input_grad[0] else None
+        gw = ConvWeightGrad.apply(x, g_pre, geom) if ctx.needs_input_grad[1] else None
+        gb = g_bias if (has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb, None, None, None
+
+
 def _check_weight(weight):
     if weight.dim() != 4 or weight.shape[2] != weight.shape[3]:
         raise hip_lib.SaeError("conv weight must be [M, C, k, k], got %s" % (tuple(weight.shape),))
@@ -149,6 +185,19 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, alpha=1.0):
     if bias is not None:
         out = out + bias.view(1, -1, 1, 1)
     return out
+
+
+def conv2d_bias_act(input, weight, bias=None, stride=1, padding=0, alpha=1.0, negative_slope=0.2, scale=2 ** 0.5):
+    """fused_leaky_relu(conv2d(input, weight) * alpha, bias, negative_slope, scale) as one kernel."""
+    _check_weight(weight)
+    if stride not in (1, 2):
+        raise hip_lib.SaeError("MI355X conv kernels cover stride in {1, 2}; got %r" % (stride,))
+    n, c, h, w = input.shape
+    m, c2, k, _ = weight.shape
+    if c2 != c:
+        raise hip_lib.SaeError("conv2d: input has %d channels, weight expects %d" % (c, c2))
+    geom = _Geom(n, c, h, w, m, k, stride, padding, False, alpha)
+    return ConvBiasAct.apply(input, weight, bias, geom, negative_slope, scale)
 
 
 def conv_transpose2d(input, weight, stride=2, alpha=1.0):

@@ -94,6 +94,16 @@ def conv(lib, op, d, a, b, out_shape, alpha=1.0, device=None):
     return bo.numpy()
 
 
+def conv_bias_act(lib, d, x, w, bias, alpha=1.0, slope=0.2, scale=2 ** 0.5, device=None):
+    n = lib.query("conv2d_workspace", C.byref(d), 0)
+    bx, bw = _Buf(x, device), _Buf(w, device)
+    bb = _Buf(bias, device) if bias is not None else None
+    bo, ws = _out((d.n, d.m, d.oh, d.ow), device), _out((max(n, 1),), device)
+    lib.call("conv2d_fwd_bias_act_f32", bx.ptr, bw.ptr, bb.ptr if bb else None, bo.ptr, C.byref(d), alpha, slope, scale,
+             ws.ptr, n, _stream(device))
+    return bo.numpy()
+
+
 def gemm(lib, a, b, bias, m, n, k, a_si, a_sk, b_sk, b_sj, alpha=1.0, device=None):
     ba, bb = _Buf(a, device), _Buf(b, device)
     bbias = _Buf(bias, device) if bias is not None else None

@@ -105,3 +105,18 @@ def test_upsample2x(emu_lib, oracle_lib, shape):
     up = H.upsample2x_add(oracle_lib, x, None, 1.0).astype(np.float64)
     dn = H.upsample2x_bwd(oracle_lib, res, 1.0).astype(np.float64)
     assert abs((up * res).sum() - (x * dn).sum()) < 1e-4 * max(1.0, abs((up * res).sum()))
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 8, 32, 3, 1, 1), (1, 5, 17, 17, 40, 3, 2, 0), (2, 64, 8, 8, 40, 3, 1, 1),
+                                  (2, 33, 7, 7, 130, 1, 1, 0)], ids=str)
+def test_conv2d_bias_act(emu_lib, oracle_lib, case):
+    n, c, h, w, m, k, s, p = case
+    d = H.conv_desc(n, c, h, w, m, k, s, p)
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = rng.standard_normal((m, c, k, k)).astype(np.float32)
+    b = rng.standard_normal(m).astype(np.float32)
+    for bias in (b, None):
+        e = H.conv_bias_act(emu_lib, d, x, wt, bias, alpha=0.11, device=None)
+        o = H.conv_bias_act(oracle_lib, d, x, wt, bias, alpha=0.11)
+        assert H.rel_err(e, o) < TOL
