@@ -35,6 +35,8 @@
 // to the parameter layout (deterministic, no atomics).
 #include "sae_common.h"
 
+#include <cstdlib>
+
 namespace sae {
 namespace {
 
@@ -271,7 +273,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
 struct TrParams {
     int N, C, IH, IW;     // input tensor (the small, "y side" image)
     int M, OH, OW;        // output tensor (the large, "x side" image)
-    int QH, QW;           // half-resolution grid covered
+    int QH, QW;           // half-resolution grid covered by THIS launch: [qy_base, QH) x [qx_base, QW)
+    int qy_base, qx_base;
     int Cp, Mp;
     int pad;
     int tw, th, tn;       // q tile = TN images x TH x TW positions (any sizes with TN*TH*TW <= BQ: the
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
     const int tix = bt % p.tiles_x; bt /= p.tiles_x;
     const int tiy = bt % p.tiles_y;
     const int tin = bt / p.tiles_y;
-    const int qx0 = tix * TW, qy0 = tiy * TH, n0 = tin * TN;
+    const int qx0 = p.qx_base + tix * TW, qy0 = p.qy_base + tiy * TH, n0 = tin * TN;
     const int m0 = blockIdx.y * BM;
 
     const int PH = TH + 1, PW = TW + 1;          // patch row r <-> input row qy0 - 1 + r
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
     }
 
     const int n = n0 + pn, qy = qy0 + py, qx = qx0 + px;
-    if (lane_ok && n < p.N) {
+    if (lane_ok && n < p.N && qy < p.QH && qx < p.QW) {   // q beyond this launch's region belongs to another launch
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) {
             const int oy = 2 * qy + (cl >> 1) - p.pad;
@@ -494,7 +497,6 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     const int TN = PK >> (p.tw_log2 + p.th_log2);
     const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
     const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
-    const int HALFW = (PW + 1) >> 1;
     const int RS = PW;
     const int IP = PH * RS;
     const int CPs = TN * IP;
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         const int ky = t / KS, kx = t % KS;
-        tapoff[t] = (KS == 1) ? 0 : ky * RS + ((S == 2) ? (kx & 1) * HALFW + (kx >> 1) : kx);
+        tapoff[t] = (KS == 1) ? 0 : ky * RS + kx;
     }
 
     f32x16 acc[TA][TB][TT];
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
         const int ch = l31 / T, t = l31 - ch * T;
         const int ky = t / KS, kx = t % KS;
         pk_row = (ch < BB ? ch : BB - 1) * LP;
-        pk_tapoff = (KS == 1) ? 0 : ky * RS + ((S == 2) ? (kx & 1) * HALFW + (kx >> 1) : kx);
+        pk_tapoff = (KS == 1) ? 0 : ky * RS + kx;
     }
 
     const int ch_begin = slice * p.chunks_per_slice;
@@ -575,7 +577,8 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
                     const int r = rem / RS;
                     const int cl = rem - r * RS;
                     int c = cl;
-                    if (KS != 1 && S == 2) c = (cl < HALFW) ? 2 * cl : 2 * (cl - HALFW) + 1;
+                    // natural column order: lanes of a wgrad B-read differ in CHANNEL, not pixel, so the
+                    // stride-2 pixel walk causes no bank conflict and the global loads stay contiguous
                     int iy, ix;
                     if (KS == 1) { iy = (oy0 + r) * S - p.pad; ix = (ox0 + c) * S - p.pad; }
                     else { iy = oy0 * S - p.pad + r; ix = ox0 * S - p.pad + c; }
@@ -625,7 +628,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
             const int px = pk & (TW - 1);
             const int py = (pk >> p.tw_log2) & (TH - 1);
             const int pn = pk >> (p.tw_log2 + p.th_log2);
-            const int pbase = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px;
+            const int pbase = pn * IP + ((KS == 1) ? py * RS + px : py * S * RS + px * S);
 #pragma unroll
             for (int ta = 0; ta < TA; ++ta) a[ta] = Ss[((wa * TA + ta) * 32 + l31) * SLD + pk];
             if constexpr (PACKCT) {
@@ -765,7 +768,10 @@ inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 struct FwdShape { int cfg; int bm, bn; int ck; };   // cfg 0: 128x128, 1: 64x256, 2: 32x512
 FwdShape fwd_shape(int mout, int ks, int stride) {
     FwdShape s{};
-    if (mout > 64) { s.cfg = 0; s.bm = 128; s.bn = 128; }
+    // tuning knob (benchmarks only): SAE_IGEMM_WIDE=1 gives 3x3 stride-1 layers a 128 x 256 tile
+    static const int wide_knob = [] { const char* e = getenv("SAE_IGEMM_WIDE"); return e ? atoi(e) : 0; }();
+    if (mout > 64 && wide_knob && ks == 3 && stride == 1) { s.cfg = 3; s.bm = 128; s.bn = 256; }
+    else if (mout > 64) { s.cfg = 0; s.bm = 128; s.bn = 128; }
     else if (mout > 32 || stride == 2) { s.cfg = 1; s.bm = 64; s.bn = 256; }
     else { s.cfg = 2; s.bm = 32; s.bn = 512; }
     // channels per K-chunk: 3x3 -> 8 (72 k per chunk); 1x1 -> 32, 16 for the 512-pixel tile (LDS)
@@ -904,6 +910,13 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
     constexpr int CK = (KS == 1) ? 32 : 8;
     constexpr int CK2 = (KS == 1) ? 16 : 8;
     switch (sh.cfg) {
+        case 3:
+            if constexpr (KS == 3 && S == 1) {
+                hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 2, 4, 2, 2, 8>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                break;
+            } else {
+                return fail(SAE_EINVAL, "conv igemm: 128x256 tile is 3x3 stride-1 only");
+            }
         case 0: hipLaunchKernelGGL((conv_igemm_kernel<KS, S, 2, 2, 2, 2, CK>), grid, dim3(kBlock), 0, s, x, wp, y, p); break;
         case 1: hipLaunchKernelGGL((conv_igemm_kernel<KS, S, 2, 2, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, wp, y, p); break;
         default:
@@ -978,34 +991,53 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
     run_wprep(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s);
     TrParams p{};
     p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
-    p.QH = (OH + pad - 1) / 2 + 1;
-    p.QW = (OW + pad - 1) / 2 + 1;
-    {   // tile = tn x th x tw q-positions: fewest workgroups (each costs bq lanes of MFMA work), with a
+    const int QH = (OH + pad - 1) / 2 + 1, QW = (OW + pad - 1) / 2 + 1;
+    // The transposed problems of this network have 2^k + 1 wide q grids (129, 65, 33, ...): one
+    // launch with 32-wide tiles would spend 25 % (129) to 94 % (33) of its MFMAs on padding.  The
+    // grid is cut into a main region whose sides are multiples of the natural tile side plus thin
+    // right / bottom strips, each launched with its own best tile shape.
+    auto main_side = [](int q) {
+        int t = 32;
+        while (t > q) t >>= 1;
+        const int m = (q / t) * t;
+        return (q - m > 0 && (q - m) * 4 <= t && m > 0) ? m : q;    // split only a thin remainder
+    };
+    const int QHm = main_side(QH), QWm = main_side(QW);
+    struct Region { int y0, y1, x0, x1; };
+    Region regions[3];
+    int nreg = 0;
+    regions[nreg++] = {0, QHm, 0, QWm};
+    if (QWm < QW) regions[nreg++] = {0, QH, QWm, QW};          // right strip (full height)
+    if (QHm < QH) regions[nreg++] = {QHm, QH, 0, QWm};          // bottom strip
+    for (int r = 0; r < nreg; ++r) {
+        const int qh = regions[r].y1 - regions[r].y0, qw = regions[r].x1 - regions[r].x0;
+        p.qy_base = regions[r].y0; p.qx_base = regions[r].x0; p.QH = regions[r].y1; p.QW = regions[r].x1;
+        // tile = tn x th x tw q-positions: fewest workgroups (each costs bq lanes of MFMA work), with a
         // penalty for narrow rows (short global-memory runs: a 9-wide tile measured no faster than a
         // 32-wide one with 12 % more workgroups)
         const int cap = (25 * sh.bq) / 16;
         double best = -1.0;
-        for (int tw = 4; tw <= 32; ++tw)
+        for (int tw = 1; tw <= 32; ++tw)
             for (int th = 1; th * tw <= sh.bq; ++th) {
+                if (tw < 4 && tw < qw) continue;               // narrow tiles only for narrow strips
                 int tn = sh.bq / (tw * th);
                 if (tn > N) tn = N;
                 if (tn * (th + 1) * (tw + 1) > cap) continue;
-                const double cost = (double)ceil_div(p.QW, tw) * ceil_div(p.QH, th) * ceil_div(N, tn) * (1.0 + 8.0 / tw);
+                const double cost = (double)ceil_div(qw, tw) * ceil_div(qh, th) * ceil_div(N, tn) * (1.0 + 8.0 / (tw < qw ? tw : 32));
                 if (best < 0 || cost < best) {
                     best = cost; p.tw = tw; p.th = th; p.tn = tn;
                 }
             }
         if (best < 0) return fail(SAE_EINVAL, "conv tr: no tile fits the LDS patch cap");
-    }
-    const int tw = p.tw, th = p.th, tn = p.tn;
-    p.tiles_x = ceil_div(p.QW, tw);
-    p.tiles_y = ceil_div(p.QH, th);
-    p.tiles_n = ceil_div(N, tn);
-    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(Mp / sh.bm));
-    switch (sh.cfg) {
-        case 0: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 2, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
-        case 1: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
-        default: hipLaunchKernelGGL((conv_igemm_tr_kernel<1, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
+        p.tiles_x = ceil_div(qw, p.tw);
+        p.tiles_y = ceil_div(qh, p.th);
+        p.tiles_n = ceil_div(N, p.tn);
+        const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(Mp / sh.bm));
+        switch (sh.cfg) {
+            case 0: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 2, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
+            case 1: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
+            default: hipLaunchKernelGGL((conv_igemm_tr_kernel<1, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
+        }
     }
     return SAE_OK;
 }

@@ -35,6 +35,8 @@ CONV_SMALL = [
     # long K, few tiles: exercises the split-K (blockIdx.z) path of forward and stride-1 dgrad
     (2, 64, 8, 8, 40, 3, 1, 1, False), (1, 72, 9, 9, 40, 3, 2, 0, False), (1, 256, 4, 4, 40, 1, 1, 0, False),
     (2, 40, 6, 6, 70, 3, 1, 1, False),
+    # stride-2 dgrad with 2^k + 1 wide half-resolution grids: main region + right/bottom strips
+    (1, 4, 67, 67, 12, 3, 2, 0, False), (2, 4, 35, 67, 12, 3, 2, 0, False), (1, 4, 131, 35, 40, 3, 2, 0, False),
     # narrow layers: wgrad MODE 1 (M, C <= 32) and MODE 2 (C * taps <= 32, RGB stems)
     (3, 20, 12, 12, 24, 3, 1, 1, False), (2, 3, 16, 16, 40, 3, 1, 1, False), (2, 3, 9, 9, 20, 3, 2, 0, False),
     (2, 3, 8, 8, 70, 1, 1, 0, False), (1, 30, 15, 15, 36, 1, 2, 0, False),
