@@ -148,6 +148,10 @@ int sae_upsample2x_bilinear_add_f32(const float* x, const float* res, float* y, 
 int sae_upsample2x_bilinear_bwd_f32(const float* gy, float* gx, int64_t planes, int64_t h, int64_t w,
                                     float alpha, sae_stream_t stream);
 
+/* Residual merge y = alpha * (a + b): the (out + skip) / sqrt(2) of ResBlock (stylegan2_layers.py:689)
+ * and of the generator's resolution-preserving block (generator.py:36) as one elementwise pass. */
+int sae_add_scale_f32(const float* a, const float* b, float* y, int64_t numel, float alpha, sae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -380,3 +380,11 @@ int oracle_conv2d_fwd_bias_act_f32(const float* x, const float* w, const float* 
     int64_t hw = d->oh * d->ow;
     return oracle_bias_act_f32(y, bias, NULL, y, d->n * d->m * hw, hw, d->m, 3, 0, act_slope, act_scale, stream);
 }
+
+/* (out + skip) / sqrt(2), stylegan2_layers.py:689 / generator.py:36, as alpha * (a + b) in float. */
+int oracle_add_scale_f32(const float* a, const float* b, float* y, int64_t numel, float alpha, sae_stream_t stream) {
+    (void)stream;
+    if (numel < 0 || (numel > 0 && (!a || !b || !y))) return SAE_EINVAL;
+    for (int64_t i = 0; i < numel; ++i) y[i] = (a[i] + b[i]) * alpha;
+    return SAE_OK;
+}

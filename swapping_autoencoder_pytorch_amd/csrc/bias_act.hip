@@ -299,3 +299,43 @@ extern "C" int sae_bias_act_bwd_f32(const float* gy, const float* y_ref, float* 
                        dim3(kBlock), 0, s, (const float*)workspace, gb, size_b, p.q_count);
     return check_launch("sae_bias_act_bwd_f32");
 }
+
+
+// ---- residual merge: y = alpha * (a + b)  (ResBlock / generator blocks: (out + skip) / sqrt(2),
+// stylegan2_layers.py:689, generator.py:36) in one pass instead of an add and a divide ----------
+namespace sae {
+namespace {
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void add_scale_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ y, int64_t nvec, float alpha) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t v = (int64_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+        if constexpr (VEC == 4) {
+            const f32x4 x = reinterpret_cast<const f32x4*>(a)[v];
+            const f32x4 z = reinterpret_cast<const f32x4*>(b)[v];
+            reinterpret_cast<f32x4*>(y)[v] = (x + z) * alpha;
+        } else {
+            y[v] = (a[v] + b[v]) * alpha;
+        }
+    }
+}
+}  // namespace
+}  // namespace sae
+
+extern "C" int sae_add_scale_f32(const float* a, const float* b, float* y, int64_t numel, float alpha,
+                                 sae_stream_t stream) {
+    if (numel < 0) return fail(SAE_EINVAL, "sae_add_scale_f32: negative size");
+    if (numel == 0) return SAE_OK;
+    if (!a || !b || !y) return fail(SAE_EINVAL, "sae_add_scale_f32: null tensor");
+    const bool vec4 = numel % 4 == 0 && aligned16(a) && aligned16(b) && aligned16(y);
+    const int64_t nvec = vec4 ? numel / 4 : numel;
+    int64_t blocks = ceil_div64(nvec, kBlock);
+    if (blocks > 16384) blocks = 16384;
+    if (vec4)
+        hipLaunchKernelGGL((add_scale_kernel<4>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, b, y,
+                           nvec, alpha);
+    else
+        hipLaunchKernelGGL((add_scale_kernel<1>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, a, b, y,
+                           nvec, alpha);
+    return check_launch("sae_add_scale_f32");
+}

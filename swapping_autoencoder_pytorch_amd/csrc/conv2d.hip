@@ -826,7 +826,9 @@ WgPlan wg_plan(const sae_conv2d_desc* d) {
     w.Ap = round_up((int)d->m, w.sh.ba);
     w.Bp = round_up((int)d->c, w.sh.bb);
     const int mn_tiles = (w.Ap / w.sh.ba) * (w.Bp / w.sh.bb);
-    int slices = ceil_div(512, mn_tiles);
+    // MODE 0 runs one workgroup per CU (register prefetch): one full wave of 256 workgroups; the
+    // narrow modes co-reside 2-3 per CU
+    int slices = ceil_div(w.sh.mode == 0 ? 256 : 512, mn_tiles);
     if (slices > w.chunks) slices = w.chunks;
     if (slices < 1) slices = 1;
     w.cps = ceil_div(w.chunks, slices);

@@ -51,6 +51,7 @@ _SIGNATURES = {
     "conv2d_dgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "conv2d_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "gemm_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _stream]),
+    "add_scale_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _f32, _stream]),
     "upsample2x_bilinear_add_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),
     "upsample2x_bilinear_bwd_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),
 }

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from .. import util
 from ..stylegan2_layers import ConvLayer, EqualLinear, ModulatedConv2d, StyledConv, ToRGB
-from ..stylegan2_op import linear, upsample2x_add
+from ..stylegan2_op import add_scale, linear, upsample2x_add
 from .base_network import BaseNetwork
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
@@ -38,7 +38,7 @@ class ResolutionPreservingResnetBlock(torch.nn.Module):
 
     def forward(self, x, style):
         res = self.conv2(self.conv1(x, style), style)
-        return (self.skip(x) + res) / math.sqrt(2)
+        return add_scale(self.skip(x), res, _INV_SQRT2)
 
 
 class UpsamplingResnetBlock(torch.nn.Module):

@@ -17,8 +17,8 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import rng
-from .stylegan2_op import (FusedLeakyReLU, conv2d, conv2d_bias_act, conv_transpose2d, fused_leaky_relu, linear,
-                           upfirdn2d)
+from .stylegan2_op import (FusedLeakyReLU, add_scale, conv2d, conv2d_bias_act, conv_transpose2d, fused_leaky_relu,
+                           linear, upfirdn2d)
 
 
 def make_kernel(k):
@@ -329,7 +329,7 @@ class ResBlock(nn.Module):
                               activate=False, bias=False)
 
     def forward(self, input):
-        return (self.conv2(self.conv1(input)) + self.skip(input)) / math.sqrt(2)
+        return add_scale(self.conv2(self.conv1(input)), self.skip(input), 1.0 / math.sqrt(2))
 
 
 class Discriminator(nn.Module):

@@ -3,7 +3,7 @@ names, models/networks/stylegan2_op/__init__.py:1-2) plus the dense conv / linea
 layer library is built on."""
 from .fused_act import FusedLeakyReLU, fused_leaky_relu
 from .upfirdn2d import upfirdn2d
-from .conv2d_gemm import conv2d, conv2d_bias_act, conv_transpose2d, linear
-from .upsample import upsample2x_add
+from .conv2d_gemm import conv2d, conv2d_bias_act, conv_transpose2d, input_grads_only, linear
+from .upsample import add_scale, upsample2x_add
 
-__all__ = ["FusedLeakyReLU", "fused_leaky_relu", "upfirdn2d", "conv2d", "conv2d_bias_act", "conv_transpose2d", "linear", "upsample2x_add"]
+__all__ = ["FusedLeakyReLU", "fused_leaky_relu", "upfirdn2d", "conv2d", "conv2d_bias_act", "conv_transpose2d", "input_grads_only", "linear", "upsample2x_add", "add_scale"]

@@ -22,6 +22,27 @@ from .. import hip_lib
 from ..hip_lib import SAE_CONV_DGRAD, SAE_CONV_FWD, SAE_CONV_WGRAD, ConvDesc
 
 
+class _Flags:
+    weight_grads = True
+
+
+class input_grads_only:
+    """Context manager: inside it, backward passes skip the WEIGHT gradients of convs / linears.
+
+    ``torch.autograd.grad(out, inputs=[image])`` prunes the weight-gradient branches of built-in
+    ops, but a custom ``Function`` only sees the static ``ctx.needs_input_grad`` and would launch a
+    wgrad kernel per layer whose result nobody reads.  The R1 penalty's first backward
+    (swapping_autoencoder_model.py:143-148,169-174) is exactly that case."""
+
+    def __enter__(self):
+        self._prev = _Flags.weight_grads
+        _Flags.weight_grads = False
+
+    def __exit__(self, *exc):
+        _Flags.weight_grads = self._prev
+        return False
+
+
 class _Geom:
     """Immutable description of one conv problem (forward orientation) + weight layout."""
     __slots__ = ("n", "c", "h", "w", "m", "k", "stride", "pad", "oh", "ow", "cm_layout", "alpha")
@@ -89,7 +110,7 @@ class ConvForward(Function):
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gx = ConvDataGrad.apply(gy, w, ctx.geom) if ctx.needs_input_grad[0] else None
-        gw = ConvWeightGrad.apply(x, gy, ctx.geom) if ctx.needs_input_grad[1] else None
+        gw = ConvWeightGrad.apply(x, gy, ctx.geom) if (ctx.needs_input_grad[1] and _Flags.weight_grads) else None
         return gx, gw, None
 
 
@@ -158,7 +179,7 @@ class ConvBiasAct(Function):
         geom, slope, scale, has_bias = ctx.cfg
         g_pre, g_bias = FusedLeakyReLUFunctionBackward.apply(gout, out, slope, scale)
         gx = ConvDataGrad.apply(g_pre, w, geom) if ctx.needs_input_grad[0] else None
-        gw = ConvWeightGrad.apply(x, g_pre, geom) if ctx.needs_input_grad[1] else None
+        gw = ConvWeightGrad.apply(x, g_pre, geom) if (ctx.needs_input_grad[1] and _Flags.weight_grads) else None
         gb = g_bias if (has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None, None
 
@@ -260,7 +281,7 @@ class MatMul(Function):
                 ga = MatMul.apply(gc, b, None, False, not tb, alpha)     # gc @ op(b)^T
             else:
                 ga = MatMul.apply(b, gc, None, tb, True, alpha)          # op(b) @ gc^T
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _Flags.weight_grads:
             if not tb:
                 gb = MatMul.apply(a, gc, None, not ta, False, alpha)     # op(a)^T @ gc
             else:

@@ -60,3 +60,30 @@ class Upsample2xAdjoint(Function):
 
 def upsample2x_add(x, res=None, alpha=1.0):
     return Upsample2xAdd.apply(x, res, alpha)
+
+
+class AddScale(Function):
+    """alpha * (a + b) in one pass: the residual merge ``(out + skip) / sqrt(2)`` of ResBlock
+    (stylegan2_layers.py:689) and of the generator's blocks (generator.py:36)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        lib = hip_lib.get()
+        a = a.contiguous()
+        b = b.contiguous()
+        lib.check(a, b)
+        if a.shape != b.shape:
+            raise hip_lib.SaeError("add_scale: shapes differ %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+        y = torch.empty_like(a)
+        lib.call("add_scale_f32", a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), float(alpha), lib.stream(a))
+        ctx.alpha = alpha
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        g = gy * ctx.alpha          # one pass; both inputs receive the same tensor
+        return (g if ctx.needs_input_grad[0] else None), (g if ctx.needs_input_grad[1] else None), None
+
+
+def add_scale(a, b, alpha):
+    return AddScale.apply(a, b, alpha)

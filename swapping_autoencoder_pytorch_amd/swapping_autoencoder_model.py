@@ -10,6 +10,7 @@ import torch
 
 from . import loss, util
 from . import networks
+from .stylegan2_op import input_grads_only
 
 
 class SwappingAutoencoderModel(torch.nn.Module):
@@ -84,18 +85,29 @@ class SwappingAutoencoderModel(torch.nn.Module):
         if self.opt.lambda_GAN == 0.0:
             return {}
         lam = self.opt.lambda_GAN
+        # one pass over the concatenated batch instead of three (D has no cross-sample statistics,
+        # so the per-sample predictions are unchanged): fewer, larger launches, and the three
+        # weight-gradient accumulations of every layer become one
+        pred_real, pred_rec, pred_mix = torch.split(self.D(torch.cat([real, rec, mix], 0)),
+                                                    [real.size(0), rec.size(0), mix.size(0)])
         return {
-            "D_real": loss.gan_loss(self.D(real), should_be_classified_as_real=True) * lam,
-            "D_rec": loss.gan_loss(self.D(rec), should_be_classified_as_real=False) * (0.5 * lam),
-            "D_mix": loss.gan_loss(self.D(mix), should_be_classified_as_real=False) * (0.5 * lam),
+            "D_real": loss.gan_loss(pred_real, should_be_classified_as_real=True) * lam,
+            "D_rec": loss.gan_loss(pred_rec, should_be_classified_as_real=False) * (0.5 * lam),
+            "D_mix": loss.gan_loss(pred_mix, should_be_classified_as_real=False) * (0.5 * lam),
         }
 
     def compute_patch_discriminator_losses(self, real, mix):
         """:95-114 (crop order: reference patches, target patches, mix patches)"""
         agg = self.opt.patch_use_aggregation
-        real_feat = self.Dpatch.extract_features(self.get_random_crops(real), aggregate=agg)
-        target_feat = self.Dpatch.extract_features(self.get_random_crops(real))
-        mix_feat = self.Dpatch.extract_features(self.get_random_crops(mix))
+        # crops are drawn in the reference's order (reference patches, target patches, mix patches),
+        # then the three feature extractions run as one pass over the concatenated crops
+        crops = [self.get_random_crops(real), self.get_random_crops(real), self.get_random_crops(mix)]
+        b, t = crops[0].shape[:2]
+        feats = self.Dpatch.extract_features(torch.cat(crops, 0))
+        real_feat, target_feat, mix_feat = torch.split(feats, [c.size(0) * t for c in crops])
+        if agg:   # extract_features(aggregate=True): mean over the crops of an image (patch_discriminator.py:155-157)
+            real_feat = real_feat.view(b, t, *real_feat.shape[1:]).mean(1, keepdim=True)
+            real_feat = real_feat.expand(-1, t, -1, -1, -1).flatten(0, 1)
         lam = self.opt.lambda_PatchGAN
         return {
             "PatchD_real": loss.gan_loss(self.Dpatch.discriminate_features(real_feat, target_feat), True) * lam,
@@ -123,7 +135,8 @@ class SwappingAutoencoderModel(torch.nn.Module):
         if opt.lambda_R1 > 0.0:
             real.requires_grad_()
             pred_real = self.D(real).sum()
-            grad_real, = torch.autograd.grad(outputs=pred_real, inputs=[real], create_graph=True, retain_graph=True)
+            with input_grads_only():     # only d(pred)/d(image) is asked for: no weight-gradient kernels
+                grad_real, = torch.autograd.grad(outputs=pred_real, inputs=[real], create_graph=True, retain_graph=True)
             grad_penalty = grad_real.pow(2).sum(list(range(1, grad_real.ndim))) * (opt.lambda_R1 * 0.5)
         else:
             grad_penalty = 0.0
@@ -134,8 +147,9 @@ class SwappingAutoencoderModel(torch.nn.Module):
             real_feat = self.Dpatch.extract_features(real_crop, aggregate=opt.patch_use_aggregation)
             target_feat = self.Dpatch.extract_features(target_crop)
             pred = self.Dpatch.discriminate_features(real_feat, target_feat).sum()
-            g_real, g_target = torch.autograd.grad(outputs=pred, inputs=[real_crop, target_crop], create_graph=True,
-                                                   retain_graph=True)
+            with input_grads_only():
+                g_real, g_target = torch.autograd.grad(outputs=pred, inputs=[real_crop, target_crop], create_graph=True,
+                                                       retain_graph=True)
             dims = list(range(1, g_real.ndim))
             grad_crop_penalty = (g_real.pow(2).sum(dims) + g_target.pow(2).sum(dims)) * (0.5 * opt.lambda_patch_R1 * 0.5)
         else:
@@ -163,8 +177,9 @@ class SwappingAutoencoderModel(torch.nn.Module):
         mix = self.G(sp_mix, gl)
 
         if opt.lambda_GAN > 0.0:
-            losses["G_GAN_rec"] = loss.gan_loss(self.D(rec), True) * (opt.lambda_GAN * 0.5)
-            losses["G_GAN_mix"] = loss.gan_loss(self.D(mix), True) * (opt.lambda_GAN * 1.0)
+            pred_rec, pred_mix = torch.split(self.D(torch.cat([rec, mix], 0)), [rec.size(0), mix.size(0)])
+            losses["G_GAN_rec"] = loss.gan_loss(pred_rec, True) * (opt.lambda_GAN * 0.5)
+            losses["G_GAN_mix"] = loss.gan_loss(pred_mix, True) * (opt.lambda_GAN * 1.0)
 
         if opt.lambda_PatchGAN > 0.0:
             real_feat = self.Dpatch.extract_features(self.get_random_crops(real),
