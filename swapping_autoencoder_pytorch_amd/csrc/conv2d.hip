@@ -472,8 +472,8 @@ template <int KS, int S, int TA, int TB, int WA, int WB, int MODE>
 __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restrict__ xl,
                                                             const float* __restrict__ gs,
                                                             float* __restrict__ slab, const WgradParams p) {
-    constexpr bool PIXSPLIT = MODE >= 1;
-    constexpr bool PACKCT = MODE == 2;
+    constexpr bool PIXSPLIT = MODE == 1 || MODE == 2;
+    constexpr bool PACKCT = MODE == 2;     // MODE 4 = MODE 0 with the operand double buffer forced on
     static_assert(PIXSPLIT ? (WA == 1 && WB == 1 && TA == 1 && TB == 1) : (WA * WB == 4), "wave arrangement");
     constexpr int T = KS * KS;
     constexpr int TT = PACKCT ? 1 : T;      // accumulator tap-tiles per (ta, tb)
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
         const int kp0 = PIXSPLIT ? wid : 0;
         // the stride-2 instantiation already sits at the register ceiling (80 prefetch + 144
         // accumulator registers): it keeps a single operand set
-        constexpr bool DOUBLE_BUFFER = !(KS == 3 && S == 2 && MODE == 0);
+        constexpr bool DOUBLE_BUFFER = (MODE == 4) || !(KS == 3 && S == 2 && MODE == 0);
         if constexpr (DOUBLE_BUFFER) {
             float a_even[TA], b_even[NB], a_odd[TA], b_odd[NB];
             fetch(kp0, a_even, b_even);
@@ -795,7 +795,8 @@ void pick_tile(int bn, int oh, int ow, int max_tw, int* tw_log2, int* th_log2) {
 struct TrShape { int cfg; int bm, bq; };   // cfg 0: 128 x 64q, 1: 64 x 128q, 2: 32 x 128q
 TrShape tr_shape(int mout) {
     TrShape s{};
-    if (mout > 64) { s.cfg = 0; s.bm = 128; s.bq = 64; }
+    static const int cfg_knob = [] { const char* e = getenv("SAE_TR_CFG"); return e ? atoi(e) : -1; }();
+    if (mout > 64 && cfg_knob != 1) { s.cfg = 0; s.bm = 128; s.bq = 64; }
     else if (mout > 32) { s.cfg = 1; s.bm = 64; s.bq = 128; }
     else { s.cfg = 2; s.bm = 32; s.bq = 128; }
     return s;
@@ -1162,7 +1163,11 @@ extern "C" int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
         } else if (w.sh.mode == 1) {
             launch_wgrad<3, 1, 1, 1, 1, 1, 1>(x, gy, workspace, p, w, s);
         } else if (d->kh == 3 && d->stride == 1) launch_wgrad<3, 1, 1, 1, 2, 2, 0>(x, gy, workspace, p, w, s);
-        else if (d->kh == 3) launch_wgrad<3, 2, 1, 1, 4, 1, 0>(x, gy, workspace, p, w, s);
+        else if (d->kh == 3) {
+            static const int db_knob = [] { const char* e = getenv("SAE_WGRAD_S2_DB"); return e ? atoi(e) : 0; }();
+            if (db_knob) launch_wgrad<3, 2, 1, 1, 4, 1, 4>(x, gy, workspace, p, w, s);
+            else launch_wgrad<3, 2, 1, 1, 4, 1, 0>(x, gy, workspace, p, w, s);
+        }
         else if (d->stride == 1) launch_wgrad<1, 1, 2, 2, 2, 2, 0>(x, gy, workspace, p, w, s);
         else launch_wgrad<1, 2, 2, 2, 2, 2, 0>(x, gy, workspace, p, w, s);
     }
