@@ -304,6 +304,22 @@ class ConvLayer(nn.Sequential):
     def forward(self, input):
         """Same result as running the children in order; the Conv -> Act pair is ONE kernel (the
         bias + leaky-ReLU sits in the conv's epilogue)."""
+        if "Blur" in self._modules and self.Conv.weight.shape[2] == 1 and self.Conv.stride == 2:
+            # skip path of a downsampling ResBlock: blur at full resolution, then a 1x1 conv that
+            # reads every other pixel (:627-634,:647-655).  Decimating inside upfirdn2d (down=2)
+            # computes only the pixels the conv reads: a quarter of the FIR work and traffic, and
+            # the conv becomes stride 1 on the small image.  Same values (same taps, same sums).
+            blur, conv = self.Blur, self.Conv
+            if blur.reflection:
+                input = blur.reflection_pad(input)
+            input = upfirdn2d(input, blur.kernel, up=1, down=2, pad=blur.pad)
+            if not self._activated:
+                return conv2d(input, conv.weight, bias=conv.bias, stride=1, padding=0, alpha=conv.scale)
+            act = self.Act
+            bias = act.bias if isinstance(act, FusedLeakyReLU) else None
+            act_scale = act.scale if isinstance(act, FusedLeakyReLU) else math.sqrt(2)
+            return conv2d_bias_act(input, conv.weight, bias, stride=1, padding=0, alpha=conv.scale,
+                                   negative_slope=act.negative_slope, scale=act_scale)
         if not self._activated:
             return super().forward(input)
         for name, child in self.named_children():
