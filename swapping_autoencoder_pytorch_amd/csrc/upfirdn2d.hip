@@ -28,6 +28,12 @@
 namespace sae {
 namespace {
 
+__device__ __forceinline__ int floor_div_i(int a, int b) {  // upfirdn2d_kernel.cu:18-26
+    int c = a / b;
+    if (c * b > a) c--;
+    return c;
+}
+
 struct BlurParams {
     int64_t planes;
     int in_h, in_w, out_h, out_w;
@@ -137,12 +143,6 @@ struct GenericParams {
     int64_t total;  // major * out_h * out_w * minor
 };
 
-__device__ __forceinline__ int floor_div_i(int a, int b) {  // upfirdn2d_kernel.cu:18-26
-    int c = a / b;
-    if (c * b > a) c--;
-    return c;
-}
-
 __global__ __launch_bounds__(kBlock) void upfirdn2d_generic_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ k,
                                                                    float* __restrict__ y,
@@ -175,6 +175,106 @@ __global__ __launch_bounds__(kBlock) void upfirdn2d_generic_kernel(const float* 
         }
         y[i] = v;
     }
+}
+
+// x2 decimation (up 1, down 2) and x2 zero-insertion upsampling (up 2, down 1) with <= 4x4 taps:
+// the pair that appears when the skip path of a downsampling block decimates inside the FIR
+// (forward = down 2, backward = up 2).  Same layout as the blur kernel: lanes own consecutive
+// OUTPUT columns, the input strip a thread row needs is staged to LDS once, per-output arithmetic
+// is upfirdn2d_kernel.cu:114-129 with compile-time up/down.
+struct UpDownParams {
+    int64_t planes;
+    int in_h, in_w, out_h, out_w;
+    int pad_x0, pad_y0;
+    int kh, kw;
+    int groups_per_plane, x_tiles;
+    int64_t groups;
+};
+
+template <int UP, int DOWN, int KH, int KW, int TW, int RB>
+__global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                        float* __restrict__ y, const UpDownParams p) {
+    constexpr int NR = kBlock / TW;
+    constexpr int SR = ((RB - 1) * DOWN + KH - 1) / UP + 1;     // upfirdn2d_kernel.cu:54-55
+    constexpr int SW = ((TW - 1) * DOWN + KW - 1) / UP + 1;
+    constexpr int SWP = SW | 1;
+    constexpr int NE = (SR * SW + TW - 1) / TW;
+    __shared__ float strip[NR][SR * SWP];
+    __shared__ float taps[KH * KW];
+
+    const int tx = threadIdx.x % TW;
+    const int tr = threadIdx.x / TW;
+    if (threadIdx.x < KH * KW) {
+        const int ky = threadIdx.x / KW, kx = threadIdx.x % KW;
+        float v = 0.0f;
+        if (ky < p.kh && kx < p.kw) v = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+        taps[threadIdx.x] = v;
+    }
+    const int64_t bid = blockIdx.x;
+    const int xt = (int)(bid % p.x_tiles);
+    const int64_t g = (bid / p.x_tiles) * NR + tr;
+    const bool live = g < p.groups;
+    const int64_t plane = live ? g / p.groups_per_plane : 0;
+    const int oy0 = live ? (int)(g - plane * p.groups_per_plane) * RB : 0;
+    const int ox0 = xt * TW;
+    const int tile_mid_y = oy0 * DOWN + UP - 1 - p.pad_y0;
+    const int tile_mid_x = ox0 * DOWN + UP - 1 - p.pad_x0;
+    const int tile_in_y = floor_div_i(tile_mid_y, UP);
+    const int tile_in_x = floor_div_i(tile_mid_x, UP);
+
+    const float* xp = x + plane * (int64_t)p.in_h * p.in_w;
+    float* sp = strip[tr];
+    float staged[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tx + i * TW;
+        const int r = e / SW, c = e - r * SW;
+        const int iy = tile_in_y + r, ix = tile_in_x + c;
+        float v = 0.0f;
+        if (live && e < SR * SW && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = xp[(int64_t)iy * p.in_w + ix];
+        staged[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int e = tx + i * TW;
+        const int r = e / SW, c = e - r * SW;
+        if (e < SR * SW) sp[r * SWP + c] = staged[i];
+    }
+    __syncthreads();
+
+    const int mid_x = tile_mid_x + tx * DOWN;
+    const int in_x = floor_div_i(mid_x, UP);
+    const int rel_x = in_x - tile_in_x;
+    const int kx0 = (in_x + 1) * UP - mid_x - 1;
+    const int ox = ox0 + tx;
+    float* yp = y + plane * (int64_t)p.out_h * p.out_w;
+#pragma unroll
+    for (int o = 0; o < RB; ++o) {
+        const int mid_y = tile_mid_y + o * DOWN;
+        const int in_y = floor_div_i(mid_y, UP);
+        const int rel_y = in_y - tile_in_y;
+        const int ky0 = (in_y + 1) * UP - mid_y - 1;
+        float v = 0.0f;
+#pragma unroll
+        for (int yy = 0; yy < (KH + UP - 1) / UP; ++yy)
+#pragma unroll
+            for (int xx = 0; xx < (KW + UP - 1) / UP; ++xx) {
+                const int ky = ky0 + yy * UP, kx = kx0 + xx * UP;
+                if (ky < KH && kx < KW) v = fmaf(sp[(rel_y + yy) * SWP + rel_x + xx], taps[ky * KW + kx], v);
+            }
+        const int oy = oy0 + o;
+        if (live && ox < p.out_w && oy < p.out_h) yp[(int64_t)oy * p.out_w + ox] = v;
+    }
+}
+
+template <int UP, int DOWN, int TW, int RB>
+void launch_updown(const float* x, const float* k, float* y, UpDownParams p, hipStream_t s) {
+    constexpr int NR = kBlock / TW;
+    p.groups_per_plane = ceil_div(p.out_h, RB);
+    p.x_tiles = ceil_div(p.out_w, TW);
+    p.groups = p.planes * p.groups_per_plane;
+    const int64_t blocks = ceil_div64(p.groups, NR) * p.x_tiles;
+    hipLaunchKernelGGL((updown_kernel<UP, DOWN, 4, 4, TW, RB>), dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, p);
 }
 
 template <int KH, int KW, int TW, int RB>
@@ -242,6 +342,21 @@ extern "C" int sae_upfirdn2d_f32(const float* x, const float* k, float* y, int64
         else if (kh <= 3 && kw <= 3) dispatch_blur<3, 3>(x, k, y, p, s);
         else dispatch_blur<4, 4>(x, k, y, p, s);
         return check_launch("sae_upfirdn2d_f32(blur)");
+    }
+    const bool is_x2 = minor == 1 && kh <= 4 && kw <= 4 && up_x == up_y && down_x == down_y &&
+                       ((up_x == 1 && down_x == 2) || (up_x == 2 && down_x == 1));
+    if (is_x2) {
+        UpDownParams p{};
+        p.planes = major;
+        p.in_h = (int)in_h; p.in_w = (int)in_w; p.out_h = (int)out_h; p.out_w = (int)out_w;
+        p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
+        const bool wide = out_w > 16;
+        if (down_x == 2) {
+            if (wide) launch_updown<1, 2, 64, 8>(x, k, y, p, s); else launch_updown<1, 2, 16, 4>(x, k, y, p, s);
+        } else {
+            if (wide) launch_updown<2, 1, 64, 8>(x, k, y, p, s); else launch_updown<2, 1, 16, 4>(x, k, y, p, s);
+        }
+        return check_launch("sae_upfirdn2d_f32(x2)");
     }
     GenericParams g{};
     g.major = major; g.minor = minor;

@@ -18,6 +18,11 @@ UPFIRDN_SMALL = [
     ((2, 9, 7, 1), (5, 5), (1, 1), (1, 1), (2, 2, 2, 2)),        # > 4 taps (reference: uninitialised)
     ((2, 9, 7, 1), (3, 4), (2, 1), (1, 3), (2, 0, 1, 1)),        # anisotropic everything
     ((3, 130, 40, 1), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2)),
+    # x2 decimation / upsampling tile kernel: the skip-path pair (forward down 2, backward up 2)
+    ((3, 64, 64, 1), (4, 4), (1, 1), (2, 2), (1, 1, 1, 1)), ((3, 32, 32, 1), (4, 4), (2, 2), (1, 1), (2, 2, 2, 2)),
+    ((5, 37, 70, 1), (4, 4), (1, 1), (2, 2), (1, 1, 1, 1)), ((5, 19, 35, 1), (4, 4), (2, 2), (1, 1), (2, 3, 2, 3)),
+    ((7, 9, 9, 1), (3, 3), (1, 1), (2, 2), (0, 0, 0, 0)), ((7, 4, 4, 1), (3, 3), (2, 2), (1, 1), (2, 2, 2, 2)),
+    ((2, 257, 257, 1), (3, 3), (1, 1), (2, 2), (0, 0, 0, 0)),
 ]
 
 BIAS_ACT_SHAPES = [(2, 8, 16, 16), (3, 5, 7, 7), (4, 16), (2, 4, 33, 31), (2, 3, 32, 32), (5, 6, 20, 20)]
