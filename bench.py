@@ -73,6 +73,19 @@ class DominantKernelTimer:
             return out
 
         cg._launch = launch
+        orig_fused = cg._launch_fused
+
+        def launch_fused(geom, x, w, bias, slope, scale):     # forward with the fused bias + leaky-ReLU epilogue
+            if not (timer.active and geom.k == 3 and geom.stride == 1 and geom.m > 64):
+                return orig_fused(geom, x, w, bias, slope, scale)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_fused(geom, x, w, bias, slope, scale)
+            e1.record()
+            timer.records.append((2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9, e0, e1))
+            return out
+
+        cg._launch_fused = launch_fused
 
     def summary(self):
         if not self.records:

@@ -85,6 +85,21 @@ def _launch(name, op, geom, a, b, out_shape):
     return out
 
 
+def _launch_fused(geom, x, w, bias, slope, scale):
+    lib = hip_lib.get()
+    x = x.contiguous()
+    w = w.contiguous()
+    bias = bias.contiguous() if bias is not None else None
+    lib.check(x, w, bias)
+    d = geom.desc()
+    n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
+    out = torch.empty((geom.n, geom.m, geom.oh, geom.ow), dtype=torch.float32, device=x.device)
+    lib.call("conv2d_fwd_bias_act_f32", x.data_ptr(), w.data_ptr(), hip_lib.ptr(bias), out.data_ptr(), C.byref(d),
+             geom.alpha, float(slope), float(scale), ws.data_ptr(), n_ws, lib.stream(x))
+    return out
+
+
 def _fwd(x, w, g):
     return _launch("conv2d_fwd_f32", SAE_CONV_FWD, g, x, w, (g.n, g.m, g.oh, g.ow))
 
@@ -157,17 +172,7 @@ class ConvBiasAct(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, geom, slope, scale):
-        lib = hip_lib.get()
-        x = x.contiguous()
-        w = w.contiguous()
-        bias_c = bias.contiguous() if bias is not None else None
-        lib.check(x, w, bias_c)
-        d = geom.desc()
-        n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)
-        ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
-        out = torch.empty((geom.n, geom.m, geom.oh, geom.ow), dtype=torch.float32, device=x.device)
-        lib.call("conv2d_fwd_bias_act_f32", x.data_ptr(), w.data_ptr(), hip_lib.ptr(bias_c), out.data_ptr(), C.byref(d),
-                 geom.alpha, float(slope), float(scale), ws.data_ptr(), n_ws, lib.stream(x))
+        out = _launch_fused(geom, x, w, bias, slope, scale)
         ctx.cfg = (geom, slope, scale, bias is not None)
         ctx.save_for_backward(x, w, out)
         return out
