@@ -433,20 +433,29 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
         return;
     }
     if (lane_ok && n < p.N && qy < p.QH && qx < p.QW) {   // q beyond this launch's region belongs to another launch
+        // the two x-classes of a lane are horizontally adjacent output pixels (ox, ox + 1): store them as
+        // one 8-byte access (4-byte aligned: the 2^k + 1 wide rows rule out more), so a half-wave writes a
+        // contiguous 256-byte run instead of two interleaved stride-2 scatters
+        struct __attribute__((packed, aligned(4))) Pair { float a, b; };
+        const int ox = 2 * qx - p.pad;
 #pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
-            const int oy = 2 * qy + (cl >> 1) - p.pad;
-            const int ox = 2 * qx + (cl & 1) - p.pad;
-            if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
-                float* yb = y + ((int64_t)n * p.M * p.OH + oy) * p.OW + ox;
+        for (int ey = 0; ey < 2; ++ey) {
+            const int oy = 2 * qy + ey - p.pad;
+            if (oy < 0 || oy >= p.OH) continue;
+            float* yb = y + ((int64_t)n * p.M * p.OH + oy) * p.OW + ox;
+            const bool ok0 = ox >= 0 && ox < p.OW, ok1 = ox + 1 >= 0 && ox + 1 < p.OW;
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (m < p.M) yb[(int64_t)m * p.OH * p.OW] = acc[mi][cl][r];
-                    }
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m >= p.M) continue;
+                    float* dst = yb + (int64_t)m * p.OH * p.OW;
+                    const float v0 = acc[mi][2 * ey][r], v1 = acc[mi][2 * ey + 1][r];
+                    if (ok0 && ok1) *reinterpret_cast<Pair*>(dst) = Pair{v0, v1};
+                    else if (ok0) dst[0] = v0;
+                    else if (ok1) dst[1] = v1;
+                }
         }
     }
 }
@@ -781,9 +790,16 @@ FwdShape fwd_shape(int mout, int ks, int stride) {
     // tuning knob (benchmarks only): SAE_IGEMM_WIDE=1 gives 3x3 stride-1 layers a 128 x 256 tile
     static const int wide_knob = [] { const char* e = getenv("SAE_IGEMM_WIDE"); return e ? atoi(e) : 0; }();
     if (mout > 64 && wide_knob && ks == 3 && stride == 1) { s.cfg = 3; s.bm = 128; s.bn = 256; }
-    else if (mout > 64) { s.cfg = 0; s.bm = 128; s.bn = 128; }
+    else if (mout > 64 && round_up(mout, 64) * 100 >= round_up(mout, 128) * 92) { s.cfg = 0; s.bm = 128; s.bn = 128; }
+    else if (mout > 64) { s.cfg = 1; s.bm = 64; s.bn = 256; }    // e.g. 409 -> 448 instead of 512 padded rows
     else if (mout > 32 || stride == 2) { s.cfg = 1; s.bm = 64; s.bn = 256; }
-    else { s.cfg = 2; s.bm = 32; s.bn = 512; }
+    else {
+        // narrow layers (M <= 32).  SAE_IGEMM_NARROW=1 (tuning knob) selects a 32 x 256 tile at three
+        // workgroups per CU instead of 32 x 512 at one
+        static const int narrow_knob = [] { const char* e = getenv("SAE_IGEMM_NARROW"); return e ? atoi(e) : 0; }();
+        if (narrow_knob && ks == 3 && stride == 1) { s.cfg = 4; s.bm = 32; s.bn = 256; }
+        else { s.cfg = 2; s.bm = 32; s.bn = 512; }
+    }
     // channels per K-chunk: 3x3 -> 8 (72 k per chunk); 1x1 -> 32, 16 for the 512-pixel tile (LDS)
     s.ck = (ks == 1) ? (s.cfg == 2 ? 16 : 32) : 8;
     return s;
@@ -925,6 +941,13 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
     constexpr int CK = (KS == 1) ? 32 : 8;
     constexpr int CK2 = (KS == 1) ? 16 : 8;
     switch (sh.cfg) {
+        case 4:
+            if constexpr (KS == 3 && S == 1) {
+                hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 1, 2, 1, 4, 8>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                break;
+            } else {
+                return fail(SAE_EINVAL, "conv igemm: 32x256 tile is 3x3 stride-1 only");
+            }
         case 3:
             if constexpr (KS == 3 && S == 1) {
                 hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 2, 4, 2, 2, 8>), grid, dim3(kBlock), 0, s, x, wp, y, p);
