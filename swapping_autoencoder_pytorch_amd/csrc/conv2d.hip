@@ -433,29 +433,22 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
         return;
     }
     if (lane_ok && n < p.N && qy < p.QH && qx < p.QW) {   // q beyond this launch's region belongs to another launch
-        // the two x-classes of a lane are horizontally adjacent output pixels (ox, ox + 1): store them as
-        // one 8-byte access (4-byte aligned: the 2^k + 1 wide rows rule out more), so a half-wave writes a
-        // contiguous 256-byte run instead of two interleaved stride-2 scatters
-        struct __attribute__((packed, aligned(4))) Pair { float a, b; };
-        const int ox = 2 * qx - p.pad;
+        // (pairing the two x-classes of a lane into one 4-byte-aligned 8-byte store was measured
+        // slower, 87 vs 94 TFLOP/s: the rows are 2^k + 1 wide, so half of those stores are misaligned)
 #pragma unroll
-        for (int ey = 0; ey < 2; ++ey) {
-            const int oy = 2 * qy + ey - p.pad;
-            if (oy < 0 || oy >= p.OH) continue;
-            float* yb = y + ((int64_t)n * p.M * p.OH + oy) * p.OW + ox;
-            const bool ok0 = ox >= 0 && ox < p.OW, ok1 = ox + 1 >= 0 && ox + 1 < p.OW;
+        for (int cl = 0; cl < 4; ++cl) {
+            const int oy = 2 * qy + (cl >> 1) - p.pad;
+            const int ox = 2 * qx + (cl & 1) - p.pad;
+            if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
+                float* yb = y + ((int64_t)n * p.M * p.OH + oy) * p.OW + ox;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (m >= p.M) continue;
-                    float* dst = yb + (int64_t)m * p.OH * p.OW;
-                    const float v0 = acc[mi][2 * ey][r], v1 = acc[mi][2 * ey + 1][r];
-                    if (ok0 && ok1) *reinterpret_cast<Pair*>(dst) = Pair{v0, v1};
-                    else if (ok0) dst[0] = v0;
-                    else if (ok1) dst[1] = v1;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (m < p.M) yb[(int64_t)m * p.OH * p.OW] = acc[mi][cl][r];
+                    }
+            }
         }
     }
 }
@@ -794,9 +787,10 @@ FwdShape fwd_shape(int mout, int ks, int stride) {
     else if (mout > 64) { s.cfg = 1; s.bm = 64; s.bn = 256; }    // e.g. 409 -> 448 instead of 512 padded rows
     else if (mout > 32 || stride == 2) { s.cfg = 1; s.bm = 64; s.bn = 256; }
     else {
-        // narrow layers (M <= 32).  SAE_IGEMM_NARROW=1 (tuning knob) selects a 32 x 256 tile at three
-        // workgroups per CU instead of 32 x 512 at one
-        static const int narrow_knob = [] { const char* e = getenv("SAE_IGEMM_NARROW"); return e ? atoi(e) : 0; }();
+        // narrow layers (M <= 32).  a 32 x 256 tile at three workgroups per CU
+        // (SAE_IGEMM_NARROW=0, tuning knob: 32 x 512 at one)
+        // measured on 32->32 3x3 @128x128 B=128: 104 TFLOP/s (32 x 256) vs 81 (32 x 512)
+        static const int narrow_knob = [] { const char* e = getenv("SAE_IGEMM_NARROW"); return e ? atoi(e) : 1; }();
         if (narrow_knob && ks == 3 && stride == 1) { s.cfg = 4; s.bm = 32; s.bn = 256; }
         else { s.cfg = 2; s.bm = 32; s.bn = 512; }
     }
