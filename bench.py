@@ -173,9 +173,18 @@ def main():
     if not args.no_kernel_timing:
         timer.install()
 
+    call_ms = {"d": [], "g": []}
+
     def iteration(i):
+        # every train_one_step ends with a device->host copy of the losses (util.to_numpy, as in the
+        # reference), so host clocks around a call measure that call
+        t0 = time.perf_counter()
         optimizer.train_one_step({"real_A": pool[(2 * i) % 4]}, i)       # discriminator call
+        t1 = time.perf_counter()
         optimizer.train_one_step({"real_A": pool[(2 * i + 1) % 4]}, i)   # generator call
+        t2 = time.perf_counter()
+        call_ms["d"].append((t1 - t0) * 1e3)
+        call_ms["g"].append((t2 - t1) * 1e3)
 
     for i in range(args.warmup):
         iteration(i)
@@ -215,6 +224,13 @@ def main():
         if per_image:
             line["model_tflops_per_gpu"] = round(value / world * per_image / 1e12, 2)
             line["frac_of_mfma_f32_roofline"] = round(value / world * per_image / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+        d_calls = sorted(call_ms["d"][args.warmup:])
+        g_calls = sorted(call_ms["g"][args.warmup:])
+        if d_calls and g_calls:
+            # median D call (without the lazy R1 extra), median G call, and the R1 surcharge of the slowest D call
+            line["ms_d_call_median"] = round(d_calls[len(d_calls) // 2], 2)
+            line["ms_g_call_median"] = round(g_calls[len(g_calls) // 2], 2)
+            line["ms_r1_extra_max"] = round(d_calls[-1] - d_calls[len(d_calls) // 2], 2)
         roof = timer.summary()
         if roof:
             line["roofline"] = roof
