@@ -52,6 +52,20 @@ typedef void* sae_stream_t; /* hipStream_t */
 int sae_abi_version(void);
 const char* sae_last_error(void);
 
+/* Arithmetic of the 3x3 stride-1 convolution kernels (process-wide; initial value from the
+ * environment variable SAE_CONV_MATH = "f32" | "bf16x6").  Inputs, outputs and accumulation are
+ * fp32 in both modes.
+ *   SAE_CONV_MATH_F32     v_mfma_f32_32x32x2_f32, bitwise an fp32 fma chain (default; what
+ *                         F.conv2d computes in the reference, stylegan2_layers.py:136).
+ *   SAE_CONV_MATH_BF16X6  every operand split exactly into three bf16 pieces, the six leading
+ *                         cross products on v_mfma_f32_32x32x16_bf16 (dropped terms <= 2^-26
+ *                         relative); same error class against fp64 as the fp32 chain.
+ * sae_conv2d_workspace() depends on the mode: query it after switching. */
+#define SAE_CONV_MATH_F32 0
+#define SAE_CONV_MATH_BF16X6 1
+int sae_set_conv_math(int32_t mode);
+int sae_get_conv_math(void);
+
 /* ------------------------------------------------------------------------------------------
  * upfirdn2d: zero-insertion upsample -> pad/crop -> 2-D FIR (true convolution) -> decimate.
  * x: [major, in_h, in_w, minor]   k: [kh, kw] (row-major, as passed by the caller, NOT flipped)

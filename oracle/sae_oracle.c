@@ -41,6 +41,15 @@ static __thread char g_err[256];
 int oracle_abi_version(void) { return 1; }
 const char* oracle_last_error(void) { return g_err; }
 
+/* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
+static int g_conv_math = 0;
+int oracle_set_conv_math(int32_t mode) {
+    if (mode != 0 && mode != 1) return -1;
+    g_conv_math = mode;
+    return 0;
+}
+int oracle_get_conv_math(void) { return g_conv_math; }
+
 /* upfirdn2d_kernel.cu:18-26 */
 static inline int64_t floor_div(int64_t a, int64_t b) {
     int64_t c = a / b;

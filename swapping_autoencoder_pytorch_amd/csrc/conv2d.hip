@@ -267,6 +267,249 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// "bx" arithmetic (opt-in, sae_set_conv_math(1)): fp32 products on the bf16 matrix cores.
+//
+// Every fp32 operand is split exactly into three bf16 pieces a = a0 + a1 + a2 (round-to-nearest
+// residual chain: |a1| <= 2^-9 |a|, |a2| <= 2^-18 |a|, remainder <= 2^-27 |a|).  A product block is
+// six v_mfma_f32_32x32x16_bf16 (a0b2, a2b0, a1b1, a0b1, a1b0, a0b0; the three dropped cross terms are
+// <= 2^-26 |ab|) accumulated in fp32: measured error against fp64 equals the exact-fp32 MFMA chain
+// (5.0e-7 vs 6.0e-7 rel-L2 at K = 1152, tools/probe/bf16x6_probe.hip) at 6/16 of its matrix-pipe time.
+//
+// Layout: a 16-byte LDS/global cell holds the 8 channels of one K-chunk for one (tap, split, m) of A
+// or one (split, patch position) of B, i.e. exactly one lane's MFMA operand.  The 16 k of an
+// instruction are 8 channels x 2 taps (lanes 0-31 tap 2g, lanes 32-63 tap 2g+1); the ninth tap pairs
+// with an all-zero A cell.  Weights are split once per call by conv_wprep_bx_kernel into
+// wpb[m-tile][chunk][tap][split][m][8 ch], so A staging is a linear 16-byte copy; input patch
+// elements are split when they are written to LDS.
+// ------------------------------------------------------------------------------------------
+__device__ inline void split3_bf16(const float (&v)[8], bf16x8& s0, bf16x8& s1, bf16x8& s2) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 h = (__bf16)v[e];
+        float r = v[e] - (float)h;
+        const __bf16 m = (__bf16)r;
+        r -= (float)m;
+        s0[e] = h; s1[e] = m; s2[e] = (__bf16)r;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void conv_wprep_bx_kernel(const float* __restrict__ w,
+                                                               u32x4* __restrict__ wpb, int M, int C, int Mp,
+                                                               int Cp, int BM, int64_t sm, int64_t sc, int flip,
+                                                               float alpha) {
+    const int nchunks = Cp / 8;
+    const int64_t total = (int64_t)(Mp / BM) * nchunks * 9 * BM;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * kBlock) {
+        const int ml = (int)(i % BM);
+        int64_t t = i / BM;
+        const int tap = (int)(t % 9); t /= 9;
+        const int chunk = (int)(t % nchunks);
+        const int mtile = (int)(t / nchunks);
+        const int m = mtile * BM + ml;
+        float v[8];
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const int c = chunk * 8 + ch;
+            v[ch] = (m < M && c < C) ? alpha * w[m * sm + c * sc + (flip ? 8 - tap : tap)] : 0.0f;
+        }
+        bf16x8 s0, s1, s2;
+        split3_bf16(v, s0, s1, s2);
+        u32x4* cell = wpb + (((int64_t)mtile * nchunks + chunk) * 9 + tap) * 3 * BM + ml;
+        cell[0] = __builtin_bit_cast(u32x4, s0);
+        cell[BM] = __builtin_bit_cast(u32x4, s1);
+        cell[2 * BM] = __builtin_bit_cast(u32x4, s2);
+    }
+}
+
+template <int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(kBlock) void conv_igemm_bx_kernel(const float* __restrict__ x,
+                                                               const u32x4* __restrict__ wpb,
+                                                               float* __restrict__ y, const IgemmParams p) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int T = 9, CK = 8;
+    constexpr int BM = 32 * MI * WM;
+    constexpr int BN = 32 * NI * WN;
+    constexpr int XCAP = PatchCap<3, 1, BN>::value;
+    constexpr int PPT = (XCAP + kBlock - 1) / kBlock;      // patch positions per thread
+    constexpr int A_CELLS = T * 3 * BM;                     // 16-byte cells per A chunk
+    constexpr int APT = (A_CELLS + kBlock - 1) / kBlock;
+    __shared__ u32x4 As[A_CELLS + 1];                       // + the all-zero cell
+    __shared__ u32x4 Xs[3 * XCAP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+
+    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
+    const int TN = BN >> (p.tw_log2 + p.th_log2);
+    int bt = blockIdx.x;
+    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
+    const int tiy = bt % p.tiles_y;
+    const int tin = bt / p.tiles_y;
+    const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
+    const int m0 = blockIdx.y * BM;
+
+    const int PH = TH + 2, PW = TW + 2;
+    const int IP = PH * PW;
+    const int CP = TN * IP;           // staged positions (<= XCAP, checked on the host)
+    const int HW = p.H * p.W;
+
+    int poff[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int e = tid + kBlock * s;
+        int off = -1;
+        if (e < CP) {
+            const int pn = e / IP;
+            const int rem = e - pn * IP;
+            const int r = rem / PW;
+            const int c = rem - r * PW;
+            const int iy = oy0 - p.pad + r, ix = ox0 - p.pad + c;
+            if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                off = pn * p.C * HW + iy * p.W + ix;
+        }
+        poff[s] = off;
+    }
+
+    // per-lane LDS cell of each N-tile pixel; per-lane tap offset of each tap pair
+    int pixbase[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int pp = (wn * NI + ni) * 32 + l31;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> p.tw_log2) & (TH - 1);
+        const int pn = pp >> (p.tw_log2 + p.th_log2);
+        pixbase[ni] = pn * IP + py * PW + px;
+    }
+    int boff[5], aoff[5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        const int t = (g < 4) ? 2 * g + half : 8;
+        boff[g] = (t / 3) * PW + (t % 3);
+        aoff[g] = (g == 4 && half) ? A_CELLS : t * 3 * BM + wm * MI * 32 + l31;
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    const float* xb = x + (int64_t)n0 * p.C * HW;
+    const u32x4* wt = wpb + (int64_t)blockIdx.y * (p.Cp / CK) * A_CELLS;
+    float xv[CK][PPT];
+    u32x4 av[APT];
+
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch) {
+            const bool ch_ok = (c0 + ch) < p.C;
+            const float* xc = xb + (int64_t)(c0 + ch) * HW;
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) xv[ch][s] = (ch_ok && poff[s] >= 0) ? xc[poff[s]] : 0.0f;
+        }
+        const u32x4* wc = wt + (int64_t)(c0 / CK) * A_CELLS;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e = tid + kBlock * i;
+            if (e < A_CELLS) av[i] = wc[e];
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int e = tid + kBlock * s;
+            if (e < CP) {
+                float v[CK];
+#pragma unroll
+                for (int ch = 0; ch < CK; ++ch) v[ch] = xv[ch][s];
+                bf16x8 s0, s1, s2;
+                split3_bf16(v, s0, s1, s2);
+                Xs[e] = __builtin_bit_cast(u32x4, s0);
+                Xs[XCAP + e] = __builtin_bit_cast(u32x4, s1);
+                Xs[2 * XCAP + e] = __builtin_bit_cast(u32x4, s2);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e = tid + kBlock * i;
+            if (e < A_CELLS) As[e] = av[i];
+        }
+    };
+
+    if (tid == 0) As[A_CELLS] = u32x4{0u, 0u, 0u, 0u};
+    const int c_begin = blockIdx.z * p.chunks_per_split * CK;
+    int c_end = c_begin + p.chunks_per_split * CK;
+    if (c_end > p.Cp) c_end = p.Cp;
+    load_chunk(c_begin);
+    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
+        __syncthreads();   // everyone finished reading the previous chunk
+        store_chunk();
+        __syncthreads();
+        if (c0 + CK < c_end) load_chunk(c0 + CK);   // in flight under the MFMAs below
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            bf16x8 a[MI][3], b[NI][3];
+            // the zero cell has no split planes: its lanes read it for every split
+            const int astep = (g == 4 && half) ? 0 : BM;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    a[mi][sp] = __builtin_bit_cast(bf16x8, As[aoff[g] + sp * astep + ((g == 4 && half) ? 0 : mi * 32)]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    b[ni][sp] = __builtin_bit_cast(bf16x8, Xs[sp * XCAP + pixbase[ni] + boff[g]]);
+            // smallest terms first
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][TA[q]], b[ni][TB[q]],
+                                                                              acc[mi][ni], 0, 0, 0);
+        }
+    }
+
+    // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int pp = (wn * NI + ni) * 32 + l31;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> p.tw_log2) & (TH - 1);
+        const int pn = pp >> (p.tw_log2 + p.th_log2);
+        const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
+        if (n < p.N && oy < p.OH && ox < p.OW) {
+            float* yb = y + (int64_t)blockIdx.z * p.slab_stride +
+                        ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < p.M) {
+                        float v = acc[mi][ni][r];
+                        if (p.act) {
+                            if (p.bias) v += p.bias[m];
+                            v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
+                        }
+                        yb[(int64_t)m * p.YH * p.YW] = v;
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // stride-2 transposed gather ("tr"): out[m][o] = sum_{c,k : o + pad = 2 i + k} wp[k][c][m] * in[c][i]
 // 3x3 taps only.  N-tiles of a wave = the 4 parity classes of the same 32 q positions.
 // ------------------------------------------------------------------------------------------
@@ -886,6 +1129,7 @@ __global__ __launch_bounds__(kBlock) void conv_splitk_reduce_kernel(const float*
 // [ wp : taps*Cp*Mp ][ slabs : ksplit * round4(N*M*OH*OW) ]  (slabs only when ksplit > 1).
 struct GatherPlan {
     FwdShape sh; int Mp, Cp, taps; int tw_log2, th_log2, tiles_x, tiles_y, tiles_n; int ksplit, cps;
+    bool bx;   // bf16-split arithmetic (3x3 stride 1, 128x128 tile)
     int64_t wp_floats, out_floats4, ws_floats;
 };
 GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int stride, bool scatter) {
@@ -915,6 +1159,8 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
         }
     }
     g.wp_floats = (int64_t)g.taps * g.Cp * g.Mp;
+    g.bx = conv_math() == 1 && ks == 3 && stride == 1 && g.sh.cfg == 0;
+    if (g.bx) g.wp_floats = (int64_t)27 * g.Mp * (g.Cp / 8) * 4;   // 16-byte cells: [tap][split][m] per 8 channels
     g.out_floats4 = ((int64_t)N * mout * OH * OW + 3) / 4 * 4;
     g.ws_floats = g.wp_floats + (g.ksplit > 1 ? g.ksplit * g.out_floats4 : 0);
     return g;
@@ -934,6 +1180,13 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
     const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(p.Mp / sh.bm), (unsigned)g.ksplit);
     constexpr int CK = (KS == 1) ? 32 : 8;
     constexpr int CK2 = (KS == 1) ? 16 : 8;
+    if constexpr (KS == 3 && S == 1) {
+        if (g.bx) {
+            hipLaunchKernelGGL((conv_igemm_bx_kernel<2, 2, 2, 2>), grid, dim3(kBlock), 0, s, x,
+                               reinterpret_cast<const u32x4*>(wp), y, p);
+            return SAE_OK;
+        }
+    }
     switch (sh.cfg) {
         case 4:
             if constexpr (KS == 3 && S == 1) {
@@ -980,7 +1233,15 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     const GatherPlan g = gather_plan(N, cin, mout, OH, OW, ks, stride, oys != 1 || oxs != 1);
     if (!ws || ws_floats < g.ws_floats)
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)g.ws_floats);
-    run_wprep(w, ws, mout, cin, g.Mp, g.Cp, g.taps, sm, sc, flip, alpha, s);
+    if (g.bx) {
+        const int64_t total = (int64_t)g.Mp * (g.Cp / 8) * 9;
+        int64_t blocks = ceil_div64(total, kBlock);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_wprep_bx_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, w,
+                           reinterpret_cast<u32x4*>(ws), mout, cin, g.Mp, g.Cp, g.sh.bm, sm, sc, flip, alpha);
+    } else {
+        run_wprep(w, ws, mout, cin, g.Mp, g.Cp, g.taps, sm, sc, flip, alpha, s);
+    }
     IgemmParams p{};
     p.N = N; p.C = cin; p.H = H; p.W = W; p.M = mout; p.OH = OH; p.OW = OW; p.YH = YH; p.YW = YW;
     p.oys = oys; p.oxs = oxs; p.Cp = g.Cp; p.Mp = g.Mp; p.pad = pad;

@@ -11,6 +11,8 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));   // A/B operand of v_mfma_f32_32x32x16_bf16
 
 namespace sae {
 
@@ -34,6 +36,10 @@ inline int ilog2_ceil(int64_t v) {  // smallest e with (1 << e) >= v, v >= 1
     while (((int64_t)1 << e) < v) ++e;
     return e;
 }
+
+// conv arithmetic: 0 = v_mfma_f32_32x32x2_f32 (default), 1 = three-way bf16 split, six bf16 MFMAs per
+// product block, fp32 accumulate (see conv2d.hip "bx"); set by sae_set_conv_math / SAE_CONV_MATH
+int conv_math();
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -39,6 +39,8 @@ class ConvDesc(C.Structure):
 _SIGNATURES = {
     "abi_version": (C.c_int, []),
     "last_error": (C.c_char_p, []),
+    "set_conv_math": (C.c_int, [_i32]),
+    "get_conv_math": (C.c_int, []),
     "upfirdn2d_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i32, _i32,
                                 _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _stream]),
     "bias_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _stream]),

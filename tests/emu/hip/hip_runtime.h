@@ -78,6 +78,8 @@ struct WaveState {
     float fa[2][kWave];
     float fb[2][kWave];
     uint64_t bits[2][kWave];
+    uint16_t ha[2][kWave][8];
+    uint16_t hb[2][kWave][8];
 };
 
 struct Fiber {
@@ -272,6 +274,37 @@ inline f32x4 mfma_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
     return c;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+inline float bf16_bits_to_float(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i = l&31][k = 8*(l>>5) + e] and B[k][j = l&31],
+// e = 0..7; C/D layout as the f32 32x32 form.  Products of bf16 are exact in fp32; the 16-term
+// sum is formed in double and rounded once (the hardware's internal order is not documented).
+inline f32x16 mfma_32x32x16bf16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
+    WaveState& W = my_wave();
+    const int l = lane_id();
+    const int slot = W.gen & 1;
+    std::memcpy(W.ha[slot][l], &a, 16);
+    std::memcpy(W.hb[slot][l], &b, 16);
+    wave_rendezvous(W);
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        double acc = c[r];
+        for (int k = 0; k < 16; ++k)
+            acc += (double)bf16_bits_to_float(W.ha[slot][(k >> 3) * 32 + row][k & 7]) *
+                   (double)bf16_bits_to_float(W.hb[slot][(k >> 3) * 32 + col][k & 7]);
+        c[r] = (float)acc;
+    }
+    return c;
+}
+
 template <typename T>
 inline T exchange(T v, int src_lane) {
     static_assert(sizeof(T) <= 8, "hipemu exchange: type too wide");
@@ -301,6 +334,7 @@ static inline void __syncthreads() { hipemu::block_barrier(); }
 
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_16x16x4f32
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_32x32x16bf16
 
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {

@@ -47,6 +47,13 @@ CONV_SMALL = [
     (2, 3, 8, 8, 70, 1, 1, 0, False), (1, 30, 15, 15, 36, 1, 2, 0, False),
 ]
 
+# 3x3 stride-1 launches that take the 128x128 tile (the bf16x6 split-arithmetic kernel when
+# sae_set_conv_math(1)): forward with M > 64, dgrad with C > 64, split-K tail, valid padding, [C,M] weights
+CONV_BX = [
+    (3, 10, 4, 4, 70, 3, 1, 1, False), (2, 64, 8, 8, 70, 3, 1, 1, False), (1, 9, 36, 33, 128, 3, 1, 0, False),
+    (1, 70, 8, 8, 12, 3, 1, 1, False), (2, 72, 6, 6, 100, 3, 1, 1, True), (1, 5, 16, 40, 256, 3, 1, 1, False),
+]
+
 # larger shapes for the GPU (oracle still finishes in seconds): church-preset layer classes scaled down
 CONV_GPU = CONV_SMALL + [
     (2, 128, 32, 32, 128, 3, 1, 1, False),     # D 3x3 s1

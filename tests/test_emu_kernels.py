@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import abi_harness as H
-from kernel_cases import BIAS_ACT_SHAPES, CONV_SMALL, GEMM_CASES, UPFIRDN_SMALL
+from kernel_cases import BIAS_ACT_SHAPES, CONV_BX, CONV_SMALL, GEMM_CASES, UPFIRDN_SMALL
 
 TOL = 2e-5   # fp32 kernel vs double-accumulating oracle, relative to the output's max magnitude
 
@@ -56,6 +56,35 @@ def test_conv2d(emu_lib, oracle_lib, case):
         o = H.conv(oracle_lib, op, d, a, b, shape, alpha=0.37)
         assert not np.isnan(e).any(), op
         assert H.rel_err(e, o) < TOL, (op, H.rel_err(e, o))
+
+
+@pytest.mark.parametrize("case", CONV_BX, ids=lambda c: "n%d_c%d_%dx%d_m%d_k%d_s%d_p%d_%s" % c)
+def test_conv2d_bf16x6(emu_lib, oracle_lib, case):
+    """sae_set_conv_math(SAE_CONV_MATH_BF16X6): three-way bf16 split, six MFMAs per product block.
+    Must stay in the fp32 error class (same tolerance as the exact-fp32 kernels)."""
+    n, c, h, w, m, k, s, p, cm = case
+    d = H.conv_desc(n, c, h, w, m, k, s, p, cm)
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((n, c, h, w)) * np.exp(rng.uniform(-3, 3, (n, c, 1, 1)))).astype(np.float32)
+    wt = rng.standard_normal((c, m, k, k) if cm else (m, c, k, k)).astype(np.float32)
+    gy = rng.standard_normal((n, m, d.oh, d.ow)).astype(np.float32)
+    b = rng.standard_normal(m).astype(np.float32)
+    assert emu_lib.query("get_conv_math") == 0
+    emu_lib.call("set_conv_math", 1)
+    try:
+        assert emu_lib.query("get_conv_math") == 1
+        for op, (a, bb, shape) in enumerate([(x, wt, gy.shape), (gy, wt, x.shape)]):
+            e = H.conv(emu_lib, op, d, a, bb, shape, alpha=0.37)
+            o = H.conv(oracle_lib, op, d, a, bb, shape, alpha=0.37)
+            assert not np.isnan(e).any(), op
+            assert H.rel_err(e, o) < 2e-6, (op, H.rel_err(e, o))
+        e = H.conv_bias_act(emu_lib, d, x, wt, b, alpha=0.11, device=None)
+        o = H.conv_bias_act(oracle_lib, d, x, wt, b, alpha=0.11)
+        assert H.rel_err(e, o) < 2e-6
+    finally:
+        emu_lib.call("set_conv_math", 0)
+    with pytest.raises(Exception):
+        emu_lib.call("set_conv_math", 7)
 
 
 @pytest.mark.parametrize("mnk", GEMM_CASES, ids=str)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import abi_harness as H
-from kernel_cases import BIAS_ACT_SHAPES, CONV_GPU, GEMM_CASES, UPFIRDN_SMALL
+from kernel_cases import CONV_BX, BIAS_ACT_SHAPES, CONV_GPU, GEMM_CASES, UPFIRDN_SMALL
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -75,6 +75,39 @@ def test_conv2d(hip_lib, oracle_lib, case):
         o = H.conv(oracle_lib, op, d, a, b, shape, alpha=0.37)
         assert not np.isnan(e).any(), op
         assert H.rel_err(e, o) < TOL, (op, H.rel_err(e, o))
+
+
+CONV_BX_GPU = CONV_BX + [(2, 128, 32, 32, 128, 3, 1, 1, False), (8, 96, 4, 4, 96, 3, 1, 1, False),
+                         (1, 256, 64, 64, 128, 3, 1, 1, True), (2, 72, 34, 34, 72, 3, 1, 0, False)]
+
+
+@pytest.mark.parametrize("case", CONV_BX_GPU, ids=lambda c: "n%d_c%d_%dx%d_m%d_k%d_s%d_p%d_%s" % c)
+def test_conv2d_bf16x6(hip_lib, oracle_lib, case):
+    """SAE_CONV_MATH_BF16X6 (three-way bf16 split on the bf16 matrix cores) against the double
+    oracle: must be in the fp32 error class, i.e. inside the tolerance of the exact-fp32 kernels."""
+    n, c, h, w, m, k, s, p, cm = case
+    d = H.conv_desc(n, c, h, w, m, k, s, p, cm)
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((n, c, h, w)) * np.exp(rng.uniform(-3, 3, (n, c, 1, 1)))).astype(np.float32)
+    wt = rng.standard_normal((c, m, k, k) if cm else (m, c, k, k)).astype(np.float32)
+    gy = rng.standard_normal((n, m, d.oh, d.ow)).astype(np.float32)
+    b = rng.standard_normal(m).astype(np.float32)
+    ops = [(x, wt, gy.shape), (gy, wt, x.shape), (x, gy, wt.shape)]
+    exact = [H.conv(hip_lib, op, d, a, bb, shape, alpha=0.37, device=DEV) for op, (a, bb, shape) in enumerate(ops)]
+    hip_lib.call("set_conv_math", 1)
+    try:
+        for op, (a, bb, shape) in enumerate(ops):
+            e = H.conv(hip_lib, op, d, a, bb, shape, alpha=0.37, device=DEV)
+            o = H.conv(oracle_lib, op, d, a, bb, shape, alpha=0.37)
+            assert not np.isnan(e).any(), op
+            err, err_exact = H.rel_err(e, o), H.rel_err(exact[op], o)
+            assert err < 3e-6, (op, err)
+            assert err < 3 * err_exact + 2e-7, (op, err, err_exact)     # no worse than the fp32 MFMA chain
+        e = H.conv_bias_act(hip_lib, d, x, wt, b, alpha=0.11, device=DEV)
+        o = H.conv_bias_act(oracle_lib, d, x, wt, b, alpha=0.11)
+        assert H.rel_err(e, o) < 3e-6
+    finally:
+        hip_lib.call("set_conv_math", 0)
 
 
 @pytest.mark.parametrize("mnk", GEMM_CASES + [(128, 2048, 3072), (16, 512, 2048)], ids=str)
