@@ -697,6 +697,180 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// "bx" arithmetic of the transposed gather (128 x 64q tile).  Same cell layouts as
+// conv_igemm_bx_kernel.  The 16 k of an MFMA are 8 channels x the two taps of a pair that feed
+// the SAME parity class: (0,2) (6,8) -> class 0, (1,7) -> 1, (3,5) -> 2, (4, zero cell) -> 3.
+// ------------------------------------------------------------------------------------------
+template <int MI, int WM, int WN>
+__global__ __launch_bounds__(kBlock) void conv_igemm_tr_bx_kernel(const float* __restrict__ x,
+                                                                  const u32x4* __restrict__ wpb,
+                                                                  float* __restrict__ y, const TrParams p) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int T = 9, CK = 8;
+    constexpr int BM = 32 * MI * WM;
+    constexpr int BQ = 32 * WN;
+    constexpr int XCAP = (25 * BQ) / 16;
+    constexpr int PPT = (XCAP + kBlock - 1) / kBlock;
+    constexpr int A_CELLS = T * 3 * BM;
+    constexpr int APT = (A_CELLS + kBlock - 1) / kBlock;
+    __shared__ u32x4 As[A_CELLS + 1];
+    __shared__ u32x4 Xs[3 * XCAP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+
+    const int TW = p.tw, TH = p.th, TN = p.tn;
+    int bt = blockIdx.x;
+    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
+    const int tiy = bt % p.tiles_y;
+    const int tin = bt / p.tiles_y;
+    const int qx0 = p.qx_base + tix * TW, qy0 = p.qy_base + tiy * TH, n0 = tin * TN;
+    const int m0 = blockIdx.y * BM;
+
+    const int PH = TH + 1, PW = TW + 1;
+    const int IP = PH * PW;
+    const int CP = TN * IP;
+    const int HW = p.IH * p.IW;
+
+    int poff[PPT];
+#pragma unroll
+    for (int s = 0; s < PPT; ++s) {
+        const int e = tid + kBlock * s;
+        int off = -1;
+        if (e < CP) {
+            const int pn = e / IP;
+            const int rem = e - pn * IP;
+            const int r = rem / PW;
+            const int c = rem - r * PW;
+            const int iy = qy0 - 1 + r, ix = qx0 - 1 + c;
+            if (n0 + pn < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+                off = pn * p.C * HW + iy * p.IW + ix;
+        }
+        poff[s] = off;
+    }
+
+    const int pp = wn * 32 + l31;
+    const int pn = pp / (TW * TH);
+    const int prem = pp - pn * (TW * TH);
+    const int py = prem / TW;
+    const int px = prem - py * TW;
+    const bool lane_ok = pn < TN;
+    const int pixbase = lane_ok ? pn * IP + py * PW + px : 0;
+    constexpr int TLO[5] = {0, 6, 1, 3, 4};
+    constexpr int THI[5] = {2, 8, 7, 5, 4};
+    constexpr int GCLS[5] = {0, 0, 1, 2, 3};
+    int boff[5], aoff[5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        const int t = half ? THI[g] : TLO[g];
+        const int ky = t / 3, kx = t % 3;
+        boff[g] = ((ky == 2) ? 0 : 1) * PW + ((kx == 2) ? 0 : 1);
+        aoff[g] = (g == 4 && half) ? A_CELLS : t * 3 * BM + wm * MI * 32 + l31;
+    }
+    const int astep4 = half ? 0 : BM, mstep4 = half ? 0 : 32;   // the zero cell has no planes
+
+    f32x16 acc[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][cl][r] = 0.0f;
+
+    const float* xb = x + (int64_t)n0 * p.C * HW;
+    const u32x4* wt = wpb + (int64_t)blockIdx.y * (p.Cp / CK) * A_CELLS;
+    float xv[CK][PPT];
+    u32x4 av[APT];
+
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch) {
+            const bool ch_ok = (c0 + ch) < p.C;
+            const float* xc = xb + (int64_t)(c0 + ch) * HW;
+#pragma unroll
+            for (int s = 0; s < PPT; ++s) xv[ch][s] = (ch_ok && poff[s] >= 0) ? xc[poff[s]] : 0.0f;
+        }
+        const u32x4* wc = wt + (int64_t)(c0 / CK) * A_CELLS;
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e = tid + kBlock * i;
+            if (e < A_CELLS) av[i] = wc[e];
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int s = 0; s < PPT; ++s) {
+            const int e = tid + kBlock * s;
+            if (e < CP) {
+                float v[CK];
+#pragma unroll
+                for (int ch = 0; ch < CK; ++ch) v[ch] = xv[ch][s];
+                bf16x8 s0, s1, s2;
+                split3_bf16(v, s0, s1, s2);
+                Xs[e] = __builtin_bit_cast(u32x4, s0);
+                Xs[XCAP + e] = __builtin_bit_cast(u32x4, s1);
+                Xs[2 * XCAP + e] = __builtin_bit_cast(u32x4, s2);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e = tid + kBlock * i;
+            if (e < A_CELLS) As[e] = av[i];
+        }
+    };
+
+    if (tid == 0) As[A_CELLS] = u32x4{0u, 0u, 0u, 0u};
+    load_chunk(0);
+    for (int c0 = 0; c0 < p.Cp; c0 += CK) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (c0 + CK < p.Cp) load_chunk(c0 + CK);
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            bf16x8 a[MI][3], b[3];
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) b[sp] = __builtin_bit_cast(bf16x8, Xs[sp * XCAP + pixbase + boff[g]]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    a[mi][sp] = __builtin_bit_cast(
+                        bf16x8, As[aoff[g] + ((g == 4) ? sp * astep4 + mi * mstep4 : sp * BM + mi * 32)]);
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    acc[mi][GCLS[g]] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][TA[q]], b[TB[q]],
+                                                                               acc[mi][GCLS[g]], 0, 0, 0);
+        }
+    }
+
+    const int n = n0 + pn, qy = qy0 + py, qx = qx0 + px;
+    if (lane_ok && n < p.N && qy < p.QH && qx < p.QW) {
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl) {
+            const int oy = 2 * qy + (cl >> 1) - p.pad;
+            const int ox = 2 * qx + (cl & 1) - p.pad;
+            if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
+                float* yb = y + ((int64_t)n * p.M * p.OH + oy) * p.OW + ox;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (m < p.M) yb[(int64_t)m * p.OH * p.OW] = acc[mi][cl][r];
+                    }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // wgrad: slab[slice][tap][a][b] = sum over the slice's pixels of  S[a][pix] * L[b][pix*stride + tap - pad]
 //   S = gy (a = y-side channel m), L = x (b = x-side channel c)
 // ------------------------------------------------------------------------------------------
@@ -1224,6 +1398,16 @@ int run_wprep(const float* w, float* wp, int M, int C, int Mp, int Cp, int taps,
     return SAE_OK;
 }
 
+int run_wprep_bx(const float* w, float* wpb, int M, int C, int Mp, int Cp, int BM, int64_t sm, int64_t sc, int flip,
+                 float alpha, hipStream_t s) {
+    const int64_t total = (int64_t)Mp * (Cp / 8) * 9;
+    int64_t blocks = ceil_div64(total, kBlock);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(conv_wprep_bx_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, w,
+                       reinterpret_cast<u32x4*>(wpb), M, C, Mp, Cp, BM, sm, sc, flip, alpha);
+    return SAE_OK;
+}
+
 // forward-type gather producing `mout` channels from `cin` channels
 struct Epilogue { const float* bias; int act; float slope, scale; };
 
@@ -1234,11 +1418,7 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     if (!ws || ws_floats < g.ws_floats)
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)g.ws_floats);
     if (g.bx) {
-        const int64_t total = (int64_t)g.Mp * (g.Cp / 8) * 9;
-        int64_t blocks = ceil_div64(total, kBlock);
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(conv_wprep_bx_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, w,
-                           reinterpret_cast<u32x4*>(ws), mout, cin, g.Mp, g.Cp, g.sh.bm, sm, sc, flip, alpha);
+        run_wprep_bx(w, ws, mout, cin, g.Mp, g.Cp, g.sh.bm, sm, sc, flip, alpha, s);
     } else {
         run_wprep(w, ws, mout, cin, g.Mp, g.Cp, g.taps, sm, sc, flip, alpha, s);
     }
@@ -1278,10 +1458,12 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
     const TrShape sh = tr_shape(mout);
     constexpr int CK = 8;
     const int Mp = round_up(mout, sh.bm), Cp = round_up(cin, sh.ck);
-    const int64_t need = (int64_t)9 * Cp * Mp;
+    const bool bx = conv_math() == 1 && sh.cfg == 0;
+    const int64_t need = bx ? (int64_t)27 * Mp * (Cp / 8) * 4 : (int64_t)9 * Cp * Mp;
     if (!ws || ws_floats < need)
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
-    run_wprep(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s);
+    if (bx) run_wprep_bx(w, ws, mout, cin, Mp, Cp, sh.bm, sm, sc, 0, alpha, s);
+    else run_wprep(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s);
     TrParams p{};
     p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
     static const int nostore_knob = [] { const char* e = getenv("SAE_TR_NOSTORE"); return e ? atoi(e) : 0; }();
@@ -1328,6 +1510,11 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
         p.tiles_y = ceil_div(qh, p.th);
         p.tiles_n = ceil_div(N, p.tn);
         const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(Mp / sh.bm));
+        if (bx) {
+            hipLaunchKernelGGL((conv_igemm_tr_bx_kernel<2, 2, 2>), grid, dim3(kBlock), 0, s, x,
+                               reinterpret_cast<const u32x4*>(ws), y, p);
+            continue;
+        }
         switch (sh.cfg) {
             case 3: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 1, 4, 16>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
             case 0: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 2, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
@@ -1340,6 +1527,7 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
 
 int64_t tr_ws(int cin, int mout) {
     const TrShape sh = tr_shape(mout);
+    if (conv_math() == 1 && sh.cfg == 0) return (int64_t)27 * round_up(mout, sh.bm) * (round_up(cin, 8) / 8) * 4;
     return (int64_t)9 * round_up(cin, sh.ck) * round_up(mout, sh.bm);
 }
 

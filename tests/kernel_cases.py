@@ -52,6 +52,8 @@ CONV_SMALL = [
 CONV_BX = [
     (3, 10, 4, 4, 70, 3, 1, 1, False), (2, 64, 8, 8, 70, 3, 1, 1, False), (1, 9, 36, 33, 128, 3, 1, 0, False),
     (1, 70, 8, 8, 12, 3, 1, 1, False), (2, 72, 6, 6, 100, 3, 1, 1, True), (1, 5, 16, 40, 256, 3, 1, 1, False),
+    # stride-2 dgrad / transposed conv producing > 64 channels: the 128 x 64q transposed-gather tile
+    (1, 70, 17, 17, 12, 3, 2, 0, False), (2, 72, 35, 67, 8, 3, 2, 0, True), (1, 70, 10, 12, 20, 3, 2, 1, False),
 ]
 
 # larger shapes for the GPU (oracle still finishes in seconds): church-preset layer classes scaled down
