@@ -1146,6 +1146,291 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// "bx" arithmetic of the 3x3 wgrad (see conv_igemm_bx_kernel for the split).  K = pixels: the 16 k
+// of an MFMA are two OCTETS, an octet = 8 consecutive pixels of one row of the y side, held as one
+// 16-byte cell per (split, channel).  S (gy) cells are staged as they lie; the x-side operand of tap
+// (ky, kx) is the octet shifted by kx columns: for stride 1 the lane reads the aligned cell plus the
+// first dword of its right neighbour and forms kx = 1 by a 16-bit funnel shift (v_alignbit) and
+// kx = 2 by dropping a dword; for stride 2 the patch columns are stored de-interleaved (even cells,
+// odd cells) so kx = 0 / 1 / 2 = even / odd / even shifted by one element.
+// One workgroup per CU (accumulators: 9 tap tiles = 144 AGPRs per wave), register prefetch of the
+// next chunk; operand splitting happens when the prefetched fp32 values are written to LDS.
+// ------------------------------------------------------------------------------------------
+struct WgBxParams {
+    int N, C, H, W;       // L tensor (x side)
+    int M, OH, OW;        // S tensor (y side), OW % 8 == 0
+    int pad;
+    int tw8_log2, th_log2; // y-side tile: TH rows x (8 << tw8_log2) columns x TN images = 8 * NO pixels
+    int tiles_x, tiles_y, tiles_n;
+    int chunks, chunks_per_slice;
+    int Ap, Bp;
+};
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned 16-byte global access
+
+template <int S>
+struct WgBx {
+    static constexpr int NO = (S == 1) ? 16 : 8;      // octets per chunk
+    static constexpr int SOS = NO + 1;                // odd cell strides: conflict-free 16-byte reads across channels
+    static constexpr int LCAP = (S == 1) ? 30 : 45;   // x-side cells per channel
+    static constexpr int LOS = (S == 1) ? 31 : 45;
+    static constexpr int UCAP = (S == 1) ? 30 : 27;   // staging units per channel (s2: a unit = 16 columns = even + odd cell)
+};
+
+template <int S, int WA, int WB, bool DB>
+__global__ __launch_bounds__(kBlock) void conv_wgrad_bx_kernel(const float* __restrict__ xl,
+                                                               const float* __restrict__ gs,
+                                                               float* __restrict__ slab, const WgBxParams p) {
+    static_assert(WA * WB == 4, "4 waves per workgroup");
+    constexpr int T = 9;
+    constexpr int BA = 32 * WA, BB = 32 * WB;
+    constexpr int NO = WgBx<S>::NO, SOS = WgBx<S>::SOS, LOS = WgBx<S>::LOS;
+    constexpr int SPT = BA * NO / kBlock;
+    constexpr int LPT = (BB * WgBx<S>::UCAP + kBlock - 1) / kBlock;
+    constexpr int UW = (S == 1) ? 8 : 16;              // columns per staging unit
+    static_assert(BA * NO % kBlock == 0, "S cells per thread");
+    __shared__ u32x4 Ss[3 * BA * SOS];
+    __shared__ u32x4 Ls[3 * BB * LOS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wa = wid / WB, wb = wid % WB;
+    const int b0 = blockIdx.x * BB, a0 = blockIdx.y * BA, slice = blockIdx.z;
+
+    const int TWO = 1 << p.tw8_log2, TH = 1 << p.th_log2;
+    const int TN = NO >> (p.tw8_log2 + p.th_log2);
+    const int PH = (TH - 1) * S + 3;
+    const int NOLE = TWO + 1;                           // stride 1: cells per patch row; stride 2: even cells per row
+    const int RC = (S == 1) ? NOLE : 2 * TWO + 1;       // cells per patch row
+    const int UPC = TN * PH * NOLE;                     // staging units per channel
+    const int HWl = p.H * p.W, HWs = p.OH * p.OW;
+
+    // chunk-independent part of the staging maps
+    int s_off[SPT], s_oy[SPT], s_ox[SPT], s_n[SPT], s_cell[SPT];
+#pragma unroll
+    for (int i = 0; i < SPT; ++i) {
+        const int e = tid + kBlock * i;
+        const int a = e / NO, o = e % NO;
+        const int poct = o & (TWO - 1);
+        const int py = (o >> p.tw8_log2) & (TH - 1);
+        const int pn = o >> (p.tw8_log2 + p.th_log2);
+        s_off[i] = (a0 + a < p.M) ? (pn * p.M + a) * HWs + py * p.OW + 8 * poct : -1;
+        s_oy[i] = py; s_ox[i] = 8 * poct; s_n[i] = pn;
+        s_cell[i] = a * SOS + o;
+    }
+    int l_off[LPT], l_r[LPT], l_c[LPT], l_n[LPT], l_cell[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int u = tid + kBlock * i;
+        const int ub = u / UPC, ur = u - ub * UPC;
+        const int j = ur % NOLE;
+        const int rr = ur / NOLE;
+        const int r = rr % PH, pn = rr / PH;
+        const bool ok = ub < BB && b0 + ub < p.C;
+        l_off[i] = ok ? (pn * p.C + ub) * HWl + r * p.W + UW * j : -1;
+        l_r[i] = r; l_c[i] = UW * j; l_n[i] = pn;
+        // units beyond the tile's channels write nothing: cell = -1
+        l_cell[i] = (ub < BB) ? ub * LOS + (pn * PH + r) * RC + j : -1;
+        if (S == 2 && j == TWO) l_c[i] |= 0x10000;      // last unit of a row: one column only (even cell)
+    }
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    const int ch_begin = slice * p.chunks_per_slice;
+    int ch_end = ch_begin + p.chunks_per_slice;
+    if (ch_end > p.chunks) ch_end = p.chunks;
+
+    float sv[SPT][8];
+    float lv[LPT][UW];
+
+    auto load_chunk = [&](int chunk) {
+        int bt = chunk;
+        const int tix = bt % p.tiles_x; bt /= p.tiles_x;
+        const int tiy = bt % p.tiles_y;
+        const int tin = bt / p.tiles_y;
+        const int ox0 = tix * 8 * TWO, oy0 = tiy * TH, n0 = tin * TN;
+        const float* sbase = gs + ((int64_t)n0 * p.M + a0) * HWs + oy0 * p.OW + ox0;
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            const bool ok = s_off[i] >= 0 && n0 + s_n[i] < p.N && oy0 + s_oy[i] < p.OH && ox0 + s_ox[i] < p.OW;
+            f32x4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = v0;
+            if (ok) {
+                const f32x4u* g = reinterpret_cast<const f32x4u*>(sbase + s_off[i]);
+                v0 = g[0]; v1 = g[1];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sv[i][e] = v0[e]; sv[i][4 + e] = v1[e]; }
+        }
+        const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+        const float* lbase = xl + ((int64_t)n0 * p.C + b0) * HWl + iy0 * p.W + ix0;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            const int iy = iy0 + l_r[i], ix = ix0 + (l_c[i] & 0xffff);
+            const bool single = S == 2 && (l_c[i] >> 16);
+            const bool row_ok = l_off[i] >= 0 && n0 + l_n[i] < p.N && iy >= 0 && iy < p.H;
+            const float* g = lbase + l_off[i];
+            if (row_ok && !single && ix >= 0 && ix + UW <= p.W) {     // interior: 16-byte accesses
+#pragma unroll
+                for (int q = 0; q < UW / 4; ++q) {
+                    const f32x4 v = reinterpret_cast<const f32x4u*>(g)[q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) lv[i][4 * q + e] = v[e];
+                }
+            } else {                                                   // image border / tail: element-wise
+#pragma unroll
+                for (int e = 0; e < UW; ++e)
+                    lv[i][e] = (row_ok && ix + e >= 0 && ix + e < p.W && !(single && e > 0)) ? g[e] : 0.0f;
+            }
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < SPT; ++i) {
+            bf16x8 s0, s1, s2;
+            split3_bf16(sv[i], s0, s1, s2);
+            Ss[s_cell[i]] = __builtin_bit_cast(u32x4, s0);
+            Ss[BA * SOS + s_cell[i]] = __builtin_bit_cast(u32x4, s1);
+            Ss[2 * BA * SOS + s_cell[i]] = __builtin_bit_cast(u32x4, s2);
+        }
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            if (l_cell[i] < 0) continue;
+            if constexpr (S == 1) {
+                bf16x8 s0, s1, s2;
+                split3_bf16(lv[i], s0, s1, s2);
+                Ls[l_cell[i]] = __builtin_bit_cast(u32x4, s0);
+                Ls[BB * LOS + l_cell[i]] = __builtin_bit_cast(u32x4, s1);
+                Ls[2 * BB * LOS + l_cell[i]] = __builtin_bit_cast(u32x4, s2);
+            } else {
+                float ev[8], od[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { ev[e] = lv[i][2 * e]; od[e] = lv[i][2 * e + 1]; }
+                bf16x8 s0, s1, s2;
+                split3_bf16(ev, s0, s1, s2);
+                Ls[l_cell[i]] = __builtin_bit_cast(u32x4, s0);
+                Ls[BB * LOS + l_cell[i]] = __builtin_bit_cast(u32x4, s1);
+                Ls[2 * BB * LOS + l_cell[i]] = __builtin_bit_cast(u32x4, s2);
+                if (!(l_c[i] >> 16)) {
+                    split3_bf16(od, s0, s1, s2);
+                    Ls[l_cell[i] + NOLE] = __builtin_bit_cast(u32x4, s0);
+                    Ls[BB * LOS + l_cell[i] + NOLE] = __builtin_bit_cast(u32x4, s1);
+                    Ls[2 * BB * LOS + l_cell[i] + NOLE] = __builtin_bit_cast(u32x4, s2);
+                }
+            }
+        }
+    };
+
+    // operands of one K block (two octets): A cells, and per ky the aligned x-side cell(s) + the
+    // first dword of the right neighbour
+    struct Frag {
+        u32x4 a[3];
+        u32x4 be[3][3];
+        unsigned bn[3][3];
+        u32x4 bo[(S == 2) ? 3 : 1][3];
+    };
+    const int a_row = (wa * 32 + l31) * SOS;
+    const int b_row = (wb * 32 + l31) * LOS;
+    auto fetch = [&](int kb, Frag& f) {
+        const int o = 2 * kb + half;
+        const int poct = o & (TWO - 1);
+        const int py = (o >> p.tw8_log2) & (TH - 1);
+        const int pn = o >> (p.tw8_log2 + p.th_log2);
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) f.a[sp] = Ss[sp * BA * SOS + a_row + o];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int c0 = b_row + (pn * PH + py * S + ky) * RC + poct;
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                f.be[ky][sp] = Ls[sp * BB * LOS + c0];
+                f.bn[ky][sp] = Ls[sp * BB * LOS + c0 + 1][0];
+                if constexpr (S == 2) f.bo[ky][sp] = Ls[sp * BB * LOS + c0 + NOLE];
+            }
+        }
+    };
+    auto shift1 = [](const u32x4& c, unsigned n) {
+        u32x4 r;
+        r[0] = (c[0] >> 16) | (c[1] << 16);
+        r[1] = (c[1] >> 16) | (c[2] << 16);
+        r[2] = (c[2] >> 16) | (c[3] << 16);
+        r[3] = (c[3] >> 16) | (n << 16);
+        return r;
+    };
+    auto mma = [&](const Frag& f) {
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+        bf16x8 a[3];
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) a[sp] = __builtin_bit_cast(bf16x8, f.a[sp]);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            bf16x8 b[3][3];     // [kx][split]
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                const u32x4 e = f.be[ky][sp];
+                b[0][sp] = __builtin_bit_cast(bf16x8, e);
+                if constexpr (S == 1) {
+                    b[1][sp] = __builtin_bit_cast(bf16x8, shift1(e, f.bn[ky][sp]));
+                    const u32x4 d = {e[1], e[2], e[3], f.bn[ky][sp]};
+                    b[2][sp] = __builtin_bit_cast(bf16x8, d);
+                } else {
+                    b[1][sp] = __builtin_bit_cast(bf16x8, f.bo[ky][sp]);
+                    b[2][sp] = __builtin_bit_cast(bf16x8, shift1(e, f.bn[ky][sp]));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], b[kx][TB[q]],
+                                                                               acc[ky * 3 + kx], 0, 0, 0);
+        }
+    };
+
+    if (ch_begin < ch_end) load_chunk(ch_begin);
+    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (chunk + 1 < ch_end) load_chunk(chunk + 1);
+        constexpr int KB = NO / 2;
+        if constexpr (DB) {
+            Frag f0, f1;
+            fetch(0, f0);
+            for (int kb = 0; kb < KB; kb += 2) {
+                fetch(kb + 1, f1);
+                mma(f0);
+                if (kb + 2 < KB) fetch(kb + 2, f0);
+                mma(f1);
+            }
+        } else {
+            for (int kb = 0; kb < KB; ++kb) {
+                Frag f;
+                fetch(kb, f);
+                mma(f);
+            }
+        }
+    }
+
+    // slab store: rows = a (m), cols = b (c)
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int bcol = b0 + wb * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int arow = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            slab[(((int64_t)slice * T + t) * p.Ap + arow) * p.Bp + bcol] = acc[t][r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void conv_wgrad_reduce_kernel(const float* __restrict__ slab,
                                                                    float* __restrict__ gw, int M, int C,
                                                                    int Ap, int Bp, int taps, int slices,
@@ -1252,13 +1537,32 @@ WgShape wg_shape(int m, int c, int ks, int stride) {
 
 struct WgPlan {
     WgShape sh; int tw_log2, th_log2; int tiles_x, tiles_y, tiles_n; int chunks, cps, slices; int Ap, Bp; int taps;
+    bool bx; int tw8_log2;   // bf16-split arithmetic: tiles of TH rows x (8 << tw8_log2) columns
 };
 WgPlan wg_plan(const sae_conv2d_desc* d) {
     WgPlan w{};
     w.sh = wg_shape((int)d->m, (int)d->c, d->kh, d->stride);
     w.taps = d->kh * d->kw;
     pick_tile(kWgPix, (int)d->oh, (int)d->ow, 32, &w.tw_log2, &w.th_log2);
-    const int tw = 1 << w.tw_log2, th = 1 << w.th_log2, tn = kWgPix / (tw * th);
+    int tw = 1 << w.tw_log2, th = 1 << w.th_log2, tn = kWgPix / (tw * th);
+    w.bx = false;
+    if (conv_math() == 1 && d->kh == 3 && w.sh.mode == 0 && d->ow % 8 == 0 && d->ow >= 16) {
+        // octet tiles: 128 (stride 1) / 64 (stride 2) pixels per chunk, rows of 16 or 32 columns
+        const int no = (d->stride == 1) ? 16 : 8;
+        const int two = (d->ow > 16) ? 4 : 2;
+        int bth = 1 << ilog2_ceil(d->oh);
+        if (bth > no / two) bth = no / two;
+        const int btn = no / (two * bth);
+        const int ph = (bth - 1) * d->stride + 3;
+        const bool fits = (d->stride == 1) ? btn * ph * (two + 1) <= 30
+                                           : (btn * ph * (2 * two + 1) <= 45 && btn * ph * (two + 1) <= 27);
+        if (fits) {
+            w.bx = true;
+            w.tw8_log2 = (two == 4) ? 2 : 1;
+            w.th_log2 = ilog2_ceil(bth);
+            tw = 8 * two; th = bth; tn = btn;
+        }
+    }
     w.tiles_x = ceil_div((int)d->ow, tw);
     w.tiles_y = ceil_div((int)d->oh, th);
     w.tiles_n = ceil_div((int)d->n, tn);
@@ -1628,14 +1932,24 @@ extern "C" int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
     p.OW = (int)d->ow; p.pad = d->pad; p.tw_log2 = w.tw_log2; p.th_log2 = w.th_log2; p.tiles_x = w.tiles_x;
     p.tiles_y = w.tiles_y; p.tiles_n = w.tiles_n; p.chunks = w.chunks; p.chunks_per_slice = w.cps; p.Ap = w.Ap;
     p.Bp = w.Bp;
-    {
+    if (!w.bx) {
         const int tw = 1 << w.tw_log2, th = 1 << w.th_log2, tn = kWgPix / (tw * th);
         const int ph = (d->kh == 1) ? th : (th - 1) * d->stride + d->kh;
         const int pw = (d->kh == 1) ? tw : (tw - 1) * d->stride + d->kh;
         const int cap = (d->kh == 1) ? 65 : (d->stride == 1 ? 145 : 325);
         if (tn * ph * pw > cap) return fail(SAE_EINVAL, "sae_conv2d_wgrad_f32: patch exceeds LDS cap");
     }
-    if (d->n > 0) {
+    if (d->n > 0 && w.bx) {
+        WgBxParams q{};
+        q.N = p.N; q.C = p.C; q.H = p.H; q.W = p.W; q.M = p.M; q.OH = p.OH; q.OW = p.OW; q.pad = p.pad;
+        q.tw8_log2 = w.tw8_log2; q.th_log2 = w.th_log2; q.tiles_x = w.tiles_x; q.tiles_y = w.tiles_y;
+        q.tiles_n = w.tiles_n; q.chunks = w.chunks; q.chunks_per_slice = w.cps; q.Ap = w.Ap; q.Bp = w.Bp;
+        const dim3 grid((unsigned)(w.Bp / w.sh.bb), (unsigned)(w.Ap / w.sh.ba), (unsigned)w.slices);
+        if (d->stride == 1)
+            hipLaunchKernelGGL((conv_wgrad_bx_kernel<1, 2, 2, true>), grid, dim3(kBlock), 0, s, x, gy, workspace, q);
+        else
+            hipLaunchKernelGGL((conv_wgrad_bx_kernel<2, 4, 1, false>), grid, dim3(kBlock), 0, s, x, gy, workspace, q);
+    } else if (d->n > 0) {
         if (w.sh.mode == 2) {
             if (d->kh == 3 && d->stride == 1) launch_wgrad<3, 1, 1, 1, 1, 1, 2>(x, gy, workspace, p, w, s);
             else if (d->kh == 3) launch_wgrad<3, 2, 1, 1, 1, 1, 2>(x, gy, workspace, p, w, s);

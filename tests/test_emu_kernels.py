@@ -73,7 +73,7 @@ def test_conv2d_bf16x6(emu_lib, oracle_lib, case):
     emu_lib.call("set_conv_math", 1)
     try:
         assert emu_lib.query("get_conv_math") == 1
-        for op, (a, bb, shape) in enumerate([(x, wt, gy.shape), (gy, wt, x.shape)]):
+        for op, (a, bb, shape) in enumerate([(x, wt, gy.shape), (gy, wt, x.shape), (x, gy, wt.shape)]):
             e = H.conv(emu_lib, op, d, a, bb, shape, alpha=0.37)
             o = H.conv(oracle_lib, op, d, a, bb, shape, alpha=0.37)
             assert not np.isnan(e).any(), op
