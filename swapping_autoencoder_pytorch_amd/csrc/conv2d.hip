@@ -36,6 +36,7 @@
 #include "sae_common.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace sae {
 namespace {
@@ -1178,7 +1179,7 @@ struct WgBx {
     static constexpr int UCAP = (S == 1) ? 30 : 27;   // staging units per channel (s2: a unit = 16 columns = even + odd cell)
 };
 
-template <int S, int WA, int WB, bool DB>
+template <int S, int WA, int WB>
 __global__ __launch_bounds__(kBlock) void conv_wgrad_bx_kernel(const float* __restrict__ xl,
                                                                const float* __restrict__ gs,
                                                                float* __restrict__ slab, const WgBxParams p) {
@@ -1208,20 +1209,19 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_bx_kernel(const float* __re
     const int UPC = TN * PH * NOLE;                     // staging units per channel
     const int HWl = p.H * p.W, HWs = p.OH * p.OW;
 
-    // chunk-independent part of the staging maps
-    int s_off[SPT], s_oy[SPT], s_ox[SPT], s_n[SPT], s_cell[SPT];
-#pragma unroll
-    for (int i = 0; i < SPT; ++i) {
-        const int e = tid + kBlock * i;
-        const int a = e / NO, o = e % NO;
-        const int poct = o & (TWO - 1);
-        const int py = (o >> p.tw8_log2) & (TH - 1);
-        const int pn = o >> (p.tw8_log2 + p.th_log2);
-        s_off[i] = (a0 + a < p.M) ? (pn * p.M + a) * HWs + py * p.OW + 8 * poct : -1;
-        s_oy[i] = py; s_ox[i] = 8 * poct; s_n[i] = pn;
-        s_cell[i] = a * SOS + o;
-    }
-    int l_off[LPT], l_r[LPT], l_c[LPT], l_n[LPT], l_cell[LPT];
+    // chunk-independent part of the staging maps (kept packed: these live across the whole kernel)
+    //   S: cell e = tid + 256 i -> channel a = e / NO, octet o = e % NO; 256 % NO == 0, so a thread's
+    //      cells share the octet (same pixel position) and differ by 256 / NO channels
+    constexpr int SA = kBlock / NO;
+    const int s_o = tid % NO, s_a = tid / NO;
+    const int s_ox = 8 * (s_o & (TWO - 1));
+    const int s_oy = (s_o >> p.tw8_log2) & (TH - 1);
+    const int s_n = s_o >> (p.tw8_log2 + p.th_log2);
+    const int s_off = (s_n * p.M + s_a) * HWs + s_oy * p.OW + s_ox;
+    const int s_cell = s_a * SOS + s_o;
+    //   L: unit u = tid + 256 i -> (channel, image, patch row, unit column); meta = cell | row << 12 |
+    //      column << 17 | image << 24 | single-column unit << 30
+    int l_off[LPT], l_meta[LPT];
 #pragma unroll
     for (int i = 0; i < LPT; ++i) {
         const int u = tid + kBlock * i;
@@ -1231,10 +1231,8 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_bx_kernel(const float* __re
         const int r = rr % PH, pn = rr / PH;
         const bool ok = ub < BB && b0 + ub < p.C;
         l_off[i] = ok ? (pn * p.C + ub) * HWl + r * p.W + UW * j : -1;
-        l_r[i] = r; l_c[i] = UW * j; l_n[i] = pn;
-        // units beyond the tile's channels write nothing: cell = -1
-        l_cell[i] = (ub < BB) ? ub * LOS + (pn * PH + r) * RC + j : -1;
-        if (S == 2 && j == TWO) l_c[i] |= 0x10000;      // last unit of a row: one column only (even cell)
+        const int cell = (ub < BB) ? ub * LOS + (pn * PH + r) * RC + j : 0xfff;   // 0xfff: writes nothing
+        l_meta[i] = cell | (r << 12) | ((UW * j) << 17) | (pn << 24) | ((S == 2 && j == TWO) ? (1 << 30) : 0);
     }
 
     f32x16 acc[T];
@@ -1248,7 +1246,11 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_bx_kernel(const float* __re
     if (ch_end > p.chunks) ch_end = p.chunks;
 
     float sv[SPT][8];
-    float lv[LPT][UW];
+    float lv[LPT][UW];      // raw windows as loaded; the border fix-up waits until store_chunk so that
+    int lcode[LPT];         // nothing in load_chunk depends on a load (its latency hides under the MFMAs)
+    int s_okmask = 0;
+    bool chunk_border = false;   // workgroup-uniform: the prefetched chunk needs the border fix-up
+    float ltail[(S == 2) ? LPT : 1];
 
     auto load_chunk = [&](int chunk) {
         int bt = chunk;
@@ -1256,103 +1258,151 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_bx_kernel(const float* __re
         const int tiy = bt % p.tiles_y;
         const int tin = bt / p.tiles_y;
         const int ox0 = tix * 8 * TWO, oy0 = tiy * TH, n0 = tin * TN;
-        const float* sbase = gs + ((int64_t)n0 * p.M + a0) * HWs + oy0 * p.OW + ox0;
+        chunk_border = ox0 == 0 || ox0 + 8 * TWO >= p.OW || oy0 == 0 || oy0 + TH >= p.OH || n0 + TN > p.N ||
+                       a0 + BA > p.M || b0 + BB > p.C;
+        {
+            const float* sbase = gs + ((int64_t)n0 * p.M + a0) * HWs + oy0 * p.OW + ox0;
+            const bool pos_ok = n0 + s_n < p.N && oy0 + s_oy < p.OH && ox0 + s_ox < p.OW;
+            s_okmask = 0;
 #pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            const bool ok = s_off[i] >= 0 && n0 + s_n[i] < p.N && oy0 + s_oy[i] < p.OH && ox0 + s_ox[i] < p.OW;
-            f32x4 v0 = {0.0f, 0.0f, 0.0f, 0.0f}, v1 = v0;
-            if (ok) {
-                const f32x4u* g = reinterpret_cast<const f32x4u*>(sbase + s_off[i]);
-                v0 = g[0]; v1 = g[1];
+            for (int i = 0; i < SPT; ++i) {
+                const bool ok = pos_ok && a0 + s_a + SA * i < p.M;
+                s_okmask |= (ok ? 1 : 0) << i;
+                const f32x4u* g = reinterpret_cast<const f32x4u*>(ok ? sbase + s_off + SA * i * HWs : gs);
+                const f32x4 v0 = g[0], v1 = g[1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { sv[i][e] = v0[e]; sv[i][4 + e] = v1[e]; }
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { sv[i][e] = v0[e]; sv[i][4 + e] = v1[e]; }
         }
+        // x side.  No branch may contain a load here: hipcc drains vmcnt at every control-flow join, which
+        // would serialise the chunk's loads.  Every unit reads a full window from an address that is always
+        // inside the tensor (clamped into its row, or the tensor base for rows that do not exist) and the
+        // border cases are resolved with selects afterwards.
         const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
         const float* lbase = xl + ((int64_t)n0 * p.C + b0) * HWl + iy0 * p.W + ix0;
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            const int iy = iy0 + l_r[i], ix = ix0 + (l_c[i] & 0xffff);
-            const bool single = S == 2 && (l_c[i] >> 16);
-            const bool row_ok = l_off[i] >= 0 && n0 + l_n[i] < p.N && iy >= 0 && iy < p.H;
-            const float* g = lbase + l_off[i];
-            if (row_ok && !single && ix >= 0 && ix + UW <= p.W) {     // interior: 16-byte accesses
+            const int m = l_meta[i];
+            const int iy = iy0 + ((m >> 12) & 31), ix = ix0 + ((m >> 17) & 127);
+            const bool row_ok = l_off[i] >= 0 && n0 + ((m >> 24) & 63) < p.N && iy >= 0 && iy < p.H;
+            if constexpr (S == 1) {
+                // window [ixc, ixc + 8) with ixc = clamp(ix, 0, W - 8); d = ix - ixc is -1 at the left image
+                // border (pad 1), 0 inside, > 0 at the right border, where only the row's last cell can be
+                // and only its elements 0 and 1 are ever read (host: OW % tile width == 0)
+                int ixc = ix < 0 ? 0 : ix;
+                if (ixc > p.W - 8) ixc = p.W - 8;
+                const int d = row_ok ? ix - ixc : 64;
+                const f32x4u* g = reinterpret_cast<const f32x4u*>(row_ok ? lbase + l_off[i] + (ixc - ix) : xl);
+                const f32x4 v0 = g[0], v1 = g[1];
 #pragma unroll
-                for (int q = 0; q < UW / 4; ++q) {
-                    const f32x4 v = reinterpret_cast<const f32x4u*>(g)[q];
+                for (int e = 0; e < 4; ++e) { lv[i][e] = v0[e]; lv[i][4 + e] = v1[e]; }
+                lcode[i] = d;
+            } else {
+                // stride 2, pad 0 (host): 16-column units are inside their row; the single-column tail unit
+                // (even cell of column 2 TW) reads one element
+                const bool single = (m >> 30) & 1;
+                const bool vec = row_ok && !single;
+                const float* gu = lbase + l_off[i];
+                const f32x4u* g = reinterpret_cast<const f32x4u*>(vec ? gu : xl);
+                ltail[i] = *((row_ok && single) ? gu : xl);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = g[q];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) lv[i][4 * q + e] = v[e];
                 }
-            } else {                                                   // image border / tail: element-wise
-#pragma unroll
-                for (int e = 0; e < UW; ++e)
-                    lv[i][e] = (row_ok && ix + e >= 0 && ix + e < p.W && !(single && e > 0)) ? g[e] : 0.0f;
+                lcode[i] = vec ? 1 : ((row_ok && single) ? 2 : 0);
             }
         }
+    };
+    // Border fix-up happens on the packed bf16 cells (dword funnel shifts and selects, no arrays) and only
+    // in chunks that touch an image border or a channel / batch tail (workgroup-uniform branch).
+    //   stride 1: code = window shift d: -1 -> the window starts one column right of the cell (left border),
+    //             6 / 7 -> right border cell, whose elements 0, 1 are window elements d, d + 1; 64 -> dead row
+    //   stride 2: code 1 = 16 columns, 2 = single-column tail unit, 0 = dead row
+    auto put3 = [&](u32x4* base, int plane, int c, const bf16x8& s0, const bf16x8& s1, const bf16x8& s2, int code) {
+        u32x4 v[3] = {__builtin_bit_cast(u32x4, s0), __builtin_bit_cast(u32x4, s1), __builtin_bit_cast(u32x4, s2)};
+        if (chunk_border && S == 1) {
+#pragma unroll
+            for (int sp = 0; sp < 3; ++sp) {
+                const u32x4 q = v[sp];
+                const u32x4 sh = {q[0] << 16, (q[0] >> 16) | (q[1] << 16), (q[1] >> 16) | (q[2] << 16),
+                                  (q[2] >> 16) | (q[3] << 16)};
+                u32x4 r = (code == -1) ? sh : q;
+                if (code > 0) r[0] = (code == 6) ? q[3] : (q[3] >> 16);
+                if (code > 7) r = u32x4{0u, 0u, 0u, 0u};
+                v[sp] = r;
+            }
+        }
+        base[c] = v[0];
+        base[plane + c] = v[1];
+        base[2 * plane + c] = v[2];
     };
     auto store_chunk = [&]() {
 #pragma unroll
         for (int i = 0; i < SPT; ++i) {
+            float fx[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fx[e] = (!chunk_border || ((s_okmask >> i) & 1)) ? sv[i][e] : 0.0f;
             bf16x8 s0, s1, s2;
-            split3_bf16(sv[i], s0, s1, s2);
-            Ss[s_cell[i]] = __builtin_bit_cast(u32x4, s0);
-            Ss[BA * SOS + s_cell[i]] = __builtin_bit_cast(u32x4, s1);
-            Ss[2 * BA * SOS + s_cell[i]] = __builtin_bit_cast(u32x4, s2);
+            split3_bf16(fx, s0, s1, s2);
+            put3(Ss, BA * SOS, s_cell + SA * SOS * i, s0, s1, s2, 0);
         }
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            if (l_cell[i] < 0) continue;
+            const int c = l_meta[i] & 0xfff;
+            if (c == 0xfff) continue;
             if constexpr (S == 1) {
                 bf16x8 s0, s1, s2;
                 split3_bf16(lv[i], s0, s1, s2);
-                Ls[l_cell[i]] = __builtin_bit_cast(u32x4, s0);
-                Ls[BB * LOS + l_cell[i]] = __builtin_bit_cast(u32x4, s1);
-                Ls[2 * BB * LOS + l_cell[i]] = __builtin_bit_cast(u32x4, s2);
+                put3(Ls, BB * LOS, c, s0, s1, s2, lcode[i]);
             } else {
+                const int code = lcode[i];
                 float ev[8], od[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { ev[e] = lv[i][2 * e]; od[e] = lv[i][2 * e + 1]; }
+                for (int e = 0; e < 8; ++e) {
+                    ev[e] = (code == 1) ? lv[i][2 * e] : 0.0f;
+                    od[e] = (code == 1) ? lv[i][2 * e + 1] : 0.0f;
+                }
+                if (code == 2) ev[0] = ltail[i];
                 bf16x8 s0, s1, s2;
                 split3_bf16(ev, s0, s1, s2);
-                Ls[l_cell[i]] = __builtin_bit_cast(u32x4, s0);
-                Ls[BB * LOS + l_cell[i]] = __builtin_bit_cast(u32x4, s1);
-                Ls[2 * BB * LOS + l_cell[i]] = __builtin_bit_cast(u32x4, s2);
-                if (!(l_c[i] >> 16)) {
+                put3(Ls, BB * LOS, c, s0, s1, s2, 0);
+                if (!((l_meta[i] >> 30) & 1)) {
                     split3_bf16(od, s0, s1, s2);
-                    Ls[l_cell[i] + NOLE] = __builtin_bit_cast(u32x4, s0);
-                    Ls[BB * LOS + l_cell[i] + NOLE] = __builtin_bit_cast(u32x4, s1);
-                    Ls[2 * BB * LOS + l_cell[i] + NOLE] = __builtin_bit_cast(u32x4, s2);
+                    put3(Ls, BB * LOS, c + NOLE, s0, s1, s2, 0);
                 }
             }
         }
     };
 
-    // operands of one K block (two octets): A cells, and per ky the aligned x-side cell(s) + the
-    // first dword of the right neighbour
-    struct Frag {
-        u32x4 a[3];
-        u32x4 be[3][3];
-        unsigned bn[3][3];
-        u32x4 bo[(S == 2) ? 3 : 1][3];
+    // operands: A cells of one K block (two octets); per (K block, ky) the aligned x-side cell(s) + the
+    // first dword of the right neighbour.  One wave per SIMD: the LDS reads of step (kb, ky) + 1 are
+    // issued before the 18 MFMAs of step (kb, ky) (two alternating register sets).
+    struct FragA { u32x4 a[3]; };
+    struct FragB {
+        u32x4 be[3];
+        unsigned bn[3];
+        u32x4 bo[(S == 2) ? 3 : 1];
     };
     const int a_row = (wa * 32 + l31) * SOS;
     const int b_row = (wb * 32 + l31) * LOS;
-    auto fetch = [&](int kb, Frag& f) {
+    auto fetchA = [&](int kb, FragA& f) {
+        const int o = 2 * kb + half;
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) f.a[sp] = Ss[sp * BA * SOS + a_row + o];
+    };
+    auto fetchB = [&](int kb, int ky, FragB& f) {
         const int o = 2 * kb + half;
         const int poct = o & (TWO - 1);
         const int py = (o >> p.tw8_log2) & (TH - 1);
         const int pn = o >> (p.tw8_log2 + p.th_log2);
+        const int c0 = b_row + (pn * PH + py * S + ky) * RC + poct;
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) f.a[sp] = Ss[sp * BA * SOS + a_row + o];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int c0 = b_row + (pn * PH + py * S + ky) * RC + poct;
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) {
-                f.be[ky][sp] = Ls[sp * BB * LOS + c0];
-                f.bn[ky][sp] = Ls[sp * BB * LOS + c0 + 1][0];
-                if constexpr (S == 2) f.bo[ky][sp] = Ls[sp * BB * LOS + c0 + NOLE];
-            }
+        for (int sp = 0; sp < 3; ++sp) {
+            f.be[sp] = Ls[sp * BB * LOS + c0];
+            f.bn[sp] = Ls[sp * BB * LOS + c0 + 1][0];
+            if constexpr (S == 2) f.bo[sp] = Ls[sp * BB * LOS + c0 + NOLE];
         }
     };
     auto shift1 = [](const u32x4& c, unsigned n) {
@@ -1363,36 +1413,35 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_bx_kernel(const float* __re
         r[3] = (c[3] >> 16) | (n << 16);
         return r;
     };
-    auto mma = [&](const Frag& f) {
+    auto mma = [&](const FragA& fa, const FragB& f, auto KY) {
+        constexpr int ky = decltype(KY)::value;
         constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
         constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
-        bf16x8 a[3];
+        bf16x8 a[3], b[3][3];     // b[kx][split]
 #pragma unroll
-        for (int sp = 0; sp < 3; ++sp) a[sp] = __builtin_bit_cast(bf16x8, f.a[sp]);
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            bf16x8 b[3][3];     // [kx][split]
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) {
-                const u32x4 e = f.be[ky][sp];
-                b[0][sp] = __builtin_bit_cast(bf16x8, e);
-                if constexpr (S == 1) {
-                    b[1][sp] = __builtin_bit_cast(bf16x8, shift1(e, f.bn[ky][sp]));
-                    const u32x4 d = {e[1], e[2], e[3], f.bn[ky][sp]};
-                    b[2][sp] = __builtin_bit_cast(bf16x8, d);
-                } else {
-                    b[1][sp] = __builtin_bit_cast(bf16x8, f.bo[ky][sp]);
-                    b[2][sp] = __builtin_bit_cast(bf16x8, shift1(e, f.bn[ky][sp]));
-                }
+        for (int sp = 0; sp < 3; ++sp) {
+            a[sp] = __builtin_bit_cast(bf16x8, fa.a[sp]);
+            const u32x4 e = f.be[sp];
+            b[0][sp] = __builtin_bit_cast(bf16x8, e);
+            if constexpr (S == 1) {
+                b[1][sp] = __builtin_bit_cast(bf16x8, shift1(e, f.bn[sp]));
+                const u32x4 d = {e[1], e[2], e[3], f.bn[sp]};
+                b[2][sp] = __builtin_bit_cast(bf16x8, d);
+            } else {
+                b[1][sp] = __builtin_bit_cast(bf16x8, f.bo[sp]);
+                b[2][sp] = __builtin_bit_cast(bf16x8, shift1(e, f.bn[sp]));
             }
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], b[kx][TB[q]],
-                                                                               acc[ky * 3 + kx], 0, 0, 0);
         }
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], b[kx][TB[q]],
+                                                                           acc[ky * 3 + kx], 0, 0, 0);
     };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
 
     if (ch_begin < ch_end) load_chunk(ch_begin);
     for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
@@ -1401,21 +1450,19 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_bx_kernel(const float* __re
         __syncthreads();
         if (chunk + 1 < ch_end) load_chunk(chunk + 1);
         constexpr int KB = NO / 2;
-        if constexpr (DB) {
-            Frag f0, f1;
-            fetch(0, f0);
-            for (int kb = 0; kb < KB; kb += 2) {
-                fetch(kb + 1, f1);
-                mma(f0);
-                if (kb + 2 < KB) fetch(kb + 2, f0);
-                mma(f1);
-            }
-        } else {
-            for (int kb = 0; kb < KB; ++kb) {
-                Frag f;
-                fetch(kb, f);
-                mma(f);
-            }
+        static_assert(KB % 2 == 0, "K-block loop is unrolled by two");
+        FragA a0, a1;
+        FragB f0, f1;
+        fetchA(0, a0);
+        fetchB(0, 0, f0);
+        for (int kb = 0; kb < KB; kb += 2) {
+            fetchB(kb, 1, f1); mma(a0, f0, K0{});
+            fetchB(kb, 2, f0); mma(a0, f1, K1{});
+            fetchA(kb + 1, a1); fetchB(kb + 1, 0, f1); mma(a0, f0, K2{});
+            fetchB(kb + 1, 1, f0); mma(a1, f1, K0{});
+            fetchB(kb + 1, 2, f1); mma(a1, f0, K1{});
+            if (kb + 2 < KB) { fetchA(kb + 2, a0); fetchB(kb + 2, 0, f0); }
+            mma(a1, f1, K2{});
         }
     }
 
@@ -1554,8 +1601,10 @@ WgPlan wg_plan(const sae_conv2d_desc* d) {
         if (bth > no / two) bth = no / two;
         const int btn = no / (two * bth);
         const int ph = (bth - 1) * d->stride + 3;
-        const bool fits = (d->stride == 1) ? btn * ph * (two + 1) <= 30
-                                           : (btn * ph * (2 * two + 1) <= 45 && btn * ph * (two + 1) <= 27);
+        bool fits = (d->stride == 1) ? btn * ph * (two + 1) <= 30
+                                     : (btn * ph * (2 * two + 1) <= 45 && btn * ph * (two + 1) <= 27);
+        // border handling of the staging loads: whole tiles only; stride 2 with pad 0 only
+        if (d->ow % (8 * two) != 0 || (d->stride == 2 && d->pad != 0)) fits = false;
         if (fits) {
             w.bx = true;
             w.tw8_log2 = (two == 4) ? 2 : 1;
@@ -1946,9 +1995,9 @@ extern "C" int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
         q.tiles_n = w.tiles_n; q.chunks = w.chunks; q.chunks_per_slice = w.cps; q.Ap = w.Ap; q.Bp = w.Bp;
         const dim3 grid((unsigned)(w.Bp / w.sh.bb), (unsigned)(w.Ap / w.sh.ba), (unsigned)w.slices);
         if (d->stride == 1)
-            hipLaunchKernelGGL((conv_wgrad_bx_kernel<1, 2, 2, true>), grid, dim3(kBlock), 0, s, x, gy, workspace, q);
+            hipLaunchKernelGGL((conv_wgrad_bx_kernel<1, 2, 2>), grid, dim3(kBlock), 0, s, x, gy, workspace, q);
         else
-            hipLaunchKernelGGL((conv_wgrad_bx_kernel<2, 4, 1, false>), grid, dim3(kBlock), 0, s, x, gy, workspace, q);
+            hipLaunchKernelGGL((conv_wgrad_bx_kernel<2, 4, 1>), grid, dim3(kBlock), 0, s, x, gy, workspace, q);
     } else if (d->n > 0) {
         if (w.sh.mode == 2) {
             if (d->kh == 3 && d->stride == 1) launch_wgrad<3, 1, 1, 1, 1, 1, 2>(x, gy, workspace, p, w, s);
