@@ -67,6 +67,23 @@ def bench_bias_act(shape):
     print(json.dumps({"op": "bias_act_bwd", "shape": list(shape), "ms": ms, "GBps": 12.0 * x.numel() / 1e6 / ms}), flush=True)
 
 
+def bench_conv_fused(n, c, h, w, m, k, s, p, tag):
+    """forward conv with the fused bias + leaky-ReLU epilogue (sae_conv2d_fwd_bias_act_f32)"""
+    d = H.conv_desc(n, c, h, w, m, k, s, p)
+    x = torch.randn(n, c, h, w, device=dev)
+    wt = torch.randn(m, c, k, k, device=dev)
+    b = torch.randn(m, device=dev)
+    y = torch.empty(n, m, d.oh, d.ow, device=dev)
+    nws = lib.query("conv2d_workspace", C.byref(d), 0)
+    ws = torch.empty(max(nws, 1), device=dev)
+    fn = lambda: lib.call("conv2d_fwd_bias_act_f32", x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), C.byref(d),
+                          1.0, 0.2, 2 ** 0.5, ws.data_ptr(), nws, stream())
+    ms = timeit(fn)
+    fl = 2.0 * n * m * d.oh * d.ow * c * k * k
+    print(json.dumps({"op": "conv_fwd_bias_act", "tag": tag, "geom": [n, c, h, w, m, k, s, p], "ms": ms,
+                      "TFLOPs": fl / ms / 1e9}), flush=True)
+
+
 def bench_conv(n, c, h, w, m, k, s, p, tag):
     d = H.conv_desc(n, c, h, w, m, k, s, p)
     x = torch.randn(n, c, h, w, device=dev)
