@@ -28,6 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # same table, dense bf16 matrix; the bf16x6 arithmetic spends 6 bf16 products
+                                      # (20/3 with the zero-padded ninth tap) per fp32 product
 FLOPS_PER_IMAGE = {"church256": 1.815e12, "bedroom256": 1.815e12, "ffhq512": 3.91e12, "ffhq1024": 6.08e12}
 DEFAULT_BATCH = {"church256": 16, "bedroom256": 16, "ffhq512": 8, "ffhq1024": 4, "tiny32": 4}
 
@@ -39,6 +41,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--preset", default="church256", choices=sorted(DEFAULT_BATCH))
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (default: the preset's)")
+    ap.add_argument("--conv-math", default="f32", choices=["f32", "bf16x6"],
+                    help="arithmetic of the 3x3 conv kernels for the reported value (include/sae_hip.h: sae_set_conv_math)")
+    ap.add_argument("--alt-steps", type=int, default=8,
+                    help="steps of the extra measurement with the OTHER conv arithmetic (0 = skip); reported as alt_conv_math")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -87,18 +93,27 @@ class DominantKernelTimer:
 
         cg._launch_fused = launch_fused
 
-    def summary(self):
+    def summary(self, conv_math="f32"):
         if not self.records:
             return None
         ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self.records)
         fl = sum(f for f, _, _ in self.records)
         n = len(self.records)
         achieved = fl / (ms * 1e-3) / 1e12
-        return {"bound": "mfma", "kernel": "conv_igemm_kernel<3,1,2,2,2,2,8>", "achieved": round(achieved, 2),
-                "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+        note = "event bracket includes the <1% weight re-layout launch that precedes each conv"
+        if conv_math == "bf16x6":
+            # algorithmic fp32 FLOPs against the bf16 matrix peak divided by the 6 bf16 products one fp32
+            # product costs in this arithmetic
+            peak = MFMA_BF16_PEAK_TFLOPS / 6.0
+            kernel = "conv_igemm_bx_kernel<2,2,2,2>"
+            note += "; peak = 2500 TFLOP/s dense bf16 / 6 split products per fp32 product"
+        else:
+            peak = MFMA_F32_PEAK_TFLOPS
+            kernel = "conv_igemm_kernel<3,1,2,2,2,2,8>"
+        return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2),
+                "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": None, "launches": n, "avg_launch_ms": round(ms / n, 4),
-                "avg_launch_gflop": round(fl / n / 1e9, 2),
-                "note": "event bracket includes the <1% weight re-layout launch that precedes each conv"}
+                "avg_launch_gflop": round(fl / n / 1e9, 2), "note": note}
 
 
 def cpu_baseline(preset):
@@ -156,7 +171,8 @@ def main():
     from swapping_autoencoder_pytorch_amd.options import make_options
     from swapping_autoencoder_pytorch_amd.swapping_autoencoder_model import create_model
     from swapping_autoencoder_pytorch_amd.swapping_autoencoder_optimizer import create_optimizer
-    hip_lib.get()     # fail loudly here if the HIP library is missing
+    hip_lib.get()           # fail loudly here if the HIP library is missing
+    hip_lib.set_conv_math(args.conv_math)
 
     batch = args.batch or DEFAULT_BATCH[args.preset]
     opt = make_options(args.preset, batch_size=batch, num_gpus=1)
@@ -208,6 +224,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the same iterations with the other conv arithmetic (not `value`)
+    alt = None
+    if args.alt_steps > 0:
+        other = "bf16x6" if args.conv_math == "f32" else "f32"
+        hip_lib.set_conv_math(other)
+        for i in range(2):                       # workspaces change size with the arithmetic: let the allocator settle
+            iteration(args.warmup + args.steps + i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.alt_steps):
+            iteration(args.warmup + args.steps + 2 + i)
+        fence()
+        adt = time.perf_counter() - t0
+        hip_lib.set_conv_math(args.conv_math)
+        if world > 1:
+            t = torch.tensor([adt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            adt = float(t.item())
+        alt = {"conv_math": other, "steps": args.alt_steps, "value": round(world * batch * args.alt_steps / adt, 3),
+               "unit": "images/s", "ms_per_step": round(adt / args.alt_steps * 1e3, 3),
+               "note": "no lazy-R1 iteration in this window unless it spans a multiple of 16"}
+
     if rank == 0:
         images = world * batch * args.steps
         value = images / dt
@@ -219,8 +257,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s preset, %dx%d, B=%d/GPU: full E/G/D/Dpatch D-step + G-step with Adam, lazy R1 "
                                    "every 16th D iteration" % (args.preset, size, size, batch),
-                       "global_batch": world * batch, "parallelism": "dp%d" % world},
+                       "global_batch": world * batch, "parallelism": "dp%d" % world, "conv_math": args.conv_math},
         }
+        if alt:
+            line["alt_conv_math"] = alt
         if per_image:
             line["model_tflops_per_gpu"] = round(value / world * per_image / 1e12, 2)
             line["frac_of_mfma_f32_roofline"] = round(value / world * per_image / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
@@ -231,7 +271,7 @@ def main():
             line["ms_d_call_median"] = round(d_calls[len(d_calls) // 2], 2)
             line["ms_g_call_median"] = round(g_calls[len(g_calls) // 2], 2)
             line["ms_r1_extra_max"] = round(d_calls[-1] - d_calls[len(d_calls) // 2], 2)
-        roof = timer.summary()
+        roof = timer.summary(args.conv_math)
         if roof:
             line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:

@@ -133,3 +133,20 @@ def get():
 
 def ptr(t):
     return None if t is None else t.data_ptr()
+
+
+CONV_MATH_MODES = {"f32": 0, "bf16x6": 1}
+
+
+def set_conv_math(mode):
+    """Arithmetic of the 3x3 conv kernels: "f32" (default; v_mfma_f32_32x32x2_f32, an exact fp32 fma chain)
+    or "bf16x6" (operands split exactly into three bf16 pieces, six bf16 MFMAs per product block, fp32
+    accumulate; same error class, 1.3-2x faster).  include/sae_hip.h: sae_set_conv_math."""
+    if mode not in CONV_MATH_MODES:
+        raise SaeError("conv math must be one of %s, got %r" % (sorted(CONV_MATH_MODES), mode))
+    get().call("set_conv_math", CONV_MATH_MODES[mode])
+
+
+def get_conv_math():
+    code = get().query("get_conv_math")
+    return next(k for k, v in CONV_MATH_MODES.items() if v == code)

@@ -12,6 +12,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(scope="module", autouse=True, params=["f32", "bf16x6"])
+def _conv_math(request):
+    """BASELINE-size properties under both conv arithmetics (sae_set_conv_math)."""
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    hip_lib.set_conv_math(request.param)
+    yield request.param
+    hip_lib.set_conv_math("f32")
+
+
 def _dot(a, b):
     return float((a.double() * b.double()).sum())
 

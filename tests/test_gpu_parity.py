@@ -10,13 +10,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.fixture(scope="module", autouse=True)
-def _native_lib_loaded():
+@pytest.fixture(scope="module", autouse=True, params=["f32", "bf16x6"])
+def _native_lib_loaded(request):
+    """Every check of this module runs under both conv arithmetics (include/sae_hip.h:
+    sae_set_conv_math); the golden tolerances are the same for both."""
     assert torch.cuda.is_available()
     from swapping_autoencoder_pytorch_amd import hip_lib
     lib = hip_lib.get()
     assert lib.prefix == "sae_" and lib.device_only and lib.path.endswith("libsae_hip.so")
+    hip_lib.set_conv_math(request.param)
+    assert hip_lib.get_conv_math() == request.param
     yield
+    hip_lib.set_conv_math("f32")
 
 
 def test_ops():
