@@ -972,6 +972,9 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     constexpr int LS = (KS == 1) ? 1 : (LP + kWave - 1) / kWave;
     float sv[NS];
     float lv[NLB][LS];
+    constexpr bool BRANCHFREE = KS == 3 && S == 2 && !PIXSPLIT;
+    bool s_ok = false;      // validity of the prefetched chunk's elements (applied in store_chunk)
+    int l_okmask = 0;
 
     auto load_chunk = [&](int chunk) {
         int bt = chunk;
@@ -989,10 +992,16 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
             const bool ok = n < p.N && oy < p.OH && ox < p.OW;
             const float* sbase = gs + ((int64_t)n0 * p.M + a0) * HWs;
             const int lane_off = pn * p.M * HWs + oy * p.OW + ox;
+            // BRANCHFREE: no load sits in a divergent branch (hipcc drains vmcnt at the join, which serialised
+            // the loads of the register-starved stride-2 instantiation: 78 -> 98 TFLOP/s); invalid elements
+            // read element 0 of the block's tile and are zeroed in store_chunk.  The stride-1 kernel keeps
+            // predicated loads (measured 111 vs 102 TFLOP/s with the select-and-mask form).
+            s_ok = ok;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int a = wid + 4 * i;
-                sv[i] = (ok && a0 + a < p.M) ? sbase[lane_off + a * HWs] : 0.0f;
+                if constexpr (BRANCHFREE) sv[i] = sbase[(ok && a0 + a < p.M) ? lane_off + a * HWs : 0];
+                else sv[i] = (ok && a0 + a < p.M) ? sbase[lane_off + a * HWs] : 0.0f;
             }
         }
         {
@@ -1018,25 +1027,35 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
                 poff[s] = off;
             }
             const float* lbase = xl + ((int64_t)n0 * p.C + b0) * HWl;
+            l_okmask = 0;
+#pragma unroll
+            for (int s = 0; s < LS; ++s) l_okmask |= (poff[s] >= 0 ? 1 : 0) << s;
 #pragma unroll
             for (int j = 0; j < NLB; ++j) {
                 const int b = wid + 4 * j;
                 const bool ch_ok = (b0 + b) < p.C;
 #pragma unroll
-                for (int s = 0; s < LS; ++s) lv[j][s] = (ch_ok && poff[s] >= 0) ? lbase[poff[s] + b * HWl] : 0.0f;
+                for (int s = 0; s < LS; ++s) {
+                    if constexpr (BRANCHFREE) lv[j][s] = lbase[(ch_ok && poff[s] >= 0) ? poff[s] + b * HWl : 0];
+                    else lv[j][s] = (ch_ok && poff[s] >= 0) ? lbase[poff[s] + b * HWl] : 0.0f;
+                }
             }
         }
     };
     auto store_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) Ss[(wid + 4 * i) * SLD + lane] = sv[i];
+        for (int i = 0; i < NS; ++i)
+            Ss[(wid + 4 * i) * SLD + lane] = (!BRANCHFREE || (s_ok && a0 + wid + 4 * i < p.M)) ? sv[i] : 0.0f;
 #pragma unroll
-        for (int j = 0; j < NLB; ++j)
+        for (int j = 0; j < NLB; ++j) {
+            const bool ch_ok = (b0 + wid + 4 * j) < p.C;
 #pragma unroll
             for (int s = 0; s < LS; ++s) {
                 const int e = lane + kWave * s;
-                if (e < CPs) Ls[(wid + 4 * j) * LP + e] = lv[j][s];
+                if (e < CPs)
+                    Ls[(wid + 4 * j) * LP + e] = (!BRANCHFREE || (ch_ok && ((l_okmask >> s) & 1))) ? lv[j][s] : 0.0f;
             }
+        }
     };
 
     if (ch_begin < ch_end) load_chunk(ch_begin);
