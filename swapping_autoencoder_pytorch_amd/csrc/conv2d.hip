@@ -514,17 +514,24 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_bx_kernel(const float* __re
 // stride-2 transposed gather ("tr"): out[m][o] = sum_{c,k : o + pad = 2 i + k} wp[k][c][m] * in[c][i]
 // 3x3 taps only.  N-tiles of a wave = the 4 parity classes of the same 32 q positions.
 // ------------------------------------------------------------------------------------------
-struct TrParams {
-    int N, C, IH, IW;     // input tensor (the small, "y side" image)
-    int M, OH, OW;        // output tensor (the large, "x side" image)
-    int QH, QW;           // half-resolution grid covered by THIS launch: [qy_base, QH) x [qx_base, QW)
+struct TrRegion {
+    int QH, QW;           // half-resolution rectangle [qy_base, QH) x [qx_base, QW)
     int qy_base, qx_base;
-    int debug_skip_store;   // profiling aid (SAE_TR_NOSTORE): results are NOT written
-    int Cp, Mp;
-    int pad;
     int tw, th, tn;       // q tile = TN images x TH x TW positions (any sizes with TN*TH*TW <= BQ: the
                           // transposed problems have 2^k + 1 wide grids, power-of-two tiles waste 25-90 %)
     int tiles_x, tiles_y, tiles_n;
+    int blocks;           // tiles_x * tiles_y * tiles_n
+};
+struct TrParams {
+    int N, C, IH, IW;     // input tensor (the small, "y side" image)
+    int M, OH, OW;        // output tensor (the large, "x side" image)
+    int debug_skip_store;   // profiling aid (SAE_TR_NOSTORE): results are NOT written
+    int Cp, Mp;
+    int pad;
+    // main region + right / bottom strips, all in ONE launch (blockIdx.x runs through the regions):
+    // launched one after the other the two thin strips cost a full K loop of latency each on a
+    // nearly empty GPU
+    TrRegion reg[3];
 };
 
 template <int MI, int WM, int WN, int CK>
@@ -547,12 +554,18 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wid / WN, wn = wid % WN;
 
-    const int TW = p.tw, TH = p.th, TN = p.tn;
     int bt = blockIdx.x;
-    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
-    const int tiy = bt % p.tiles_y;
-    const int tin = bt / p.tiles_y;
-    const int qx0 = p.qx_base + tix * TW, qy0 = p.qy_base + tiy * TH, n0 = tin * TN;
+    int ridx = 0;
+    if (bt >= p.reg[0].blocks) {
+        bt -= p.reg[0].blocks; ridx = 1;
+        if (bt >= p.reg[1].blocks) { bt -= p.reg[1].blocks; ridx = 2; }
+    }
+    const TrRegion g = p.reg[ridx];
+    const int TW = g.tw, TH = g.th, TN = g.tn;
+    const int tix = bt % g.tiles_x; bt /= g.tiles_x;
+    const int tiy = bt % g.tiles_y;
+    const int tin = bt / g.tiles_y;
+    const int qx0 = g.qx_base + tix * TW, qy0 = g.qy_base + tiy * TH, n0 = tin * TN;
     const int m0 = blockIdx.y * BM;
 
     const int PH = TH + 1, PW = TW + 1;          // patch row r <-> input row qy0 - 1 + r
@@ -676,7 +689,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
         if (keep == 12345.678f) y[0] = keep;
         return;
     }
-    if (lane_ok && n < p.N && qy < p.QH && qx < p.QW) {   // q beyond this launch's region belongs to another launch
+    if (lane_ok && n < p.N && qy < g.QH && qx < g.QW) {   // q beyond this launch's region belongs to another launch
         // (pairing the two x-classes of a lane into one 4-byte-aligned 8-byte store was measured
         // slower, 87 vs 94 TFLOP/s: the rows are 2^k + 1 wide, so half of those stores are misaligned)
 #pragma unroll
@@ -722,12 +735,18 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_bx_kernel(const float* _
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wid / WN, wn = wid % WN;
 
-    const int TW = p.tw, TH = p.th, TN = p.tn;
     int bt = blockIdx.x;
-    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
-    const int tiy = bt % p.tiles_y;
-    const int tin = bt / p.tiles_y;
-    const int qx0 = p.qx_base + tix * TW, qy0 = p.qy_base + tiy * TH, n0 = tin * TN;
+    int ridx = 0;
+    if (bt >= p.reg[0].blocks) {
+        bt -= p.reg[0].blocks; ridx = 1;
+        if (bt >= p.reg[1].blocks) { bt -= p.reg[1].blocks; ridx = 2; }
+    }
+    const TrRegion g = p.reg[ridx];
+    const int TW = g.tw, TH = g.th, TN = g.tn;
+    const int tix = bt % g.tiles_x; bt /= g.tiles_x;
+    const int tiy = bt % g.tiles_y;
+    const int tin = bt / g.tiles_y;
+    const int qx0 = g.qx_base + tix * TW, qy0 = g.qy_base + tiy * TH, n0 = tin * TN;
     const int m0 = blockIdx.y * BM;
 
     const int PH = TH + 1, PW = TW + 1;
@@ -852,7 +871,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_bx_kernel(const float* _
     }
 
     const int n = n0 + pn, qy = qy0 + py, qx = qx0 + px;
-    if (lane_ok && n < p.N && qy < p.QH && qx < p.QW) {
+    if (lane_ok && n < p.N && qy < g.QH && qx < g.QW) {
 #pragma unroll
         for (int cl = 0; cl < 4; ++cl) {
             const int oy = 2 * qy + (cl >> 1) - p.pad;
@@ -1858,9 +1877,13 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
     regions[nreg++] = {0, QHm, 0, QWm};
     if (QWm < QW) regions[nreg++] = {0, QH, QWm, QW};          // right strip (full height)
     if (QHm < QH) regions[nreg++] = {QHm, QH, 0, QWm};          // bottom strip
-    for (int r = 0; r < nreg; ++r) {
+    int total_blocks = 0;
+    for (int r = 0; r < 3; ++r) {
+        TrRegion& g = p.reg[r];
+        g = TrRegion{};
+        if (r >= nreg) { g.tw = g.th = g.tn = g.tiles_x = g.tiles_y = g.tiles_n = 1; continue; }   // empty: blocks = 0
         const int qh = regions[r].y1 - regions[r].y0, qw = regions[r].x1 - regions[r].x0;
-        p.qy_base = regions[r].y0; p.qx_base = regions[r].x0; p.QH = regions[r].y1; p.QW = regions[r].x1;
+        g.qy_base = regions[r].y0; g.qx_base = regions[r].x0; g.QH = regions[r].y1; g.QW = regions[r].x1;
         // tile = tn x th x tw q-positions: fewest workgroups (each costs bq lanes of MFMA work), with a
         // penalty for narrow rows (short global-memory runs: a 9-wide tile measured no faster than a
         // 32-wide one with 12 % more workgroups)
@@ -1874,18 +1897,22 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
                 if (tn * (th + 1) * (tw + 1) > cap) continue;
                 const double cost = (double)ceil_div(qw, tw) * ceil_div(qh, th) * ceil_div(N, tn) * (1.0 + 8.0 / (tw < qw ? tw : 32));
                 if (best < 0 || cost < best) {
-                    best = cost; p.tw = tw; p.th = th; p.tn = tn;
+                    best = cost; g.tw = tw; g.th = th; g.tn = tn;
                 }
             }
         if (best < 0) return fail(SAE_EINVAL, "conv tr: no tile fits the LDS patch cap");
-        p.tiles_x = ceil_div(qw, p.tw);
-        p.tiles_y = ceil_div(qh, p.th);
-        p.tiles_n = ceil_div(N, p.tn);
-        const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(Mp / sh.bm));
+        g.tiles_x = ceil_div(qw, g.tw);
+        g.tiles_y = ceil_div(qh, g.th);
+        g.tiles_n = ceil_div(N, g.tn);
+        g.blocks = g.tiles_x * g.tiles_y * g.tiles_n;
+        total_blocks += g.blocks;
+    }
+    {
+        const dim3 grid((unsigned)total_blocks, (unsigned)(Mp / sh.bm));
         if (bx) {
             hipLaunchKernelGGL((conv_igemm_tr_bx_kernel<2, 2, 2>), grid, dim3(kBlock), 0, s, x,
                                reinterpret_cast<const u32x4*>(ws), y, p);
-            continue;
+            return SAE_OK;
         }
         switch (sh.cfg) {
             case 3: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 1, 4, 16>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;

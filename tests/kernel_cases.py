@@ -42,6 +42,9 @@ CONV_SMALL = [
     (2, 40, 6, 6, 70, 3, 1, 1, False),
     # stride-2 dgrad with 2^k + 1 wide half-resolution grids: main region + right/bottom strips
     (1, 4, 67, 67, 12, 3, 2, 0, False), (2, 4, 35, 67, 12, 3, 2, 0, False), (1, 4, 131, 35, 40, 3, 2, 0, False),
+    # stride-2 dgrad / transposed conv producing > 64 channels: the class-split 128 x 128q transposed gather
+    (1, 70, 17, 17, 12, 3, 2, 0, False), (2, 72, 35, 67, 8, 3, 2, 0, True), (1, 70, 10, 12, 20, 3, 2, 1, False),
+    (1, 130, 9, 11, 6, 3, 2, 0, False),
     # narrow layers: wgrad MODE 1 (M, C <= 32) and MODE 2 (C * taps <= 32, RGB stems)
     (3, 20, 12, 12, 24, 3, 1, 1, False), (2, 3, 16, 16, 40, 3, 1, 1, False), (2, 3, 9, 9, 20, 3, 2, 0, False),
     (2, 3, 8, 8, 70, 1, 1, 0, False), (1, 30, 15, 15, 36, 1, 2, 0, False),
