@@ -9,6 +9,9 @@
  *                               (kernel: upfirdn2d_kernel.cu:52-137, host: :140-272)
  *   sae_bias_act_f32         <- fused.fused_bias_act(...)      models/networks/stylegan2_op/fused_bias_act.cpp:11-17
  *                               (kernel: fused_bias_act_kernel.cu:18-49, host: :52-99)
+ *   sae_noise_bias_act_f32   <- NoiseInjection.forward + FusedLeakyReLU.forward   models/networks/stylegan2_layers.py:340-351, :54-65
+ *   sae_noise_bias_act_bwd_f32, sae_plane_scale_dot_f32 <- the autograd graph of StyledConv's elementwise ops
+ *                               (stylegan2_layers.py:280-286 style modulation, :340-351 noise, :54-65 bias + leaky-ReLU)
  *   sae_bias_act_bwd_f32     <- fused_bias_act(grad=1) followed by grad_input.sum(dim)
  *                               models/networks/stylegan2_op/fused_act.py:32-41 (one fused pass here)
  *   sae_conv2d_{fwd,dgrad,wgrad}_f32
@@ -91,6 +94,27 @@ int sae_bias_act_f32(const float* x, const float* b, const float* ref, float* y,
                      int64_t numel, int64_t step_b, int64_t size_b,
                      int32_t act, int32_t grad, float alpha, float scale,
                      sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * StyledConv glue (generator), x / y / gy / gx: [outer][channels][hw] contiguous, hw % 4 == 0, 16-byte
+ * aligned; noise: [outer][hw] (one map per sample, broadcast over channels) or NULL; noise_weight: one float
+ * ON THE DEVICE (the NoiseInjection parameter, stylegan2_layers.py:334); bias: [channels] or NULL.
+ *   sae_noise_bias_act_f32      y = lrelu((x + noise_weight * noise) + bias, alpha) * scale
+ *   sae_noise_bias_act_bwd_f32  gx = (y_ref > 0 ? gy : alpha gy) * scale;  gbias[c] = sum_{n,hw} gx;
+ *                               gnoise_weight[0] = sum gx * noise   (two-stage, fixed order; gbias /
+ *                               gnoise_weight may be NULL; workspace: sae_noise_bias_act_bwd_workspace floats)
+ *   sae_plane_scale_dot_f32     backward of y = x * s[plane] (style modulation of the conv input):
+ *                               gx = g * s[plane], gs[plane] = sum_hw g * x;  g, x, gx: [planes][hw]
+ * ------------------------------------------------------------------------------------------ */
+int sae_noise_bias_act_f32(const float* x, const float* noise, const float* noise_weight, const float* bias,
+                           float* y, int64_t outer, int64_t channels, int64_t hw, float alpha, float scale,
+                           sae_stream_t stream);
+int64_t sae_noise_bias_act_bwd_workspace(int64_t outer, int64_t channels, int64_t hw);
+int sae_noise_bias_act_bwd_f32(const float* gy, const float* y_ref, const float* noise, float* gx, float* gbias,
+                               float* gnoise_weight, float* workspace, int64_t workspace_floats, int64_t outer,
+                               int64_t channels, int64_t hw, float alpha, float scale, sae_stream_t stream);
+int sae_plane_scale_dot_f32(const float* g, const float* x, const float* s, float* gx, float* gs, int64_t planes,
+                            int64_t hw, sae_stream_t stream);
 
 /* Fused backward of the leaky-ReLU form: gx = (y_ref > 0 ? gy : alpha*gy) * scale and
  * gb[c] = sum over everything but the channel axis of gx (deterministic two-stage reduction,

@@ -397,3 +397,75 @@ int oracle_add_scale_f32(const float* a, const float* b, float* y, int64_t numel
     for (int64_t i = 0; i < numel; ++i) y[i] = (a[i] + b[i]) * alpha;
     return SAE_OK;
 }
+
+
+static int set_err(const char* msg) {
+    snprintf(g_err, sizeof g_err, "oracle: %s", msg);
+    return -1;
+}
+
+/* ---- StyledConv glue (include/sae_hip.h): stylegan2_layers.py:340-351 (noise), :54-65 (bias + leaky-ReLU),
+ * :280-286 (style modulation) and their autograd ---------------------------------------------------------- */
+int oracle_noise_bias_act_f32(const float* x, const float* noise, const float* noise_weight, const float* bias,
+                              float* y, int64_t outer, int64_t channels, int64_t hw, float alpha, float scale,
+                              void* stream) {
+    (void)stream;
+    if (outer < 0 || channels < 1 || hw < 4 || hw % 4) return set_err("noise_bias_act: bad shape");
+    const float wn = noise ? noise_weight[0] : 0.0f;
+#pragma omp parallel for collapse(2)
+    for (int64_t n = 0; n < outer; ++n)
+        for (int64_t c = 0; c < channels; ++c) {
+            const float* xp = x + (n * channels + c) * hw;
+            float* yp = y + (n * channels + c) * hw;
+            for (int64_t p = 0; p < hw; ++p) {
+                float t = xp[p] + (noise ? wn * noise[n * hw + p] : 0.0f);
+                t += bias ? bias[c] : 0.0f;
+                yp[p] = (t > 0.0f ? t : t * alpha) * scale;
+            }
+        }
+    return 0;
+}
+
+int64_t oracle_noise_bias_act_bwd_workspace(int64_t outer, int64_t channels, int64_t hw) {
+    (void)outer; (void)channels; (void)hw;
+    return 1;
+}
+
+int oracle_noise_bias_act_bwd_f32(const float* gy, const float* y_ref, const float* noise, float* gx, float* gbias,
+                                  float* gnoise_weight, float* workspace, int64_t workspace_floats, int64_t outer,
+                                  int64_t channels, int64_t hw, float alpha, float scale, void* stream) {
+    (void)stream; (void)workspace; (void)workspace_floats;
+    if (outer < 0 || channels < 1 || hw < 4 || hw % 4) return set_err("noise_bias_act_bwd: bad shape");
+    double gw = 0.0;
+    for (int64_t c = 0; c < channels; ++c) {
+        double gb = 0.0;
+        for (int64_t n = 0; n < outer; ++n) {
+            const int64_t base = (n * channels + c) * hw;
+            for (int64_t p = 0; p < hw; ++p) {
+                const float o = (y_ref[base + p] > 0.0f ? gy[base + p] : gy[base + p] * alpha) * scale;
+                gx[base + p] = o;
+                gb += o;
+                if (noise) gw += (double)o * noise[n * hw + p];
+            }
+        }
+        if (gbias) gbias[c] = (float)gb;
+    }
+    if (gnoise_weight && noise) gnoise_weight[0] = (float)gw;
+    return 0;
+}
+
+int oracle_plane_scale_dot_f32(const float* g, const float* x, const float* s, float* gx, float* gs, int64_t planes,
+                               int64_t hw, void* stream) {
+    (void)stream;
+    if (planes < 0 || hw < 4 || hw % 4) return set_err("plane_scale_dot: bad shape");
+#pragma omp parallel for
+    for (int64_t q = 0; q < planes; ++q) {
+        double acc = 0.0;
+        for (int64_t p = 0; p < hw; ++p) {
+            gx[q * hw + p] = g[q * hw + p] * s[q];
+            acc += (double)g[q * hw + p] * x[q * hw + p];
+        }
+        gs[q] = (float)acc;
+    }
+    return 0;
+}

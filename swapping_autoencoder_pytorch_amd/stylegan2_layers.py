@@ -17,8 +17,8 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import rng
-from .stylegan2_op import (FusedLeakyReLU, add_scale, conv2d, conv2d_bias_act, conv_transpose2d, fused_leaky_relu,
-                           linear, upfirdn2d)
+from .stylegan2_op import (FusedLeakyReLU, add_scale, conv2d, conv2d_bias_act, conv_transpose2d, fusable,
+                           fused_leaky_relu, linear, noise_bias_act, plane_scale, upfirdn2d)
 
 
 def make_kernel(k):
@@ -198,7 +198,7 @@ class ModulatedConv2d(nn.Module):
             s = self.modulation(style.view(input.shape[0], -1))
         if self.demodulate:
             s = s * torch.rsqrt(s.pow(2).mean([1], keepdim=True) + 1e-8)
-        return s[:, :, None, None]
+        return s        # [N, C]: broadcast over the plane by the caller
 
     def _weight(self):
         w = self.weight[0] * self.scale
@@ -207,7 +207,12 @@ class ModulatedConv2d(nn.Module):
         return w
 
     def forward(self, input, style):
-        x = input * self._input_scale(input, style)
+        s = self._input_scale(input, style)
+        if s.dim() == 2:
+            # x * s[:, :, None, None]; its backward (g * s and sum_hw g * x) is one fused pass
+            x = plane_scale(input, s) if fusable(input) else input * s[:, :, None, None]
+        else:
+            x = input * s
         w = self._weight()
         if self.upsample:
             return self.blur(conv_transpose2d(x, w, stride=2))
@@ -227,7 +232,8 @@ class NoiseInjection(nn.Module):
         self.fixed_noise = None
         self.image_size = None
 
-    def forward(self, image, noise=None):
+    def resolve(self, image, noise=None):
+        """The noise map this call uses (:343-350): the fixed one, the one passed in, or a fresh N(0,1) map."""
         if self.image_size is None:
             self.image_size = image.shape
         if self.fixed_noise is not None:
@@ -236,7 +242,10 @@ class NoiseInjection(nn.Module):
                 noise = F.interpolate(noise, image.shape[2:], mode="nearest")
         elif noise is None:
             noise = rng.randn_like_image(image)
-        return image + self.weight * noise
+        return noise
+
+    def forward(self, image, noise=None):
+        return image + self.weight * self.resolve(image, noise)
 
 
 class StyledConv(nn.Module):
@@ -254,7 +263,12 @@ class StyledConv(nn.Module):
     def forward(self, input, style, noise=None):
         out = self.conv(input, style)
         if self.use_noise:
-            out = self.noise(out, noise=noise)
+            z = self.noise.resolve(out, noise)
+            if fusable(out) and z.shape == (out.shape[0], 1) + out.shape[2:]:
+                # noise + bias + leaky-ReLU in one pass (and one backward pass for all three gradients)
+                return noise_bias_act(out, z, self.noise.weight, self.activate.bias, self.activate.negative_slope,
+                                      self.activate.scale)
+            out = out + self.noise.weight * z
         return self.activate(out)
 
 

@@ -129,5 +129,35 @@ def upsample2x_bwd(lib, gy, alpha=1.0, device=None):
     return bo.numpy()
 
 
+def noise_bias_act(lib, x, noise, nw, bias, alpha=0.2, scale=2 ** 0.5, device=None):
+    n, c = x.shape[:2]
+    hw = int(np.prod(x.shape[2:]))
+    bx, bn, bw, bb, bo = (_Buf(x, device), _Buf(noise, device) if noise is not None else None, _Buf(nw, device),
+                          _Buf(bias, device) if bias is not None else None, _out(x.shape, device))
+    lib.call("noise_bias_act_f32", bx.ptr, bn.ptr if bn else None, bw.ptr, bb.ptr if bb else None, bo.ptr, n, c, hw,
+             alpha, scale, _stream(device))
+    return bo.numpy()
+
+
+def noise_bias_act_bwd(lib, gy, y, noise, alpha=0.2, scale=2 ** 0.5, device=None):
+    n, c = gy.shape[:2]
+    hw = int(np.prod(gy.shape[2:]))
+    nws = lib.query("noise_bias_act_bwd_workspace", n, c, hw)
+    bg, by, bn = _Buf(gy, device), _Buf(y, device), _Buf(noise, device) if noise is not None else None
+    bgx, bgb, bgw, bws = _out(gy.shape, device), _out((c,), device), _out((1,), device), _out((max(nws, 1),), device)
+    lib.call("noise_bias_act_bwd_f32", bg.ptr, by.ptr, bn.ptr if bn else None, bgx.ptr, bgb.ptr, bgw.ptr, bws.ptr, nws,
+             n, c, hw, alpha, scale, _stream(device))
+    return bgx.numpy(), bgb.numpy(), bgw.numpy()
+
+
+def plane_scale_dot(lib, g, x, s, device=None):
+    planes = int(np.prod(g.shape[:2]))
+    hw = int(np.prod(g.shape[2:]))
+    bg, bx, bs = _Buf(g, device), _Buf(x, device), _Buf(s, device)
+    bgx, bgs = _out(g.shape, device), _out(s.shape, device)
+    lib.call("plane_scale_dot_f32", bg.ptr, bx.ptr, bs.ptr, bgx.ptr, bgs.ptr, planes, hw, _stream(device))
+    return bgx.numpy(), bgs.numpy()
+
+
 def rel_err(a, b):
     return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(float(np.abs(b).max()), 1e-30))

@@ -149,3 +149,42 @@ def test_conv2d_bias_act(emu_lib, oracle_lib, case):
         e = H.conv_bias_act(emu_lib, d, x, wt, bias, alpha=0.11, device=None)
         o = H.conv_bias_act(oracle_lib, d, x, wt, bias, alpha=0.11)
         assert H.rel_err(e, o) < TOL
+
+
+GLUE_SHAPES = [(2, 5, 16, 16), (3, 8, 4, 8), (1, 70, 32, 36), (4, 3, 2, 2), (2, 600, 8, 8)]
+
+
+@pytest.mark.parametrize("shape", GLUE_SHAPES, ids=str)
+def test_noise_bias_act(emu_lib, oracle_lib, shape):
+    """StyledConv glue: noise + bias + leaky-ReLU forward, its fused backward (bias and noise-weight
+    gradients) and the style-modulation backward, against the double-accumulating oracle."""
+    rng = np.random.default_rng(21)
+    n, c = shape[:2]
+    x = rng.standard_normal(shape).astype(np.float32)
+    noise = rng.standard_normal((n, 1) + shape[2:]).astype(np.float32)
+    nw = np.array([0.37], np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    for nz, bias in ((noise, b), (None, b), (noise, None)):
+        e = H.noise_bias_act(emu_lib, x, nz, nw, bias)
+        o = H.noise_bias_act(oracle_lib, x, nz, nw, bias)
+        assert np.array_equal(e, o)
+    y = H.noise_bias_act(oracle_lib, x, noise, nw, b)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    gx_e, gb_e, gw_e = H.noise_bias_act_bwd(emu_lib, gy, y, noise)
+    gx_o, gb_o, gw_o = H.noise_bias_act_bwd(oracle_lib, gy, y, noise)
+    assert np.array_equal(gx_e, gx_o)
+    assert np.allclose(gb_e, gb_o, rtol=1e-5, atol=1e-4)
+    assert np.allclose(gw_e, gw_o, rtol=1e-5, atol=1e-3)
+    s = rng.standard_normal((n, c)).astype(np.float32)
+    g2_e, gs_e = H.plane_scale_dot(emu_lib, gy, x, s)
+    g2_o, gs_o = H.plane_scale_dot(oracle_lib, gy, x, s)
+    assert np.array_equal(g2_e, g2_o)
+    assert np.allclose(gs_e, gs_o, rtol=1e-5, atol=1e-4)
+
+
+def test_glue_rejects_odd_planes(emu_lib):
+    x = np.zeros((1, 2, 3, 3), np.float32)
+    with pytest.raises(Exception):
+        H.noise_bias_act(emu_lib, x, None, np.zeros(1, np.float32), None)
+    with pytest.raises(Exception):
+        H.plane_scale_dot(emu_lib, x, x, np.zeros((1, 2), np.float32))

@@ -156,3 +156,32 @@ def test_conv2d_bias_act(hip_lib, oracle_lib, case):
         e = H.conv_bias_act(hip_lib, d, x, wt, bias, alpha=0.11, device=DEV)
         o = H.conv_bias_act(oracle_lib, d, x, wt, bias, alpha=0.11)
         assert H.rel_err(e, o) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 16, 16), (3, 8, 4, 8), (1, 70, 32, 36), (2, 600, 8, 8), (4, 128, 64, 64),
+                                   (2, 32, 256, 256)], ids=str)
+def test_noise_bias_act(hip_lib, oracle_lib, shape):
+    """StyledConv glue kernels (csrc/modulate.hip) against the double-accumulating oracle."""
+    rng = np.random.default_rng(21)
+    n, c = shape[:2]
+    x = rng.standard_normal(shape).astype(np.float32)
+    noise = rng.standard_normal((n, 1) + shape[2:]).astype(np.float32)
+    nw = np.array([0.37], np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    for nz, bias in ((noise, b), (None, b), (noise, None)):
+        e = H.noise_bias_act(hip_lib, x, nz, nw, bias, device=DEV)
+        o = H.noise_bias_act(oracle_lib, x, nz, nw, bias)
+        assert H.rel_err(e, o) < 1e-6
+    y = H.noise_bias_act(oracle_lib, x, noise, nw, b)
+    gy = rng.standard_normal(shape).astype(np.float32)
+    gx_e, gb_e, gw_e = H.noise_bias_act_bwd(hip_lib, gy, y, noise, device=DEV)
+    gx_o, gb_o, gw_o = H.noise_bias_act_bwd(oracle_lib, gy, y, noise)
+    assert np.array_equal(gx_e, gx_o)
+    scale = float(np.abs(gx_o).sum() / c)
+    assert np.abs(gb_e - gb_o).max() <= 1e-6 * scale
+    assert abs(float(gw_e[0]) - float(gw_o[0])) <= 1e-6 * float(np.abs(gx_o).sum())
+    s = rng.standard_normal((n, c)).astype(np.float32)
+    g2_e, gs_e = H.plane_scale_dot(hip_lib, gy, x, s, device=DEV)
+    g2_o, gs_o = H.plane_scale_dot(oracle_lib, gy, x, s)
+    assert np.array_equal(g2_e, g2_o)
+    assert np.abs(gs_e - gs_o).max() <= 1e-6 * float(np.abs(gy * x).sum() / (n * c))
