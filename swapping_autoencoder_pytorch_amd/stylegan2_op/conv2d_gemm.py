@@ -112,17 +112,29 @@ def _wgrad(x, gy, g):
     return _launch("conv2d_wgrad_f32", SAE_CONV_WGRAD, g, x, gy, g.weight_shape())
 
 
+def _zero_param_grad(ctx, index, param):
+    """Explicit zero gradient of a weight-like input when the output gradient is undefined."""
+    if ctx.needs_input_grad[index] and _Flags.weight_grads:
+        return torch.zeros_like(param)
+    return None
+
+
 class ConvForward(Function):
     """y = alpha * conv(x, w)"""
 
     @staticmethod
     def forward(ctx, x, w, geom):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         ctx.geom = geom
         ctx.save_for_backward(x, w)
         return _fwd(x, w, geom)
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            # an undefined output gradient means "zero": nothing for the activation, an explicit zero for the
+            # parameter (what a materialised zero gradient would have produced, without the kernels)
+            return None, _zero_param_grad(ctx, 1, ctx.saved_tensors[1]), None
         x, w = ctx.saved_tensors
         gx = ConvDataGrad.apply(gy, w, ctx.geom) if ctx.needs_input_grad[0] else None
         gw = ConvWeightGrad.apply(x, gy, ctx.geom) if (ctx.needs_input_grad[1] and _Flags.weight_grads) else None
@@ -134,12 +146,15 @@ class ConvDataGrad(Function):
 
     @staticmethod
     def forward(ctx, gy, w, geom):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         ctx.geom = geom
         ctx.save_for_backward(gy, w)
         return _dgrad(gy, w, geom)
 
     @staticmethod
     def backward(ctx, ggx):
+        if ggx is None:
+            return None, _zero_param_grad(ctx, 1, ctx.saved_tensors[1]), None
         gy, w = ctx.saved_tensors
         g_gy = ConvForward.apply(ggx, w, ctx.geom) if ctx.needs_input_grad[0] else None
         g_w = ConvWeightGrad.apply(ggx, gy, ctx.geom) if ctx.needs_input_grad[1] else None
@@ -151,12 +166,15 @@ class ConvWeightGrad(Function):
 
     @staticmethod
     def forward(ctx, x, gy, geom):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         ctx.geom = geom
         ctx.save_for_backward(x, gy)
         return _wgrad(x, gy, geom)
 
     @staticmethod
     def backward(ctx, ggw):
+        if ggw is None:
+            return None, None, None
         x, gy = ctx.saved_tensors
         g_x = ConvDataGrad.apply(gy, ggw, ctx.geom) if ctx.needs_input_grad[0] else None
         g_gy = ConvForward.apply(x, ggw, ctx.geom) if ctx.needs_input_grad[1] else None
@@ -172,6 +190,7 @@ class ConvBiasAct(Function):
 
     @staticmethod
     def forward(ctx, x, w, bias, geom, slope, scale):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         out = _launch_fused(geom, x, w, bias, slope, scale)
         ctx.cfg = (geom, slope, scale, bias is not None)
         ctx.save_for_backward(x, w, out)
@@ -179,6 +198,10 @@ class ConvBiasAct(Function):
 
     @staticmethod
     def backward(ctx, gout):
+        if gout is None:
+            w = ctx.saved_tensors[1]
+            gb = torch.zeros(w.shape[0], dtype=w.dtype, device=w.device) if (ctx.cfg[3] and ctx.needs_input_grad[2]) else None
+            return None, _zero_param_grad(ctx, 1, w), gb, None, None, None
         from .fused_act import FusedLeakyReLUFunctionBackward
         x, w, out = ctx.saved_tensors
         geom, slope, scale, has_bias = ctx.cfg
@@ -272,6 +295,7 @@ class MatMul(Function):
 
     @staticmethod
     def forward(ctx, a, b, bias, ta, tb, alpha):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         ctx.cfg = (ta, tb, alpha)
         ctx.save_for_backward(a, b)
         return _gemm(a, b, bias, ta, tb, alpha)
@@ -280,6 +304,11 @@ class MatMul(Function):
     def backward(ctx, gc):
         a, b = ctx.saved_tensors
         ta, tb, alpha = ctx.cfg
+        if gc is None:
+            gbias = None
+            if ctx.needs_input_grad[2]:
+                gbias = torch.zeros(b.shape[0] if tb else b.shape[1], dtype=b.dtype, device=b.device)
+            return None, _zero_param_grad(ctx, 1, b), gbias, None, None, None
         ga = gb = gbias = None
         if ctx.needs_input_grad[0]:
             if not ta:

@@ -44,6 +44,7 @@ def _bias_act(x, bias, ref, grad, alpha, scale):
 class FusedLeakyReLUFunction(Function):
     @staticmethod
     def forward(ctx, input, bias, negative_slope, scale):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         out = _bias_act(input, bias, None, 0, negative_slope, scale)
         ctx.save_for_backward(out)
         ctx.cfg = (negative_slope, scale, bias is not None)
@@ -51,6 +52,10 @@ class FusedLeakyReLUFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_output):
+        if grad_output is None:      # undefined = zero: nothing for the activation, an explicit zero for the bias
+            out, = ctx.saved_tensors
+            gb = torch.zeros(out.shape[1], dtype=out.dtype, device=out.device) if (ctx.cfg[2] and ctx.needs_input_grad[1]) else None
+            return None, gb, None, None
         out, = ctx.saved_tensors
         negative_slope, scale, has_bias = ctx.cfg
         grad_input, grad_bias = FusedLeakyReLUFunctionBackward.apply(grad_output, out, negative_slope, scale)
@@ -60,6 +65,7 @@ class FusedLeakyReLUFunction(Function):
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, out, negative_slope, scale):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         lib = hip_lib.get()
         grad_output = grad_output.contiguous()
         lib.check(grad_output, out)
@@ -77,6 +83,8 @@ class FusedLeakyReLUFunctionBackward(Function):
 
     @staticmethod
     def backward(ctx, gradgrad_input, gradgrad_bias):
+        if gradgrad_input is None and gradgrad_bias is None:
+            return None, None, None, None
         out, = ctx.saved_tensors
         negative_slope, scale = ctx.cfg
         # d(grad_input)/d(grad_output) and d(grad_bias)/d(grad_output) share the same mask:

@@ -23,6 +23,7 @@ def fusable(x):
 class NoiseBiasActFunction(Function):
     @staticmethod
     def forward(ctx, input, noise, noise_weight, bias, negative_slope, scale):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         lib = hip_lib.get()
         input = input.contiguous()
         noise = noise.contiguous()
@@ -39,6 +40,11 @@ class NoiseBiasActFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_output):
+        if grad_output is None:      # undefined = zero: explicit zeros for the two parameters only
+            out, noise = ctx.saved_tensors
+            gw = torch.zeros(1, dtype=out.dtype, device=out.device) if ctx.needs_input_grad[2] else None
+            gb = torch.zeros(out.shape[1], dtype=out.dtype, device=out.device) if (ctx.cfg[2] and ctx.needs_input_grad[3]) else None
+            return None, None, gw, gb, None, None
         out, noise = ctx.saved_tensors
         negative_slope, scale, has_bias = ctx.cfg
         gx, gb, gw = NoiseBiasActBackward.apply(grad_output, out, noise, negative_slope, scale)
@@ -48,6 +54,7 @@ class NoiseBiasActFunction(Function):
 class NoiseBiasActBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, out, noise, negative_slope, scale):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         lib = hip_lib.get()
         grad_output = grad_output.contiguous()
         lib.check(grad_output, out, noise)
@@ -66,6 +73,8 @@ class NoiseBiasActBackward(Function):
 
     @staticmethod
     def backward(ctx, gg_x, gg_b, gg_w):
+        if gg_x is None and gg_b is None and gg_w is None:
+            return None, None, None, None, None
         # gx, gb and gw are linear in grad_output through the same mask:
         # d/d(grad_output) = (out > 0 ? 1 : slope) * scale * (gg_x + gg_b[c] + gg_w * noise)
         out, noise = ctx.saved_tensors
@@ -84,11 +93,14 @@ def noise_bias_act(input, noise, noise_weight, bias, negative_slope=0.2, scale=2
 class PlaneScaleFunction(Function):
     @staticmethod
     def forward(ctx, x, s):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         ctx.save_for_backward(x, s)
         return x * s[:, :, None, None]
 
     @staticmethod
     def backward(ctx, grad_output):
+        if grad_output is None:
+            return None, None
         x, s = ctx.saved_tensors
         return PlaneScaleBackward.apply(grad_output, x, s)
 
@@ -96,6 +108,7 @@ class PlaneScaleFunction(Function):
 class PlaneScaleBackward(Function):
     @staticmethod
     def forward(ctx, g, x, s):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         lib = hip_lib.get()
         g = g.contiguous()
         x = x.contiguous()
@@ -111,6 +124,8 @@ class PlaneScaleBackward(Function):
 
     @staticmethod
     def backward(ctx, gg_x, gg_s):
+        if gg_x is None and gg_s is None:
+            return None, None, None
         # gx = g * s, gs = <g, x>: bilinear, differentiated with plain tensor ops
         g, x, s = ctx.saved_tensors
         grad_g = grad_x = grad_s = None

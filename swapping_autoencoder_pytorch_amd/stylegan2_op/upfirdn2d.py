@@ -56,6 +56,7 @@ def _adjoint_pad(in_hw, out_hw, taps_hw, up, down, pad):
 class UpFirDn2d(Function):
     @staticmethod
     def forward(ctx, input, kernel, up, down, pad):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         out = _run(input, kernel, up, down, pad)
         ctx.save_for_backward(kernel)
         ctx.cfg = (up, down, pad, tuple(input.shape[2:]), tuple(out.shape[2:]))
@@ -63,6 +64,8 @@ class UpFirDn2d(Function):
 
     @staticmethod
     def backward(ctx, grad_output):
+        if grad_output is None:
+            return None, None, None, None, None
         kernel, = ctx.saved_tensors
         grad_input = None
         if ctx.needs_input_grad[0]:
@@ -73,6 +76,7 @@ class UpFirDn2d(Function):
 class UpFirDn2dBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, kernel, up, down, pad, in_hw, out_hw):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         g_pad = _adjoint_pad(in_hw, out_hw, tuple(kernel.shape), up, down, pad)
         flipped = torch.flip(kernel, [0, 1])
         grad_input = _run(grad_output, flipped, down, up, g_pad)   # (up, down) exchanged
@@ -83,6 +87,8 @@ class UpFirDn2dBackward(Function):
 
     @staticmethod
     def backward(ctx, gradgrad_input):
+        if gradgrad_input is None:
+            return None, None, None, None, None, None, None
         kernel, = ctx.saved_tensors
         up, down, pad = ctx.cfg
         gradgrad_out = None

@@ -37,11 +37,14 @@ def _down(gy, alpha):
 class Upsample2xAdd(Function):
     @staticmethod
     def forward(ctx, x, res, alpha):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         ctx.alpha = alpha
         return _up(x, res, alpha)
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return None, None, None
         gx = Upsample2xAdjoint.apply(gy, ctx.alpha) if ctx.needs_input_grad[0] else None
         gres = gy * ctx.alpha if ctx.needs_input_grad[1] else None
         return gx, gres, None
@@ -50,11 +53,14 @@ class Upsample2xAdd(Function):
 class Upsample2xAdjoint(Function):
     @staticmethod
     def forward(ctx, gy, alpha):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         ctx.alpha = alpha
         return _down(gy, alpha)
 
     @staticmethod
     def backward(ctx, ggx):
+        if ggx is None:
+            return None, None
         return (Upsample2xAdd.apply(ggx, None, ctx.alpha) if ctx.needs_input_grad[0] else None), None
 
 
@@ -68,6 +74,7 @@ class AddScale(Function):
 
     @staticmethod
     def forward(ctx, a, b, alpha):
+        ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         lib = hip_lib.get()
         a = a.contiguous()
         b = b.contiguous()
@@ -81,6 +88,8 @@ class AddScale(Function):
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return None, None, None
         g = gy * ctx.alpha          # one pass; both inputs receive the same tensor
         return (g if ctx.needs_input_grad[0] else None), (g if ctx.needs_input_grad[1] else None), None
 
