@@ -87,10 +87,11 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
         const int e = tx + i * TW;
         const int r = e / SW, c = e - r * SW;
         const int iy = iy0 + r, ix = ix0 + c;
-        float v = 0.0f;
-        if (live && e < SR * SW && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w)
-            v = xp[(int64_t)iy * p.in_w + ix];
-        staged[i] = v;
+        // branch-free: a load inside a divergent branch makes hipcc drain vmcnt at the join, which left two
+        // loads in flight per wave; out-of-image elements read element 0 of the plane and are zeroed
+        const bool ok = live && e < SR * SW && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
+        staged[i] = ok ? v : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
@@ -230,9 +231,9 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
         const int e = tx + i * TW;
         const int r = e / SW, c = e - r * SW;
         const int iy = tile_in_y + r, ix = tile_in_x + c;
-        float v = 0.0f;
-        if (live && e < SR * SW && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = xp[(int64_t)iy * p.in_w + ix];
-        staged[i] = v;
+        const bool ok = live && e < SR * SW && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;   // branch-free, see blur_kernel
+        const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
+        staged[i] = ok ? v : 0.0f;
     }
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
