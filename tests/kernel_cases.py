@@ -45,6 +45,9 @@ CONV_SMALL = [
     # stride-2 dgrad / transposed conv producing > 64 channels: the class-split 128 x 128q transposed gather
     (1, 70, 17, 17, 12, 3, 2, 0, False), (2, 72, 35, 67, 8, 3, 2, 0, True), (1, 70, 10, 12, 20, 3, 2, 1, False),
     (1, 130, 9, 11, 6, 3, 2, 0, False),
+    # fp32 wgrad with vectorised staging (OW % 16|32 == 0): 16- and 32-column tiles, valid padding, M/C tails
+    (2, 40, 16, 16, 40, 3, 1, 1, False), (1, 36, 32, 32, 70, 3, 1, 1, False), (1, 33, 18, 34, 40, 3, 1, 0, False),
+    (1, 130, 8, 64, 36, 3, 1, 1, False),
     # narrow layers: wgrad MODE 1 (M, C <= 32) and MODE 2 (C * taps <= 32, RGB stems)
     (3, 20, 12, 12, 24, 3, 1, 1, False), (2, 3, 16, 16, 40, 3, 1, 1, False), (2, 3, 9, 9, 20, 3, 2, 0, False),
     (2, 3, 8, 8, 70, 1, 1, 0, False), (1, 30, 15, 15, 36, 1, 2, 0, False),
