@@ -511,6 +511,207 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_bx_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------
+// "bx" gather, 8 waves, LDS-DMA weights (128 x 256-pixel tile, one 512-thread workgroup per CU).
+// conv_igemm_bx_kernel loses ~20 % to its staging phase (with the staging removed it runs 245 TFLOP/s-eq):
+// two 4-wave workgroups per CU drift into phase and then both sit in store-wait-barrier while the matrix
+// pipe idles.  Here the whole CU is ONE workgroup with everything double buffered in its 160 KB of LDS:
+//   * the split weights of chunk k+1 go global -> LDS by DMA (global_load_lds_dwordx4: the wpb tile is a
+//     linear image of the LDS tile, lane l lands at base + 16 l), no registers, no ds_write pass;
+//   * the input patch of chunk k+1 is loaded to registers (one position per thread), split and written to
+//     the other Xs buffer after the MFMAs of chunk k;
+//   * one barrier per chunk (s_waitcnt vmcnt(0) first: DMA data is ordered for other waves' ds_reads only
+//     by the issuer's vmcnt followed by a barrier the reader has passed).
+// The A tile is shared by 8 waves instead of 4, halving its L2 traffic per MFMA.
+// ------------------------------------------------------------------------------------------
+constexpr int kBlock8 = 512;
+
+template <int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(kBlock8) void conv_igemm_bx8_kernel(const float* __restrict__ x,
+                                                                 const u32x4* __restrict__ wpb,
+                                                                 float* __restrict__ y, const IgemmParams p) {
+    static_assert(WM * WN == 8, "8 waves per workgroup");
+    constexpr int T = 9, CK = 8;
+    constexpr int BM = 32 * MI * WM;
+    constexpr int BN = 32 * NI * WN;
+    constexpr int XCAP = 2 * BN;                            // patch positions (host-checked): one per thread
+    static_assert(XCAP == kBlock8, "one patch position per thread");
+    constexpr int A_CELLS = T * 3 * BM;                     // 16-byte cells per A chunk
+    constexpr int A_INSTR = A_CELLS / kWave;                // DMA instructions per chunk (64 cells each)
+    static_assert(A_CELLS % kWave == 0, "A tile is a whole number of wave DMAs");
+    __shared__ u32x4 As[2][A_CELLS];
+    __shared__ u32x4 Xs[2][3 * XCAP];
+    __shared__ u32x4 Zs[1];                                 // the all-zero cell paired with the ninth tap
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+
+    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
+    const int TN = BN >> (p.tw_log2 + p.th_log2);
+    int bt = blockIdx.x;
+    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
+    const int tiy = bt % p.tiles_y;
+    const int tin = bt / p.tiles_y;
+    const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
+    const int m0 = blockIdx.y * BM;
+
+    const int PH = TH + 2, PW = TW + 2;
+    const int IP = PH * PW;
+    const int CP = TN * IP;           // staged positions (<= XCAP, checked on the host)
+    const int HW = p.H * p.W;
+
+    int poff = -1;
+    if (tid < CP) {
+        const int pn = tid / IP;
+        const int rem = tid - pn * IP;
+        const int r = rem / PW;
+        const int c = rem - r * PW;
+        const int iy = oy0 - p.pad + r, ix = ox0 - p.pad + c;
+        if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+            poff = pn * p.C * HW + iy * p.W + ix;
+    }
+
+    int pixbase[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int pp = (wn * NI + ni) * 32 + l31;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> p.tw_log2) & (TH - 1);
+        const int pn = pp >> (p.tw_log2 + p.th_log2);
+        pixbase[ni] = pn * IP + py * PW + px;
+    }
+    int boff[5], aoff[5];
+#pragma unroll
+    for (int g = 0; g < 5; ++g) {
+        const int t = (g < 4) ? 2 * g + half : 8;
+        boff[g] = (t / 3) * PW + (t % 3);
+        aoff[g] = t * 3 * BM + wm * MI * 32 + l31;
+    }
+    const bool zero_a = half != 0;     // group 4: the upper half-wave multiplies the zero cell
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    const float* xb = x + (int64_t)n0 * p.C * HW;
+    const u32x4* wt = wpb + (int64_t)blockIdx.y * (p.Cp / CK) * A_CELLS;
+    float xv[CK];
+
+    auto dma_a = [&](int c0, int buf) {
+        const u32x4* wc = wt + (int64_t)(c0 / CK) * A_CELLS + lane;
+        for (int j = wid; j < A_INSTR; j += WM * WN)
+            __builtin_amdgcn_global_load_lds(wc + j * kWave, (__attribute__((address_space(3))) void*)(&As[buf][j * kWave]),
+                                             16, 0, 0);
+    };
+    auto load_x = [&](int c0) {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch) {
+            // branch-free: invalid positions read element 0 of the tile's first image and are zeroed in store_x
+            const bool ok = (c0 + ch) < p.C && poff >= 0;
+            xv[ch] = xb[ok ? (int64_t)(c0 + ch) * HW + poff : 0];
+        }
+    };
+    auto store_x = [&](int c0, int buf) {
+        if (tid < CP) {
+            float v[CK];
+#pragma unroll
+            for (int ch = 0; ch < CK; ++ch) v[ch] = ((c0 + ch) < p.C && poff >= 0) ? xv[ch] : 0.0f;
+            bf16x8 s0, s1, s2;
+            split3_bf16(v, s0, s1, s2);
+            Xs[buf][tid] = __builtin_bit_cast(u32x4, s0);
+            Xs[buf][XCAP + tid] = __builtin_bit_cast(u32x4, s1);
+            Xs[buf][2 * XCAP + tid] = __builtin_bit_cast(u32x4, s2);
+        }
+    };
+
+    const int c_begin = blockIdx.z * p.chunks_per_split * CK;
+    int c_end = c_begin + p.chunks_per_split * CK;
+    if (c_end > p.Cp) c_end = p.Cp;
+    if (tid == 0) Zs[0] = u32x4{0u, 0u, 0u, 0u};
+    dma_a(c_begin, 0);
+    load_x(c_begin);
+    store_x(c_begin, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA has landed
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
+        const bool more = c0 + CK < c_end;
+        if (more) {
+            dma_a(c0 + CK, buf ^ 1);         // lands in the other buffer under the MFMAs below
+            load_x(c0 + CK);
+        }
+        const u32x4* Ac = As[buf];
+        const u32x4* Xc = Xs[buf];
+#pragma unroll
+        for (int g = 0; g < 5; ++g) {
+            // the split + LDS write of the next patch sits in the middle of the MFMA stream (same basic block:
+            // its VALU / ds_write instructions issue in the shadow of the matrix pipe)
+            if (g == 3 && more) store_x(c0 + CK, buf ^ 1);
+            bf16x8 a[MI][3], b[NI][3];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) {
+                    const u32x4 cell = Ac[aoff[g] + sp * BM + mi * 32];
+                    a[mi][sp] = __builtin_bit_cast(bf16x8, (g == 4 && zero_a) ? Zs[0] : cell);
+                }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    b[ni][sp] = __builtin_bit_cast(bf16x8, Xc[sp * XCAP + pixbase[ni] + boff[g]]);
+            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
+            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][TA[q]], b[ni][TB[q]],
+                                                                              acc[mi][ni], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) before the barrier: see the header comment
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int pp = (wn * NI + ni) * 32 + l31;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> p.tw_log2) & (TH - 1);
+        const int pn = pp >> (p.tw_log2 + p.th_log2);
+        const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
+        if (n < p.N && oy < p.OH && ox < p.OW) {
+            float* yb = y + (int64_t)blockIdx.z * p.slab_stride +
+                        ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < p.M) {
+                        float v = acc[mi][ni][r];
+                        if (p.act) {
+                            if (p.bias) v += p.bias[m];
+                            v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
+                        }
+                        yb[(int64_t)m * p.YH * p.YW] = v;
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // stride-2 transposed gather ("tr"): out[m][o] = sum_{c,k : o + pad = 2 i + k} wp[k][c][m] * in[c][i]
 // 3x3 taps only.  N-tiles of a wave = the 4 parity classes of the same 32 q positions.
 // ------------------------------------------------------------------------------------------
@@ -1695,6 +1896,7 @@ __global__ __launch_bounds__(kBlock) void conv_splitk_reduce_kernel(const float*
 struct GatherPlan {
     FwdShape sh; int Mp, Cp, taps; int tw_log2, th_log2, tiles_x, tiles_y, tiles_n; int ksplit, cps;
     bool bx;   // bf16-split arithmetic (3x3 stride 1, 128x128 tile)
+    bool bx8;  // ... on the 8-wave LDS-DMA kernel (128 x 256-pixel tile)
     int64_t wp_floats, out_floats4, ws_floats;
 };
 GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int stride, bool scatter) {
@@ -1703,6 +1905,14 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
     g.Mp = round_up(mout, g.sh.bm);
     g.Cp = round_up(cin, g.sh.ck);
     g.taps = ks * ks;
+    g.bx8 = false;
+    static const int bx8_knob = [] { const char* e = getenv("SAE_BX8"); return e ? atoi(e) : 1; }();
+    if (bx8_knob && conv_math() == 1 && ks == 3 && stride == 1 && g.sh.cfg == 0) {
+        int twl, thl;
+        pick_tile(256, OH, OW, 32, &twl, &thl);
+        const int tw8 = 1 << twl, th8 = 1 << thl, tn8 = 256 / (tw8 * th8);
+        if (tn8 * (th8 + 2) * (tw8 + 2) <= 512) { g.bx8 = true; g.sh.bn = 256; }   // one patch position per thread
+    }
     pick_tile(g.sh.bn, OH, OW, 32, &g.tw_log2, &g.th_log2);
     const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tn = g.sh.bn / (tw * th);
     g.tiles_x = ceil_div(OW, tw);
@@ -1746,6 +1956,11 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
     constexpr int CK = (KS == 1) ? 32 : 8;
     constexpr int CK2 = (KS == 1) ? 16 : 8;
     if constexpr (KS == 3 && S == 1) {
+        if (g.bx8) {
+            hipLaunchKernelGGL((conv_igemm_bx8_kernel<2, 2, 2, 4>), grid, dim3(kBlock8), 0, s, x,
+                               reinterpret_cast<const u32x4*>(wp), y, p);
+            return SAE_OK;
+        }
         if (g.bx) {
             hipLaunchKernelGGL((conv_igemm_bx_kernel<2, 2, 2, 2>), grid, dim3(kBlock), 0, s, x,
                                reinterpret_cast<const u32x4*>(wp), y, p);

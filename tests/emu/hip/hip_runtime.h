@@ -335,6 +335,12 @@ static inline void __syncthreads() { hipemu::block_barrier(); }
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu::mfma_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu::mfma_16x16x4f32
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 hipemu::mfma_32x32x16bf16
+// LDS-DMA (global_load_lds_*): lane l of the wave writes `size` bytes at (wave-uniform LDS base) + size * l.
+// The copy is performed at once; the real instruction is asynchronous (ordered by vmcnt + a barrier), which
+// a correct program cannot observe.
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
+    std::memcpy((char*)(l) + (size) * hipemu::lane_id() + (off), (const void*)(g), (size))
+#define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
 
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
