@@ -12,6 +12,7 @@
  *   sae_noise_bias_act_f32   <- NoiseInjection.forward + FusedLeakyReLU.forward   models/networks/stylegan2_layers.py:340-351, :54-65
  *   sae_noise_bias_act_bwd_f32, sae_plane_scale_dot_f32 <- the autograd graph of StyledConv's elementwise ops
  *                               (stylegan2_layers.py:280-286 style modulation, :340-351 noise, :54-65 bias + leaky-ReLU)
+ *   sae_random_crop_f32, sae_random_crop_bwd_f32 <- util.apply_random_crop's F.grid_sample   util/util.py:323-343
  *   sae_bias_act_bwd_f32     <- fused_bias_act(grad=1) followed by grad_input.sum(dim)
  *                               models/networks/stylegan2_op/fused_act.py:32-41 (one fused pass here)
  *   sae_conv2d_{fwd,dgrad,wgrad}_f32
@@ -115,6 +116,21 @@ int sae_noise_bias_act_bwd_f32(const float* gy, const float* y_ref, const float*
                                int64_t channels, int64_t hw, float alpha, float scale, sae_stream_t stream);
 int sae_plane_scale_dot_f32(const float* g, const float* x, const float* s, float* gx, float* gs, int64_t planes,
                             int64_t hw, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Random-crop sampler (patch discriminator input): crop k of image b = k / crops_per_image is
+ *   y[k, ch, r, c] = bilinear(x[b, ch], gx, gy)   gx = (lin[c] * flip) * sx + ox,  gy = lin[r] * sy + oy
+ * with F.grid_sample's conventions (align_corners = False: pixel = ((g + 1) * extent - 1) / 2, zero padding),
+ * exactly what util.apply_random_crop builds (util/util.py:323-343).  params: [images * crops][5] =
+ * {flip (+1 / -1), sx, sy, ox, oy}; lin: [size] = linspace(-1, 1, size); x: [images, channels, h, w];
+ * y / gy: [images * crops, channels, size, size].  The backward is a deterministic gather (no atomics).
+ * ------------------------------------------------------------------------------------------ */
+int sae_random_crop_f32(const float* x, const float* params, const float* lin, float* y, int64_t images,
+                        int64_t channels, int64_t h, int64_t w, int64_t crops_per_image, int64_t size,
+                        sae_stream_t stream);
+int sae_random_crop_bwd_f32(const float* gy, const float* params, const float* lin, float* gx, int64_t images,
+                            int64_t channels, int64_t h, int64_t w, int64_t crops_per_image, int64_t size,
+                            sae_stream_t stream);
 
 /* Fused backward of the leaky-ReLU form: gx = (y_ref > 0 ? gy : alpha*gy) * scale and
  * gb[c] = sum over everything but the channel axis of gx (deterministic two-stage reduction,

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <math.h>
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)
@@ -467,5 +468,82 @@ int oracle_plane_scale_dot_f32(const float* g, const float* x, const float* s, f
         }
         gs[q] = (float)acc;
     }
+    return 0;
+}
+
+
+/* ---- random-crop sampler (include/sae_hip.h): util/util.py:323-343, i.e. F.grid_sample(bilinear, zeros,
+ * align_corners=False) on the grid lin * flip * scale + offset.  Coordinates in float exactly as ATen's
+ * grid_sampler computes them; interpolation accumulated in double; the backward is the plain scatter. ------ */
+static float crop_coord_o(float lin, float mul, float off, int extent) {
+    volatile float g = lin * mul;
+    g = g + off;
+    volatile float t = g + 1.0f;
+    t = t * (float)extent;
+    t = t - 1.0f;
+    return t * 0.5f;
+}
+
+int oracle_random_crop_f32(const float* x, const float* params, const float* lin, float* y, int64_t images,
+                           int64_t channels, int64_t h, int64_t w, int64_t crops, int64_t size, void* stream) {
+    (void)stream;
+    if (images < 0 || channels < 1 || h < 1 || w < 1 || crops < 1 || size < 2) return set_err("random_crop: bad geometry");
+#pragma omp parallel for
+    for (int64_t k = 0; k < images * crops; ++k) {
+        const int64_t b = k / crops;
+        const float* pr = params + 5 * k;
+        for (int64_t r = 0; r < size; ++r)
+            for (int64_t c = 0; c < size; ++c) {
+                volatile float lf = lin[c] * pr[0];
+                const float ix = crop_coord_o(lf, pr[1], pr[3], (int)w), iy = crop_coord_o(lin[r], pr[2], pr[4], (int)h);
+                const float fx = floorf(ix), fy = floorf(iy);
+                const int64_t x0 = (int64_t)fx, y0 = (int64_t)fy;
+                const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+                for (int64_t ch = 0; ch < channels; ++ch) {
+                    const float* xp = x + (b * channels + ch) * h * w;
+                    double acc = 0.0;
+                    for (int dy = 0; dy < 2; ++dy)
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int64_t yy = y0 + dy, xx = x0 + dx;
+                            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                            acc += (double)xp[yy * w + xx] * (double)((dx ? wx1 : wx0) * (dy ? wy1 : wy0));
+                        }
+                    y[((k * channels + ch) * size + r) * size + c] = (float)acc;
+                }
+            }
+    }
+    return 0;
+}
+
+int oracle_random_crop_bwd_f32(const float* gy, const float* params, const float* lin, float* gx, int64_t images,
+                               int64_t channels, int64_t h, int64_t w, int64_t crops, int64_t size, void* stream) {
+    (void)stream;
+    if (images < 0 || channels < 1 || h < 1 || w < 1 || crops < 1 || size < 2) return set_err("random_crop_bwd: bad geometry");
+    const int64_t plane = h * w;
+    double* acc = (double*)calloc((size_t)(images * channels * plane), sizeof(double));
+    if (!acc) return set_err("random_crop_bwd: out of memory");
+    for (int64_t k = 0; k < images * crops; ++k) {
+        const int64_t b = k / crops;
+        const float* pr = params + 5 * k;
+        for (int64_t r = 0; r < size; ++r)
+            for (int64_t c = 0; c < size; ++c) {
+                volatile float lf = lin[c] * pr[0];
+                const float ix = crop_coord_o(lf, pr[1], pr[3], (int)w), iy = crop_coord_o(lin[r], pr[2], pr[4], (int)h);
+                const float fx = floorf(ix), fy = floorf(iy);
+                const int64_t x0 = (int64_t)fx, y0 = (int64_t)fy;
+                const float wx1 = ix - fx, wx0 = (fx + 1.0f) - ix, wy1 = iy - fy, wy0 = (fy + 1.0f) - iy;
+                for (int64_t ch = 0; ch < channels; ++ch) {
+                    const double g = gy[((k * channels + ch) * size + r) * size + c];
+                    for (int dy = 0; dy < 2; ++dy)
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int64_t yy = y0 + dy, xx = x0 + dx;
+                            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;
+                            acc[(b * channels + ch) * plane + yy * w + xx] += g * (double)((dx ? wx1 : wx0) * (dy ? wy1 : wy0));
+                        }
+                }
+            }
+    }
+    for (int64_t i = 0; i < images * channels * plane; ++i) gx[i] = (float)acc[i];
+    free(acc);
     return 0;
 }

@@ -51,6 +51,8 @@ _SIGNATURES = {
     "noise_bias_act_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _f32,
                                          _f32, _stream]),
     "plane_scale_dot_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _stream]),
+    "random_crop_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),
+    "random_crop_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),
     "conv2d_workspace": (_i64, [C.POINTER(ConvDesc), _i32]),
     "conv2d_fwd_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "conv2d_fwd_bias_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32, _f32, _f32p, _i64,

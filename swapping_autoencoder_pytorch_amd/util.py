@@ -7,7 +7,8 @@ import argparse
 import torch
 import torch.nn.functional as F
 
-from . import rng
+from . import hip_lib, rng
+from .stylegan2_op import random_crop
 
 
 def normalize(v):
@@ -37,6 +38,15 @@ def apply_random_crop(x, target_size, scale_range, num_crops=1):
     b = x.size(0) * num_crops
     dev = x.device
     flip = torch.round(rng.rand((b, 1, 1, 1), dev)) * 2 - 1.0
+    lib = hip_lib.get()
+    if x.dtype == torch.float32 and (x.is_cuda or not lib.device_only):
+        # same RNG draws in the same order, then the sampler kernel (stylegan2_op.random_crop) instead of
+        # expand + grid + grid_sample.  First-order differentiable, which is all the train step asks of it (the
+        # R1 crops are detached leaves, swapping_autoencoder_model.py:206-207).
+        scale = rng.rand((b, 1, 1, 2), dev) * (scale_range[1] - scale_range[0]) + scale_range[0]
+        offset = (rng.rand((b, 1, 1, 2), dev) * 2 - 1) * (1 - scale)
+        crop = random_crop(x, flip, scale, offset, target_size, num_crops)
+        return crop.view(b // num_crops, num_crops, crop.size(1), crop.size(2), crop.size(3))
     lin = torch.linspace(-1.0, 1.0, target_size, device=dev)
     gx = lin.view(1, 1, target_size, 1).expand(b, target_size, target_size, 1)
     gy = lin.view(1, target_size, 1, 1).expand(b, target_size, target_size, 1)

@@ -159,5 +159,24 @@ def plane_scale_dot(lib, g, x, s, device=None):
     return bgx.numpy(), bgs.numpy()
 
 
+def random_crop(lib, x, params, size, crops, device=None):
+    n, c, h, w = x.shape
+    import torch
+    lin = torch.linspace(-1.0, 1.0, size).numpy()      # the grid the reference builds (util/util.py:330)
+    bx, bp, bl, bo = _Buf(x, device), _Buf(params, device), _Buf(lin, device), _out((n * crops, c, size, size), device)
+    lib.call("random_crop_f32", bx.ptr, bp.ptr, bl.ptr, bo.ptr, n, c, h, w, crops, size, _stream(device))
+    return bo.numpy()
+
+
+def random_crop_bwd(lib, gy, params, shape, crops, device=None):
+    n, c, h, w = shape
+    size = gy.shape[-1]
+    import torch
+    lin = torch.linspace(-1.0, 1.0, size).numpy()
+    bg, bp, bl, bo = _Buf(gy, device), _Buf(params, device), _Buf(lin, device), _out(shape, device)
+    lib.call("random_crop_bwd_f32", bg.ptr, bp.ptr, bl.ptr, bo.ptr, n, c, h, w, crops, size, _stream(device))
+    return bo.numpy()
+
+
 def rel_err(a, b):
     return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(float(np.abs(b).max()), 1e-30))

@@ -381,6 +381,10 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) {
 }
 
 static inline float __fmaf_rn(float a, float b, float c) { return std::fmaf(a, b, c); }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+// floorf / ceilf: the C library's global-namespace functions (<cmath>)
 static inline float __frsqrt_rn(float x) { return 1.0f / std::sqrt(x); }
 using std::fmaf;
 using std::fmaxf;

@@ -188,3 +188,42 @@ def test_glue_rejects_odd_planes(emu_lib):
         H.noise_bias_act(emu_lib, x, None, np.zeros(1, np.float32), None)
     with pytest.raises(Exception):
         H.plane_scale_dot(emu_lib, x, x, np.zeros((1, 2), np.float32))
+
+
+def _crop_params(rng, k, lo=0.125, hi=0.25):
+    flip = np.round(rng.random(k)) * 2 - 1
+    scale = rng.random((k, 2)) * (hi - lo) + lo
+    offset = (rng.random((k, 2)) * 2 - 1) * (1 - scale)
+    return np.stack([flip, scale[:, 0], scale[:, 1], offset[:, 0], offset[:, 1]], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", [(2, 3, 32, 32, 4, 16, 0.125, 0.25), (1, 2, 20, 28, 3, 9, 0.3, 1.0),
+                                  (3, 1, 16, 16, 2, 8, 0.9, 1.0)], ids=str)
+def test_random_crop(emu_lib, oracle_lib, case):
+    """Patch sampler: the oracle is pinned to F.grid_sample (what util.apply_random_crop calls,
+    util/util.py:338) and to its autograd; the kernels are checked against the oracle."""
+    import torch
+    import torch.nn.functional as F
+    n, c, h, w, crops, size, lo, hi = case
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    params = _crop_params(rng, n * crops, lo, hi)
+    gy = rng.standard_normal((n * crops, c, size, size)).astype(np.float32)
+    # reference construction of the sampling grid
+    lin = torch.linspace(-1.0, 1.0, size)
+    pt = torch.from_numpy(params)
+    gxs = lin.view(1, 1, size, 1).expand(n * crops, size, size, 1) * pt[:, 0].view(-1, 1, 1, 1)
+    gys = lin.view(1, size, 1, 1).expand(n * crops, size, size, 1)
+    grid = torch.cat([gxs, gys], 3) * pt[:, 1:3].view(-1, 1, 1, 2) + pt[:, 3:5].view(-1, 1, 1, 2)
+    xt = torch.from_numpy(x).requires_grad_()
+    xe = xt.unsqueeze(1).expand(-1, crops, -1, -1, -1).flatten(0, 1)
+    ref = F.grid_sample(xe, grid, align_corners=False)
+    ref.backward(torch.from_numpy(gy))
+    o = H.random_crop(oracle_lib, x, params, size, crops)
+    assert H.rel_err(o, ref.detach().numpy()) < 2e-6
+    ob = H.random_crop_bwd(oracle_lib, gy, params, x.shape, crops)
+    assert H.rel_err(ob, xt.grad.numpy()) < 5e-6
+    e = H.random_crop(emu_lib, x, params, size, crops)
+    assert H.rel_err(e, o) < 2e-6
+    eb = H.random_crop_bwd(emu_lib, gy, params, x.shape, crops)
+    assert H.rel_err(eb, ob) < 5e-6

@@ -185,3 +185,24 @@ def test_noise_bias_act(hip_lib, oracle_lib, shape):
     g2_o, gs_o = H.plane_scale_dot(oracle_lib, gy, x, s)
     assert np.array_equal(g2_e, g2_o)
     assert np.abs(gs_e - gs_o).max() <= 1e-6 * float(np.abs(gy * x).sum() / (n * c))
+
+
+@pytest.mark.parametrize("case", [(2, 3, 32, 32, 4, 16, 0.125, 0.25), (1, 2, 20, 28, 3, 9, 0.3, 1.0),
+                                  (4, 3, 256, 256, 8, 128, 0.125, 0.25)], ids=str)
+def test_random_crop(hip_lib, oracle_lib, case):
+    """Patch sampler kernels against the oracle (itself pinned to F.grid_sample in the CPU suite)."""
+    n, c, h, w, crops, size, lo, hi = case
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    k = n * crops
+    flip = np.round(rng.random(k)) * 2 - 1
+    scale = rng.random((k, 2)) * (hi - lo) + lo
+    offset = (rng.random((k, 2)) * 2 - 1) * (1 - scale)
+    params = np.stack([flip, scale[:, 0], scale[:, 1], offset[:, 0], offset[:, 1]], 1).astype(np.float32)
+    gy = rng.standard_normal((k, c, size, size)).astype(np.float32)
+    e = H.random_crop(hip_lib, x, params, size, crops, device=DEV)
+    o = H.random_crop(oracle_lib, x, params, size, crops)
+    assert H.rel_err(e, o) < 5e-6
+    eb = H.random_crop_bwd(hip_lib, gy, params, x.shape, crops, device=DEV)
+    ob = H.random_crop_bwd(oracle_lib, gy, params, x.shape, crops)
+    assert H.rel_err(eb, ob) < 5e-6
