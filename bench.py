@@ -161,7 +161,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    launched = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)    # torch.distributed.run, any N
+    if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
@@ -277,7 +278,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.preset)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if launched:
         dist.destroy_process_group()
 
 

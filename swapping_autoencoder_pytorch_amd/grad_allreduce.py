@@ -18,6 +18,8 @@ replicate / scatter / gather / reduce_add through GPU 0 on every call).  Design 
   frozen branch might not) contribute zeros, keeping the collective shape identical on all ranks.
 
 With world_size == 1 (or torch.distributed not initialised) every method is a no-op."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -36,7 +38,11 @@ class GradAllReducer:
     def __init__(self, params, bucket_bytes=BUCKET_BYTES, process_group=None):
         self.params = [p for p in params]
         self.group = process_group
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        # SAE_FORCE_ALLREDUCE=1 runs the full bucket / hook / collective path even on a single rank (a
+        # one-GPU rehearsal of the multi-GPU code over RCCL; see tests/test_gpu_allreduce.py)
+        forced = os.environ.get("SAE_FORCE_ALLREDUCE", "0") == "1"
+        self.enabled = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(process_group) > 1 or forced)
         self.world = dist.get_world_size(process_group) if self.enabled else 1
         self.armed = False
         self.buckets = []
