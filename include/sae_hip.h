@@ -12,6 +12,7 @@
  *   sae_noise_bias_act_f32   <- NoiseInjection.forward + FusedLeakyReLU.forward   models/networks/stylegan2_layers.py:340-351, :54-65
  *   sae_noise_bias_act_bwd_f32, sae_plane_scale_dot_f32 <- the autograd graph of StyledConv's elementwise ops
  *                               (stylegan2_layers.py:280-286 style modulation, :340-351 noise, :54-65 bias + leaky-ReLU)
+ *   sae_reflect_pad_f32, sae_reflect_pad_adj_f32 <- nn.ReflectionPad2d / F.pad(mode="reflect")   stylegan2_layers.py:57-63,100-105,643
  *   sae_random_crop_f32, sae_random_crop_bwd_f32 <- util.apply_random_crop's F.grid_sample   util/util.py:323-343
  *   sae_bias_act_bwd_f32     <- fused_bias_act(grad=1) followed by grad_input.sum(dim)
  *                               models/networks/stylegan2_op/fused_act.py:32-41 (one fused pass here)
@@ -131,6 +132,15 @@ int sae_random_crop_f32(const float* x, const float* params, const float* lin, f
 int sae_random_crop_bwd_f32(const float* gy, const float* params, const float* lin, float* gx, int64_t images,
                             int64_t channels, int64_t h, int64_t w, int64_t crops_per_image, int64_t size,
                             sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Reflection padding (no edge repeat, as nn.ReflectionPad2d) of [planes][h][w] and its adjoint (the sum of gy over
+ * the padded positions that mirror onto each input pixel; a deterministic gather).  Pads must be < the image size.
+ * ------------------------------------------------------------------------------------------ */
+int sae_reflect_pad_f32(const float* x, float* y, int64_t planes, int64_t h, int64_t w, int32_t left, int32_t right,
+                        int32_t top, int32_t bottom, sae_stream_t stream);
+int sae_reflect_pad_adj_f32(const float* gy, float* gx, int64_t planes, int64_t h, int64_t w, int32_t left,
+                            int32_t right, int32_t top, int32_t bottom, sae_stream_t stream);
 
 /* Fused backward of the leaky-ReLU form: gx = (y_ref > 0 ? gy : alpha*gy) * scale and
  * gb[c] = sum over everything but the channel axis of gx (deterministic two-stage reduction,

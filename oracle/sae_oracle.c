@@ -547,3 +547,37 @@ int oracle_random_crop_bwd_f32(const float* gy, const float* params, const float
     free(acc);
     return 0;
 }
+
+
+/* ---- reflection padding and its adjoint (include/sae_hip.h): nn.ReflectionPad2d, stylegan2_layers.py:57-63,100-105,643 */
+static int64_t refl_o(int64_t i, int64_t n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+int oracle_reflect_pad_f32(const float* x, float* y, int64_t planes, int64_t h, int64_t w, int32_t left, int32_t right,
+                           int32_t top, int32_t bottom, void* stream) {
+    (void)stream;
+    if (planes < 0 || h < 1 || w < 1 || left < 0 || right < 0 || top < 0 || bottom < 0 || left >= w || right >= w ||
+        top >= h || bottom >= h) return set_err("reflect_pad: bad geometry");
+    const int64_t oh = h + top + bottom, ow = w + left + right;
+    for (int64_t p = 0; p < planes; ++p)
+        for (int64_t oy = 0; oy < oh; ++oy)
+            for (int64_t ox = 0; ox < ow; ++ox)
+                y[(p * oh + oy) * ow + ox] = x[(p * h + refl_o(oy - top, h)) * w + refl_o(ox - left, w)];
+    return 0;
+}
+
+int oracle_reflect_pad_adj_f32(const float* gy, float* gx, int64_t planes, int64_t h, int64_t w, int32_t left,
+                               int32_t right, int32_t top, int32_t bottom, void* stream) {
+    (void)stream;
+    if (planes < 0 || h < 1 || w < 1 || left < 0 || right < 0 || top < 0 || bottom < 0 || left >= w || right >= w ||
+        top >= h || bottom >= h) return set_err("reflect_pad_adj: bad geometry");
+    const int64_t oh = h + top + bottom, ow = w + left + right;
+    double* acc = (double*)calloc((size_t)(planes * h * w), sizeof(double));
+    if (!acc) return set_err("reflect_pad_adj: out of memory");
+    for (int64_t p = 0; p < planes; ++p)
+        for (int64_t oy = 0; oy < oh; ++oy)
+            for (int64_t ox = 0; ox < ow; ++ox)
+                acc[(p * h + refl_o(oy - top, h)) * w + refl_o(ox - left, w)] += gy[(p * oh + oy) * ow + ox];
+    for (int64_t i = 0; i < planes * h * w; ++i) gx[i] = (float)acc[i];
+    free(acc);
+    return 0;
+}

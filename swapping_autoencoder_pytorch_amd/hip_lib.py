@@ -53,6 +53,8 @@ _SIGNATURES = {
     "plane_scale_dot_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _stream]),
     "random_crop_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),
     "random_crop_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),
+    "reflect_pad_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _stream]),
+    "reflect_pad_adj_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _stream]),
     "conv2d_workspace": (_i64, [C.POINTER(ConvDesc), _i32]),
     "conv2d_fwd_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "conv2d_fwd_bias_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32, _f32, _f32p, _i64,

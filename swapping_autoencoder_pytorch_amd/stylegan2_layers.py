@@ -17,8 +17,8 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import rng
-from .stylegan2_op import (FusedLeakyReLU, add_scale, conv2d, conv2d_bias_act, conv_transpose2d, fusable,
-                           fused_leaky_relu, linear, noise_bias_act, plane_scale, upfirdn2d)
+from .stylegan2_op import (FusedLeakyReLU, ReflectionPad2d, add_scale, conv2d, conv2d_bias_act, conv_transpose2d,
+                           fusable, fused_leaky_relu, linear, noise_bias_act, plane_scale, reflect_pad, upfirdn2d)
 
 
 def make_kernel(k):
@@ -60,7 +60,7 @@ class Downsample(nn.Module):
     def forward(self, input):
         pad = self.pad
         if self.reflection:
-            input = F.pad(input, (pad[0], pad[1], pad[0], pad[1]), mode="reflect")
+            input = reflect_pad(input, (pad[0], pad[1], pad[0], pad[1]))
             pad = (0, 0)
         return upfirdn2d(input, self.kernel, up=1, down=self.factor, pad=pad)
 
@@ -77,7 +77,7 @@ class Blur(nn.Module):
         self.pad = pad
         self.reflection = reflection_pad
         if reflection_pad:
-            self.reflection_pad = nn.ReflectionPad2d((pad[0], pad[1], pad[0], pad[1]))
+            self.reflection_pad = ReflectionPad2d((pad[0], pad[1], pad[0], pad[1]))
             self.pad = (0, 0)
 
     def forward(self, input):
@@ -306,7 +306,7 @@ class ConvLayer(nn.Sequential):
             stride = 1
             self.padding = kernel_size // 2 if pad is None else pad
             if reflection_pad:
-                layers.append(("RefPad", nn.ReflectionPad2d(self.padding)))
+                layers.append(("RefPad", ReflectionPad2d(self.padding)))
                 self.padding = 0
         layers.append(("Conv", EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding, stride=stride,
                                            bias=bias and not activate)))

@@ -178,5 +178,23 @@ def random_crop_bwd(lib, gy, params, shape, crops, device=None):
     return bo.numpy()
 
 
+def reflect_pad(lib, x, pads, device=None):
+    l, r, t, b = pads
+    planes = int(np.prod(x.shape[:-2]))
+    h, w = x.shape[-2:]
+    bx, bo = _Buf(x, device), _out(x.shape[:-2] + (h + t + b, w + l + r), device)
+    lib.call("reflect_pad_f32", bx.ptr, bo.ptr, planes, h, w, l, r, t, b, _stream(device))
+    return bo.numpy()
+
+
+def reflect_pad_adj(lib, gy, pads, device=None):
+    l, r, t, b = pads
+    planes = int(np.prod(gy.shape[:-2]))
+    h, w = gy.shape[-2] - t - b, gy.shape[-1] - l - r
+    bg, bo = _Buf(gy, device), _out(gy.shape[:-2] + (h, w), device)
+    lib.call("reflect_pad_adj_f32", bg.ptr, bo.ptr, planes, h, w, l, r, t, b, _stream(device))
+    return bo.numpy()
+
+
 def rel_err(a, b):
     return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(float(np.abs(b).max()), 1e-30))

@@ -227,3 +227,26 @@ def test_random_crop(emu_lib, oracle_lib, case):
     assert H.rel_err(e, o) < 2e-6
     eb = H.random_crop_bwd(emu_lib, gy, params, x.shape, crops)
     assert H.rel_err(eb, ob) < 5e-6
+
+
+@pytest.mark.parametrize("case", [((2, 3, 8, 8), (1, 1, 1, 1)), ((1, 2, 5, 7), (2, 1, 0, 3)), ((2, 1, 2, 2), (1, 1, 1, 1)),
+                                  ((1, 4, 16, 16), (1, 2, 1, 2))], ids=str)
+def test_reflect_pad(emu_lib, oracle_lib, case):
+    """Reflection pad and its adjoint: oracle pinned to F.pad(mode="reflect") + autograd, kernels to the oracle."""
+    import torch
+    import torch.nn.functional as F
+    shape, pads = case
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal(shape).astype(np.float32)
+    xt = torch.from_numpy(x).requires_grad_()
+    ref = F.pad(xt, pads, mode="reflect")
+    gy = rng.standard_normal(tuple(ref.shape)).astype(np.float32)
+    ref.backward(torch.from_numpy(gy))
+    o = H.reflect_pad(oracle_lib, x, pads)
+    assert np.array_equal(o, ref.detach().numpy())
+    oa = H.reflect_pad_adj(oracle_lib, gy, pads)
+    assert np.allclose(oa, xt.grad.numpy(), rtol=1e-6, atol=1e-6)
+    assert np.array_equal(H.reflect_pad(emu_lib, x, pads), o)
+    assert np.allclose(H.reflect_pad_adj(emu_lib, gy, pads), oa, rtol=1e-6, atol=1e-6)
+    with pytest.raises(Exception):
+        H.reflect_pad(emu_lib, x, (shape[-1], 0, 0, 0))

@@ -206,3 +206,16 @@ def test_random_crop(hip_lib, oracle_lib, case):
     eb = H.random_crop_bwd(hip_lib, gy, params, x.shape, crops, device=DEV)
     ob = H.random_crop_bwd(oracle_lib, gy, params, x.shape, crops)
     assert H.rel_err(eb, ob) < 5e-6
+
+
+@pytest.mark.parametrize("case", [((2, 3, 8, 8), (1, 1, 1, 1)), ((1, 2, 5, 7), (2, 1, 0, 3)), ((16, 32, 256, 256), (1, 1, 1, 1)),
+                                  ((4, 64, 128, 128), (1, 2, 1, 2))], ids=str)
+def test_reflect_pad(hip_lib, oracle_lib, case):
+    shape, pads = case
+    rng = np.random.default_rng(41)
+    x = rng.standard_normal(shape).astype(np.float32)
+    o = H.reflect_pad(oracle_lib, x, pads)
+    assert np.array_equal(H.reflect_pad(hip_lib, x, pads, device=DEV), o)
+    gy = rng.standard_normal(o.shape).astype(np.float32)
+    assert np.allclose(H.reflect_pad_adj(hip_lib, gy, pads, device=DEV), H.reflect_pad_adj(oracle_lib, gy, pads),
+                       rtol=1e-6, atol=1e-6)
