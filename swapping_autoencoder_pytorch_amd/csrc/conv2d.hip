@@ -540,7 +540,6 @@ __global__ __launch_bounds__(kBlock8) void conv_igemm_bx8_kernel(const float* __
     static_assert(A_CELLS % kWave == 0, "A tile is a whole number of wave DMAs");
     __shared__ u32x4 As[2][A_CELLS];
     __shared__ u32x4 Xs[2][3 * XCAP];
-    __shared__ u32x4 Zs[1];                                 // the all-zero cell paired with the ninth tap
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -589,7 +588,19 @@ __global__ __launch_bounds__(kBlock8) void conv_igemm_bx8_kernel(const float* __
         boff[g] = (t / 3) * PW + (t % 3);
         aoff[g] = t * 3 * BM + wm * MI * 32 + l31;
     }
-    const bool zero_a = half != 0;     // group 4: the upper half-wave multiplies the zero cell
+    // The ninth tap has no partner inside a chunk.  Instead of pairing it with zeros (10 % of all MFMAs), the
+    // lower half-wave keeps the tap-8 operands of every EVEN chunk in registers and the upper half-wave loads
+    // those of the following ODD chunk: one MFMA group per chunk pair whose 16 k are 8 channels of each chunk.
+    bf16x8 a8[MI][3], b8[NI][3];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) a8[mi][sp] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) b8[ni][sp] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+    bool odd = false;
 
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -633,7 +644,6 @@ __global__ __launch_bounds__(kBlock8) void conv_igemm_bx8_kernel(const float* __
     const int c_begin = blockIdx.z * p.chunks_per_split * CK;
     int c_end = c_begin + p.chunks_per_split * CK;
     if (c_end > p.Cp) c_end = p.Cp;
-    if (tid == 0) Zs[0] = u32x4{0u, 0u, 0u, 0u};
     dma_a(c_begin, 0);
     load_x(c_begin);
     store_x(c_begin, 0);
@@ -648,8 +658,10 @@ __global__ __launch_bounds__(kBlock8) void conv_igemm_bx8_kernel(const float* __
         }
         const u32x4* Ac = As[buf];
         const u32x4* Xc = Xs[buf];
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
-        for (int g = 0; g < 5; ++g) {
+        for (int g = 0; g < 4; ++g) {
             // the split + LDS write of the next patch sits in the middle of the MFMA stream (same basic block:
             // its VALU / ds_write instructions issue in the shadow of the matrix pipe)
             if (g == 3 && more) store_x(c0 + CK, buf ^ 1);
@@ -657,17 +669,12 @@ __global__ __launch_bounds__(kBlock8) void conv_igemm_bx8_kernel(const float* __
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int sp = 0; sp < 3; ++sp) {
-                    const u32x4 cell = Ac[aoff[g] + sp * BM + mi * 32];
-                    a[mi][sp] = __builtin_bit_cast(bf16x8, (g == 4 && zero_a) ? Zs[0] : cell);
-                }
+                for (int sp = 0; sp < 3; ++sp) a[mi][sp] = __builtin_bit_cast(bf16x8, Ac[aoff[g] + sp * BM + mi * 32]);
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int sp = 0; sp < 3; ++sp)
                     b[ni][sp] = __builtin_bit_cast(bf16x8, Xc[sp * XCAP + pixbase[ni] + boff[g]]);
-            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
             for (int q = 0; q < 6; ++q)
 #pragma unroll
@@ -677,9 +684,52 @@ __global__ __launch_bounds__(kBlock8) void conv_igemm_bx8_kernel(const float* __
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][TA[q]], b[ni][TB[q]],
                                                                               acc[mi][ni], 0, 0, 0);
         }
+        // tap 8: even chunk -> the lower half-wave latches its operands; odd chunk -> the upper half-wave loads
+        // its own and the pair is multiplied
+        if (!odd || half) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) a8[mi][sp] = __builtin_bit_cast(bf16x8, Ac[aoff[4] + sp * BM + mi * 32]);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp)
+                    b8[ni][sp] = __builtin_bit_cast(bf16x8, Xc[sp * XCAP + pixbase[ni] + boff[4]]);
+        }
+        if (odd) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[mi][TA[q]], b8[ni][TB[q]],
+                                                                              acc[mi][ni], 0, 0, 0);
+        }
+        odd = !odd;
         __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) before the barrier: see the header comment
         __syncthreads();
         buf ^= 1;
+    }
+
+    if (odd) {   // odd number of chunks: the last tap-8 operands pair with zeros in the upper half-wave
+        constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
+        constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
+        if (half) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) a8[mi][sp] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[mi][TA[q]], b8[ni][TB[q]], acc[mi][ni],
+                                                                          0, 0, 0);
     }
 
     // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
