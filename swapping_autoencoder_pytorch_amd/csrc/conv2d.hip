@@ -1984,7 +1984,11 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
         }
     }
     g.wp_floats = (int64_t)g.taps * g.Cp * g.Mp;
-    g.bx = conv_math() == 1 && ks == 3 && stride == 1 && g.sh.cfg == 0;
+    // bf16x6: the 128-row tile (8-wave or 4-wave kernel) and, on the 4-wave kernel, the 64- and 32-row tiles of the
+    // narrow layers (cfg 1: 64 x 256, cfg 4: 32 x 256)
+    static const int bx_narrow_knob = [] { const char* e = getenv("SAE_BX_NARROW"); return e ? atoi(e) : 1; }();
+    g.bx = conv_math() == 1 && ks == 3 && stride == 1 &&
+           (g.sh.cfg == 0 || (bx_narrow_knob && (g.sh.cfg == 1 || g.sh.cfg == 4)));
     if (g.bx) g.wp_floats = (int64_t)27 * g.Mp * (g.Cp / 8) * 4;   // 16-byte cells: [tap][split][m] per 8 channels
     g.out_floats4 = ((int64_t)N * mout * OH * OW + 3) / 4 * 4;
     g.ws_floats = g.wp_floats + (g.ksplit > 1 ? g.ksplit * g.out_floats4 : 0);
@@ -2012,8 +2016,10 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
             return SAE_OK;
         }
         if (g.bx) {
-            hipLaunchKernelGGL((conv_igemm_bx_kernel<2, 2, 2, 2>), grid, dim3(kBlock), 0, s, x,
-                               reinterpret_cast<const u32x4*>(wp), y, p);
+            const u32x4* wb = reinterpret_cast<const u32x4*>(wp);
+            if (sh.cfg == 1) hipLaunchKernelGGL((conv_igemm_bx_kernel<2, 2, 1, 4>), grid, dim3(kBlock), 0, s, x, wb, y, p);
+            else if (sh.cfg == 4) hipLaunchKernelGGL((conv_igemm_bx_kernel<1, 2, 1, 4>), grid, dim3(kBlock), 0, s, x, wb, y, p);
+            else hipLaunchKernelGGL((conv_igemm_bx_kernel<2, 2, 2, 2>), grid, dim3(kBlock), 0, s, x, wb, y, p);
             return SAE_OK;
         }
     }

@@ -60,6 +60,8 @@ CONV_BX = [
     (1, 70, 8, 8, 12, 3, 1, 1, False), (2, 72, 6, 6, 100, 3, 1, 1, True), (1, 5, 16, 40, 256, 3, 1, 1, False),
     # stride-2 dgrad / transposed conv producing > 64 channels: the 128 x 64q transposed-gather tile
     (1, 70, 17, 17, 12, 3, 2, 0, False), (2, 72, 35, 67, 8, 3, 2, 0, True), (1, 70, 10, 12, 20, 3, 2, 1, False),
+    # narrow layers on the 64- and 32-row bf16x6 tiles
+    (2, 24, 12, 12, 48, 3, 1, 1, False), (3, 20, 12, 12, 24, 3, 1, 1, False), (2, 64, 8, 8, 40, 3, 1, 1, False),
     # wgrad on octet tiles (OW % 8 == 0, OW >= 16): 16- and 32-column rows, valid padding, stride 2 (even/odd cells)
     (2, 40, 16, 16, 40, 3, 1, 1, False), (1, 36, 32, 32, 70, 3, 1, 1, False), (1, 33, 18, 34, 40, 3, 1, 0, False),
     (1, 40, 33, 33, 70, 3, 2, 0, False), (2, 33, 65, 65, 40, 3, 2, 0, False), (1, 36, 32, 32, 40, 3, 2, 1, True),
