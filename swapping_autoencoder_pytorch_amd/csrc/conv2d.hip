@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void conv_wprep_bx_kernel(const float* __re
     }
 }
 
-template <int MI, int NI, int WM, int WN>
+template <int S, int MI, int NI, int WM, int WN>
 __global__ __launch_bounds__(kBlock) void conv_igemm_bx_kernel(const float* __restrict__ x,
                                                                const u32x4* __restrict__ wpb,
                                                                float* __restrict__ y, const IgemmParams p) {
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_bx_kernel(const float* __re
     constexpr int T = 9, CK = 8;
     constexpr int BM = 32 * MI * WM;
     constexpr int BN = 32 * NI * WN;
-    constexpr int XCAP = PatchCap<3, 1, BN>::value;
+    constexpr int XCAP = PatchCap<3, S, BN>::value;
     constexpr int PPT = (XCAP + kBlock - 1) / kBlock;      // patch positions per thread
     constexpr int A_CELLS = T * 3 * BM;                     // 16-byte cells per A chunk
     constexpr int APT = (A_CELLS + kBlock - 1) / kBlock;
@@ -352,7 +352,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_bx_kernel(const float* __re
     const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
     const int m0 = blockIdx.y * BM;
 
-    const int PH = TH + 2, PW = TW + 2;
+    const int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
+    const int HALFW = (PW + 1) >> 1;      // stride 2: patch columns are stored de-interleaved, even | odd
     const int IP = PH * PW;
     const int CP = TN * IP;           // staged positions (<= XCAP, checked on the host)
     const int HW = p.H * p.W;
@@ -366,8 +367,9 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_bx_kernel(const float* __re
             const int pn = e / IP;
             const int rem = e - pn * IP;
             const int r = rem / PW;
-            const int c = rem - r * PW;
-            const int iy = oy0 - p.pad + r, ix = ox0 - p.pad + c;
+            const int cl = rem - r * PW;
+            const int c = (S == 2) ? (cl < HALFW ? 2 * cl : 2 * (cl - HALFW) + 1) : cl;
+            const int iy = oy0 * S - p.pad + r, ix = ox0 * S - p.pad + c;
             if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
                 off = pn * p.C * HW + iy * p.W + ix;
         }
@@ -382,13 +384,13 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_bx_kernel(const float* __re
         const int px = pp & (TW - 1);
         const int py = (pp >> p.tw_log2) & (TH - 1);
         const int pn = pp >> (p.tw_log2 + p.th_log2);
-        pixbase[ni] = pn * IP + py * PW + px;
+        pixbase[ni] = pn * IP + py * S * PW + px;
     }
     int boff[5], aoff[5];
 #pragma unroll
     for (int g = 0; g < 5; ++g) {
         const int t = (g < 4) ? 2 * g + half : 8;
-        boff[g] = (t / 3) * PW + (t % 3);
+        boff[g] = (t / 3) * PW + ((S == 2) ? ((t % 3) & 1) * HALFW + ((t % 3) >> 1) : (t % 3));
         aoff[g] = (g == 4 && half) ? A_CELLS : t * 3 * BM + wm * MI * 32 + l31;
     }
 
@@ -1820,7 +1822,9 @@ FwdShape fwd_shape(int mout, int ks, int stride) {
     FwdShape s{};
     // tuning knob (benchmarks only): SAE_IGEMM_WIDE=1 gives 3x3 stride-1 layers a 128 x 256 tile
     static const int wide_knob = [] { const char* e = getenv("SAE_IGEMM_WIDE"); return e ? atoi(e) : 0; }();
+    static const int bx_s2_knob = [] { const char* e = getenv("SAE_BX_S2"); return e ? atoi(e) : 1; }();
     if (mout > 64 && wide_knob && ks == 3 && stride == 1) { s.cfg = 3; s.bm = 128; s.bn = 256; }
+    else if (mout > 32 && ks == 3 && stride == 2 && conv_math() == 1 && bx_s2_knob) { s.cfg = 6; s.bm = 64; s.bn = 128; }   // bf16x6 stride 2
     else if (mout > 64 && round_up(mout, 64) * 100 >= round_up(mout, 128) * 92) { s.cfg = 0; s.bm = 128; s.bn = 128; }
     else if (mout > 64) { s.cfg = 1; s.bm = 64; s.bn = 256; }    // e.g. 409 -> 448 instead of 512 padded rows
     else if (mout > 32 || stride == 2) { s.cfg = 1; s.bm = 64; s.bn = 256; }
@@ -1989,6 +1993,7 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
     static const int bx_narrow_knob = [] { const char* e = getenv("SAE_BX_NARROW"); return e ? atoi(e) : 1; }();
     g.bx = conv_math() == 1 && ks == 3 && stride == 1 &&
            (g.sh.cfg == 0 || (bx_narrow_knob && (g.sh.cfg == 1 || g.sh.cfg == 4)));
+    if (conv_math() == 1 && ks == 3 && stride == 2 && g.sh.cfg == 6) g.bx = true;
     if (g.bx) g.wp_floats = (int64_t)27 * g.Mp * (g.Cp / 8) * 4;   // 16-byte cells: [tap][split][m] per 8 channels
     g.out_floats4 = ((int64_t)N * mout * OH * OW + 3) / 4 * 4;
     g.ws_floats = g.wp_floats + (g.ksplit > 1 ? g.ksplit * g.out_floats4 : 0);
@@ -2017,9 +2022,16 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
         }
         if (g.bx) {
             const u32x4* wb = reinterpret_cast<const u32x4*>(wp);
-            if (sh.cfg == 1) hipLaunchKernelGGL((conv_igemm_bx_kernel<2, 2, 1, 4>), grid, dim3(kBlock), 0, s, x, wb, y, p);
-            else if (sh.cfg == 4) hipLaunchKernelGGL((conv_igemm_bx_kernel<1, 2, 1, 4>), grid, dim3(kBlock), 0, s, x, wb, y, p);
-            else hipLaunchKernelGGL((conv_igemm_bx_kernel<2, 2, 2, 2>), grid, dim3(kBlock), 0, s, x, wb, y, p);
+            if (sh.cfg == 1) hipLaunchKernelGGL((conv_igemm_bx_kernel<1, 2, 2, 1, 4>), grid, dim3(kBlock), 0, s, x, wb, y, p);
+            else if (sh.cfg == 4) hipLaunchKernelGGL((conv_igemm_bx_kernel<1, 1, 2, 1, 4>), grid, dim3(kBlock), 0, s, x, wb, y, p);
+            else hipLaunchKernelGGL((conv_igemm_bx_kernel<1, 2, 2, 2, 2>), grid, dim3(kBlock), 0, s, x, wb, y, p);
+            return SAE_OK;
+        }
+    }
+    if constexpr (KS == 3 && S == 2) {
+        if (g.bx) {     // 64 x 128 tile (cfg 6): the stride-2 patch is four times the pixels, LDS allows no more
+            hipLaunchKernelGGL((conv_igemm_bx_kernel<2, 1, 2, 2, 2>), grid, dim3(kBlock), 0, s, x,
+                               reinterpret_cast<const u32x4*>(wp), y, p);
             return SAE_OK;
         }
     }
