@@ -250,3 +250,17 @@ def test_reflect_pad(emu_lib, oracle_lib, case):
     assert np.allclose(H.reflect_pad_adj(emu_lib, gy, pads), oa, rtol=1e-6, atol=1e-6)
     with pytest.raises(Exception):
         H.reflect_pad(emu_lib, x, (shape[-1], 0, 0, 0))
+
+
+def test_new_ops_accept_empty_batches_and_reject_bad_geometry(emu_lib, oracle_lib):
+    """Edge cases of the glue / sampler / pad entry points: empty inputs are no-ops, bad geometry is an error
+    (never a crash), identically in the kernels and the oracle."""
+    for lib in (emu_lib, oracle_lib):
+        z = np.zeros((0, 3, 4, 4), np.float32)
+        assert H.noise_bias_act(lib, z, np.zeros((0, 1, 4, 4), np.float32), np.ones(1, np.float32), np.zeros(3, np.float32)).shape == z.shape
+        assert H.reflect_pad(lib, z, (1, 1, 1, 1)).shape == (0, 3, 6, 6)
+        assert H.random_crop(lib, z, np.zeros((0, 5), np.float32), 4, 2).shape == (0, 3, 4, 4)
+        with pytest.raises(Exception):
+            H.reflect_pad(lib, np.zeros((1, 1, 3, 3), np.float32), (3, 0, 0, 0))      # pad >= size
+        with pytest.raises(Exception):
+            H.random_crop(lib, np.zeros((1, 1, 4, 4), np.float32), np.zeros((1, 5), np.float32), 1, 1)   # size < 2
