@@ -1773,18 +1773,34 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_reduce_kernel(const float* 
                                                                    float* __restrict__ gw, int M, int C,
                                                                    int Ap, int Bp, int taps, int slices,
                                                                    int64_t sm, int64_t sc, float alpha) {
+    // Four lanes per output element, each summing every fourth slice with eight loads in flight, combined in a
+    // fixed order ((q0 + q1) + (q2 + q3)): a chain of `slices` dependent loads per thread on ~2 workgroups per CU
+    // ran at 1.2 TB/s.  Deterministic (the order depends only on `slices`).
     const int64_t total = (int64_t)taps * M * C;
     const int64_t slice_stride = (int64_t)taps * Ap * Bp;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * kBlock) {
+    const int q = threadIdx.x & 3;
+    for (int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 2; i0 < ((total + 63) & ~(int64_t)63);
+         i0 += ((int64_t)gridDim.x * kBlock) >> 2) {
+        const bool live = i0 < total;          // whole quads stay together for the shuffles
+        const int64_t i = live ? i0 : 0;
         const int c = (int)(i % C);
         const int64_t t = i / C;
         const int m = (int)(t % M);
         const int tap = (int)(t / M);
         const float* s = slab + ((int64_t)tap * Ap + m) * Bp + c;
         float acc = 0.0f;
-        for (int sl = 0; sl < slices; ++sl) acc += s[sl * slice_stride];
-        gw[m * sm + c * sc + tap] = alpha * acc;
+        int sl = q;
+        for (; sl + 28 < slices; sl += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = s[(sl + 4 * u) * slice_stride];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; sl < slices; sl += 4) acc += s[sl * slice_stride];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (live && q == 0) gw[m * sm + c * sc + tap] = alpha * acc;
     }
 }
 
@@ -2346,8 +2362,8 @@ extern "C" int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
         else launch_wgrad<1, 2, 2, 2, 2, 2, 0>(x, gy, workspace, p, w, s);
     }
     const int64_t total = (int64_t)w.taps * d->m * d->c;
-    int64_t blocks = ceil_div64(total, kBlock);
-    if (blocks > 4096) blocks = 4096;
+    int64_t blocks = ceil_div64(total * 4, kBlock);      // four lanes per output element
+    if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const float*)workspace,
                        gw, (int)d->m, (int)d->c, w.Ap, w.Bp, w.taps, d->n > 0 ? w.slices : 0, d->w_stride_m,
                        d->w_stride_c, alpha);
