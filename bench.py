@@ -150,8 +150,30 @@ def cpu_baseline(preset):
                                                                                       per_image / 1e12)}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch_command(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: the command that re-runs this
+    script as N ranks (one per GPU) under torch.distributed.run, or None when this process is the worker."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return None
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
+    relaunch = self_launch_command(args, sys.argv[1:])
+    if relaunch is not None:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL needs dmabuf IPC on this host driver
+        os.execv(relaunch[0], relaunch)                              # never returns
     import torch
     import torch.distributed as dist
 
@@ -160,11 +182,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); one rank per GPU is the "
+                         "contract" % (args.gpus, world))
+    if torch.cuda.device_count() < min(args.gpus, local_rank + 1):
+        raise SystemExit("bench.py: --gpus %d but only %d device(s) are visible" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     launched = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)    # torch.distributed.run, any N
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus
+        world = dist.get_world_size()
     dev = torch.device("cuda", local_rank)
 
     from swapping_autoencoder_pytorch_amd import hip_lib

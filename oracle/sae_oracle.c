@@ -10,7 +10,7 @@
  * restatement is pinned against outputs of the reference's own Python modules run in the build
  * container (native-fallback path, upfirdn2d.py:162-222, fused_act.py:93-96,
  * stylegan2_layers.py) — fixtures under tests/golden/, generator tests/golden/make_golden.py —
- * and checked in tests/test_oracle_golden.py.
+ * and checked in tests/test_reference_parity.py.
  *
  * Each function carries the same signature as its sae_* counterpart in include/sae_hip.h
  * (host pointers; the stream argument is ignored) and cites the reference lines it follows.
@@ -191,6 +191,14 @@ int64_t oracle_conv2d_workspace(const sae_conv2d_desc* d, int32_t op) {
     return 0;
 }
 
+/* Loop structure of the three conv functions: the parallel axis is (image, channel, block of
+ * ORB output rows) so that a one-image / few-channel slice of a BASELINE-size layer (what the
+ * full-size GPU parity tests ask for) still spreads over a few hundred host cores; every output
+ * element is the double sum over (c, ky, kx) [forward], (m, ky, kx) [dgrad] or (n, oy, ox)
+ * [wgrad] of single-rounded-to-double products, accumulated in row buffers so the innermost loop
+ * runs along W. */
+#define ORB 16
+
 int oracle_conv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d,
                           float alpha, float* workspace, int64_t workspace_floats,
                           sae_stream_t stream) {
@@ -199,25 +207,37 @@ int oracle_conv2d_fwd_f32(const float* x, const float* w, float* y, const sae_co
         snprintf(g_err, sizeof g_err, "oracle_conv2d_fwd_f32: bad argument");
         return SAE_EINVAL;
     }
-#pragma omp parallel for collapse(2) schedule(static)
+    const int64_t nblk = (d->oh + ORB - 1) / ORB;
+    const int64_t S = d->stride, P = d->pad;
+#pragma omp parallel for collapse(3) schedule(dynamic, 1)
     for (int64_t n = 0; n < d->n; ++n)
         for (int64_t m = 0; m < d->m; ++m)
-            for (int64_t oy = 0; oy < d->oh; ++oy)
-                for (int64_t ox = 0; ox < d->ow; ++ox) {
-                    double acc = 0.0;
-                    for (int64_t c = 0; c < d->c; ++c)
-                        for (int ky = 0; ky < d->kh; ++ky) {
-                            int64_t iy = oy * d->stride + ky - d->pad;
-                            if (iy < 0 || iy >= d->h) continue;
-                            for (int kx = 0; kx < d->kw; ++kx) {
-                                int64_t ix = ox * d->stride + kx - d->pad;
-                                if (ix < 0 || ix >= d->w) continue;
-                                acc += (double)w[m * d->w_stride_m + c * d->w_stride_c + ky * d->kw + kx] *
-                                       (double)x[((n * d->c + c) * d->h + iy) * d->w + ix];
+            for (int64_t blk = 0; blk < nblk; ++blk) {
+                const int64_t oy0 = blk * ORB, oy1 = oy0 + ORB < d->oh ? oy0 + ORB : d->oh;
+                double* acc = (double*)calloc((size_t)(ORB * d->ow), sizeof(double));
+                for (int64_t c = 0; c < d->c; ++c)
+                    for (int ky = 0; ky < d->kh; ++ky)
+                        for (int kx = 0; kx < d->kw; ++kx) {
+                            const double wv = w[m * d->w_stride_m + c * d->w_stride_c + ky * d->kw + kx];
+                            /* ox range with 0 <= ox*S + kx - P < W */
+                            int64_t lo = P - kx > 0 ? (P - kx + S - 1) / S : 0;
+                            int64_t hi = (d->w - 1 + P - kx) / S + 1;
+                            if (d->w - 1 + P - kx < 0) hi = 0;
+                            if (hi > d->ow) hi = d->ow;
+                            for (int64_t oy = oy0; oy < oy1; ++oy) {
+                                const int64_t iy = oy * S + ky - P;
+                                if (iy < 0 || iy >= d->h) continue;
+                                const float* xr = x + ((n * d->c + c) * d->h + iy) * d->w + (kx - P);
+                                double* ar = acc + (oy - oy0) * d->ow;
+                                for (int64_t ox = lo; ox < hi; ++ox) ar[ox] += wv * (double)xr[ox * S];
                             }
                         }
-                    y[((n * d->m + m) * d->oh + oy) * d->ow + ox] = (float)(acc * (double)alpha);
-                }
+                for (int64_t oy = oy0; oy < oy1; ++oy)
+                    for (int64_t ox = 0; ox < d->ow; ++ox)
+                        y[((n * d->m + m) * d->oh + oy) * d->ow + ox] =
+                            (float)(acc[(oy - oy0) * d->ow + ox] * (double)alpha);
+                free(acc);
+            }
     return SAE_OK;
 }
 
@@ -229,30 +249,36 @@ int oracle_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sa
         snprintf(g_err, sizeof g_err, "oracle_conv2d_dgrad_f32: bad argument");
         return SAE_EINVAL;
     }
-    int64_t plane = d->h * d->w;
-#pragma omp parallel for collapse(2) schedule(static)
+    const int64_t nblk = (d->h + ORB - 1) / ORB;
+    const int64_t S = d->stride, P = d->pad;
+#pragma omp parallel for collapse(3) schedule(dynamic, 1)
     for (int64_t n = 0; n < d->n; ++n)
-        for (int64_t c = 0; c < d->c; ++c) {
-            double* acc = (double*)calloc((size_t)plane, sizeof(double));
-            for (int64_t m = 0; m < d->m; ++m)
-                for (int ky = 0; ky < d->kh; ++ky)
-                    for (int kx = 0; kx < d->kw; ++kx) {
-                        double wv = w[m * d->w_stride_m + c * d->w_stride_c + ky * d->kw + kx];
-                        for (int64_t oy = 0; oy < d->oh; ++oy) {
-                            int64_t iy = oy * d->stride + ky - d->pad;
-                            if (iy < 0 || iy >= d->h) continue;
-                            for (int64_t ox = 0; ox < d->ow; ++ox) {
-                                int64_t ix = ox * d->stride + kx - d->pad;
-                                if (ix < 0 || ix >= d->w) continue;
-                                acc[iy * d->w + ix] +=
-                                    wv * (double)gy[((n * d->m + m) * d->oh + oy) * d->ow + ox];
+        for (int64_t c = 0; c < d->c; ++c)
+            for (int64_t blk = 0; blk < nblk; ++blk) {
+                const int64_t iy0 = blk * ORB, iy1 = iy0 + ORB < d->h ? iy0 + ORB : d->h;
+                double* acc = (double*)calloc((size_t)(ORB * d->w), sizeof(double));
+                for (int64_t m = 0; m < d->m; ++m)
+                    for (int ky = 0; ky < d->kh; ++ky)
+                        for (int kx = 0; kx < d->kw; ++kx) {
+                            const double wv = w[m * d->w_stride_m + c * d->w_stride_c + ky * d->kw + kx];
+                            int64_t lo = P - kx > 0 ? (P - kx + S - 1) / S : 0;
+                            int64_t hi = (d->w - 1 + P - kx) / S + 1;
+                            if (d->w - 1 + P - kx < 0) hi = 0;
+                            if (hi > d->ow) hi = d->ow;
+                            for (int64_t oy = 0; oy < d->oh; ++oy) {
+                                const int64_t iy = oy * S + ky - P;
+                                if (iy < iy0 || iy >= iy1) continue;
+                                const float* gr = gy + ((n * d->m + m) * d->oh + oy) * d->ow;
+                                double* ar = acc + (iy - iy0) * d->w + (kx - P);
+                                for (int64_t ox = lo; ox < hi; ++ox) ar[ox * S] += wv * (double)gr[ox];
                             }
                         }
-                    }
-            for (int64_t i = 0; i < plane; ++i)
-                gx[(n * d->c + c) * plane + i] = (float)(acc[i] * (double)alpha);
-            free(acc);
-        }
+                for (int64_t iy = iy0; iy < iy1; ++iy)
+                    for (int64_t ix = 0; ix < d->w; ++ix)
+                        gx[((n * d->c + c) * d->h + iy) * d->w + ix] =
+                            (float)(acc[(iy - iy0) * d->w + ix] * (double)alpha);
+                free(acc);
+            }
     return SAE_OK;
 }
 
@@ -264,22 +290,27 @@ int oracle_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sa
         snprintf(g_err, sizeof g_err, "oracle_conv2d_wgrad_f32: bad argument");
         return SAE_EINVAL;
     }
-#pragma omp parallel for collapse(2) schedule(static)
+    const int64_t S = d->stride, P = d->pad;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1)
     for (int64_t m = 0; m < d->m; ++m)
         for (int64_t c = 0; c < d->c; ++c)
             for (int ky = 0; ky < d->kh; ++ky)
                 for (int kx = 0; kx < d->kw; ++kx) {
+                    int64_t lo = P - kx > 0 ? (P - kx + S - 1) / S : 0;
+                    int64_t hi = (d->w - 1 + P - kx) / S + 1;
+                    if (d->w - 1 + P - kx < 0) hi = 0;
+                    if (hi > d->ow) hi = d->ow;
                     double acc = 0.0;
                     for (int64_t n = 0; n < d->n; ++n)
                         for (int64_t oy = 0; oy < d->oh; ++oy) {
-                            int64_t iy = oy * d->stride + ky - d->pad;
+                            const int64_t iy = oy * S + ky - P;
                             if (iy < 0 || iy >= d->h) continue;
-                            for (int64_t ox = 0; ox < d->ow; ++ox) {
-                                int64_t ix = ox * d->stride + kx - d->pad;
-                                if (ix < 0 || ix >= d->w) continue;
-                                acc += (double)gy[((n * d->m + m) * d->oh + oy) * d->ow + ox] *
-                                       (double)x[((n * d->c + c) * d->h + iy) * d->w + ix];
-                            }
+                            const float* gr = gy + ((n * d->m + m) * d->oh + oy) * d->ow;
+                            const float* xr = x + ((n * d->c + c) * d->h + iy) * d->w + (kx - P);
+                            double row = 0.0;
+#pragma omp simd reduction(+ : row)
+                            for (int64_t ox = lo; ox < hi; ++ox) row += (double)gr[ox] * (double)xr[ox * S];
+                            acc += row;
                         }
                     gw[m * d->w_stride_m + c * d->w_stride_c + ky * d->kw + kx] =
                         (float)(acc * (double)alpha);

@@ -1,0 +1,262 @@
+"""GPU, BASELINE sizes: the HIP kernels on the FULL tensors of every conv / blur / bias-act class of the
+church256 (256x256, B=16), ffhq512 (512x512, B=8) and ffhq1024 (1024x1024, B=4) presets, checked
+against the CPU oracle on slices that cross every tile seam.
+
+The three conv operations are linear in a way that lets the oracle restate a slice exactly:
+  forward   y[S, M', :, :]  depends on x[S] and w[M']            (S = first and last image, M' = the
+  dgrad     gx[S, C', :, :] depends on gy[S] and w[:, C']         channels either side of every 32-row
+  wgrad     gw[M', :, :, :] depends on gy[:, M'] and all of x     tile boundary + the two ends)
+so the oracle sees ALL pixels of the sliced images (every pixel-tile seam, strip, halo and parity
+class), every channel-tile seam, and — for wgrad — the full reduction over batch and pixels (every
+split-K slab).  Both conv arithmetics run against the same oracle result.
+
+Tolerance: 2e-5 of the slice's max magnitude for the exact-fp32 kernels (the per-op bar of
+tests/test_gpu_kernels.py; north star 1e-4), 2e-5 for bf16x6 as well.  Observed errors are appended to
+gpurun_out/fullsize_parity.jsonl when that directory is writable (copied to profiles/ by hand).
+Reference call sites: models/networks/stylegan2_layers.py:136,306,315,321 (convs), :99-112 (Blur),
+stylegan2_op/fused_act.py:23-96."""
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+import abi_harness as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-5
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MODES = (("f32", 0), ("bf16x6", 1))
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from swapping_autoencoder_pytorch_amd import hip_lib as L
+    return L.get()
+
+
+def _record(**row):
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "fullsize_parity.jsonl"), "a") as f:
+            f.write(json.dumps(row) + "\n")
+    except OSError:
+        pass
+
+
+def seam_channels(nch, cap=24):
+    """Channel indices either side of every 32-channel tile boundary plus both ends (all of them when few)."""
+    if nch <= cap:
+        return list(range(nch))
+    picks = {0, 1, nch - 2, nch - 1}
+    for b in range(32, nch, 32):
+        picks.update((b - 1, b))
+    picks = sorted(p for p in picks if 0 <= p < nch)
+    if len(picks) > cap:      # keep the 128-boundaries and the ends, thin the rest evenly
+        keep = {0, 1, nch - 2, nch - 1} | {p for p in picks if (p % 128) in (0, 127)}
+        rest = [p for p in picks if p not in keep]
+        step = max(1, len(rest) // max(1, cap - len(keep)))
+        picks = sorted(keep | set(rest[::step]))
+    return picks
+
+
+def _hip_conv(lib, op, d, a, b, out_shape, alpha):
+    n_ws = lib.query("conv2d_workspace", C.byref(d), op)
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=DEV)
+    out = torch.full(out_shape, float("nan"), dtype=torch.float32, device=DEV)
+    lib.call(H.OPS[op], a.data_ptr(), b.data_ptr(), out.data_ptr(), C.byref(d), alpha, ws.data_ptr(), n_ws,
+             torch.cuda.current_stream().cuda_stream)
+    return out
+
+
+def _np(t):
+    return np.ascontiguousarray(t.detach().cpu().numpy())
+
+
+# (preset / role, n, c, h, w, m, k, stride, pad, weights stored [C, M, k, k])
+CONV_FULL = [
+    ("church256 D 3x3 s1 (dominant layer)", 16, 128, 256, 256, 128, 3, 1, 1, False),
+    ("church256 D 3x3 s2 after blur, 2^k+1 grid", 16, 128, 257, 257, 256, 3, 2, 0, False),
+    ("church256 G transposed 256->128, 128 -> 257", 16, 128, 257, 257, 256, 3, 2, 0, True),
+    ("church256 Dpatch 32->32, B=128", 128, 32, 128, 128, 32, 3, 1, 1, False),
+    ("church256 Dpatch 3x3 s2 32->64 @129", 128, 32, 129, 129, 64, 3, 2, 0, False),
+    ("church256 Dpatch stem 1x1 3->32", 128, 3, 128, 128, 32, 1, 1, 0, False),
+    ("church256 RGB stem 3x3 3->32 (wgrad MODE 2)", 128, 3, 128, 128, 32, 3, 1, 1, False),
+    ("church256 tail 512->512 @16 (split-K)", 16, 512, 16, 16, 512, 3, 1, 1, False),
+    ("church256 G 512->512 @64", 16, 512, 64, 64, 512, 3, 1, 1, False),
+    ("church256 skip 1x1 128->256 @128", 16, 128, 128, 128, 256, 1, 1, 0, False),
+    ("church256 D stem 1x1 3->128 @256", 16, 3, 256, 256, 128, 1, 1, 0, False),
+    ("church256 ToRGB 1x1 128->3 @256", 16, 128, 256, 256, 3, 1, 1, 0, False),
+    ("church256 E valid 3x3 32->32 @258 (reflection padded)", 16, 32, 258, 258, 32, 3, 1, 0, False),
+    ("church256 E 3x3 s2 valid 512->1024 @16 -> 7", 16, 512, 16, 16, 1024, 3, 2, 0, False),
+    ("ffhq512 D 3x3 s1 64->64 @512", 8, 64, 512, 512, 64, 3, 1, 1, False),
+    ("ffhq512 D 3x3 s2 64->128 @513", 8, 64, 513, 513, 128, 3, 2, 0, False),
+    ("ffhq512 G transposed 128->64, 256 -> 513", 8, 64, 513, 513, 128, 3, 2, 0, True),
+    ("ffhq1024 G 102->102 @1024 (B=2 rec half)", 2, 102, 1024, 1024, 102, 3, 1, 1, False),
+    ("ffhq1024 G transposed 204->102, 512 -> 1025", 2, 102, 1025, 1025, 204, 3, 2, 0, True),
+    ("ffhq1024 G 409->409 @128", 4, 409, 128, 128, 409, 3, 1, 1, False),
+    ("ffhq1024 G transposed 409->204, 256 -> 513", 4, 204, 513, 513, 409, 3, 2, 0, True),
+    ("ffhq1024 D 3x3 s1 32->32 @1024", 4, 32, 1024, 1024, 32, 3, 1, 1, False),
+    ("ffhq1024 D 3x3 s2 32->64 @1025", 4, 32, 1025, 1025, 64, 3, 2, 0, False),
+    ("ffhq1024 ToRGB 1x1 102->3 @1024", 4, 102, 1024, 1024, 3, 1, 1, 0, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_FULL, ids=lambda c: c[0].replace(" ", "_"))
+def test_conv_fullsize_vs_oracle(hip_lib, oracle_lib, case):
+    name, n, c, h, w, m, k, s, p, cm = case
+    d = H.conv_desc(n, c, h, w, m, k, s, p, cm)
+    gen = torch.Generator(device=DEV).manual_seed(1234)
+    x = torch.randn(n, c, h, w, device=DEV, generator=gen)
+    wt = torch.randn((c, m, k, k) if cm else (m, c, k, k), device=DEV, generator=gen)
+    gy = torch.randn(n, m, d.oh, d.ow, device=DEV, generator=gen)
+    alpha = float(1.0 / np.sqrt(c * k * k))
+    imgs = sorted({0, n - 1})
+    msel, csel = seam_channels(m), seam_channels(c)
+    wsel_m = (lambda t, idx: t[:, idx]) if cm else (lambda t, idx: t[idx])      # slice the M axis of the weight
+    wsel_c = (lambda t, idx: t[idx]) if cm else (lambda t, idx: t[:, idx])      # slice the C axis of the weight
+
+    t0 = time.time()
+    # oracle on the slices (host, double accumulation)
+    x_s, gy_s, w_np = _np(x[imgs]), _np(gy[imgs]), _np(wt)
+    d_f = H.conv_desc(len(imgs), c, h, w, len(msel), k, s, p, cm)
+    o_fwd = H.conv(oracle_lib, 0, d_f, x_s, _np(wsel_m(wt, msel)), (len(imgs), len(msel), d.oh, d.ow), alpha=alpha)
+    d_d = H.conv_desc(len(imgs), len(csel), h, w, m, k, s, p, cm)
+    o_dg = H.conv(oracle_lib, 1, d_d, gy_s, _np(wsel_c(wt, csel)), (len(imgs), len(csel), h, w), alpha=alpha)
+    wsub = seam_channels(m, cap=12)
+    d_w = H.conv_desc(n, c, h, w, len(wsub), k, s, p, cm)
+    gw_shape = (c, len(wsub), k, k) if cm else (len(wsub), c, k, k)
+    o_wg = H.conv(oracle_lib, 2, d_w, _np(x), _np(gy[:, wsub]), gw_shape, alpha=alpha)
+    t_oracle = time.time() - t0
+    del x_s, gy_s, w_np
+
+    for mode, code in MODES:
+        hip_lib.call("set_conv_math", code)
+        try:
+            y = _hip_conv(hip_lib, 0, d, x, wt, (n, m, d.oh, d.ow), alpha)
+            gx = _hip_conv(hip_lib, 1, d, gy, wt, (n, c, h, w), alpha)
+            gw = _hip_conv(hip_lib, 2, d, x, gy, tuple(wt.shape), alpha)
+            torch.cuda.synchronize()
+        finally:
+            hip_lib.call("set_conv_math", 0)
+        assert not torch.isnan(y).any() and not torch.isnan(gx).any() and not torch.isnan(gw).any(), mode
+        e_fwd = H.rel_err(_np(y[imgs][:, msel]), o_fwd)
+        e_dg = H.rel_err(_np(gx[imgs][:, csel]), o_dg)
+        e_wg = H.rel_err(_np(wsel_m(gw, wsub)), o_wg)
+        _record(test="conv", case=name, geom=[n, c, h, w, m, k, s, p, int(cm)], math=mode, fwd=e_fwd, dgrad=e_dg,
+                wgrad=e_wg, oracle_s=round(t_oracle, 2))
+        assert e_fwd < TOL, (mode, "fwd", e_fwd)
+        assert e_dg < TOL, (mode, "dgrad", e_dg)
+        assert e_wg < TOL, (mode, "wgrad", e_wg)
+        del y, gx, gw
+
+
+@pytest.mark.parametrize("case", [
+    ("church256 D 128->128 @256 fused bias+lrelu", 16, 128, 256, 256, 128, 3, 1, 1),
+    ("church256 D 128->256 s2 @257 fused bias+lrelu", 16, 128, 257, 257, 256, 3, 2, 0),
+    ("church256 Dpatch 32->32 fused bias+lrelu", 128, 32, 128, 128, 32, 3, 1, 1),
+    ("ffhq1024 D 32->32 @1024 fused bias+lrelu", 4, 32, 1024, 1024, 32, 3, 1, 1),
+], ids=lambda c: c[0].replace(" ", "_"))
+def test_conv_bias_act_fullsize_vs_oracle(hip_lib, oracle_lib, case):
+    """ConvLayer's Conv -> FusedLeakyReLU pair (stylegan2_layers.py:642-659) as the ONE kernel the step runs."""
+    name, n, c, h, w, m, k, s, p = case
+    d = H.conv_desc(n, c, h, w, m, k, s, p)
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    x = torch.randn(n, c, h, w, device=DEV, generator=gen)
+    wt = torch.randn(m, c, k, k, device=DEV, generator=gen)
+    bias = torch.randn(m, device=DEV, generator=gen)
+    alpha = float(1.0 / np.sqrt(c * k * k))
+    imgs, msel = sorted({0, n - 1}), seam_channels(m)
+    d_f = H.conv_desc(len(imgs), c, h, w, len(msel), k, s, p)
+    o = H.conv_bias_act(oracle_lib, d_f, _np(x[imgs]), _np(wt[msel]), _np(bias[msel]), alpha=alpha)
+    for mode, code in MODES:
+        hip_lib.call("set_conv_math", code)
+        try:
+            n_ws = hip_lib.query("conv2d_workspace", C.byref(d), 0)
+            ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=DEV)
+            y = torch.full((n, m, d.oh, d.ow), float("nan"), device=DEV)
+            hip_lib.call("conv2d_fwd_bias_act_f32", x.data_ptr(), wt.data_ptr(), bias.data_ptr(), y.data_ptr(), C.byref(d),
+                         alpha, 0.2, 2 ** 0.5, ws.data_ptr(), n_ws, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        finally:
+            hip_lib.call("set_conv_math", 0)
+        err = H.rel_err(_np(y[imgs][:, msel]), o)
+        _record(test="conv_bias_act", case=name, math=mode, fwd=err)
+        assert err < TOL, (mode, err)
+
+
+# (role, planes, h, w, taps, up, down, pad)
+BLUR_FULL = [
+    ("church256 blur before 3x3 s2, 256 -> 257", 16 * 128, 256, 256, 4, 1, 1, (2, 2)),
+    ("church256 blur after transposed conv, 257 -> 256 (x4 gain)", 16 * 128, 257, 257, 4, 1, 1, (1, 1)),
+    ("church256 skip decimation 256 -> 128", 16 * 128, 256, 256, 4, 1, 2, (1, 1)),
+    ("church256 skip decimation backward 128 -> 256", 16 * 128, 128, 128, 4, 2, 1, (2, 2)),
+    ("church256 E [1,2,1] after reflection pad 259 -> 257", 16 * 32, 259, 259, 3, 1, 1, (0, 0)),
+    ("church256 Dpatch 128 -> 129", 128 * 32, 128, 128, 4, 1, 1, (2, 2)),
+    ("ffhq512 (8,128,513,513) -> 512 k4", 8 * 128, 513, 513, 4, 1, 1, (1, 1)),
+    ("ffhq512 (8,64,512,512) -> 513", 8 * 64, 512, 512, 4, 1, 1, (2, 2)),
+    ("ffhq512 (8,64,512,512) -> 511", 8 * 64, 512, 512, 4, 1, 1, (1, 1)),
+    ("ffhq512 (8,32,515,515) k3", 8 * 32, 515, 515, 3, 1, 1, (0, 0)),
+    ("ffhq1024 (2,102,1025,1025) -> 1024", 2 * 102, 1025, 1025, 4, 1, 1, (1, 1)),
+    ("ffhq1024 (4,32,1024,1024) -> 1025", 4 * 32, 1024, 1024, 4, 1, 1, (2, 2)),
+]
+
+
+@pytest.mark.parametrize("case", BLUR_FULL, ids=lambda c: c[0].replace(" ", "_"))
+def test_upfirdn2d_fullsize_vs_oracle(hip_lib, oracle_lib, case):
+    """K1 at the real plane sizes; the oracle restates the first, a middle and the last 8 planes (the kernel
+    packs strips of several planes per workgroup, so the ends and a middle cut exercise the packing)."""
+    name, planes, h, w, taps, up, down, pad = case
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(planes, h, w, 1, device=DEV, generator=gen)
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0] if taps == 4 else [1.0, 2.0, 1.0])
+    kk = torch.outer(k1, k1)
+    kk = (kk / kk.sum() * (up * up)).to(DEV)
+    oh = (h * up + pad[0] + pad[1] - taps + down) // down
+    ow = (w * up + pad[0] + pad[1] - taps + down) // down
+    y = torch.full((planes, oh, ow, 1), float("nan"), device=DEV)
+    hip_lib.call("upfirdn2d_f32", x.data_ptr(), kk.data_ptr(), y.data_ptr(), planes, h, w, 1, taps, taps, up, up, down,
+                 down, pad[0], pad[1], pad[0], pad[1], torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    mid = planes // 2 - 3
+    sel = list(range(8)) + list(range(mid, mid + 8)) + list(range(planes - 8, planes))
+    o = H.upfirdn2d(oracle_lib, _np(x[sel]), _np(kk), (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+    err = H.rel_err(_np(y[sel]), o)
+    _record(test="upfirdn2d", case=name, err=err)
+    assert not torch.isnan(y).any()
+    assert err < 2e-6, err
+
+
+@pytest.mark.parametrize("shape", [(16, 128, 256, 256), (128, 32, 128, 128), (8, 128, 512, 512), (4, 32, 1024, 1024)], ids=str)
+def test_bias_act_fullsize_vs_oracle(hip_lib, oracle_lib, shape):
+    """K2 forward and its fused backward (grad_input + grad_bias) on the largest activations of the presets."""
+    n, c, h, w = shape
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    x = torch.randn(shape, device=DEV, generator=gen)
+    b = torch.randn(c, device=DEV, generator=gen)
+    gyt = torch.randn(shape, device=DEV, generator=gen)
+    y = torch.empty_like(x)
+    st = torch.cuda.current_stream().cuda_stream
+    hip_lib.call("bias_act_f32", x.data_ptr(), b.data_ptr(), None, y.data_ptr(), x.numel(), h * w, c, 3, 0, 0.2, 2 ** 0.5, st)
+    nws = hip_lib.query("bias_act_bwd_workspace", x.numel(), h * w, c)
+    ws = torch.empty(max(nws, 1), device=DEV)
+    gx, gb = torch.empty_like(x), torch.empty(c, device=DEV)
+    hip_lib.call("bias_act_bwd_f32", gyt.data_ptr(), y.data_ptr(), gx.data_ptr(), gb.data_ptr(), ws.data_ptr(), nws,
+                 x.numel(), h * w, c, 0.2, 2 ** 0.5, st)
+    torch.cuda.synchronize()
+    imgs = sorted({0, n - 1})
+    o = H.bias_act(oracle_lib, _np(x[imgs]), _np(b), None, 3, 0)
+    assert np.allclose(_np(y[imgs]), o, rtol=2e-7, atol=0)
+    # the bias gradient needs every element: full-tensor oracle pass (serial, ~1 s per 100 M elements)
+    gx_o, gb_o = H.bias_act_bwd(oracle_lib, _np(gyt), _np(y))
+    assert np.allclose(_np(gx), gx_o, rtol=2e-7, atol=0)
+    scale = float(np.abs(gx_o).sum() / c)
+    err = float(np.abs(_np(gb) - gb_o).max() / max(scale, 1.0))
+    _record(test="bias_act", shape=list(shape), gb_err_over_l1=err)
+    assert err <= 1e-6

@@ -110,6 +110,68 @@ def test_conv2d_bf16x6(hip_lib, oracle_lib, case):
         hip_lib.call("set_conv_math", 0)
 
 
+def _l1_scale(oracle_lib, op, d, a, b, shape):
+    """sum_k |a_k b_k| per output element (the condition scale of the contraction), via the oracle on |a|, |b|."""
+    return H.conv(oracle_lib, op, d, np.abs(a), np.abs(b), shape, alpha=1.0).astype(np.float64)
+
+
+@pytest.mark.parametrize("kind", ["scales_1e30", "cancellation", "tiny_operands", "huge_dynamic_range_within_channel"])
+def test_conv2d_bf16x6_adversarial(hip_lib, oracle_lib, kind):
+    """Adversarial operand ranges for the bf16x6 split arithmetic (promotion condition ii).
+
+    Error is measured against the double oracle relative to the condition scale L1 = sum_k |a_k b_k| of each
+    output (the only scale any fp32 contraction can be held to), for BOTH arithmetics:
+      * scales_1e30: per-channel magnitudes 1e-30 .. 1e+30 on x, compensated on w (outputs O(1)): every split piece
+        stays a normal number, the bound is the nominal one;
+      * cancellation: channel pairs that cancel to ~1e-6 of their magnitude: the error relative to L1 must not grow;
+      * huge_dynamic_range_within_channel: magnitudes 1e-12 .. 1e+12 inside one plane;
+      * tiny_operands: |x| ~ 1e-34 (below 2^-108 the third bf16 piece is subnormal and the matrix core flushes it;
+        below 2^-117 the second one too): the documented limit of the split arithmetic — relative accuracy
+        degrades from 2^-26 towards 2^-17 there, and the test pins exactly that bound (include/sae_hip.h)."""
+    n, c, h, w, m, k, s, p = 2, 64, 16, 16, 96, 3, 1, 1
+    d = H.conv_desc(n, c, h, w, m, k, s, p)
+    rng = np.random.default_rng(101)
+    x = rng.standard_normal((n, c, h, w))
+    wt = rng.standard_normal((m, c, k, k))
+    gy = rng.standard_normal((n, m, d.oh, d.ow))
+    bound = 1e-6          # the exact-fp32 chain itself reaches ~4e-7 of L1 on these inputs
+    if kind == "scales_1e30":
+        e = rng.uniform(-30, 30, c)
+        x *= (10.0 ** e)[None, :, None, None]
+        wt *= (10.0 ** -e)[None, :, None, None]
+    elif kind == "cancellation":
+        x[:, 1::2] = -x[:, 0::2] * (1.0 + 1e-6 * rng.standard_normal(x[:, 0::2].shape))
+        wt[:, 1::2] = wt[:, 0::2]
+    elif kind == "huge_dynamic_range_within_channel":
+        x *= 10.0 ** rng.uniform(-12, 12, x.shape)
+        gy *= 10.0 ** rng.uniform(-12, 12, gy.shape)
+    elif kind == "tiny_operands":
+        x *= 1e-34
+        wt *= 1e3
+        gy *= 1e-34
+        bound = 2.0 ** -16
+    x, wt, gy = x.astype(np.float32), wt.astype(np.float32), gy.astype(np.float32)
+    ops = [(x, wt, gy.shape), (gy, wt, x.shape), (x, gy, wt.shape)]
+    rows = []
+    for op, (a, b, shape) in enumerate(ops):
+        o = H.conv(oracle_lib, op, d, a, b, shape, alpha=1.0).astype(np.float64)
+        l1 = np.maximum(_l1_scale(oracle_lib, op, d, a, b, shape), 1e-300)
+        exact = H.conv(hip_lib, op, d, a, b, shape, alpha=1.0, device=DEV).astype(np.float64)
+        hip_lib.call("set_conv_math", 1)
+        try:
+            split = H.conv(hip_lib, op, d, a, b, shape, alpha=1.0, device=DEV).astype(np.float64)
+        finally:
+            hip_lib.call("set_conv_math", 0)
+        assert np.isfinite(split).all(), (kind, op)
+        e_exact = float((np.abs(exact - o) / l1).max())
+        e_split = float((np.abs(split - o) / l1).max())
+        rows.append((op, e_exact, e_split))
+        assert e_split <= bound, (kind, op, e_exact, e_split)
+        if kind != "tiny_operands":
+            assert e_split <= 3 * e_exact + 2e-7, (kind, op, e_exact, e_split)
+    print("bf16x6 adversarial", kind, rows)
+
+
 @pytest.mark.parametrize("mnk", GEMM_CASES + [(128, 2048, 3072), (16, 512, 2048)], ids=str)
 def test_gemm(hip_lib, oracle_lib, mnk):
     m, n, k = mnk
