@@ -15,8 +15,9 @@ Also reported on the same JSON line:
   roofline     – dominant kernel (3x3 stride-1 implicit-GEMM conv, conv_igemm_kernel<3,1,2,2,2,2,8>):
                  algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
                  launch stream inside the timed region, against the fp32 MFMA peak (157.3 TFLOP/s);
-  cpu_baseline – the CPU oracle (a port, oracle/sae_oracle.c) timed on the host cores on a bounded
-                 sample of the same workload (rank 0, N = 1 only).
+  cpu_baseline – the reference's CPU path (ATen on all host cores, restated in oracle/aten_cpu_path.py and pinned
+                 to the reference's own modules) timed on a bounded sample of the same workload: the image
+                 discriminator forward + backward (rank 0, N = 1 only); the C oracle's rate rides along.
 """
 import argparse
 import json
@@ -116,38 +117,68 @@ class DominantKernelTimer:
                 "avg_launch_gflop": round(fl / n / 1e9, 2), "note": note}
 
 
-def cpu_baseline(preset):
-    """Oracle (C port, double accumulation, OpenMP) on a bounded sample: forward + dgrad + wgrad of
-    the discriminator's 128->128 3x3 conv at 256x256 on ONE image, scaled by the FLOPs per image of
-    the full iteration."""
-    import ctypes as C
+def cpu_baseline(preset, size, batch):
+    """The reference's CPU code path timed on this host (rank 0, N = 1): the image discriminator forward + backward
+    (weights trainable, input without gradient = the D(real) pass of a discriminator step) through ATen on all
+    host cores — F.conv2d / its two backward kernels (MKLDNN), upfirdn2d_native (F.pad + F.conv2d), F.leaky_relu —
+    restated in oracle/aten_cpu_path.py and pinned to the reference's own Discriminator in
+    tests/test_dropin_train.py.  The sample's conv FLOPs per second are converted to images/s with the FLOPs per
+    image of the full iteration.  The C oracle's rate on one conv layer is kept as `oracle_port`."""
     import subprocess
     import numpy as np
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import abi_harness as H
+    import aten_cpu_path as A
     from swapping_autoencoder_pytorch_amd.hip_lib import SaeLibrary
+    cores = os.cpu_count() or 1
+    per_image = FLOPS_PER_IMAGE.get(preset, 1.815e12)
+
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    disc = A.DiscriminatorCPU(size, 2)
+    n = min(batch, 8)                         # bounded: half a batch of the church preset is ~2.2 TFLOP of conv work
+    x = torch.rand(n, 3, size, size) * 2 - 1
+    flops = disc.train_flops(n, size)
+
+    def one_pass():
+        for p in disc.parameters():
+            p.grad = None
+        torch.nn.functional.softplus(-disc(x)).mean().backward()
+
+    one_pass()                                 # MKLDNN primitive creation, thread pool start-up
+    t0 = time.time()
+    one_pass()
+    dt = time.time() - t0
+    out = {"value": round(flops / dt / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
+           "port_of": "aten-cpu restatement of the reference's CPU path (oracle/aten_cpu_path.py: F.conv2d + autograd, "
+                      "upfirdn2d_native, F.leaky_relu; torch.set_num_threads(%d))" % cores,
+           "sample": "image discriminator forward + backward, %d images %dx%d: %.2f TFLOP of conv work in %.2f s = %.2f "
+                     "TFLOP/s, scaled by %.3f TFLOP/image of the full iteration" % (n, size, size, flops / 1e12, dt,
+                                                                                  flops / dt / 1e12, per_image / 1e12)}
+
     so = os.path.join(ROOT, "oracle", "libsae_oracle.so")
     if not os.path.exists(so):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")])
     ora = SaeLibrary(so, prefix="oracle_", device_only=False)
-    cores = os.cpu_count() or 1
     rng = np.random.default_rng(0)
-    n, c, hw, m = 1, 128, 256, 128
-    d = H.conv_desc(n, c, hw, hw, m, 3, 1, 1)
-    x = rng.standard_normal((n, c, hw, hw)).astype(np.float32)
+    c, hw, m = 128, 256, 128
+    d = H.conv_desc(1, c, hw, hw, m, 3, 1, 1)
+    xo = rng.standard_normal((1, c, hw, hw)).astype(np.float32)
     w = rng.standard_normal((m, c, 3, 3)).astype(np.float32)
-    gy = rng.standard_normal((n, m, hw, hw)).astype(np.float32)
-    flops = 3 * 2.0 * n * m * hw * hw * c * 9
+    gy = rng.standard_normal((1, m, hw, hw)).astype(np.float32)
+    H.conv(ora, 0, H.conv_desc(1, 8, 32, 32, 8, 3, 1, 1), xo[:, :8, :32, :32], w[:8, :8], (1, 8, 32, 32))   # OpenMP start-up
+    oflops = 3 * 2.0 * m * hw * hw * c * 9
     t0 = time.time()
-    H.conv(ora, 0, d, x, w, gy.shape)
-    H.conv(ora, 1, d, gy, w, x.shape)
-    H.conv(ora, 2, d, x, gy, w.shape)
-    dt = time.time() - t0
-    per_image = FLOPS_PER_IMAGE.get(preset, 1.815e12)
-    return {"value": round(flops / dt / per_image, 6), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "oracle conv2d fwd+dgrad+wgrad, D layer 128->128 3x3 @256x256, 1 image (%.0f GFLOP in %.1f s, "
-                      "%.2f GFLOP/s) scaled by %.3f TFLOP/image of the full iteration" % (flops / 1e9, dt, flops / dt / 1e9,
-                                                                                      per_image / 1e12)}
+    H.conv(ora, 0, d, xo, w, gy.shape)
+    H.conv(ora, 1, d, gy, w, xo.shape)
+    H.conv(ora, 2, d, xo, gy, w.shape)
+    odt = time.time() - t0
+    out["oracle_port"] = {"value": round(oflops / odt / per_image, 5), "unit": "images/s",
+                          "sample": "oracle/sae_oracle.c (double accumulation, OpenMP) conv fwd+dgrad+wgrad 128->128 3x3 "
+                                    "@256x256, 1 image: %.0f GFLOP in %.2f s" % (oflops / 1e9, odt)}
+    return out
 
 
 def _free_port():
@@ -294,6 +325,10 @@ def main():
         if per_image:
             line["model_tflops_per_gpu"] = round(value / world * per_image / 1e12, 2)
             line["frac_of_mfma_f32_roofline"] = round(value / world * per_image / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+        # lazy R1 runs on every R1_once_every-th discriminator iteration (the optimizer's own counter, 1-based)
+        every = opt.R1_once_every
+        r1_in_window = sum(1 for j in range(args.warmup + 1, args.warmup + args.steps + 1) if j % every == 0)
+        line["r1_iterations_in_window"] = r1_in_window
         d_calls = sorted(call_ms["d"][args.warmup:])
         g_calls = sorted(call_ms["g"][args.warmup:])
         if d_calls and g_calls:
@@ -301,11 +336,17 @@ def main():
             line["ms_d_call_median"] = round(d_calls[len(d_calls) // 2], 2)
             line["ms_g_call_median"] = round(g_calls[len(g_calls) // 2], 2)
             line["ms_r1_extra_max"] = round(d_calls[-1] - d_calls[len(d_calls) // 2], 2)
+            if r1_in_window > 0:
+                # the same measurement re-weighted to exactly one R1 call per `every` iterations (SURVEY 8d's metric
+                # definition); `value` itself stays the plain wall-clock figure of the K timed steps
+                x = line["ms_r1_extra_max"] * 1e-3
+                t_norm = (dt - r1_in_window * x) / args.steps + x / every
+                line["value_r1_every_%d" % every] = round(world * batch / t_norm, 3)
         roof = timer.summary(args.conv_math)
         if roof:
             line["roofline"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.preset)
+            line["cpu_baseline"] = cpu_baseline(args.preset, size, batch)
         print(json.dumps(line), flush=True)
     if launched:
         dist.destroy_process_group()

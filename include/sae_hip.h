@@ -34,7 +34,11 @@
  *   - return value: 0 on success, a negative SAE_E* code otherwise; sae_last_error() returns a
  *     thread-local human-readable message for the last failing call on this thread.  Nothing
  *     throws, nothing exits;
- *   - no global mutable state besides that thread-local message: calls are re-entrant.
+ *   - calls are re-entrant; the library keeps no mutable state besides that thread-local message and ONE
+ *     process-wide switch, the conv arithmetic of sae_set_conv_math() below (an atomic, meant to be chosen once
+ *     at start-up: PyTorch runs backward on its own engine threads, so a per-thread setting would not reach the
+ *     dgrad / wgrad calls; a conv call that races with a switch may see either value, and fails with
+ *     SAE_EWORKSPACE rather than misbehaving if its workspace was sized for the other one).
  */
 #ifndef SAE_HIP_H
 #define SAE_HIP_H

@@ -1,6 +1,6 @@
 """Run the reference's UNMODIFIED ``train.py`` (or ``test.py``) on the MI355X hot path.
 
-    python -m swapping_autoencoder_pytorch_amd.dropin /path/to/swapping-autoencoder-pytorch train.py --name ... 
+    python -m swapping_autoencoder_pytorch_amd.dropin /path/to/swapping-autoencoder-pytorch train.py --name ...
 
 How: every import of the reference is an absolute import with the repo root on
 ``sys.path`` and Python consults ``sys.modules`` before the file system, so pre-seeding
@@ -12,16 +12,99 @@ puts the gfx950 kernels underneath the reference's own networks, model, optimize
 loop.  ``util.is_custom_kernel_supported`` (util/util.py:432-436, which raises on ROCm) is never
 reached because the two modules that called it are replaced.
 
-Multi-GPU: the reference drives ``nn.DataParallel`` from one process (models/__init__.py:80).
-Launched under ``python -m torch.distributed.run --nproc-per-node N``, this runner instead gives
-every rank one GPU (``--num_gpus 1`` semantics: DataParallel over a single device is a pass-through),
+Besides the pre-seeding the runner
+  * stands in for the reference's third-party imports that are absent from a bare PyTorch-ROCm image and never
+    executed on the training path (``install_missing_dependency_stubs``: torchvision, dominate, visdom, ...),
+  * offers ``--dataset_mode synthetic``: ``data.synthetic_dataset.SyntheticDataset`` (uniform [-1, 1] images of
+    ``--crop_size``, the data contract of data/base_dataset.py:136-141) so the loop runs without a dataset on disk.
+
+Multi-GPU: the reference drives ``nn.DataParallel`` from one process (models/__init__.py:80) and addresses its
+device as the literal ``'cuda:0'`` (models/__init__.py:79, base_model.py:13, swapping_autoencoder_model.py:48).
+Launched under ``python -m torch.distributed.run --nproc-per-node N``, this runner gives every rank ONE visible
+GPU — ``HIP_VISIBLE_DEVICES`` is narrowed to the rank's device BEFORE the HIP runtime initialises
+(``pin_rank_device``), so ``'cuda:0'`` is that GPU in every rank — pass ``--num_gpus 1`` (DataParallel over a
+single device is a pass-through; ``--batch_size`` is then the PER-RANK batch, the global batch is N times it),
 broadcasts rank 0's initial weights and attaches the bucketed RCCL gradient all-reduce
-(grad_allreduce.GradAllReducer) to the reference optimizer's two Adam instances through optimizer
-step hooks — train.py and the optimizer source stay byte-identical.
+(grad_allreduce.GradAllReducer) to the reference optimizer's two Adam instances through optimizer step hooks;
+checkpoints are written by rank 0 only.  train.py and the optimizer source stay byte-identical.
 """
 import os
 import runpy
 import sys
+import types
+
+_PINNED_FLAG = "SAE_DROPIN_DEVICE_PINNED"
+
+
+def pin_rank_device(environ=None, reexec=True):
+    """Narrow HIP_VISIBLE_DEVICES to this rank's GPU.  Must run before the HIP runtime initialises (the runtime
+    reads the variable once): it is the first thing ``main`` does, before ``torch`` is imported.  If some earlier
+    import already initialised torch.cuda the process re-executes itself with the variable set.
+    Returns the device string chosen, or None when not launched with WORLD_SIZE > 1."""
+    env = os.environ if environ is None else environ
+    if int(env.get("WORLD_SIZE", "1")) <= 1:
+        return None
+    if env.get(_PINNED_FLAG) == "1":
+        return env.get("HIP_VISIBLE_DEVICES")
+    local_rank = int(env.get("LOCAL_RANK", "0"))
+    visible = [d for d in env.get("HIP_VISIBLE_DEVICES", "").split(",") if d != ""]
+    mine = visible[local_rank] if local_rank < len(visible) else str(local_rank)
+    env["HIP_VISIBLE_DEVICES"] = mine
+    env[_PINNED_FLAG] = "1"
+    torch = sys.modules.get("torch")
+    if reexec and torch is not None and torch.cuda.is_initialized():
+        os.execv(sys.executable, list(getattr(sys, "orig_argv", [sys.executable] + sys.argv)))
+    return mine
+
+
+class _Inert:
+    """Instance of a stubbed class: construction and every method call succeed and do nothing (methods return
+    True, so ``visdom.Visdom(...).check_connection()`` reports a live connection and nothing is spawned)."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        return lambda *args, **kwargs: True
+
+
+class _Stub(types.ModuleType):
+    """Import-only stand-in: any attribute is an inert class (enough for ``import x`` / ``from x import Y`` /
+    ``class Z(x.Y)`` at module top level and for objects that are constructed but never do real work)."""
+
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        return type(item, (_Inert,), {})
+
+
+OPTIONAL_DEPENDENCIES = ("torchvision", "torchvision.transforms", "torchvision.transforms.functional",
+                         "torchvision.models", "torchvision.datasets", "dominate", "dominate.tags", "func_timeout",
+                         "visdom", "GPUtil", "cv2", "lmdb")
+
+
+def install_missing_dependency_stubs():
+    """The reference imports these at module top level (util/visualizer.py, util/html.py, data/*, evaluation/*) but
+    the training step never executes them.  Only what is NOT importable is stubbed."""
+    import importlib.util
+    stubbed = []
+    for name in OPTIONAL_DEPENDENCIES:
+        if name in sys.modules:
+            continue
+        root = name.split(".")[0]
+        if root not in stubbed and not isinstance(sys.modules.get(root), _Stub):
+            try:
+                if importlib.util.find_spec(name) is not None:
+                    continue
+            except (ImportError, ValueError):
+                pass
+        m = _Stub(name)
+        m.__path__ = []
+        sys.modules[name] = m
+        stubbed.append(name)
+    return stubbed
 
 
 def preseed():
@@ -32,6 +115,36 @@ def preseed():
     sys.modules["models.networks.stylegan2_op.upfirdn2d"] = upfirdn2d
     sys.modules["models.networks.stylegan2_op.fused_act"] = fused_act
     sys.modules["models.networks.stylegan2_layers"] = stylegan2_layers
+
+
+def inject_synthetic_dataset():
+    """Register ``data.synthetic_dataset`` (found by data/__init__.py:19-39 through importlib, i.e. sys.modules
+    first): uniform [-1, 1] images of crop_size, the tensor contract of the reference's datasets."""
+    import torch
+    from data.base_dataset import BaseDataset      # the reference's own base class (reference root is on sys.path)
+
+    class SyntheticDataset(BaseDataset):
+        @staticmethod
+        def modify_commandline_options(parser, is_train):
+            parser.add_argument("--synthetic_dataset_size", type=int, default=1 << 20)
+            return parser
+
+        def __init__(self, opt):
+            BaseDataset.__init__(self, opt)
+            self.size = int(getattr(opt, "synthetic_dataset_size", 1 << 20))
+            self.res = int(opt.crop_size)
+
+        def __len__(self):
+            return self.size
+
+        def __getitem__(self, index):
+            g = torch.Generator().manual_seed(int(index))
+            return {"real_A": torch.rand(3, self.res, self.res, generator=g) * 2 - 1, "path_A": "synthetic/%09d" % index}
+
+    mod = types.ModuleType("data.synthetic_dataset")
+    mod.SyntheticDataset = SyntheticDataset
+    sys.modules["data.synthetic_dataset"] = mod
+    return mod
 
 
 def attach_gradient_allreduce(optimizer):
@@ -46,24 +159,38 @@ def attach_gradient_allreduce(optimizer):
         reducer.arm()
         opt.register_step_pre_hook(lambda o, a, k, r=reducer: r.finish())
         opt.register_step_post_hook(lambda o, a, k, r=reducer: r.arm())
+    # one writer: every rank holds the same weights, and N ranks racing on the same checkpoint file and on the
+    # remove/symlink of latest_checkpoint.pth (models/base_model.py:33-48) can tear it
+    save = optimizer.save
+
+    def save_on_rank0(*args, **kwargs):
+        if dist.get_rank() == 0:
+            save(*args, **kwargs)
+        dist.barrier()
+
+    optimizer.save = save_on_rank0
     return optimizer
 
 
 def _init_distributed():
-    import torch
+    """One rank = one visible GPU = cuda:0 (pin_rank_device ran first)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return
+    import torch
     import torch.distributed as dist
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    assert os.environ.get(_PINNED_FLAG) == "1", "pin_rank_device() must run before torch.cuda is touched"
+    if torch.cuda.device_count() != 1:
+        raise RuntimeError("rank %s sees %d devices after pinning HIP_VISIBLE_DEVICES=%s: the HIP runtime was initialised "
+                           "before the runner could narrow it" % (os.environ.get("RANK"), torch.cuda.device_count(),
+                                                                 os.environ.get("HIP_VISIBLE_DEVICES")))
+    torch.cuda.set_device(0)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    # the reference addresses "cuda:0" literally: make that this rank's GPU
-    os.environ["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", str(local_rank))
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 
 
 def main(argv=None):
+    pin_rank_device()           # first: before anything can initialise the HIP runtime
     argv = list(sys.argv[1:] if argv is None else argv)
     if len(argv) < 2:
         raise SystemExit("usage: python -m swapping_autoencoder_pytorch_amd.dropin REFERENCE_ROOT SCRIPT.py [args...]")
@@ -71,7 +198,9 @@ def main(argv=None):
     sys.path.insert(0, ref_root)
     from . import hip_lib
     hip_lib.get()               # fail loudly before anything else if the HIP library is not built
+    install_missing_dependency_stubs()
     preseed()
+    inject_synthetic_dataset()
     _init_distributed()
     import optimizers           # the reference's package (imports its models on the pre-seeded layers)
     _create = optimizers.create_optimizer

@@ -264,8 +264,10 @@ class StyledConv(nn.Module):
         out = self.conv(input, style)
         if self.use_noise:
             z = self.noise.resolve(out, noise)
-            if fusable(out) and z.shape == (out.shape[0], 1) + out.shape[2:]:
-                # noise + bias + leaky-ReLU in one pass (and one backward pass for all three gradients)
+            if fusable(out) and z.shape == (out.shape[0], 1) + out.shape[2:] and not z.requires_grad:
+                # noise + bias + leaky-ReLU in one pass (and one backward pass for all three gradients).  A noise map
+                # that itself asks for a gradient (an optimised / projected `fixed_noise` parameter,
+                # base_network.py:42-51) takes the unfused path below, which differentiates it
                 return noise_bias_act(out, z, self.noise.weight, self.activate.bias, self.activate.negative_slope,
                                       self.activate.scale)
             out = out + self.noise.weight * z

@@ -195,6 +195,32 @@ class SwappingAutoencoderModel(torch.nn.Module):
     def decode(self, spatial_code, global_code):
         return self.G(spatial_code, global_code)
 
+    def get_visuals_for_snapshot(self, real):
+        """:233-243 — reconstruction and swap of a few images for the training snapshot.  The reference paints the
+        structure code with a PCA to three channels (util/util.py:231-253, sklearn); here the layout is the first
+        three principal directions computed with torch.pca_lowrank — same picture up to sign/rotation of the PCA."""
+        if self.opt.isTrain:
+            real = real[:2] if self.opt.num_gpus > 1 else real[:4]
+        sp, gl = self.E(real)
+        rec = self.G(sp, gl)
+        mix = self.G(sp, self.swap(gl))
+        return {"real": real, "layout": self._visualize_spatial_code(sp, real.shape[-2:]), "rec": rec, "mix": mix}
+
+    @staticmethod
+    def _visualize_spatial_code(sp, size):
+        b, c, h, w = sp.shape
+        if c <= 2:
+            img = sp.repeat(1, 3, 1, 1)[:, :3]
+        elif c == 3:
+            img = sp
+        else:
+            flat = sp.detach().permute(0, 2, 3, 1).reshape(-1, c).float().cpu()
+            flat = flat - flat.mean(0, keepdim=True)
+            _, _, v = torch.pca_lowrank(flat, q=3, center=False)
+            z = (flat @ v[:, :3]).reshape(b, h, w, 3).permute(0, 3, 1, 2)
+            img = ((z - z.min()) / (z.max() - z.min() + 1e-12) * 2 - 1).to(sp.device)
+        return torch.nn.functional.interpolate(img, size=tuple(size), mode="bilinear", align_corners=False)
+
     def fix_noise(self, sample_image=None):
         """:245-257"""
         if sample_image is not None:
@@ -220,14 +246,26 @@ class SwappingAutoencoderModel(torch.nn.Module):
         return os.path.join(self.opt.checkpoints_dir, name)
 
     def save(self, total_steps_so_far):
-        savedir = self._ckpt_dir(self.opt.name)
-        os.makedirs(savedir, exist_ok=True)
-        checkpoint_name = "%dk_checkpoint.pth" % (total_steps_so_far // 1000)
-        torch.save(self.state_dict(), os.path.join(savedir, checkpoint_name))
-        sympath = os.path.join(savedir, "latest_checkpoint.pth")
-        if os.path.lexists(sympath):
-            os.remove(sympath)
-        os.symlink(checkpoint_name, sympath)
+        """base_model.py:33-48.  One process per GPU: every rank holds the same weights, so rank 0 alone writes
+        (N ranks racing on the file and on the remove/symlink of latest_checkpoint.pth can tear it); the file is
+        written under a temporary name and renamed, the others wait at a barrier."""
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not multi or dist.get_rank() == 0:
+            savedir = self._ckpt_dir(self.opt.name)
+            os.makedirs(savedir, exist_ok=True)
+            checkpoint_name = "%dk_checkpoint.pth" % (total_steps_so_far // 1000)
+            final = os.path.join(savedir, checkpoint_name)
+            torch.save(self.state_dict(), final + ".tmp")
+            os.replace(final + ".tmp", final)
+            sympath = os.path.join(savedir, "latest_checkpoint.pth")
+            tmplink = sympath + ".tmp"
+            if os.path.lexists(tmplink):
+                os.remove(tmplink)
+            os.symlink(checkpoint_name, tmplink)
+            os.replace(tmplink, sympath)
+        if multi:
+            dist.barrier()
 
     def load(self):
         opt = self.opt

@@ -5,7 +5,9 @@ optimisers (lr 0.002, betas (0, 0.99)), the lazy-regularisation correction c = 1
 discriminator's, D and G steps alternating call by call starting with D, the R1 penalty every
 ``R1_once_every`` discriminator iterations scaled by that interval.
 
-Multi-GPU: one process per GPU; when torch.distributed is initialised the gradients of the group
+Multi-GPU: one process per GPU, each with its own ``opt.batch_size`` images per call (the reference's
+``batch_size`` is the GLOBAL batch that nn.DataParallel scatters; here it is the per-rank batch and the global
+batch is world_size times it); when torch.distributed is initialised the gradients of the group
 being trained are averaged with RCCL all-reduce, bucketed and launched from grad-ready hooks so
 they overlap the rest of backward (grad_allreduce.GradAllReducer) — the MI355X replacement of the
 reference's nn.DataParallel replicate/scatter/gather/reduce (models/__init__.py:75-93)."""
@@ -105,6 +107,12 @@ class SwappingAutoencoderOptimizer:
         d_losses["D_total"] = sum(v.mean() for v in d_losses.values())
         d_losses.update(d_metrics)
         return d_losses
+
+    def get_visuals_for_snapshot(self, data_i):
+        """:113-116"""
+        images = self.prepare_images(data_i)
+        with torch.no_grad():
+            return self.model(images, command="get_visuals_for_snapshot")
 
     def save(self, total_steps_so_far):
         self.model.save(total_steps_so_far)

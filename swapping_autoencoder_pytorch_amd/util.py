@@ -5,9 +5,8 @@ the HIP kernels are the only implementation, there is nothing to gate."""
 import argparse
 
 import torch
-import torch.nn.functional as F
 
-from . import hip_lib, rng
+from . import rng
 from .stylegan2_op import random_crop
 
 
@@ -38,23 +37,13 @@ def apply_random_crop(x, target_size, scale_range, num_crops=1):
     b = x.size(0) * num_crops
     dev = x.device
     flip = torch.round(rng.rand((b, 1, 1, 1), dev)) * 2 - 1.0
-    lib = hip_lib.get()
-    if x.dtype == torch.float32 and (x.is_cuda or not lib.device_only):
-        # same RNG draws in the same order, then the sampler kernel (stylegan2_op.random_crop) instead of
-        # expand + grid + grid_sample.  First-order differentiable, which is all the train step asks of it (the
-        # R1 crops are detached leaves, swapping_autoencoder_model.py:206-207).
-        scale = rng.rand((b, 1, 1, 2), dev) * (scale_range[1] - scale_range[0]) + scale_range[0]
-        offset = (rng.rand((b, 1, 1, 2), dev) * 2 - 1) * (1 - scale)
-        crop = random_crop(x, flip, scale, offset, target_size, num_crops)
-        return crop.view(b // num_crops, num_crops, crop.size(1), crop.size(2), crop.size(3))
-    lin = torch.linspace(-1.0, 1.0, target_size, device=dev)
-    gx = lin.view(1, 1, target_size, 1).expand(b, target_size, target_size, 1)
-    gy = lin.view(1, target_size, 1, 1).expand(b, target_size, target_size, 1)
-    unit_grid = torch.cat([gx * flip, gy], dim=3)
-    x = x.unsqueeze(1).expand(-1, num_crops, -1, -1, -1).flatten(0, 1)
+    # same RNG draws in the same order as the reference, then the sampler kernel (stylegan2_op.random_crop)
+    # instead of expand + grid + F.grid_sample.  First-order differentiable, which is all the train step asks of
+    # it (the R1 crops are detached leaves, swapping_autoencoder_model.py:206-207).  There is no ATen path: a
+    # non-fp32 or non-GPU image is refused by the library binding like everywhere else in the product.
     scale = rng.rand((b, 1, 1, 2), dev) * (scale_range[1] - scale_range[0]) + scale_range[0]
     offset = (rng.rand((b, 1, 1, 2), dev) * 2 - 1) * (1 - scale)
-    crop = F.grid_sample(x, unit_grid * scale + offset, align_corners=False)
+    crop = random_crop(x, flip, scale, offset, target_size, num_crops)
     return crop.view(b // num_crops, num_crops, crop.size(1), crop.size(2), crop.size(3))
 
 

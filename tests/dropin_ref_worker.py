@@ -1,0 +1,102 @@
+"""Subprocess bodies of tests/test_dropin_train.py (kept out of the pytest process so the reference's packages
+never leak into other tests).  Both run the reference's UNMODIFIED code from /root/reference on top of
+dropin's pre-seeded modules, with the CPU oracle bound behind the C-ABI (test-only back end: the product
+itself refuses CPU tensors)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+REF = "/root/reference"
+
+MICRO_ARGV = ["--dataset_mode", "synthetic", "--num_gpus", "0", "--batch_size", "4", "--crop_size", "32", "--load_size", "32",
+              "--netE_num_downsampling_sp", "2", "--patch_size", "32", "--patch_num_crops", "2", "--global_code_ch", "64",
+              "--netE_scale_capacity", "0.25", "--netG_scale_capacity", "0.125", "--netD_scale_capacity", "0.03125",
+              "--netPatchD_scale_capacity", "0.5", "--netPatchD_max_nc", "32", "--R1_once_every", "2", "--dataroot", "."]
+
+
+def _prepare():
+    import torch
+    from swapping_autoencoder_pytorch_amd import dropin, hip_lib
+    from swapping_autoencoder_pytorch_amd.hip_lib import SaeLibrary
+    hip_lib._LIB = SaeLibrary(os.path.join(ROOT, "oracle", "libsae_oracle.so"), prefix="oracle_", device_only=False)
+    sys.path.insert(0, REF)
+    dropin.install_missing_dependency_stubs()
+    dropin.preseed()
+    dropin.inject_synthetic_dataset()
+    torch.cuda.synchronize = lambda *a, **k: None      # util/iter_counter.py calls it unconditionally; no GPU here
+    return dropin
+
+
+def train_end_to_end(ckpt_dir):
+    """python train.py ... : option parser, data loader, model, optimizer, loss log, checkpoint."""
+    import runpy
+    _prepare()
+    sys.argv = ["train.py", "--name", "dropin_e2e", "--total_nimgs", "24", "--checkpoints_dir", ckpt_dir, "--print_freq", "8",
+                "--display_freq", "100000", "--save_freq", "100000", "--evaluation_freq", "100000"] + MICRO_ARGV
+    runpy.run_path(os.path.join(REF, "train.py"), run_name="__main__")
+
+
+def _ddp_rank(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dropin = _prepare()
+    import models
+    import optimizers
+    from options import TrainOptions
+    from param_recipe import fill_params, uniform_images
+    sys.argv = ["train.py", "--name", "dropin_ddp", "--checkpoints_dir", out_dir] + MICRO_ARGV
+    opt = TrainOptions().parse(save=False) if "save" in TrainOptions.parse.__code__.co_varnames else TrainOptions().parse()
+    model = models.create_model(opt)
+    fill_params(model.singlegpu_model, seed=10 + rank)            # deliberately different replicas
+    optimizer = dropin.attach_gradient_allreduce(optimizers.create_optimizer(opt, model))
+    state0 = {k: v.clone() for k, v in model.singlegpu_model.state_dict().items()}
+    for it in range(4):                                            # D, G, D (+R1), G with DIFFERENT data per rank
+        torch.manual_seed(500 + 10 * it + rank)
+        optimizer.train_one_step({"real_A": uniform_images(4, 32, 900 + 10 * it + rank)}, it)
+    optimizer.save(0)
+    torch.save({"start": state0, "end": model.singlegpu_model.state_dict()}, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def ddp(out_dir, port):
+    import torch.multiprocessing as mp
+    mp.spawn(_ddp_rank, args=(2, int(port), out_dir), nprocs=2, join=True)
+
+
+
+
+def aten_cpu_path_pin():
+    """oracle/aten_cpu_path.py against the reference's own Discriminator on its CPU path (unmodified modules)."""
+    import torch
+    import ref_shims
+    ref_shims.install()                                  # fake torch.version.cuda: the reference takes its native path
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import aten_cpu_path as A
+    from models.networks.stylegan2_layers import Discriminator
+    torch.manual_seed(0)
+    ref = Discriminator(64, 2)
+    mine = A.DiscriminatorCPU(64, 2)
+    rp, mp_ = list(ref.parameters()), list(mine.parameters())
+    assert len(rp) == len(mp_), (len(rp), len(mp_))
+    with torch.no_grad():
+        for a, b in zip(rp, mp_):
+            assert a.shape == b.shape, (a.shape, b.shape)
+            a.copy_(torch.randn(a.shape) * (1.0 if a.dim() > 1 else 0.1))
+            b.copy_(a)
+    x = torch.rand(3, 3, 64, 64) * 2 - 1
+    yr, ym = ref(x), mine(x)
+    err = float((yr - ym).abs().max() / yr.abs().max())
+    assert err < 1e-5, err
+    gr = torch.autograd.grad(yr.sum(), rp)
+    gm = torch.autograd.grad(ym.sum(), mp_)
+    for a, b in zip(gr, gm):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max() + 1e-12)
+    print("aten-cpu-path-pinned", err)
+
+
+if __name__ == "__main__":
+    {"train": train_end_to_end, "ddp": ddp, "aten_pin": aten_cpu_path_pin}[sys.argv[1]](*sys.argv[2:])

@@ -1,0 +1,165 @@
+"""Per-kernel-class roofline table of the train step, measured live.
+
+Every C-ABI call of `--steps` timed iterations is bracketed with HIP events on the launch stream and its
+ALGORITHMIC work is computed from its own arguments (convs / linears 2*MAC FLOPs; K1
+4*(numel_in + numel_out) bytes; K2 8*numel forward, 12*numel backward; other elementwise ops their tensors once).
+Rows are grouped by kernel class (entry point x kernel size x stride, i.e. the kernel template the dispatcher
+picks), with the time, work and achieved rate per iteration and the fraction of the bound's peak
+(fp32 MFMA 157.3 TFLOP/s, HBM 8 TB/s).  "outside the C-ABI" = wall time of the iteration minus the bracketed
+time: ATen glue, Adam, allocator, launch gaps.
+
+    python tools/roofline_ledger.py --preset church256 [--conv-math f32] > profiles/r2_roofline_by_kernel_church256.txt
+"""
+import argparse
+import collections
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from swapping_autoencoder_pytorch_amd import hip_lib  # noqa: E402
+
+MFMA_PEAK, HBM_PEAK = 157.3e12, 8.0e12
+
+
+def _desc(arg):
+    return arg._obj
+
+
+def work_of(name, a):
+    """(class label, bound, algorithmic work: FLOPs for 'mfma', bytes for 'hbm')"""
+    if name.startswith("conv2d_") and name != "conv2d_workspace":
+        d = _desc(a[4] if name == "conv2d_fwd_bias_act_f32" else a[3])
+        op = {"conv2d_fwd_f32": "fwd", "conv2d_fwd_bias_act_f32": "fwd+bias+lrelu", "conv2d_dgrad_f32": "dgrad",
+              "conv2d_wgrad_f32": "wgrad"}[name]
+        width = "narrow(<=64ch)" if max(d.m if op.startswith("fwd") else d.c, 1) <= 64 else "wide"
+        if op == "wgrad":
+            width = "narrow(<=32ch)" if (d.m <= 32 and d.c <= 32) else "wide"
+        label = "conv %dx%d s%d %-14s %s" % (d.kh, d.kw, d.stride, op, width)
+        return label, "mfma", 2.0 * d.n * d.m * d.oh * d.ow * d.c * d.kh * d.kw
+    if name == "gemm_f32":
+        m, n, k = a[4], a[5], a[6]
+        return "gemm (linear layers)", "mfma", 2.0 * m * n * k
+    if name == "upfirdn2d_f32":
+        major, ih, iw, minor, kh, kw, ux, uy, dx, dy, px0, px1, py0, py1 = a[3:17]
+        oh = (ih * uy + py0 + py1 - kh + dy) // dy
+        ow = (iw * ux + px0 + px1 - kw + dx) // dx
+        kind = "blur" if (ux == 1 and dx == 1) else ("decimate x2" if dx == 2 else "zero-insert x2")
+        return "upfirdn2d %s %dx%d taps" % (kind, kh, kw), "hbm", 4.0 * major * minor * (ih * iw + oh * ow)
+    if name == "bias_act_f32":
+        return "bias_act forward", "hbm", 8.0 * a[4] + (4.0 * a[4] if a[2] else 0.0)
+    if name == "bias_act_bwd_f32":
+        return "bias_act backward (+grad_bias)", "hbm", 12.0 * a[6]
+    if name == "noise_bias_act_f32":
+        return "noise+bias+lrelu forward", "hbm", 4.0 * a[5] * a[7] * (2 * a[6] + 1)
+    if name == "noise_bias_act_bwd_f32":
+        return "noise+bias+lrelu backward", "hbm", 4.0 * a[8] * a[10] * (3 * a[9] + 1)
+    if name == "plane_scale_dot_f32":
+        return "style modulation backward", "hbm", 12.0 * a[5] * a[6]
+    if name == "add_scale_f32":
+        return "residual merge (a+b)/sqrt2", "hbm", 12.0 * a[3]
+    if name == "upsample2x_bilinear_add_f32":
+        return "upsample x2 + residual", "hbm", 4.0 * a[3] * a[4] * a[5] * (1 + 4 + (4 if a[1] else 0))
+    if name == "upsample2x_bilinear_bwd_f32":
+        return "upsample x2 backward", "hbm", 4.0 * a[2] * a[3] * a[4] * 5
+    if name in ("random_crop_f32", "random_crop_bwd_f32"):
+        images, ch, h, w, crops, size = a[4:10]
+        return name[:-4], "hbm", 4.0 * ch * (images * h * w + images * crops * size * size)
+    if name in ("reflect_pad_f32", "reflect_pad_adj_f32"):
+        planes, h, w, l, r, t, b = a[2:9]
+        return name[:-4], "hbm", 4.0 * planes * (h * w + (h + t + b) * (w + l + r))
+    return name, "hbm", 0.0
+
+
+class Ledger:
+    def __init__(self, lib):
+        self.lib, self.records, self.active = lib, [], False
+        orig = lib.call
+
+        def call(name, *args):
+            if not self.active or name in ("set_conv_math",):
+                return orig(name, *args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(name, *args)
+            e1.record()
+            self.records.append((work_of(name, args), e0, e1))
+
+        lib.call = call
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--preset", default="church256")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--conv-math", default="f32")
+    ap.add_argument("--with-r1", action="store_true", help="place the lazy-R1 iteration inside the window")
+    args = ap.parse_args()
+    sys.path.insert(0, ROOT)
+    import bench
+    from swapping_autoencoder_pytorch_amd.options import make_options
+    from swapping_autoencoder_pytorch_amd.swapping_autoencoder_model import create_model
+    from swapping_autoencoder_pytorch_amd.swapping_autoencoder_optimizer import create_optimizer
+    lib = hip_lib.get()
+    hip_lib.set_conv_math(args.conv_math)
+    ledger = Ledger(lib)
+    batch = args.batch or bench.DEFAULT_BATCH[args.preset]
+    opt = make_options(args.preset, batch_size=batch, num_gpus=1)
+    torch.manual_seed(0)
+    model = create_model(opt)
+    optimizer = create_optimizer(opt, model)
+    if args.with_r1:
+        optimizer.discriminator_iter_counter = opt.R1_once_every - args.warmup - 1
+    size = opt.crop_size
+    pool = [torch.rand(batch, 3, size, size, device="cuda") * 2 - 1 for _ in range(4)]
+    for i in range(args.warmup):
+        optimizer.train_one_step({"real_A": pool[(2 * i) % 4]}, i)
+        optimizer.train_one_step({"real_A": pool[(2 * i + 1) % 4]}, i)
+    torch.cuda.synchronize()
+    ledger.active = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        optimizer.train_one_step({"real_A": pool[(2 * i) % 4]}, i)
+        optimizer.train_one_step({"real_A": pool[(2 * i + 1) % 4]}, i)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3 / args.steps
+    ledger.active = False
+
+    rows = collections.OrderedDict()
+    for (label, bound, work), e0, e1 in ledger.records:
+        r = rows.setdefault(label, [bound, 0, 0.0, 0.0])
+        r[1] += 1
+        r[2] += work
+        r[3] += e0.elapsed_time(e1)
+    k = args.steps
+    print("# per-kernel-class roofline, %s preset, %dx%d, B=%d, conv math %s, %d timed iterations%s (event-bracketed C-ABI calls)"
+          % (args.preset, size, size, batch, args.conv_math, k, " incl. one lazy-R1 call" if args.with_r1 else ", no R1 call"))
+    print("# bound peaks: fp32 MFMA 157.3 TFLOP/s, HBM 8.0 TB/s (spec; ~6.3 achievable).  Work is ALGORITHMIC (SURVEY 8d).")
+    print("%-52s %5s %8s %12s %10s %9s %6s" % ("kernel class", "bound", "calls/it", "work/it", "ms/it", "achieved", "frac"))
+    tot_ms = tot_fl = tot_by = 0.0
+    for label, (bound, calls, work, ms) in sorted(rows.items(), key=lambda kv: -kv[1][3]):
+        rate = work / (ms * 1e-3) if ms > 0 else 0.0
+        if bound == "mfma":
+            ws, rs, frac = "%9.1f GF" % (work / k / 1e9), "%6.1f TF/s" % (rate / 1e12), rate / MFMA_PEAK
+            tot_fl += work
+        else:
+            ws, rs, frac = "%9.2f GB" % (work / k / 1e9), "%6.2f TB/s" % (rate / 1e12), rate / HBM_PEAK
+            tot_by += work
+        tot_ms += ms
+        print("%-52s %5s %8.1f %12s %10.3f %9s %6.3f" % (label, bound, calls / k, ws, ms / k, rs, frac))
+    print("%-52s %5s %8s %12s %10.3f" % ("sum of bracketed C-ABI calls", "", "", "", tot_ms / k))
+    print("%-52s %5s %8s %12s %10.3f" % ("outside the C-ABI (ATen glue, Adam, gaps)", "", "", "", wall - tot_ms / k))
+    print("%-52s %5s %8s %12s %10.3f   -> %.2f images/s" % ("wall per iteration", "", "", "", wall, batch / wall * 1e3))
+    print("# totals per iteration: %.2f TFLOP on the matrix cores (%.1f TF/s over the whole wall time = %.3f of peak), "
+          "%.1f GB algorithmic through the HBM-bound kernels" % (tot_fl / k / 1e12, tot_fl / k / wall / 1e9,
+                                                                 tot_fl / k / wall / 1e9 / 157.3e3 * 1e3, tot_by / k / 1e9))
+
+
+if __name__ == "__main__":
+    main()
