@@ -135,10 +135,9 @@ def cpu_baseline(preset, size, batch):
     cores = os.cpu_count() or 1
     per_image = FLOPS_PER_IMAGE.get(preset, 1.815e12)
 
-    torch.set_num_threads(cores)
     torch.manual_seed(0)
     disc = A.DiscriminatorCPU(size, 2)
-    n = min(batch, 8)                         # bounded: half a batch of the church preset is ~2.2 TFLOP of conv work
+    n = 2                                      # bounded sample: 2 images of the church preset = 0.56 TFLOP of conv work
     x = torch.rand(n, 3, size, size) * 2 - 1
     flops = disc.train_flops(n, size)
 
@@ -147,13 +146,26 @@ def cpu_baseline(preset, size, batch):
             p.grad = None
         torch.nn.functional.softplus(-disc(x)).mean().backward()
 
-    one_pass()                                 # MKLDNN primitive creation, thread pool start-up
-    t0 = time.time()
-    one_pass()
-    dt = time.time() - t0
-    out = {"value": round(flops / dt / per_image, 5), "unit": "images/s", "cores": cores, "kind": "port",
+    # ATen's CPU kernels do not scale to every hardware thread of a large host (256 threads measured 4x SLOWER than
+    # 8 on this workload): sweep a few thread counts inside a ~30 s budget and report the best one, with the thread
+    # count actually used in `cores`
+    candidates = sorted({max(8, min(cores, t)) for t in (cores // 8, cores // 4, cores // 2)})
+    best, sweep, t_begin = None, [], time.time()
+    for threads in candidates:
+        torch.set_num_threads(threads)
+        one_pass()                             # MKLDNN primitive creation, thread pool start-up
+        t0 = time.time()
+        one_pass()
+        dt = time.time() - t0
+        sweep.append({"threads": threads, "s": round(dt, 2)})
+        if best is None or dt < best[1]:
+            best = (threads, dt)
+        if time.time() - t_begin > 30.0:
+            break
+    threads, dt = best
+    out = {"value": round(flops / dt / per_image, 5), "unit": "images/s", "cores": threads, "host_cores": cores, "kind": "port",
            "port_of": "aten-cpu restatement of the reference's CPU path (oracle/aten_cpu_path.py: F.conv2d + autograd, "
-                      "upfirdn2d_native, F.leaky_relu; torch.set_num_threads(%d))" % cores,
+                      "upfirdn2d_native, F.leaky_relu; torch.set_num_threads(%d), best of %s)" % (threads, sweep),
            "sample": "image discriminator forward + backward, %d images %dx%d: %.2f TFLOP of conv work in %.2f s = %.2f "
                      "TFLOP/s, scaled by %.3f TFLOP/image of the full iteration" % (n, size, size, flops / 1e12, dt,
                                                                                   flops / dt / 1e12, per_image / 1e12)}

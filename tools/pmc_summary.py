@@ -26,13 +26,15 @@ def main(dirs):
                     dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     for k, cs in agg.items():
         m = {c: sum(v) / len(v) for c, v in cs.items()}
-        if m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) == 0 and "blur" not in k[0]:
+        if m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) == 0 and not any(t in k[0] for t in ("blur", "elementwise", "copy", "reduce")):
             continue
         us = sum(dur[k]) / len(dur[k]) / 1e3 if dur[k] else 0.0
         gui = m.get("GRBM_GUI_ACTIVE", 0.0)
         line = "%-58s grid=%-9s avg_us=%8.1f" % (k[0], k[1], us)
         if gui and us:
             line += "  clock~%.2fGHz  mfma_util=%.3f" % (gui / 8 / us / 1e3, m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * gui / 8))
+        if "FETCH_SIZE" in m or "WRITE_SIZE" in m:      # reported in KiB
+            line += "  FETCH=%.1f MB (as reported)  WRITE=%.1f MB" % (m.get("FETCH_SIZE", 0) * 1024 / 1e6, m.get("WRITE_SIZE", 0) * 1024 / 1e6)
         print(line)
         print("   " + "  ".join("%s=%.4g" % (c, v) for c, v in sorted(m.items())))
 
