@@ -22,6 +22,7 @@
  *   sae_gemm_f32             <- F.linear and its backward       models/networks/stylegan2_layers.py:177,186
  *   sae_upsample2x_bilinear_{add,bwd}_f32
  *                            <- F.interpolate(bilinear x2) + residual   models/networks/generator.py:51-53
+ *   sae_adam_multi_f32       <- torch.optim.Adam(...).step()            optimizers/swapping_autoencoder_optimizer.py:34-42,77,95,107
  *
  * Conventions (what the reference's pybind layer did implicitly is explicit here):
  *   - plain pointers and sizes only, no torch types; all tensors are dense fp32 in device memory
@@ -219,6 +220,24 @@ int sae_upsample2x_bilinear_bwd_f32(const float* gy, float* gx, int64_t planes, 
 /* Residual merge y = alpha * (a + b): the (out + skip) / sqrt(2) of ResBlock (stylegan2_layers.py:689)
  * and of the generator's resolution-preserving block (generator.py:36) as one elementwise pass. */
 int sae_add_scale_f32(const float* a, const float* b, float* y, int64_t numel, float alpha, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-tensor Adam step: the update torch.optim.Adam applies to every parameter of a group
+ * (optimizers/swapping_autoencoder_optimizer.py:34-42 construct the two instances; :77,:95,:107 step them),
+ * for `count` tensors in a handful of launches instead of four elementwise launches per tensor:
+ *     g = grads[i] * grad_scale
+ *     m = m + (g - m) * (1 - beta1)            v = v * beta2 + ((1 - beta2) * g) * g
+ *     p = p - lr / (1 - beta1^step[i]) * m / (sqrt(v) / sqrt(1 - beta2^step[i]) + eps)
+ * (amsgrad = False, weight_decay = 0, maximize = False: the configuration the reference uses).
+ * params / grads / exp_avg / exp_avg_sq / numel / step are HOST arrays of `count` entries; the pointers they hold
+ * are device pointers.  step[i] is the 1-based update count of tensor i AFTER this update (torch keeps it per
+ * parameter: a parameter that received no gradient is skipped and its count does not advance).  grad_scale folds
+ * the 1 / world_size of the gradient all-reduce into the update, so grads may point straight into the all-reduced
+ * flat buckets.
+ * ------------------------------------------------------------------------------------------ */
+int sae_adam_multi_f32(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                       const int64_t* numel, const int64_t* step, int64_t count, double lr, double beta1, double beta2,
+                       double eps, double grad_scale, sae_stream_t stream);
 
 #ifdef __cplusplus
 }

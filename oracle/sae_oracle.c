@@ -612,3 +612,35 @@ int oracle_reflect_pad_adj_f32(const float* gy, float* gx, int64_t planes, int64
     free(acc);
     return 0;
 }
+
+/* ---- Adam (include/sae_hip.h: sae_adam_multi_f32).  The reference steps two torch.optim.Adam instances
+ * (optimizers/swapping_autoencoder_optimizer.py:34-42,77,95,107); PyTorch is an un-vendored dependency, so what is
+ * restated is the published update of torch.optim.Adam (amsgrad = False, weight_decay = 0), evaluated in double;
+ * tests/test_adam.py pins this function to torch.optim.Adam itself. */
+int oracle_adam_multi_f32(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                          const int64_t* numel, const int64_t* step, int64_t count, double lr, double beta1, double beta2,
+                          double eps, double grad_scale, sae_stream_t stream) {
+    (void)stream;
+    if (count < 0 || (count > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !step)))
+        return set_err("oracle_adam_multi_f32: null table");
+    if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0))
+        return set_err("oracle_adam_multi_f32: betas must be in [0, 1), eps >= 0");
+    for (int64_t t = 0; t < count; ++t) {
+        if (numel[t] < 0 || step[t] < 1) return set_err("oracle_adam_multi_f32: numel < 0 or step < 1");
+        if (numel[t] > 0 && (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t]))
+            return set_err("oracle_adam_multi_f32: null pointer");
+        const double bc1 = 1.0 - pow((double)beta1, (double)step[t]);
+        const double bc2 = 1.0 - pow((double)beta2, (double)step[t]);
+        const double step_size = (double)lr / bc1, bc2_sqrt = sqrt(bc2);
+        for (int64_t i = 0; i < numel[t]; ++i) {
+            const double g = (double)grads[t][i] * (double)grad_scale;
+            const double m = (double)exp_avg[t][i] + (g - (double)exp_avg[t][i]) * (1.0 - (double)beta1);
+            const double v = (double)exp_avg_sq[t][i] * (double)beta2 + (1.0 - (double)beta2) * g * g;
+            const double denom = sqrt(v) / bc2_sqrt + (double)eps;
+            params[t][i] = (float)((double)params[t][i] - step_size * (m / denom));
+            exp_avg[t][i] = (float)m;
+            exp_avg_sq[t][i] = (float)v;
+        }
+    }
+    return SAE_OK;
+}

@@ -16,7 +16,9 @@ Besides the pre-seeding the runner
   * stands in for the reference's third-party imports that are absent from a bare PyTorch-ROCm image and never
     executed on the training path (``install_missing_dependency_stubs``: torchvision, dominate, visdom, ...),
   * offers ``--dataset_mode synthetic``: ``data.synthetic_dataset.SyntheticDataset`` (uniform [-1, 1] images of
-    ``--crop_size``, the data contract of data/base_dataset.py:136-141) so the loop runs without a dataset on disk.
+    ``--crop_size``, the data contract of data/base_dataset.py:136-141) so the loop runs without a dataset on disk,
+  * substitutes fused_adam.FusedAdam for ``torch.optim.Adam`` inside this process (same constructor, update rule and
+    state_dict; ``SAE_DROPIN_ADAM=0`` keeps ATen's).
 
 Multi-GPU: the reference drives ``nn.DataParallel`` from one process (models/__init__.py:80) and addresses its
 device as the literal ``'cuda:0'`` (models/__init__.py:79, base_model.py:13, swapping_autoencoder_model.py:48).
@@ -201,6 +203,12 @@ def main(argv=None):
     install_missing_dependency_stubs()
     preseed()
     inject_synthetic_dataset()
+    if os.environ.get("SAE_DROPIN_ADAM", "1") != "0":
+        # the reference constructs torch.optim.Adam(params, lr=, betas=) (optimizers/swapping_autoencoder_optimizer.py:
+        # 34-42): the same constructor, update and state_dict on the multi-tensor HIP kernel
+        import torch
+        from .fused_adam import FusedAdam
+        torch.optim.Adam = FusedAdam
     _init_distributed()
     import optimizers           # the reference's package (imports its models on the pre-seeded layers)
     _create = optimizers.create_optimizer

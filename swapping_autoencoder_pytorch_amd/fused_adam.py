@@ -1,0 +1,74 @@
+"""Adam on the multi-tensor HIP kernel (csrc/adam.hip, C-ABI ``sae_adam_multi_f32``).
+
+Stands where the reference constructs ``torch.optim.Adam(params, lr=..., betas=(beta1, beta2))``
+(optimizers/swapping_autoencoder_optimizer.py:34-42) and steps it (:77,:95,:107): same constructor arguments,
+same ``state_dict`` layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter, so optimiser checkpoints move
+between the two), same update.  One call to ``step`` issues a handful of launches for the whole parameter list
+(226 tensors per group at the church preset) instead of ATen's per-tensor elementwise chains.
+
+``step(grad_views=..., grad_scale=...)`` lets the gradient all-reduce hand over its flat buckets directly: the
+kernel reads the summed gradients where RCCL left them and applies the 1 / world_size itself, which removes the
+scale and scatter-back passes of ``GradAllReducer.finish`` (grad_allreduce.py)."""
+import ctypes as C
+
+import torch
+
+from . import hip_lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise hip_lib.SaeError("FusedAdam covers the reference's configuration: weight_decay = 0, amsgrad = False")
+        if not 0.0 <= lr or not 0.0 <= eps or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid Adam hyper-parameters lr=%r betas=%r eps=%r" % (lr, betas, eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0)                       # host scalar, as torch.optim.Adam keeps it
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_views=None, grad_scale=1.0, only=None):
+        """grad_views: optional {parameter: flat fp32 tensor holding its gradient} (e.g. slices of all-reduced
+        buckets); parameters absent from it use ``p.grad``.  only: optional container of parameters to restrict this
+        call to (one bucket at a time).  Parameters without a gradient are skipped, as in torch.optim.Adam."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = hip_lib.get()
+        for group in self.param_groups:
+            ps, gs, ms, vs, ns, steps, keep = [], [], [], [], [], [], []
+            for p in group["params"]:
+                if only is not None and p not in only:
+                    continue
+                g = grad_views.get(p) if grad_views is not None else None
+                if g is None:
+                    g = p.grad
+                if g is None:
+                    continue
+                if g.is_sparse:
+                    raise hip_lib.SaeError("FusedAdam does not support sparse gradients")
+                if not p.is_contiguous():
+                    raise hip_lib.SaeError("FusedAdam needs contiguous parameters")
+                g = g.contiguous()
+                st = self._state_of(p)
+                st["step"] += 1
+                lib.check(p, g, st["exp_avg"], st["exp_avg_sq"])
+                ps.append(p.data_ptr()); gs.append(g.data_ptr()); ms.append(st["exp_avg"].data_ptr())
+                vs.append(st["exp_avg_sq"].data_ptr()); ns.append(p.numel()); steps.append(int(st["step"].item()))
+                keep.append(g)
+            if not ps:
+                continue
+            n = len(ps)
+            arr_p, arr_g, arr_m, arr_v = ((C.c_void_p * n)(*x) for x in (ps, gs, ms, vs))
+            arr_n, arr_s = (C.c_int64 * n)(*ns), (C.c_int64 * n)(*steps)
+            beta1, beta2 = group["betas"]
+            lib.call("adam_multi_f32", arr_p, arr_g, arr_m, arr_v, arr_n, arr_s, n, float(group["lr"]), float(beta1),
+                     float(beta2), float(group["eps"]), float(grad_scale), lib.stream(group["params"][0]))
+        return loss

@@ -13,9 +13,10 @@ replicate / scatter / gather / reduce_add through GPU 0 on every call).  Design 
   of a step fly while the early layers' wgrad kernels still run.  xGMI is point-to-point
   (7 links x ~153 GB/s): a handful of large buckets keeps every ring step bandwidth- rather
   than latency-bound;
-* ``finish()`` waits, scales by 1/world and scatters the averaged values back into ``.grad``.
-  Parameters that received no gradient in this pass (e.g. R1 touches every D parameter but a
-  frozen branch might not) contribute zeros, keeping the collective shape identical on all ranks.
+* ``finish()`` waits, scales by 1/world and scatters the averaged values back into ``.grad``;
+  ``finish_into(optimizer)`` instead hands every completed bucket to the multi-tensor Adam kernel, which reads
+  the summed gradients in place (fused_adam.FusedAdam).  Parameters that received no gradient in this pass
+  contribute zeros to the collective (its shape stays identical on all ranks) and are skipped by the update.
 
 With world_size == 1 (or torch.distributed not initialised) every method is a no-op."""
 import os
@@ -87,26 +88,47 @@ class GradAllReducer:
         if b.pending == 0:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+    def _launch_stragglers(self):
+        """Buckets whose last gradient never arrived (some parameter got no gradient in this pass) still take part
+        in the collective, with zeros in the missing slots, so its shape is identical on every rank."""
+        for b in self.buckets:
+            if b.work is None:
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     # called after loss.backward(), before optimizer.step()
     def finish(self):
+        """Wait for the buckets and scatter the averaged gradients back into ``.grad``.  A parameter that received
+        no gradient in this pass keeps ``grad = None`` (every rank runs the same graph, so it has none on any
+        rank) and the optimizer skips it exactly as it does on one GPU."""
         if not self.enabled or not self.armed:
             return
         self.armed = False
         inv = 1.0 / self.world
-        for b in self.buckets:
-            if b.work is None:      # some parameter of the bucket got no gradient in this pass
-                for p, off in zip(b.params, b.offsets):
-                    if p.grad is not None and b.pending > 0:
-                        b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._launch_stragglers()
         for b in self.buckets:
             b.work.wait()
             b.flat.mul_(inv)
             for p, off in zip(b.params, b.offsets):
                 if p.grad is not None:
                     p.grad.copy_(b.flat[off:off + p.numel()].view_as(p.grad))
-                elif p.requires_grad:
-                    p.grad = b.flat[off:off + p.numel()].view_as(p).clone()
+            b.work = None
+
+    def finish_into(self, optimizer):
+        """finish() and optimizer.step() in one: as each bucket's all-reduce completes, the multi-tensor Adam kernel
+        (fused_adam.FusedAdam) updates that bucket's parameters reading the SUMMED gradients straight from the flat
+        bucket and applying 1 / world itself — no scale pass, no scatter back into ``.grad``, and the update of the
+        early buckets overlaps the collectives of the late ones.  ``.grad`` keeps the local (un-reduced) values."""
+        if not self.enabled or not self.armed:
+            optimizer.step()
+            return
+        self.armed = False
+        inv = 1.0 / self.world
+        self._launch_stragglers()
+        for b in self.buckets:
+            b.work.wait()
+            views = {p: b.flat[off:off + p.numel()] for p, off in zip(b.params, b.offsets) if p.grad is not None}
+            if views:
+                optimizer.step(grad_views=views, grad_scale=inv, only=views)
             b.work = None
 
 

@@ -14,6 +14,7 @@ reference's nn.DataParallel replicate/scatter/gather/reduce (models/__init__.py:
 import torch
 
 from . import util
+from .fused_adam import FusedAdam
 from .grad_allreduce import GradAllReducer
 
 
@@ -34,12 +35,14 @@ class SwappingAutoencoderOptimizer:
         self.discriminator_iter_counter = 0
         self.Gparams = model.get_parameters_for_mode("generator")
         self.Dparams = model.get_parameters_for_mode("discriminator")
+        # the multi-tensor HIP Adam (fused_adam.FusedAdam) wherever the parameters live on a GPU; torch.optim.Adam
+        # (what the reference constructs, :34-42) otherwise, i.e. in the CPU test-suite on the oracle back end
         on_gpu = len(self.Gparams) > 0 and self.Gparams[0].is_cuda
-        adam_kw = {"fused": True} if (fused_adam if fused_adam is not None else on_gpu) else {}
-        self.optimizer_G = torch.optim.Adam(self.Gparams, lr=opt.lr, betas=(opt.beta1, opt.beta2), **adam_kw)
+        Adam = FusedAdam if (fused_adam if fused_adam is not None else on_gpu) else torch.optim.Adam
+        self.optimizer_G = Adam(self.Gparams, lr=opt.lr, betas=(opt.beta1, opt.beta2))
         # StyleGAN2 appendix B: compensate for regularising only every k-th iteration (:36-42)
         c = opt.R1_once_every / (1 + opt.R1_once_every)
-        self.optimizer_D = torch.optim.Adam(self.Dparams, lr=opt.lr * c, betas=(opt.beta1 ** c, opt.beta2 ** c), **adam_kw)
+        self.optimizer_D = Adam(self.Dparams, lr=opt.lr * c, betas=(opt.beta1 ** c, opt.beta2 ** c))
         # one reducer per parameter group: the trainable set flips every call
         self.reducer_G = GradAllReducer(self.Gparams)
         self.reducer_D = GradAllReducer(self.Dparams)
@@ -68,8 +71,11 @@ class SwappingAutoencoderOptimizer:
     def _backward_and_step(self, total_loss, optimizer, reducer):
         reducer.arm()
         total_loss.backward()
-        reducer.finish()          # waits for the in-flight buckets, grads now hold the global mean
-        optimizer.step()
+        if isinstance(optimizer, FusedAdam):
+            reducer.finish_into(optimizer)   # per-bucket: wait for its all-reduce, Adam reads the bucket in place
+        else:
+            reducer.finish()                 # waits for the in-flight buckets, grads now hold the global mean
+            optimizer.step()
 
     def train_generator_one_step(self, images):
         """:67-79"""

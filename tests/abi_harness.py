@@ -198,3 +198,25 @@ def reflect_pad_adj(lib, gy, pads, device=None):
 
 def rel_err(a, b):
     return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(float(np.abs(b).max()), 1e-30))
+
+
+def adam_multi(lib, params, grads, ms, vs, steps, lr, beta1, beta2, eps, grad_scale=1.0, device=None, offset_elems=0):
+    """Runs sae_adam_multi_f32 on lists of 1-D numpy arrays; returns updated (params, ms, vs).  offset_elems > 0
+    places every tensor that many floats into its buffer (pointers not 16-byte aligned)."""
+    n = len(params)
+
+    def stage(arrs):
+        bufs = [_Buf(np.concatenate([np.zeros(offset_elems, np.float32), a]), device) for a in arrs]
+        return bufs, [b.ptr + 4 * offset_elems for b in bufs]
+
+    bp, pp = stage(params)
+    bg, pg = stage(grads)
+    bm, pm = stage(ms)
+    bv, pv = stage(vs)
+    arr = lambda xs: (C.c_void_p * n)(*xs)
+    numel = (C.c_int64 * n)(*[a.size for a in params])
+    st = (C.c_int64 * n)(*steps)
+    lib.call("adam_multi_f32", arr(pp), arr(pg), arr(pm), arr(pv), numel, st, n, lr, beta1, beta2, eps, grad_scale,
+             _stream(device))
+    cut = lambda bufs: [b.numpy()[offset_elems:] for b in bufs]
+    return cut(bp), cut(bm), cut(bv)

@@ -40,7 +40,10 @@ def test_micro_networks_forward():
 
 
 def test_micro_training_steps():
-    P.check_micro_steps(DEV, post_update_tol=5e-3)
+    # measured on the MI355X (profiles/r2_step_parity.json): the largest relative loss deviation over the four steps
+    # is 1.1e-7 with the exact-fp32 kernels and 9.1e-7 with bf16x6 (gradient norms 2.9e-6 / 4.4e-6), the same as the
+    # CPU back ends and as the oracle under 1e-6 input noise — the 5e-3 allowance of round 1 was never needed
+    P.check_micro_steps(DEV, loss_tol=5e-6, grad_tol=2e-5)
 
 
 def test_cpu_tensor_is_refused():

@@ -44,7 +44,8 @@ def main(where):
             out["gpu_" + mode] = slim(P.measure_micro_steps("cuda:0"))
             full = P.measure_micro_steps("cuda:0")
             out["gpu_" + mode + "_loss_dev_by_key"] = [r["loss_dev"] for r in full["steps"]]
-        out["gpu_f32_unfused_adam"] = slim(P.measure_micro_steps("cuda:0", fused_adam=False))
+        hip_lib.set_conv_math("f32")
+        out["gpu_f32_torch_adam"] = slim(P.measure_micro_steps("cuda:0", fused_adam=False))
         hip_lib.set_conv_math("f32")
     print(json.dumps(out, indent=1))
 
