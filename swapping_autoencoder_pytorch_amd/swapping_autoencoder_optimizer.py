@@ -121,8 +121,51 @@ class SwappingAutoencoderOptimizer:
             return self.model(images, command="get_visuals_for_snapshot")
 
     def save(self, total_steps_so_far):
+        """:118-119 saves the model; the reference never stores the optimiser, so a resumed run restarts Adam's second
+        moments from zero.  Here the two Adam states and the driver's counters are written next to the weights
+        (``<N>k_optimizer.pth`` + ``latest_optimizer.pth``, rank 0 only, atomic rename) and picked up by ``load``."""
+        import os
+        import torch.distributed as dist
         self.model.save(total_steps_so_far)
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not multi or dist.get_rank() == 0:
+            savedir = os.path.join(self.opt.checkpoints_dir, self.opt.name)
+            os.makedirs(savedir, exist_ok=True)
+            name = "%dk_optimizer.pth" % (total_steps_so_far // 1000)
+            final = os.path.join(savedir, name)
+            torch.save(self.state_dict(), final + ".tmp")
+            os.replace(final + ".tmp", final)
+            link, tmplink = os.path.join(savedir, "latest_optimizer.pth"), os.path.join(savedir, "latest_optimizer.pth.tmp")
+            if os.path.lexists(tmplink):
+                os.remove(tmplink)
+            os.symlink(name, tmplink)
+            os.replace(tmplink, link)
+        if multi:
+            dist.barrier()
+
+    def state_dict(self):
+        return {"optimizer_G": self.optimizer_G.state_dict(), "optimizer_D": self.optimizer_D.state_dict(),
+                "train_mode_counter": self.train_mode_counter,
+                "discriminator_iter_counter": self.discriminator_iter_counter}
+
+    def load_state_dict(self, state):
+        self.optimizer_G.load_state_dict(state["optimizer_G"])
+        self.optimizer_D.load_state_dict(state["optimizer_D"])
+        self.train_mode_counter = int(state["train_mode_counter"])
+        self.discriminator_iter_counter = int(state["discriminator_iter_counter"])
+
+    def load(self, resume_iter="latest"):
+        """Restore what ``save`` wrote (optimiser moments + counters); returns False when there is nothing to load."""
+        import os
+        path = os.path.join(self.opt.checkpoints_dir, self.opt.name, "%s_optimizer.pth" % resume_iter)
+        if not os.path.exists(path):
+            return False
+        self.load_state_dict(torch.load(path, map_location="cpu"))
+        return True
 
 
 def create_optimizer(opt, model):
-    return SwappingAutoencoderOptimizer(model)
+    optimizer = SwappingAutoencoderOptimizer(model)
+    if getattr(opt, "continue_train", False):
+        optimizer.load(getattr(opt, "resume_iter", "latest"))
+    return optimizer

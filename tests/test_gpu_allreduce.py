@@ -47,3 +47,20 @@ def test_forced_single_rank_allreduce_over_rccl():
     env = dict(os.environ, SAE_FORCE_ALLREDUCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, "-c", _SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ALLREDUCE_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_device_prefetcher_delivers_batches_in_order():
+    """swapping_autoencoder_pytorch_amd/data_prefetch.py: every batch arrives on the GPU, in order, bit-identical to
+    the host batch, through pinned staging on a side stream (the consumer only waits on the copy's event)."""
+    import torch
+    from swapping_autoencoder_pytorch_amd.data_prefetch import DevicePrefetcher
+    host = [{"real_A": torch.rand(4, 3, 64, 64) * 2 - 1, "path_A": ["p%d" % i] * 4, "idx": i} for i in range(7)]
+    seen = 0
+    for i, batch in enumerate(DevicePrefetcher(iter(host), device="cuda:0", depth=3)):
+        assert batch["real_A"].is_cuda and batch["idx"] == i and batch["path_A"] == host[i]["path_A"]
+        y = batch["real_A"] * 2.0                                   # consume on the current stream
+        assert torch.equal(y.cpu(), host[i]["real_A"] * 2.0)
+        seen += 1
+    assert seen == len(host)
+    with pytest.raises(RuntimeError):
+        DevicePrefetcher(iter(host), device="cpu")
