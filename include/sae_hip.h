@@ -19,6 +19,9 @@
  *   sae_conv2d_{fwd,dgrad,wgrad}_f32
  *                            <- F.conv2d / F.conv_transpose2d and their ATen backward
  *                               models/networks/stylegan2_layers.py:136,175,182,306,315,321
+ *   sae_modconv2d_{fwd,dgrad,wgrad}_f32
+ *                            <- ModulatedConv2d.forward (style scale, demodulation, conv / conv_transpose) and its
+ *                               ATen backward   models/networks/stylegan2_layers.py:266-325
  *   sae_gemm_f32             <- F.linear and its backward       models/networks/stylegan2_layers.py:177,186
  *   sae_upsample2x_bilinear_{add,bwd}_f32
  *                            <- F.interpolate(bilinear x2) + residual   models/networks/generator.py:51-53
@@ -195,6 +198,36 @@ int sae_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_c
                          float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
 int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
                          float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Style-modulated convolution (ModulatedConv2d, models/networks/stylegan2_layers.py:266-325) as ONE call per
+ * operation: the three conv operations above applied to
+ *     x * x_scale[n][c],   gy * y_scale[n][m],   w * alpha * wm_scale[m] * wc_scale[c]
+ * where every factor array may be NULL (= 1).  The activation factors (the per-sample style `s`, :280-286) are
+ * applied while the operand is staged into LDS and the weight factors (the demodulation, :290-292) while the weight
+ * is re-laid for the launch, so neither the modulated activation nor the modulated weight exists in HBM.  Indices
+ * follow the DESCRIPTOR's axes (c = x side, m = y side), whatever the operation:
+ *     plain modulated conv  O <- I    (d.m = O, d.c = I):  forward = fwd(x_scale = s, wm_scale = demod),
+ *         input gradient before the style factor = dgrad(wm_scale = demod), weight gradient = wgrad(x_scale = s);
+ *     transposed modulated conv (:302-309; the weight is used in its own [O][I] orientation, d.c = O, d.m = I):
+ *         forward = dgrad(gy := input, y_scale = s, wc_scale = demod), input gradient = fwd(wc_scale = demod),
+ *         weight gradient = wgrad(x := output gradient, gy := input, y_scale = s).
+ * Activation factors are staged by the exact-fp32 kernels; under SAE_CONV_MATH_BF16X6 a call with x_scale / y_scale
+ * returns SAE_EINVAL (modulate the activation first; weight factors work in both arithmetics).
+ * Workspaces: sae_conv2d_workspace() of the same descriptor and operation.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct sae_conv2d_mod {
+    const float* x_scale;   /* [n][c] factor of the x-side activation (forward, wgrad) */
+    const float* y_scale;   /* [n][m] factor of the y-side activation (dgrad, wgrad) */
+    const float* wm_scale;  /* [m]    factor of the weight along the m axis (forward, dgrad) */
+    const float* wc_scale;  /* [c]    factor of the weight along the c axis (forward, dgrad) */
+} sae_conv2d_mod;
+int sae_modconv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
+                          float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+int sae_modconv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
+                            float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+int sae_modconv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
+                            float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Strided GEMM on the fp32 matrix cores:  C[i*ldc + j] = alpha * sum_k A[i*a_si + k*a_sk] * B[k*b_sk + j*b_sj]

@@ -644,3 +644,77 @@ int oracle_adam_multi_f32(float* const* params, const float* const* grads, float
     }
     return SAE_OK;
 }
+
+/* ---- Style-modulated convolution (include/sae_hip.h: sae_modconv2d_*).  ModulatedConv2d.forward,
+ * stylegan2_layers.py:266-325: the style scales the INPUT per sample (:280-286: input * style), the demodulation
+ * factor scales the weight per output channel (:290-292), then the plain conv / conv_transpose runs (:306,:315,:321).
+ * Restated literally: the factors are applied to copies of the operands, then the plain oracle operation runs. */
+typedef struct sae_conv2d_mod {
+    const float* x_scale;
+    const float* y_scale;
+    const float* wm_scale;
+    const float* wc_scale;
+} sae_conv2d_mod;
+
+static float* scaled_activation(const float* t, const float* scale, int64_t n, int64_t c, int64_t hw) {
+    float* out = (float*)malloc(sizeof(float) * (size_t)(n * c * hw > 0 ? n * c * hw : 1));
+    if (!out) return NULL;
+    for (int64_t i = 0; i < n * c; ++i)
+        for (int64_t j = 0; j < hw; ++j) out[i * hw + j] = scale ? t[i * hw + j] * scale[i] : t[i * hw + j];
+    return out;
+}
+
+/* dense [m][c][k][k] copy of the weight with the factors applied; *dd describes it */
+static float* scaled_weight(const float* w, const sae_conv2d_desc* d, const sae_conv2d_mod* mod, sae_conv2d_desc* dd) {
+    const int64_t kk = (int64_t)d->kh * d->kw;
+    float* out = (float*)malloc(sizeof(float) * (size_t)(d->m * d->c * kk));
+    if (!out) return NULL;
+    for (int64_t m = 0; m < d->m; ++m)
+        for (int64_t c = 0; c < d->c; ++c)
+            for (int64_t t = 0; t < kk; ++t) {
+                float v = w[m * d->w_stride_m + c * d->w_stride_c + t];
+                if (mod && mod->wm_scale) v *= mod->wm_scale[m];
+                if (mod && mod->wc_scale) v *= mod->wc_scale[c];
+                out[(m * d->c + c) * kk + t] = v;
+            }
+    *dd = *d;
+    dd->w_stride_m = d->c * kk;
+    dd->w_stride_c = kk;
+    return out;
+}
+
+int oracle_modconv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
+                             float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    if (!x || !w || !y || !conv_desc_ok(d)) return set_err("oracle_modconv2d_fwd_f32: bad argument");
+    if (mod && mod->y_scale) return set_err("oracle_modconv2d_fwd_f32: y_scale has no meaning for the forward operation");
+    sae_conv2d_desc dd;
+    float* xs = scaled_activation(x, mod ? mod->x_scale : NULL, d->n, d->c, d->h * d->w);
+    float* ws = scaled_weight(w, d, mod, &dd);
+    int rc = (xs && ws) ? oracle_conv2d_fwd_f32(xs, ws, y, &dd, alpha, workspace, workspace_floats, stream) : SAE_EWORKSPACE;
+    free(xs); free(ws);
+    return rc;
+}
+
+int oracle_modconv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
+                               float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    if (!gy || !w || !gx || !conv_desc_ok(d)) return set_err("oracle_modconv2d_dgrad_f32: bad argument");
+    if (mod && mod->x_scale) return set_err("oracle_modconv2d_dgrad_f32: x_scale has no meaning for the data gradient");
+    sae_conv2d_desc dd;
+    float* gs = scaled_activation(gy, mod ? mod->y_scale : NULL, d->n, d->m, d->oh * d->ow);
+    float* ws = scaled_weight(w, d, mod, &dd);
+    int rc = (gs && ws) ? oracle_conv2d_dgrad_f32(gs, ws, gx, &dd, alpha, workspace, workspace_floats, stream) : SAE_EWORKSPACE;
+    free(gs); free(ws);
+    return rc;
+}
+
+int oracle_modconv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
+                               float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    if (!x || !gy || !gw || !conv_desc_ok(d)) return set_err("oracle_modconv2d_wgrad_f32: bad argument");
+    if (mod && (mod->wm_scale || mod->wc_scale))
+        return set_err("oracle_modconv2d_wgrad_f32: weight factors have no meaning for the weight gradient");
+    float* xs = scaled_activation(x, mod ? mod->x_scale : NULL, d->n, d->c, d->h * d->w);
+    float* gs = scaled_activation(gy, mod ? mod->y_scale : NULL, d->n, d->m, d->oh * d->ow);
+    int rc = (xs && gs) ? oracle_conv2d_wgrad_f32(xs, gs, gw, d, alpha, workspace, workspace_floats, stream) : SAE_EWORKSPACE;
+    free(xs); free(gs);
+    return rc;
+}

@@ -47,7 +47,11 @@ namespace {
 __global__ __launch_bounds__(kBlock) void conv_wprep_kernel(const float* __restrict__ w,
                                                             float* __restrict__ wp, int M, int C, int Mp,
                                                             int Cp, int taps, int64_t sm, int64_t sc,
-                                                            int flip, float alpha) {
+                                                            int flip, float alpha,
+                                                            const float* __restrict__ rs_m,
+                                                            const float* __restrict__ rs_c) {
+    // rs_m[m] / rs_c[c] (either may be null): per-channel factors of the staged weight along the launch's output
+    // (m) or contraction (c) axis: the demodulation of ModulatedConv2d (stylegan2_layers.py:290-292) rides here
     const int64_t total = (int64_t)taps * Cp * Mp;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * kBlock) {
@@ -56,7 +60,11 @@ __global__ __launch_bounds__(kBlock) void conv_wprep_kernel(const float* __restr
         const int c = (int)(t % Cp);
         const int tap = (int)(t / Cp);
         float v = 0.0f;
-        if (m < M && c < C) v = alpha * w[m * sm + c * sc + (flip ? taps - 1 - tap : tap)];
+        if (m < M && c < C) {
+            v = alpha * w[m * sm + c * sc + (flip ? taps - 1 - tap : tap)];
+            if (rs_m) v *= rs_m[m];
+            if (rs_c) v *= rs_c[c];
+        }
         wp[i] = v;
     }
 }
@@ -79,6 +87,9 @@ struct IgemmParams {
     const float* bias;
     float act_slope, act_scale;
     int act;
+    // style modulation of the INPUT (ModulatedConv2d, stylegan2_layers.py:280-286): when non-null, x[n][c][..] is
+    // multiplied by in_scale[n * C + c] on its way into LDS, so the modulated activation never exists in HBM
+    const float* in_scale;
 };
 
 template <int KS, int S, int BN>
@@ -87,7 +98,9 @@ struct PatchCap {
     static constexpr int value = (KS == 1) ? BN : (S == 1 ? (9 * BN) / 4 : (41 * BN) / 8);
 };
 
-template <int KS, int S, int MI, int NI, int WM, int WN, int CK>
+// MOD: the input is style-modulated while staged (IgemmParams::in_scale); a separate instantiation, so the
+// un-modulated kernels of E / D / Dpatch carry no trace of it
+template <int KS, int S, int MI, int NI, int WM, int WN, int CK, bool MOD = false>
 __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ wp,
                                                             float* __restrict__ y, const IgemmParams p) {
@@ -126,10 +139,12 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
 
     // per-thread patch slots: global offset relative to (image n0, channel 0) or -1
     int poff[PPT];
+    int sidx[MOD ? PPT : 1];   // in_scale row of the slot's image (tiles that span several images only)
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int e = tid + kBlock * s;
         int off = -1;
+        if constexpr (MOD) sidx[s] = 0;
         if (e < CP) {
             const int pn = e / IP;
             const int rem = e - pn * IP;
@@ -140,11 +155,15 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
             int iy, ix;
             if (KS == 1) { iy = (oy0 + r) * S - p.pad; ix = (ox0 + c) * S - p.pad; }
             else { iy = oy0 * S - p.pad + r; ix = ox0 * S - p.pad + c; }
-            if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+            if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
                 off = pn * p.C * HW + iy * p.W + ix;
+                if constexpr (MOD) sidx[s] = (n0 + pn) * p.C;
+            }
         }
         poff[s] = off;
     }
+    const bool one_image = TN == 1;          // the whole tile lies in image n0: one (uniform) factor per channel
+    float sc[MOD ? CK : 1];                   // ... prefetched with the chunk
 
     // per-lane LDS base of each N-tile pixel, and per-tap offsets
     int pixbase[NI];
@@ -183,6 +202,12 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
 #pragma unroll
             for (int s = 0; s < PPT; ++s) xv[ch][s] = (ch_ok && poff[s] >= 0) ? xc[poff[s]] : 0.0f;
         }
+        if constexpr (MOD) {
+            if (one_image) {
+#pragma unroll
+                for (int ch = 0; ch < CK; ++ch) sc[ch] = p.in_scale[n0 * p.C + ((c0 + ch) < p.C ? c0 + ch : 0)];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int e4 = tid + kBlock * i;
@@ -195,7 +220,15 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
             }
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int c0) {
+        if constexpr (MOD) {
+#pragma unroll
+            for (int ch = 0; ch < CK; ++ch) {
+                const int cc = (c0 + ch) < p.C ? c0 + ch : 0;
+#pragma unroll
+                for (int s = 0; s < PPT; ++s) xv[ch][s] *= one_image ? sc[ch] : p.in_scale[sidx[s] + cc];
+            }
+        }
 #pragma unroll
         for (int ch = 0; ch < CK; ++ch)
 #pragma unroll
@@ -216,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     load_chunk(c_begin);
     for (int c0 = c_begin; c0 < c_end; c0 += CK) {
         __syncthreads();   // everyone finished reading the previous chunk
-        store_chunk();
+        store_chunk(c0);
         __syncthreads();
         if (c0 + CK < c_end) load_chunk(c0 + CK);   // in flight under the MFMAs below
 #pragma unroll
@@ -297,7 +330,8 @@ __device__ inline void split3_bf16(const float (&v)[8], bf16x8& s0, bf16x8& s1, 
 __global__ __launch_bounds__(kBlock) void conv_wprep_bx_kernel(const float* __restrict__ w,
                                                                u32x4* __restrict__ wpb, int M, int C, int Mp,
                                                                int Cp, int BM, int64_t sm, int64_t sc, int flip,
-                                                               float alpha) {
+                                                               float alpha, const float* __restrict__ rs_m,
+                                                               const float* __restrict__ rs_c) {
     const int nchunks = Cp / 8;
     const int64_t total = (int64_t)(Mp / BM) * nchunks * 9 * BM;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
@@ -313,6 +347,10 @@ __global__ __launch_bounds__(kBlock) void conv_wprep_bx_kernel(const float* __re
         for (int ch = 0; ch < 8; ++ch) {
             const int c = chunk * 8 + ch;
             v[ch] = (m < M && c < C) ? alpha * w[m * sm + c * sc + (flip ? 8 - tap : tap)] : 0.0f;
+            if (m < M && c < C) {
+                if (rs_m) v[ch] *= rs_m[m];
+                if (rs_c) v[ch] *= rs_c[c];
+            }
         }
         bf16x8 s0, s1, s2;
         split3_bf16(v, s0, s1, s2);
@@ -781,13 +819,14 @@ struct TrParams {
     int debug_skip_store;   // profiling aid (SAE_TR_NOSTORE): results are NOT written
     int Cp, Mp;
     int pad;
+    const float* in_scale;  // [N][C] or null: style modulation of the input, applied while staging (see IgemmParams)
     // main region + right / bottom strips, all in ONE launch (blockIdx.x runs through the regions):
     // launched one after the other the two thin strips cost a full K loop of latency each on a
     // nearly empty GPU
     TrRegion reg[3];
 };
 
-template <int MI, int WM, int WN, int CK>
+template <int MI, int WM, int WN, int CK, bool MOD = false>
 __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ wp,
                                                                float* __restrict__ y, const TrParams p) {
@@ -828,21 +867,27 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
     const int HW = p.IH * p.IW;
 
     int poff[PPT];
+    int sidx[MOD ? PPT : 1];   // in_scale row of the slot's image (tiles that span several images only)
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int e = tid + kBlock * s;
         int off = -1;
+        if constexpr (MOD) sidx[s] = 0;
         if (e < CP) {
             const int pn = e / IP;
             const int rem = e - pn * IP;
             const int r = rem / RS;
             const int c = rem - r * RS;
             const int iy = qy0 - 1 + r, ix = qx0 - 1 + c;
-            if (n0 + pn < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
+            if (n0 + pn < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) {
                 off = pn * p.C * HW + iy * p.IW + ix;
+                if constexpr (MOD) sidx[s] = (n0 + pn) * p.C;
+            }
         }
         poff[s] = off;
     }
+    const bool one_image = TN == 1;
+    float sc[MOD ? CK : 1];
 
     const int pp = wn * 32 + l31;
     const int pn = pp / (TW * TH);
@@ -879,6 +924,12 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
 #pragma unroll
             for (int s = 0; s < PPT; ++s) xv[ch][s] = (ch_ok && poff[s] >= 0) ? xc[poff[s]] : 0.0f;
         }
+        if constexpr (MOD) {
+            if (one_image) {
+#pragma unroll
+                for (int ch = 0; ch < CK; ++ch) sc[ch] = p.in_scale[n0 * p.C + ((c0 + ch) < p.C ? c0 + ch : 0)];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int e4 = tid + kBlock * i;
@@ -891,7 +942,15 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
             }
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int c0) {
+        if constexpr (MOD) {
+#pragma unroll
+            for (int ch = 0; ch < CK; ++ch) {
+                const int cc = (c0 + ch) < p.C ? c0 + ch : 0;
+#pragma unroll
+                for (int s = 0; s < PPT; ++s) xv[ch][s] *= one_image ? sc[ch] : p.in_scale[sidx[s] + cc];
+            }
+        }
 #pragma unroll
         for (int ch = 0; ch < CK; ++ch)
 #pragma unroll
@@ -909,7 +968,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
     load_chunk(0);
     for (int c0 = 0; c0 < p.Cp; c0 += CK) {
         __syncthreads();
-        store_chunk();
+        store_chunk(c0);
         __syncthreads();
         if (c0 + CK < p.Cp) load_chunk(c0 + CK);
 #pragma unroll
@@ -1155,6 +1214,11 @@ struct WgradParams {
     int tiles_x, tiles_y, tiles_n;
     int chunks, chunks_per_slice;
     int Ap, Bp;           // slab dims (padded M, C)
+    // style modulation of either operand (null = none): L[n][c][..] * l_scale[n * C + c] (the input of a modulated
+    // forward conv) or S[n][m][..] * s_scale[n * M + m] (the input of a modulated TRANSPOSED conv, which is the
+    // y side of the forward-orientation problem), applied while the operand is written to LDS
+    const float* l_scale;
+    const float* s_scale;
 };
 
 constexpr int kWgPix = 64;
@@ -1170,7 +1234,8 @@ struct WgPatchCap {
 //         so no wave multiplies padding.
 // MODE 2: MODE 1 with the B-tile lanes enumerating (channel, tap) pairs (C * taps <= 32: the RGB
 //         stems): one MFMA per k-pair instead of one per tap.
-template <int KS, int S, int TA, int TB, int WA, int WB, int MODE>
+// MOD: an operand is style-modulated while staged (WgradParams::l_scale / s_scale); a separate instantiation
+template <int KS, int S, int TA, int TB, int WA, int WB, int MODE, bool MOD = false>
 __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restrict__ xl,
                                                             const float* __restrict__ gs,
                                                             float* __restrict__ slab, const WgradParams p) {
@@ -1247,6 +1312,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     constexpr bool BRANCHFREE = KS == 3 && S == 2 && !PIXSPLIT;
     bool s_ok = false;      // validity of the prefetched chunk's elements (applied in store_chunk)
     int l_okmask = 0;
+    [[maybe_unused]] int pf_n0 = 0;   // first image of the prefetched chunk (operand modulation looks its factors up at store time)
 
     auto load_chunk = [&](int chunk) {
         int bt = chunk;
@@ -1254,6 +1320,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
         const int tiy = bt % p.tiles_y;
         const int tin = bt / p.tiles_y;
         const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
+        if constexpr (MOD) pf_n0 = n0;
         // addressing: one wave-uniform 64-bit base per tensor + 32-bit (lane + channel) offsets,
         // so loads use the SGPR-base form and no per-channel pointer is kept in registers
         {
@@ -1315,6 +1382,27 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
         }
     };
     auto store_chunk = [&]() {
+        if (MOD && p.s_scale) {        // modulated S operand: factor of (image of this lane's pixel, channel a)
+            const int n = pf_n0 + (lane >> (p.tw_log2 + p.th_log2));
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int a = a0 + wid + 4 * i;
+                sv[i] *= p.s_scale[(n < p.N ? n : 0) * p.M + (a < p.M ? a : 0)];
+            }
+        }
+        if (MOD && p.l_scale) {        // modulated L operand: factor of (image of the patch element, channel b)
+#pragma unroll
+            for (int s = 0; s < LS; ++s) {
+                const int e = lane + kWave * s;
+                const int n = pf_n0 + (e < CPs ? e / IP : 0);
+                const int row = (n < p.N ? n : 0) * p.C;
+#pragma unroll
+                for (int j = 0; j < NLB; ++j) {
+                    const int b = b0 + wid + 4 * j;
+                    lv[j][s] *= p.l_scale[row + (b < p.C ? b : 0)];
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NS; ++i)
             Ss[(wid + 4 * i) * SLD + lane] = (!BRANCHFREE || (s_ok && a0 + wid + 4 * i < p.M)) ? sv[i] : 0.0f;
@@ -2052,49 +2140,58 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
         }
     }
     switch (sh.cfg) {
+#define SAE_IGEMM(...)                                                                                          \
+    do {                                                                                                        \
+        if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<__VA_ARGS__, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);  \
+        else hipLaunchKernelGGL((conv_igemm_kernel<__VA_ARGS__, false>), grid, dim3(kBlock), 0, s, x, wp, y, p);            \
+    } while (0)
         case 4:
             if constexpr (KS == 3 && S == 1) {
-                hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 1, 2, 1, 4, 8>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                SAE_IGEMM(3, 1, 1, 2, 1, 4, 8);
                 break;
             } else {
                 return fail(SAE_EINVAL, "conv igemm: 32x256 tile is 3x3 stride-1 only");
             }
         case 3:
             if constexpr (KS == 3 && S == 1) {
-                hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 2, 4, 2, 2, 8>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                SAE_IGEMM(3, 1, 2, 4, 2, 2, 8);
                 break;
             } else {
                 return fail(SAE_EINVAL, "conv igemm: 128x256 tile is 3x3 stride-1 only");
             }
-        case 0: hipLaunchKernelGGL((conv_igemm_kernel<KS, S, 2, 2, 2, 2, CK>), grid, dim3(kBlock), 0, s, x, wp, y, p); break;
-        case 1: hipLaunchKernelGGL((conv_igemm_kernel<KS, S, 2, 2, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, wp, y, p); break;
+        case 0: SAE_IGEMM(KS, S, 2, 2, 2, 2, CK); break;
+        case 1: SAE_IGEMM(KS, S, 2, 2, 1, 4, CK); break;
         default:
             if constexpr (S == 1)
-                hipLaunchKernelGGL((conv_igemm_kernel<KS, 1, 1, 4, 1, 4, CK2>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                SAE_IGEMM(KS, 1, 1, 4, 1, 4, CK2);
             else
                 return fail(SAE_EINVAL, "conv igemm: 32x512 tile is stride-1 only");
             break;
+#undef SAE_IGEMM
     }
     return SAE_OK;
 }
 
+// per-channel weight factors of a launch (either may be null): rs_m along its output axis, rs_c along its contraction axis
+struct WScale { const float* rs_m; const float* rs_c; };
+
 int run_wprep(const float* w, float* wp, int M, int C, int Mp, int Cp, int taps, int64_t sm, int64_t sc, int flip,
-              float alpha, hipStream_t s) {
+              float alpha, hipStream_t s, WScale ws = WScale{nullptr, nullptr}) {
     const int64_t total = (int64_t)taps * Cp * Mp;
     int64_t blocks = ceil_div64(total, kBlock);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(conv_wprep_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, w, wp, M, C, Mp, Cp, taps, sm,
-                       sc, flip, alpha);
+                       sc, flip, alpha, ws.rs_m, ws.rs_c);
     return SAE_OK;
 }
 
 int run_wprep_bx(const float* w, float* wpb, int M, int C, int Mp, int Cp, int BM, int64_t sm, int64_t sc, int flip,
-                 float alpha, hipStream_t s) {
+                 float alpha, hipStream_t s, WScale ws = WScale{nullptr, nullptr}) {
     const int64_t total = (int64_t)Mp * (Cp / 8) * 9;
     int64_t blocks = ceil_div64(total, kBlock);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(conv_wprep_bx_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, w,
-                       reinterpret_cast<u32x4*>(wpb), M, C, Mp, Cp, BM, sm, sc, flip, alpha);
+                       reinterpret_cast<u32x4*>(wpb), M, C, Mp, Cp, BM, sm, sc, flip, alpha, ws.rs_m, ws.rs_c);
     return SAE_OK;
 }
 
@@ -2103,19 +2200,24 @@ struct Epilogue { const float* bias; int act; float slope, scale; };
 
 int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int H, int W,
                int mout, int OH, int OW, int YH, int YW, int oys, int oxs, int ks, int stride, int pad, int64_t sm,
-               int64_t sc, int flip, float alpha, hipStream_t s, Epilogue ep = Epilogue{nullptr, 0, 0.0f, 1.0f}) {
+               int64_t sc, int flip, float alpha, hipStream_t s, Epilogue ep = Epilogue{nullptr, 0, 0.0f, 1.0f},
+               const float* in_scale = nullptr, WScale wsc = WScale{nullptr, nullptr}) {
     const GatherPlan g = gather_plan(N, cin, mout, OH, OW, ks, stride, oys != 1 || oxs != 1);
     if (!ws || ws_floats < g.ws_floats)
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)g.ws_floats);
+    if (in_scale && g.bx)
+        return fail(SAE_EINVAL, "modulated conv: the activation factors are staged by the exact-fp32 kernels only "
+                                "(SAE_CONV_MATH_F32); under bf16x6 modulate the activation before the call");
     if (g.bx) {
-        run_wprep_bx(w, ws, mout, cin, g.Mp, g.Cp, g.sh.bm, sm, sc, flip, alpha, s);
+        run_wprep_bx(w, ws, mout, cin, g.Mp, g.Cp, g.sh.bm, sm, sc, flip, alpha, s, wsc);
     } else {
-        run_wprep(w, ws, mout, cin, g.Mp, g.Cp, g.taps, sm, sc, flip, alpha, s);
+        run_wprep(w, ws, mout, cin, g.Mp, g.Cp, g.taps, sm, sc, flip, alpha, s, wsc);
     }
     IgemmParams p{};
     p.N = N; p.C = cin; p.H = H; p.W = W; p.M = mout; p.OH = OH; p.OW = OW; p.YH = YH; p.YW = YW;
     p.oys = oys; p.oxs = oxs; p.Cp = g.Cp; p.Mp = g.Mp; p.pad = pad;
     p.slab_stride = g.out_floats4;
+    p.in_scale = in_scale;
     if (g.ksplit == 1) { p.bias = ep.bias; p.act = ep.act; p.act_slope = ep.slope; p.act_scale = ep.scale; }
     float* out = (g.ksplit > 1) ? ws + g.wp_floats : y;
     int rc;
@@ -2144,7 +2246,8 @@ int64_t gather_ws(int N, int cin, int mout, int OH, int OW, int ks, int stride, 
 
 // stride-2 3x3 transposed gather producing `mout` channels (the large image) from `cin` channels
 int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int IH, int IW,
-           int mout, int OH, int OW, int pad, int64_t sm, int64_t sc, float alpha, hipStream_t s) {
+           int mout, int OH, int OW, int pad, int64_t sm, int64_t sc, float alpha, hipStream_t s,
+           const float* in_scale = nullptr, WScale wsc = WScale{nullptr, nullptr}) {
     const TrShape sh = tr_shape(mout);
     constexpr int CK = 8;
     const int Mp = round_up(mout, sh.bm), Cp = round_up(cin, sh.ck);
@@ -2152,9 +2255,13 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
     const int64_t need = bx ? (int64_t)27 * Mp * (Cp / 8) * 4 : (int64_t)9 * Cp * Mp;
     if (!ws || ws_floats < need)
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
-    if (bx) run_wprep_bx(w, ws, mout, cin, Mp, Cp, sh.bm, sm, sc, 0, alpha, s);
-    else run_wprep(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s);
+    if (in_scale && bx)
+        return fail(SAE_EINVAL, "modulated conv: the activation factors are staged by the exact-fp32 kernels only "
+                                "(SAE_CONV_MATH_F32); under bf16x6 modulate the activation before the call");
+    if (bx) run_wprep_bx(w, ws, mout, cin, Mp, Cp, sh.bm, sm, sc, 0, alpha, s, wsc);
+    else run_wprep(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s, wsc);
     TrParams p{};
+    p.in_scale = in_scale;
     p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
     static const int nostore_knob = [] { const char* e = getenv("SAE_TR_NOSTORE"); return e ? atoi(e) : 0; }();
     p.debug_skip_store = nostore_knob;
@@ -2213,12 +2320,18 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
                                reinterpret_cast<const u32x4*>(ws), y, p);
             return SAE_OK;
         }
+#define SAE_TR(...)                                                                                             \
+    do {                                                                                                        \
+        if (p.in_scale) hipLaunchKernelGGL((conv_igemm_tr_kernel<__VA_ARGS__, true>), grid, dim3(kBlock), 0, s, x, ws, y, p);   \
+        else hipLaunchKernelGGL((conv_igemm_tr_kernel<__VA_ARGS__, false>), grid, dim3(kBlock), 0, s, x, ws, y, p);             \
+    } while (0)
         switch (sh.cfg) {
-            case 3: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 1, 4, 16>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
-            case 0: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 2, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
-            case 1: hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
-            default: hipLaunchKernelGGL((conv_igemm_tr_kernel<1, 1, 4, CK>), grid, dim3(kBlock), 0, s, x, ws, y, p); break;
+            case 3: SAE_TR(2, 1, 4, 16); break;
+            case 0: SAE_TR(2, 2, 2, CK); break;
+            case 1: SAE_TR(2, 1, 4, CK); break;
+            default: SAE_TR(1, 1, 4, CK); break;
         }
+#undef SAE_TR
     }
     return SAE_OK;
 }
@@ -2232,7 +2345,10 @@ int64_t tr_ws(int cin, int mout) {
 template <int KS, int S, int TA, int TB, int WA, int WB, int MODE>
 void launch_wgrad(const float* x, const float* gy, float* slab, const WgradParams& p, const WgPlan& w, hipStream_t s) {
     const dim3 grid((unsigned)(w.Bp / w.sh.bb), (unsigned)(w.Ap / w.sh.ba), (unsigned)w.slices);
-    hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, TA, TB, WA, WB, MODE>), grid, dim3(kBlock), 0, s, x, gy, slab, p);
+    if (p.l_scale || p.s_scale)
+        hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, TA, TB, WA, WB, MODE, true>), grid, dim3(kBlock), 0, s, x, gy, slab, p);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, TA, TB, WA, WB, MODE, false>), grid, dim3(kBlock), 0, s, x, gy, slab, p);
 }
 
 }  // namespace
@@ -2257,17 +2373,34 @@ extern "C" int64_t sae_conv2d_workspace(const sae_conv2d_desc* d, int32_t op) {
     }
 }
 
-extern "C" int sae_conv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d, float alpha,
-                                  float* workspace, int64_t workspace_floats, sae_stream_t stream) {
-    if (!desc_ok(d, "sae_conv2d_fwd_f32")) return SAE_EINVAL;
+namespace {
+const sae_conv2d_mod kNoMod = {nullptr, nullptr, nullptr, nullptr};
+
+int conv_fwd_impl(const char* who, const float* x, const float* w, float* y, const sae_conv2d_desc* d,
+                  const sae_conv2d_mod& mod, float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    if (!desc_ok(d, who)) return SAE_EINVAL;
     if (d->n == 0) return SAE_OK;
-    if (!x || !w || !y) return fail(SAE_EINVAL, "sae_conv2d_fwd_f32: null tensor");
+    if (!x || !w || !y) return fail(SAE_EINVAL, "%s: null tensor", who);
+    if (mod.y_scale) return fail(SAE_EINVAL, "%s: y_scale has no meaning for the forward operation", who);
     hipStream_t s = (hipStream_t)stream;
     int rc = run_gather(x, w, y, workspace, workspace_floats, (int)d->n, (int)d->c, (int)d->h, (int)d->w, (int)d->m,
                         (int)d->oh, (int)d->ow, (int)d->oh, (int)d->ow, 1, 1, d->kh, d->stride, d->pad,
-                        d->w_stride_m, d->w_stride_c, 0, alpha, s);
+                        d->w_stride_m, d->w_stride_c, 0, alpha, s, Epilogue{nullptr, 0, 0.0f, 1.0f}, mod.x_scale,
+                        WScale{mod.wm_scale, mod.wc_scale});
     if (rc != SAE_OK) return rc;
-    return check_launch("sae_conv2d_fwd_f32");
+    return check_launch(who);
+}
+}  // namespace
+
+extern "C" int sae_conv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d, float alpha,
+                                  float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    return conv_fwd_impl("sae_conv2d_fwd_f32", x, w, y, d, kNoMod, alpha, workspace, workspace_floats, stream);
+}
+
+extern "C" int sae_modconv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d,
+                                     const sae_conv2d_mod* mod, float alpha, float* workspace, int64_t workspace_floats,
+                                     sae_stream_t stream) {
+    return conv_fwd_impl("sae_modconv2d_fwd_f32", x, w, y, d, mod ? *mod : kNoMod, alpha, workspace, workspace_floats, stream);
 }
 
 extern "C" int sae_conv2d_fwd_bias_act_f32(const float* x, const float* w, const float* bias, float* y,
@@ -2284,54 +2417,97 @@ extern "C" int sae_conv2d_fwd_bias_act_f32(const float* x, const float* w, const
     return check_launch("sae_conv2d_fwd_bias_act_f32");
 }
 
-extern "C" int sae_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
-                                    float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
-    if (!desc_ok(d, "sae_conv2d_dgrad_f32")) return SAE_EINVAL;
+namespace {
+int conv_dgrad_impl(const char* who, const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
+                    const sae_conv2d_mod& mod, float alpha, float* workspace, int64_t workspace_floats,
+                    sae_stream_t stream) {
+    if (!desc_ok(d, who)) return SAE_EINVAL;
     if (d->n == 0) return SAE_OK;
-    if (!gy || !w || !gx) return fail(SAE_EINVAL, "sae_conv2d_dgrad_f32: null tensor");
+    if (!gy || !w || !gx) return fail(SAE_EINVAL, "%s: null tensor", who);
+    if (mod.x_scale) return fail(SAE_EINVAL, "%s: x_scale has no meaning for the data gradient", who);
     hipStream_t s = (hipStream_t)stream;
+    // the launch produces the c axis and contracts over the m axis of the descriptor
+    const WScale wsc{mod.wc_scale, mod.wm_scale};
+    const Epilogue none{nullptr, 0, 0.0f, 1.0f};
     int rc;
     if (d->stride == 1) {
         // gx = full correlation of gy with the flipped, channel-transposed taps: pad' = k - 1 - pad
         rc = run_gather(gy, w, gx, workspace, workspace_floats, (int)d->n, (int)d->m, (int)d->oh, (int)d->ow,
                         (int)d->c, (int)d->h, (int)d->w, (int)d->h, (int)d->w, 1, 1, d->kh, 1, d->kh - 1 - d->pad,
-                        d->w_stride_c, d->w_stride_m, 1, alpha, s);
+                        d->w_stride_c, d->w_stride_m, 1, alpha, s, none, mod.y_scale, wsc);
     } else if (d->kh == 1) {
         // 1x1 stride 2 (pad 0): gx[2oy][2ox] = W^T gy, every other position is zero
         hipMemsetAsync(gx, 0, sizeof(float) * (size_t)(d->n * d->c * d->h * d->w), s);
         rc = run_gather(gy, w, gx, workspace, workspace_floats, (int)d->n, (int)d->m, (int)d->oh, (int)d->ow,
                         (int)d->c, (int)d->oh, (int)d->ow, (int)d->h, (int)d->w, 2, 2, 1, 1, 0, d->w_stride_c,
-                        d->w_stride_m, 0, alpha, s);
+                        d->w_stride_m, 0, alpha, s, none, mod.y_scale, wsc);
     } else {
         rc = run_tr(gy, w, gx, workspace, workspace_floats, (int)d->n, (int)d->m, (int)d->oh, (int)d->ow, (int)d->c,
-                    (int)d->h, (int)d->w, d->pad, d->w_stride_c, d->w_stride_m, alpha, s);
+                    (int)d->h, (int)d->w, d->pad, d->w_stride_c, d->w_stride_m, alpha, s, mod.y_scale, wsc);
     }
     if (rc != SAE_OK) return rc;
-    return check_launch("sae_conv2d_dgrad_f32");
+    return check_launch(who);
 }
+}  // namespace
+
+extern "C" int sae_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
+                                    float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    return conv_dgrad_impl("sae_conv2d_dgrad_f32", gy, w, gx, d, kNoMod, alpha, workspace, workspace_floats, stream);
+}
+
+extern "C" int sae_modconv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
+                                       const sae_conv2d_mod* mod, float alpha, float* workspace,
+                                       int64_t workspace_floats, sae_stream_t stream) {
+    return conv_dgrad_impl("sae_modconv2d_dgrad_f32", gy, w, gx, d, mod ? *mod : kNoMod, alpha, workspace, workspace_floats,
+                           stream);
+}
+
+namespace {
+int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
+                    const sae_conv2d_mod& mod, float alpha, float* workspace, int64_t workspace_floats,
+                    sae_stream_t stream);
+}  // namespace
 
 extern "C" int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
                                     float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
-    if (!desc_ok(d, "sae_conv2d_wgrad_f32")) return SAE_EINVAL;
-    if (!gw) return fail(SAE_EINVAL, "sae_conv2d_wgrad_f32: null gw");
-    if (d->n > 0 && (!x || !gy)) return fail(SAE_EINVAL, "sae_conv2d_wgrad_f32: null tensor");
+    return conv_wgrad_impl("sae_conv2d_wgrad_f32", x, gy, gw, d, kNoMod, alpha, workspace, workspace_floats, stream);
+}
+
+extern "C" int sae_modconv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
+                                       const sae_conv2d_mod* mod, float alpha, float* workspace,
+                                       int64_t workspace_floats, sae_stream_t stream) {
+    return conv_wgrad_impl("sae_modconv2d_wgrad_f32", x, gy, gw, d, mod ? *mod : kNoMod, alpha, workspace, workspace_floats,
+                           stream);
+}
+
+namespace {
+int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
+                    const sae_conv2d_mod& mod, float alpha, float* workspace, int64_t workspace_floats,
+                    sae_stream_t stream) {
+    if (!desc_ok(d, who)) return SAE_EINVAL;
+    if (!gw) return fail(SAE_EINVAL, "%s: null gw", who);
+    if (d->n > 0 && (!x || !gy)) return fail(SAE_EINVAL, "%s: null tensor", who);
+    if (mod.wm_scale || mod.wc_scale) return fail(SAE_EINVAL, "%s: weight factors have no meaning for the weight gradient", who);
     hipStream_t s = (hipStream_t)stream;
     const WgPlan w = wg_plan(d);
+    if ((mod.x_scale || mod.y_scale) && w.bx)
+        return fail(SAE_EINVAL, "modulated conv: the activation factors are staged by the exact-fp32 kernels only "
+                                "(SAE_CONV_MATH_F32); under bf16x6 modulate the activation before the call");
     const int64_t need = (int64_t)w.slices * w.taps * w.Ap * w.Bp;
     if (!workspace || workspace_floats < need)
-        return fail(SAE_EWORKSPACE, "sae_conv2d_wgrad_f32: workspace %lld < %lld floats", (long long)workspace_floats,
-                    (long long)need);
+        return fail(SAE_EWORKSPACE, "%s: workspace %lld < %lld floats", who, (long long)workspace_floats, (long long)need);
     WgradParams p{};
     p.N = (int)d->n; p.C = (int)d->c; p.H = (int)d->h; p.W = (int)d->w; p.M = (int)d->m; p.OH = (int)d->oh;
     p.OW = (int)d->ow; p.pad = d->pad; p.tw_log2 = w.tw_log2; p.th_log2 = w.th_log2; p.tiles_x = w.tiles_x;
     p.tiles_y = w.tiles_y; p.tiles_n = w.tiles_n; p.chunks = w.chunks; p.chunks_per_slice = w.cps; p.Ap = w.Ap;
     p.Bp = w.Bp;
+    p.l_scale = mod.x_scale; p.s_scale = mod.y_scale;
     if (!w.bx) {
         const int tw = 1 << w.tw_log2, th = 1 << w.th_log2, tn = kWgPix / (tw * th);
         const int ph = (d->kh == 1) ? th : (th - 1) * d->stride + d->kh;
         const int pw = (d->kh == 1) ? tw : (tw - 1) * d->stride + d->kh;
         const int cap = (d->kh == 1) ? 65 : (d->stride == 1 ? 145 : 325);
-        if (tn * ph * pw > cap) return fail(SAE_EINVAL, "sae_conv2d_wgrad_f32: patch exceeds LDS cap");
+        if (tn * ph * pw > cap) return fail(SAE_EINVAL, "%s: patch exceeds LDS cap", who);
     }
     if (d->n > 0 && w.bx) {
         WgBxParams q{};
@@ -2367,5 +2543,6 @@ extern "C" int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const float*)workspace,
                        gw, (int)d->m, (int)d->c, w.Ap, w.Bp, w.taps, d->n > 0 ? w.slices : 0, d->w_stride_m,
                        d->w_stride_c, alpha);
-    return check_launch("sae_conv2d_wgrad_f32");
+    return check_launch(who);
 }
+}  // namespace

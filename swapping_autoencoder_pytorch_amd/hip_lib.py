@@ -36,6 +36,12 @@ class ConvDesc(C.Structure):
         return tuple(getattr(self, f) for f, _ in self._fields_)
 
 
+class ConvMod(C.Structure):
+    """Mirror of ``sae_conv2d_mod``: optional per-(sample, channel) activation factors and per-channel weight factors
+    of a style-modulated convolution (device pointers, 0 = absent)."""
+    _fields_ = [("x_scale", C.c_void_p), ("y_scale", C.c_void_p), ("wm_scale", C.c_void_p), ("wc_scale", C.c_void_p)]
+
+
 _SIGNATURES = {
     "abi_version": (C.c_int, []),
     "last_error": (C.c_char_p, []),
@@ -61,6 +67,9 @@ _SIGNATURES = {
                                           _stream]),
     "conv2d_dgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "conv2d_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
+    "modconv2d_fwd_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),
+    "modconv2d_dgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),
+    "modconv2d_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),
     "gemm_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _stream]),
     "add_scale_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _f32, _stream]),
     "adam_multi_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64, C.c_double,

@@ -16,9 +16,10 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import rng
+from . import hip_lib, rng
 from .stylegan2_op import (FusedLeakyReLU, ReflectionPad2d, add_scale, conv2d, conv2d_bias_act, conv_transpose2d,
-                           fusable, fused_leaky_relu, linear, noise_bias_act, plane_scale, reflect_pad, upfirdn2d)
+                           fusable, fused_leaky_relu, linear, modulated_conv2d, noise_bias_act, plane_scale, reflect_pad,
+                           upfirdn2d)
 
 
 def make_kernel(k):
@@ -206,8 +207,20 @@ class ModulatedConv2d(nn.Module):
             w = w * torch.rsqrt(w.pow(2).sum([1, 2, 3], keepdim=True) + 1e-8)
         return w
 
+    def _demod(self):
+        """rsqrt(sum_{i,kh,kw} (W * scale)^2 + eps) per output channel (:290-292), from the un-modulated weight"""
+        w = self.weight[0]
+        return torch.rsqrt((w * w).sum(dim=(1, 2, 3)) * (self.scale * self.scale) + 1e-8)
+
     def forward(self, input, style):
         s = self._input_scale(input, style)
+        if s.dim() == 2 and not self.downsample and input.dtype == torch.float32 and hip_lib.get_conv_math() == "f32":
+            # ONE kernel per operation: style factor folded into the conv's operand staging, demodulation into its
+            # weight re-layout (stylegan2_op.conv2d_gemm.ModulatedConv).  Under the bf16x6 arithmetic the operand
+            # staging does not take activation factors yet: the two-step path below runs there.
+            out = modulated_conv2d(input, s, self.weight[0], self._demod() if self.demodulate else None,
+                                   padding=self.padding, alpha=self.scale, transposed=self.upsample)
+            return self.blur(out) if self.upsample else out
         if s.dim() == 2:
             # x * s[:, :, None, None]; its backward (g * s and sum_hw g * x) is one fused pass
             x = plane_scale(input, s) if fusable(input) else input * s[:, :, None, None]

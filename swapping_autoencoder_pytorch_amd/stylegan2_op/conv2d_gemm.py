@@ -212,6 +212,107 @@ class ConvBiasAct(Function):
         return gx, gw, gb, None, None, None
 
 
+# ------------------------------------------------------------------------------------------------
+# style-modulated convolution
+# ------------------------------------------------------------------------------------------------
+def _launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_scale=None, wc_scale=None):
+    """One sae_modconv2d_* call: the plain operation `op` on a * factor, b (weights or second activation) with the
+    optional [N, C] activation factors and per-channel weight factors staged inside the kernels."""
+    lib = hip_lib.get()
+    a = a.contiguous()
+    b = b.contiguous()
+    factors = [None if f is None else f.contiguous() for f in (x_scale, y_scale, wm_scale, wc_scale)]
+    lib.check(a, b, *factors)
+    d = geom.desc()
+    mod = hip_lib.ConvMod(*[hip_lib.ptr(f) for f in factors])
+    n_ws = lib.query("conv2d_workspace", C.byref(d), op)
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=a.device)
+    out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
+    lib.call(name, a.data_ptr(), b.data_ptr(), out.data_ptr(), C.byref(d), C.byref(mod), geom.alpha, ws.data_ptr(), n_ws,
+             lib.stream(a))
+    return out
+
+
+class ModulatedConv(Function):
+    """ModulatedConv2d's arithmetic (stylegan2_layers.py:280-321) as one kernel per operation:
+
+        out = conv(x * s[:, :, None, None],  W * alpha * demod[:, None, None, None])          (plain, stride 1)
+        out = conv_transpose(x * s[:, :, None, None],  W * alpha * demod ..., stride 2)        (upsampling form)
+
+    The style factor `s` [N, I] is applied to the activation while the conv kernel stages it into LDS and the
+    demodulation factor `demod` [O] while it re-lays the weight, so neither x * s nor the modulated weight is ever
+    written to HBM (the reference materialises both, plus `batch` copies of the weight, :287).  `w` is the parameter's
+    [O, I, k, k] slice in both forms.  Backward: the data gradient kernel (demod folded), then ONE pass that forms
+    grad_x = g * s and grad_s = sum_hw g * x, and the weight-gradient kernel with `s` folded into its operand staging;
+    the gradients w.r.t. `w` and `demod` follow from the effective-weight gradient by the product rule.  First-order
+    only (the generator is never differentiated twice; the R1 penalties touch D and Dpatch)."""
+
+    @staticmethod
+    def forward(ctx, x, s, w, demod, geom, transposed):
+        ctx.set_materialize_grads(False)
+        ctx.cfg = (geom, transposed)
+        ctx.save_for_backward(x, s, w, demod)
+        if transposed:      # dgrad of the forward-orientation problem: x is its y side, the result its x side
+            return _launch_mod("modconv2d_dgrad_f32", SAE_CONV_DGRAD, geom, x, w, (geom.n, geom.c, geom.h, geom.w),
+                               y_scale=s, wc_scale=demod)
+        return _launch_mod("modconv2d_fwd_f32", SAE_CONV_FWD, geom, x, w, (geom.n, geom.m, geom.oh, geom.ow),
+                           x_scale=s, wm_scale=demod)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x, s, w, demod = ctx.saved_tensors
+        geom, transposed = ctx.cfg
+        if gout is None:
+            gw = torch.zeros_like(w) if (ctx.needs_input_grad[2] and _Flags.weight_grads) else None
+            gd = torch.zeros_like(demod) if (demod is not None and ctx.needs_input_grad[3]) else None
+            return None, None, gw, gd, None, None
+        gout = gout.contiguous()
+        gx = gs = gw = gd = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            if transposed:
+                g = _launch_mod("modconv2d_fwd_f32", SAE_CONV_FWD, geom, gout, w, (geom.n, geom.m, geom.oh, geom.ow),
+                                wc_scale=demod)
+            else:
+                g = _launch_mod("modconv2d_dgrad_f32", SAE_CONV_DGRAD, geom, gout, w, (geom.n, geom.c, geom.h, geom.w),
+                                wm_scale=demod)
+            from .modulate import fusable, plane_scale_backward
+            if fusable(g):
+                gx, gs = plane_scale_backward(g, x, s)       # g * s and sum_hw g * x in one pass
+            else:
+                gx, gs = g * s[:, :, None, None], (g * x).sum(dim=(2, 3))
+        if (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and _Flags.weight_grads:
+            if transposed:
+                geff = _launch_mod("modconv2d_wgrad_f32", SAE_CONV_WGRAD, geom, gout, x, geom.weight_shape(), y_scale=s)
+            else:
+                geff = _launch_mod("modconv2d_wgrad_f32", SAE_CONV_WGRAD, geom, x, gout, geom.weight_shape(), x_scale=s)
+            # geff = alpha * d(loss)/d(effective weight), effective weight = w * alpha * demod[o]
+            if demod is None:
+                gw = geff
+            else:
+                gw = geff * demod[:, None, None, None]
+                gd = (geff * w).sum(dim=(1, 2, 3))
+        return gx, gs, gw, gd, None, None
+
+
+def modulated_conv2d(input, style_scale, weight, demod=None, padding=0, alpha=1.0, transposed=False):
+    """The modulated conv of ModulatedConv2d in its dense-equivalent form.  input [N, I, H, W], style_scale [N, I],
+    weight [O, I, k, k], demod [O] or None; transposed=True is the stride-2 upsampling form (output (2H+1) x (2W+1))."""
+    _check_weight(weight)
+    n, c_in, h, w = input.shape
+    o, i2, k, _ = weight.shape
+    if i2 != c_in or tuple(style_scale.shape) != (n, c_in):
+        raise hip_lib.SaeError("modulated_conv2d: input %s, style %s, weight %s do not fit" % (
+            tuple(input.shape), tuple(style_scale.shape), tuple(weight.shape)))
+    if transposed:
+        oh, ow = (h - 1) * 2 + k, (w - 1) * 2 + k
+        geom = _Geom(n, o, oh, ow, c_in, k, 2, 0, True, alpha)
+        assert (geom.oh, geom.ow) == (h, w)
+    else:
+        geom = _Geom(n, c_in, h, w, o, k, 1, padding, False, alpha)
+    return ModulatedConv.apply(input, style_scale, weight, demod, geom, transposed)
+
+
 def _check_weight(weight):
     if weight.dim() != 4 or weight.shape[2] != weight.shape[3]:
         raise hip_lib.SaeError("conv weight must be [M, C, k, k], got %s" % (tuple(weight.shape),))

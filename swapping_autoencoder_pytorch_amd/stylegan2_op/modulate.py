@@ -139,6 +139,20 @@ class PlaneScaleBackward(Function):
         return grad_g, grad_x, grad_s
 
 
+def plane_scale_backward(g, x, s):
+    """(g * s[:, :, None, None], sum_hw g * x) in one pass (plain tensors, no autograd graph): the backward of the style
+    modulation, used by conv2d_gemm.ModulatedConv."""
+    lib = hip_lib.get()
+    g, x, s = g.contiguous(), x.contiguous(), s.contiguous()
+    lib.check(g, x, s)
+    n, c, h, w = x.shape
+    gx = torch.empty_like(g)
+    gs = torch.empty_like(s)
+    lib.call("plane_scale_dot_f32", g.data_ptr(), x.data_ptr(), s.data_ptr(), gx.data_ptr(), gs.data_ptr(), n * c, h * w,
+             lib.stream(x))
+    return gx, gs
+
+
 def plane_scale(x, s):
     """x * s[:, :, None, None] for x: [N, C, H, W], s: [N, C]."""
     return PlaneScaleFunction.apply(x, s)

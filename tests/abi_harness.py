@@ -7,7 +7,7 @@ import ctypes as C
 
 import numpy as np
 
-from swapping_autoencoder_pytorch_amd.hip_lib import ConvDesc
+from swapping_autoencoder_pytorch_amd.hip_lib import ConvDesc, ConvMod
 
 OPS = ("conv2d_fwd_f32", "conv2d_dgrad_f32", "conv2d_wgrad_f32")
 
@@ -220,3 +220,16 @@ def adam_multi(lib, params, grads, ms, vs, steps, lr, beta1, beta2, eps, grad_sc
              _stream(device))
     cut = lambda bufs: [b.numpy()[offset_elems:] for b in bufs]
     return cut(bp), cut(bm), cut(bv)
+
+
+MOD_OPS = ("modconv2d_fwd_f32", "modconv2d_dgrad_f32", "modconv2d_wgrad_f32")
+
+
+def modconv(lib, op, d, a, b, out_shape, x_scale=None, y_scale=None, wm_scale=None, wc_scale=None, alpha=1.0, device=None):
+    """sae_modconv2d_{fwd,dgrad,wgrad}_f32 on numpy operands; the factor arrays are optional."""
+    n = lib.query("conv2d_workspace", C.byref(d), op)
+    ba, bb, bo, ws = _Buf(a, device), _Buf(b, device), _out(out_shape, device), _out((max(n, 1),), device)
+    keep = [(_Buf(v, device) if v is not None else None) for v in (x_scale, y_scale, wm_scale, wc_scale)]
+    mod = ConvMod(*[(k.ptr if k is not None else None) for k in keep])
+    lib.call(MOD_OPS[op], ba.ptr, bb.ptr, bo.ptr, C.byref(d), C.byref(mod), alpha, ws.ptr, n, _stream(device))
+    return bo.numpy()
