@@ -103,6 +103,7 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamArgs a, float gs
 extern "C" int sae_adam_multi_f32(float* const* params, const float* const* grads, float* const* exp_avg,
                                   float* const* exp_avg_sq, const int64_t* numel, const int64_t* step, int64_t count,
                                   double lr, double beta1, double beta2, double eps, double grad_scale, sae_stream_t stream) {
+    sae::clear_stale_error();
     using namespace sae;
     if (count < 0 || (count > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !step)))
         return fail(SAE_EINVAL, "sae_adam_multi_f32: null table");

@@ -222,6 +222,7 @@ using namespace sae;
 extern "C" int sae_bias_act_f32(const float* x, const float* b, const float* ref, float* y,
                                 int64_t numel, int64_t step_b, int64_t size_b, int32_t act,
                                 int32_t grad, float alpha, float scale, sae_stream_t stream) {
+    sae::clear_stale_error();
     if (numel < 0 || (act != 1 && act != 3) || grad < 0 || grad > 2)
         return fail(SAE_EINVAL, "sae_bias_act_f32: unsupported act=%d grad=%d or numel=%lld", act, grad,
                     (long long)numel);
@@ -267,6 +268,7 @@ extern "C" int sae_bias_act_bwd_f32(const float* gy, const float* y_ref, float* 
                                     float* workspace, int64_t workspace_floats, int64_t numel,
                                     int64_t step_b, int64_t size_b, float alpha, float scale,
                                     sae_stream_t stream) {
+    sae::clear_stale_error();
     if (step_b < 1 || size_b < 1 || numel < 0 || numel % (step_b * size_b) != 0)
         return fail(SAE_EINVAL, "sae_bias_act_bwd_f32: numel=%lld is not outer*size_b*step_b (%lld,%lld)",
                     (long long)numel, (long long)size_b, (long long)step_b);
@@ -324,6 +326,7 @@ __global__ __launch_bounds__(kBlock) void add_scale_kernel(const float* __restri
 
 extern "C" int sae_add_scale_f32(const float* a, const float* b, float* y, int64_t numel, float alpha,
                                  sae_stream_t stream) {
+    sae::clear_stale_error();
     if (numel < 0) return fail(SAE_EINVAL, "sae_add_scale_f32: negative size");
     if (numel == 0) return SAE_OK;
     if (!a || !b || !y) return fail(SAE_EINVAL, "sae_add_scale_f32: null tensor");

@@ -2394,18 +2394,21 @@ int conv_fwd_impl(const char* who, const float* x, const float* w, float* y, con
 
 extern "C" int sae_conv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d, float alpha,
                                   float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
     return conv_fwd_impl("sae_conv2d_fwd_f32", x, w, y, d, kNoMod, alpha, workspace, workspace_floats, stream);
 }
 
 extern "C" int sae_modconv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d,
                                      const sae_conv2d_mod* mod, float alpha, float* workspace, int64_t workspace_floats,
                                      sae_stream_t stream) {
+    sae::clear_stale_error();
     return conv_fwd_impl("sae_modconv2d_fwd_f32", x, w, y, d, mod ? *mod : kNoMod, alpha, workspace, workspace_floats, stream);
 }
 
 extern "C" int sae_conv2d_fwd_bias_act_f32(const float* x, const float* w, const float* bias, float* y,
                                            const sae_conv2d_desc* d, float alpha, float act_slope, float act_scale,
                                            float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
     if (!desc_ok(d, "sae_conv2d_fwd_bias_act_f32")) return SAE_EINVAL;
     if (d->n == 0) return SAE_OK;
     if (!x || !w || !y) return fail(SAE_EINVAL, "sae_conv2d_fwd_bias_act_f32: null tensor");
@@ -2452,12 +2455,14 @@ int conv_dgrad_impl(const char* who, const float* gy, const float* w, float* gx,
 
 extern "C" int sae_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
                                     float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
     return conv_dgrad_impl("sae_conv2d_dgrad_f32", gy, w, gx, d, kNoMod, alpha, workspace, workspace_floats, stream);
 }
 
 extern "C" int sae_modconv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
                                        const sae_conv2d_mod* mod, float alpha, float* workspace,
                                        int64_t workspace_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
     return conv_dgrad_impl("sae_modconv2d_dgrad_f32", gy, w, gx, d, mod ? *mod : kNoMod, alpha, workspace, workspace_floats,
                            stream);
 }
@@ -2470,12 +2475,14 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
 
 extern "C" int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
                                     float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
     return conv_wgrad_impl("sae_conv2d_wgrad_f32", x, gy, gw, d, kNoMod, alpha, workspace, workspace_floats, stream);
 }
 
 extern "C" int sae_modconv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
                                        const sae_conv2d_mod* mod, float alpha, float* workspace,
                                        int64_t workspace_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
     return conv_wgrad_impl("sae_modconv2d_wgrad_f32", x, gy, gw, d, mod ? *mod : kNoMod, alpha, workspace, workspace_floats,
                            stream);
 }

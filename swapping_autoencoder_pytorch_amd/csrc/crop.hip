@@ -136,6 +136,7 @@ using namespace sae;
 extern "C" int sae_random_crop_f32(const float* x, const float* params, const float* lin, float* y, int64_t images,
                                    int64_t channels, int64_t h, int64_t w, int64_t crops_per_image, int64_t size,
                                    sae_stream_t stream) {
+    sae::clear_stale_error();
     if (!crop_ok(images, channels, h, w, crops_per_image, size)) return fail(SAE_EINVAL, "sae_random_crop_f32: bad geometry");
     if (images == 0) return SAE_OK;
     if (!x || !params || !lin || !y) return fail(SAE_EINVAL, "sae_random_crop_f32: null tensor");
@@ -149,6 +150,7 @@ extern "C" int sae_random_crop_f32(const float* x, const float* params, const fl
 extern "C" int sae_random_crop_bwd_f32(const float* gy, const float* params, const float* lin, float* gx, int64_t images,
                                        int64_t channels, int64_t h, int64_t w, int64_t crops_per_image, int64_t size,
                                        sae_stream_t stream) {
+    sae::clear_stale_error();
     if (!crop_ok(images, channels, h, w, crops_per_image, size)) return fail(SAE_EINVAL, "sae_random_crop_bwd_f32: bad geometry");
     if (images == 0) return SAE_OK;
     if (!gy || !params || !lin || !gx) return fail(SAE_EINVAL, "sae_random_crop_bwd_f32: null tensor");

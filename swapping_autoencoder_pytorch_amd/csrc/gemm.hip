@@ -146,6 +146,7 @@ using namespace sae;
 extern "C" int sae_gemm_f32(const float* a, const float* b, const float* bias, float* c, int64_t m, int64_t n,
                             int64_t k, int64_t a_si, int64_t a_sk, int64_t b_sk, int64_t b_sj, int64_t ldc,
                             float alpha, sae_stream_t stream) {
+    sae::clear_stale_error();
     if (m < 0 || n < 0 || k < 0) return fail(SAE_EINVAL, "sae_gemm_f32: negative size");
     if (m == 0 || n == 0) return SAE_OK;
     if (!c || (k > 0 && (!a || !b))) return fail(SAE_EINVAL, "sae_gemm_f32: null matrix");

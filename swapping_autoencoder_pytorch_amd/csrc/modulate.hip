@@ -205,6 +205,7 @@ using namespace sae;
 extern "C" int sae_noise_bias_act_f32(const float* x, const float* noise, const float* noise_weight,
                                       const float* bias, float* y, int64_t outer, int64_t channels, int64_t hw,
                                       float alpha, float scale, sae_stream_t stream) {
+    sae::clear_stale_error();
     if (!shape_ok(outer, channels, hw))
         return fail(SAE_EINVAL, "sae_noise_bias_act_f32: need hw %% 4 == 0, got [%lld, %lld, %lld]", (long long)outer,
                     (long long)channels, (long long)hw);
@@ -230,6 +231,7 @@ extern "C" int sae_noise_bias_act_bwd_f32(const float* gy, const float* y_ref, c
                                           float* gbias, float* gnoise_weight, float* workspace,
                                           int64_t workspace_floats, int64_t outer, int64_t channels, int64_t hw,
                                           float alpha, float scale, sae_stream_t stream) {
+    sae::clear_stale_error();
     if (!shape_ok(outer, channels, hw))
         return fail(SAE_EINVAL, "sae_noise_bias_act_bwd_f32: need hw %% 4 == 0, got [%lld, %lld, %lld]",
                     (long long)outer, (long long)channels, (long long)hw);
@@ -260,6 +262,7 @@ extern "C" int sae_noise_bias_act_bwd_f32(const float* gy, const float* y_ref, c
 
 extern "C" int sae_plane_scale_dot_f32(const float* g, const float* x, const float* s, float* gx, float* gs,
                                        int64_t planes, int64_t hw, sae_stream_t stream) {
+    sae::clear_stale_error();
     if (planes < 0 || hw < 4 || hw % 4 != 0 || hw >= ((int64_t)1 << 30) || planes >= ((int64_t)1 << 31))
         return fail(SAE_EINVAL, "sae_plane_scale_dot_f32: need hw %% 4 == 0, got planes=%lld hw=%lld",
                     (long long)planes, (long long)hw);

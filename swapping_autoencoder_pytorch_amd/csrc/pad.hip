@@ -68,6 +68,7 @@ using namespace sae;
 
 extern "C" int sae_reflect_pad_f32(const float* x, float* y, int64_t planes, int64_t h, int64_t w, int32_t left,
                                    int32_t right, int32_t top, int32_t bottom, sae_stream_t stream) {
+    sae::clear_stale_error();
     if (!pad_ok(planes, h, w, left, right, top, bottom))
         return fail(SAE_EINVAL, "sae_reflect_pad_f32: pads must be non-negative and smaller than the image");
     if (planes == 0) return SAE_OK;
@@ -81,6 +82,7 @@ extern "C" int sae_reflect_pad_f32(const float* x, float* y, int64_t planes, int
 
 extern "C" int sae_reflect_pad_adj_f32(const float* gy, float* gx, int64_t planes, int64_t h, int64_t w, int32_t left,
                                        int32_t right, int32_t top, int32_t bottom, sae_stream_t stream) {
+    sae::clear_stale_error();
     if (!pad_ok(planes, h, w, left, right, top, bottom))
         return fail(SAE_EINVAL, "sae_reflect_pad_adj_f32: pads must be non-negative and smaller than the image");
     if (planes == 0) return SAE_OK;

@@ -22,6 +22,10 @@ constexpr int kBlock = 256;     // 4 waves, one per SIMD of a CU
 char* err_buf();                // thread-local message buffer (sae_api.hip)
 int fail(int code, const char* fmt, ...);
 
+// hipGetLastError() is per thread and sticky: a probe that failed inside another library (e.g. during the framework's
+// device discovery) would otherwise be reported by our first check_launch.  Every entry point clears it on entry.
+inline void clear_stale_error() { (void)hipGetLastError(); }
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SAE_ELAUNCH, "%s: %s", what, hipGetErrorString(e));

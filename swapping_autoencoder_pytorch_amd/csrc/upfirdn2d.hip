@@ -319,6 +319,7 @@ extern "C" int sae_upfirdn2d_f32(const float* x, const float* k, float* y, int64
                                  int64_t in_w, int64_t minor, int32_t kh, int32_t kw, int32_t up_x,
                                  int32_t up_y, int32_t down_x, int32_t down_y, int32_t pad_x0,
                                  int32_t pad_x1, int32_t pad_y0, int32_t pad_y1, sae_stream_t stream) {
+    sae::clear_stale_error();
     if (up_x < 1 || up_y < 1 || down_x < 1 || down_y < 1 || kh < 1 || kw < 1 || (int64_t)kh * kw > 1024)
         return fail(SAE_EINVAL, "sae_upfirdn2d_f32: bad up/down/taps (%d,%d,%d,%d,%dx%d)", up_x, up_y, down_x,
                     down_y, kh, kw);

@@ -115,6 +115,7 @@ static int check_up2(const char* who, const void* a, const void* b, int64_t plan
 
 extern "C" int sae_upsample2x_bilinear_add_f32(const float* x, const float* res, float* y, int64_t planes,
                                                int64_t h, int64_t w, float alpha, sae_stream_t stream) {
+    sae::clear_stale_error();
     const int rc = check_up2("sae_upsample2x_bilinear_add_f32", x, y, planes, h, w);
     if (rc != SAE_OK || planes == 0) return rc;
     Up2Params p{planes, (int)h, (int)w, alpha};
@@ -126,6 +127,7 @@ extern "C" int sae_upsample2x_bilinear_add_f32(const float* x, const float* res,
 
 extern "C" int sae_upsample2x_bilinear_bwd_f32(const float* gy, float* gx, int64_t planes, int64_t h, int64_t w,
                                                float alpha, sae_stream_t stream) {
+    sae::clear_stale_error();
     const int rc = check_up2("sae_upsample2x_bilinear_bwd_f32", gy, gx, planes, h, w);
     if (rc != SAE_OK || planes == 0) return rc;
     Up2Params p{planes, (int)h, (int)w, alpha};

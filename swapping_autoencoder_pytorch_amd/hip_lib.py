@@ -95,6 +95,11 @@ class SaeLibrary:
         self.path = path
         self.prefix = prefix
         self.device_only = device_only
+        if device_only:
+            # PyTorch-ROCm ships its own libamdhip64: it must be in the process BEFORE this library is loaded, so that
+            # both bind to the same HIP runtime (loading ours first pulls in the system runtime, whose launches then
+            # fail with "no ROCm-capable device" on pointers the other runtime allocated)
+            import torch  # noqa: F401
         self._dll = C.CDLL(path)
         self._fn = {}
         for name, (restype, argtypes) in _SIGNATURES.items():

@@ -10,6 +10,7 @@ Not carried over (unused by the Swapping-Autoencoder networks, SURVEY.md §2 row
 ``ConstantInput`` and the original StyleGAN2 ``Generator``.
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -20,6 +21,10 @@ from . import hip_lib, rng
 from .stylegan2_op import (FusedLeakyReLU, ReflectionPad2d, add_scale, conv2d, conv2d_bias_act, conv_transpose2d,
                            fusable, fused_leaky_relu, linear, modulated_conv2d, noise_bias_act, plane_scale, reflect_pad,
                            upfirdn2d)
+
+
+# SAE_MODCONV_FUSED=0 (debug / A-B measurements): ModulatedConv2d takes the two-step path (x * s, then a plain conv)
+_FUSED_MODCONV = os.environ.get("SAE_MODCONV_FUSED", "1") != "0"
 
 
 def make_kernel(k):
@@ -209,12 +214,16 @@ class ModulatedConv2d(nn.Module):
 
     def _demod(self):
         """rsqrt(sum_{i,kh,kw} (W * scale)^2 + eps) per output channel (:290-292), from the un-modulated weight"""
-        w = self.weight[0]
-        return torch.rsqrt((w * w).sum(dim=(1, 2, 3)) * (self.scale * self.scale) + 1e-8)
+        # evaluated exactly as the reference does (scale first, then square, sum, rsqrt): the conv kernels then see
+        # bit-identical operands on the fused and on the two-step path (a leaky-ReLU sitting within 1e-7 of zero
+        # downstream turns any other rounding into a visibly different gradient)
+        w = self.weight[0] * self.scale
+        return torch.rsqrt(w.pow(2).sum(dim=(1, 2, 3)) + 1e-8)
 
     def forward(self, input, style):
         s = self._input_scale(input, style)
-        if s.dim() == 2 and not self.downsample and input.dtype == torch.float32 and hip_lib.get_conv_math() == "f32":
+        if (s.dim() == 2 and not self.downsample and input.dtype == torch.float32 and _FUSED_MODCONV
+                and hip_lib.get_conv_math() == "f32"):
             # ONE kernel per operation: style factor folded into the conv's operand staging, demodulation into its
             # weight re-layout (stylegan2_op.conv2d_gemm.ModulatedConv).  Under the bf16x6 arithmetic the operand
             # staging does not take activation factors yet: the two-step path below runs there.
