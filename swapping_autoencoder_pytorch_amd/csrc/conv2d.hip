@@ -90,6 +90,10 @@ struct IgemmParams {
     // style modulation of the INPUT (ModulatedConv2d, stylegan2_layers.py:280-286): when non-null, x[n][c][..] is
     // multiplied by in_scale[n * C + c] on its way into LDS, so the modulated activation never exists in HBM
     const float* in_scale;
+    // always 0.  The per-channel factor of a one-image tile is wave-uniform; indexing it with (lane & zmask) keeps the
+    // compiler from turning it into scalar-cache loads, whose out-of-order return shares the LDS wait counter
+    // (lgkmcnt) and would serialise the ds_read pipeline of the MFMA loop
+    int zmask;
 };
 
 template <int KS, int S, int BN>
@@ -204,8 +208,9 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
         }
         if constexpr (MOD) {
             if (one_image) {
+                const float* srow = p.in_scale + n0 * p.C + (lane & p.zmask);
 #pragma unroll
-                for (int ch = 0; ch < CK; ++ch) sc[ch] = p.in_scale[n0 * p.C + ((c0 + ch) < p.C ? c0 + ch : 0)];
+                for (int ch = 0; ch < CK; ++ch) sc[ch] = srow[(c0 + ch) < p.C ? c0 + ch : 0];
             }
         }
 #pragma unroll
@@ -222,11 +227,18 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     };
     auto store_chunk = [&](int c0) {
         if constexpr (MOD) {
+            if (one_image) {
 #pragma unroll
-            for (int ch = 0; ch < CK; ++ch) {
-                const int cc = (c0 + ch) < p.C ? c0 + ch : 0;
+                for (int ch = 0; ch < CK; ++ch)
 #pragma unroll
-                for (int s = 0; s < PPT; ++s) xv[ch][s] *= one_image ? sc[ch] : p.in_scale[sidx[s] + cc];
+                    for (int s = 0; s < PPT; ++s) xv[ch][s] *= sc[ch];
+            } else {     // small images, several per tile: the factor depends on the slot's image
+#pragma unroll
+                for (int ch = 0; ch < CK; ++ch) {
+                    const int cc = (c0 + ch) < p.C ? c0 + ch : 0;
+#pragma unroll
+                    for (int s = 0; s < PPT; ++s) xv[ch][s] *= p.in_scale[sidx[s] + cc];
+                }
             }
         }
 #pragma unroll
@@ -820,6 +832,7 @@ struct TrParams {
     int Cp, Mp;
     int pad;
     const float* in_scale;  // [N][C] or null: style modulation of the input, applied while staging (see IgemmParams)
+    int zmask;              // always 0 (see IgemmParams)
     // main region + right / bottom strips, all in ONE launch (blockIdx.x runs through the regions):
     // launched one after the other the two thin strips cost a full K loop of latency each on a
     // nearly empty GPU
@@ -926,8 +939,9 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
         }
         if constexpr (MOD) {
             if (one_image) {
+                const float* srow = p.in_scale + n0 * p.C + (lane & p.zmask);
 #pragma unroll
-                for (int ch = 0; ch < CK; ++ch) sc[ch] = p.in_scale[n0 * p.C + ((c0 + ch) < p.C ? c0 + ch : 0)];
+                for (int ch = 0; ch < CK; ++ch) sc[ch] = srow[(c0 + ch) < p.C ? c0 + ch : 0];
             }
         }
 #pragma unroll
@@ -944,11 +958,18 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
     };
     auto store_chunk = [&](int c0) {
         if constexpr (MOD) {
+            if (one_image) {
 #pragma unroll
-            for (int ch = 0; ch < CK; ++ch) {
-                const int cc = (c0 + ch) < p.C ? c0 + ch : 0;
+                for (int ch = 0; ch < CK; ++ch)
 #pragma unroll
-                for (int s = 0; s < PPT; ++s) xv[ch][s] *= one_image ? sc[ch] : p.in_scale[sidx[s] + cc];
+                    for (int s = 0; s < PPT; ++s) xv[ch][s] *= sc[ch];
+            } else {     // small images, several per tile: the factor depends on the slot's image
+#pragma unroll
+                for (int ch = 0; ch < CK; ++ch) {
+                    const int cc = (c0 + ch) < p.C ? c0 + ch : 0;
+#pragma unroll
+                    for (int s = 0; s < PPT; ++s) xv[ch][s] *= p.in_scale[sidx[s] + cc];
+                }
             }
         }
 #pragma unroll
@@ -1219,6 +1240,7 @@ struct WgradParams {
     // y side of the forward-orientation problem), applied while the operand is written to LDS
     const float* l_scale;
     const float* s_scale;
+    int zmask;            // always 0 (see IgemmParams)
 };
 
 constexpr int kWgPix = 64;
@@ -1312,7 +1334,11 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     constexpr bool BRANCHFREE = KS == 3 && S == 2 && !PIXSPLIT;
     bool s_ok = false;      // validity of the prefetched chunk's elements (applied in store_chunk)
     int l_okmask = 0;
-    [[maybe_unused]] int pf_n0 = 0;   // first image of the prefetched chunk (operand modulation looks its factors up at store time)
+    [[maybe_unused]] int pf_n0 = 0;   // first image of the prefetched chunk (operand modulation)
+    // factors of the prefetched chunk when it lies in one image (TN == 1: every layer with >= 64 pixels per image),
+    // fetched with the chunk so their latency hides under the MFMAs like the operands' own
+    [[maybe_unused]] float ssc[MOD ? NS : 1];
+    [[maybe_unused]] float lsc[MOD ? NLB : 1];
 
     auto load_chunk = [&](int chunk) {
         int bt = chunk;
@@ -1320,7 +1346,26 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
         const int tiy = bt % p.tiles_y;
         const int tin = bt / p.tiles_y;
         const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
-        if constexpr (MOD) pf_n0 = n0;
+        if constexpr (MOD) {
+            pf_n0 = n0;
+            if (TN == 1) {
+                const int z = lane & p.zmask;
+                if (p.s_scale) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) {
+                        const int a = a0 + wid + 4 * i;
+                        ssc[i] = p.s_scale[n0 * p.M + (a < p.M ? a : 0) + z];
+                    }
+                }
+                if (p.l_scale) {
+#pragma unroll
+                    for (int j = 0; j < NLB; ++j) {
+                        const int b = b0 + wid + 4 * j;
+                        lsc[j] = p.l_scale[n0 * p.C + (b < p.C ? b : 0) + z];
+                    }
+                }
+            }
+        }
         // addressing: one wave-uniform 64-bit base per tensor + 32-bit (lane + channel) offsets,
         // so loads use the SGPR-base form and no per-channel pointer is kept in registers
         {
@@ -1383,23 +1428,35 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     };
     auto store_chunk = [&]() {
         if (MOD && p.s_scale) {        // modulated S operand: factor of (image of this lane's pixel, channel a)
-            const int n = pf_n0 + (lane >> (p.tw_log2 + p.th_log2));
+            if (TN == 1) {
 #pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const int a = a0 + wid + 4 * i;
-                sv[i] *= p.s_scale[(n < p.N ? n : 0) * p.M + (a < p.M ? a : 0)];
+                for (int i = 0; i < NS; ++i) sv[i] *= ssc[i];
+            } else {
+                const int n = pf_n0 + (lane >> (p.tw_log2 + p.th_log2));
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int a = a0 + wid + 4 * i;
+                    sv[i] *= p.s_scale[(n < p.N ? n : 0) * p.M + (a < p.M ? a : 0)];
+                }
             }
         }
         if (MOD && p.l_scale) {        // modulated L operand: factor of (image of the patch element, channel b)
+            if (TN == 1) {
 #pragma unroll
-            for (int s = 0; s < LS; ++s) {
-                const int e = lane + kWave * s;
-                const int n = pf_n0 + (e < CPs ? e / IP : 0);
-                const int row = (n < p.N ? n : 0) * p.C;
+                for (int j = 0; j < NLB; ++j)
 #pragma unroll
-                for (int j = 0; j < NLB; ++j) {
-                    const int b = b0 + wid + 4 * j;
-                    lv[j][s] *= p.l_scale[row + (b < p.C ? b : 0)];
+                    for (int s = 0; s < LS; ++s) lv[j][s] *= lsc[j];
+            } else {
+#pragma unroll
+                for (int s = 0; s < LS; ++s) {
+                    const int e = lane + kWave * s;
+                    const int n = pf_n0 + (e < CPs ? e / IP : 0);
+                    const int row = (n < p.N ? n : 0) * p.C;
+#pragma unroll
+                    for (int j = 0; j < NLB; ++j) {
+                        const int b = b0 + wid + 4 * j;
+                        lv[j][s] *= p.l_scale[row + (b < p.C ? b : 0)];
+                    }
                 }
             }
         }
@@ -1857,10 +1914,16 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_bx_kernel(const float* __re
     }
 }
 
+// l_scale / s_scale / spi (slices per image, 0 = none): operand modulation applied per K-slice.  When every slice
+// of the pixel range lies inside one image n, the factor of a modulated operand, l_scale[n][c] or s_scale[n][m], is
+// constant over the slice and can multiply the slice's partial sum here instead of every staged operand element
+// in the main kernel (host: conv_wgrad_impl), which then runs its un-modulated instantiation.
 __global__ __launch_bounds__(kBlock) void conv_wgrad_reduce_kernel(const float* __restrict__ slab,
                                                                    float* __restrict__ gw, int M, int C,
                                                                    int Ap, int Bp, int taps, int slices,
-                                                                   int64_t sm, int64_t sc, float alpha) {
+                                                                   int64_t sm, int64_t sc, float alpha,
+                                                                   const float* __restrict__ l_scale,
+                                                                   const float* __restrict__ s_scale, int spi) {
     // Four lanes per output element, each summing every fourth slice with eight loads in flight, combined in a
     // fixed order ((q0 + q1) + (q2 + q3)): a chain of `slices` dependent loads per thread on ~2 workgroups per CU
     // ran at 1.2 TB/s.  Deterministic (the order depends only on `slices`).
@@ -1878,6 +1941,15 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_reduce_kernel(const float* 
         const float* s = slab + ((int64_t)tap * Ap + m) * Bp + c;
         float acc = 0.0f;
         int sl = q;
+        if (spi > 0) {       // per-slice operand factors (same slice order as below: the sum stays deterministic)
+            for (; sl < slices; sl += 4) {
+                const int n = sl / spi;
+                float f = 1.0f;
+                if (l_scale) f *= l_scale[(int64_t)n * C + c];
+                if (s_scale) f *= s_scale[(int64_t)n * M + m];
+                acc += s[sl * slice_stride] * f;
+            }
+        }
         for (; sl + 28 < slices; sl += 32) {
             float v[8];
 #pragma unroll
@@ -2508,7 +2580,18 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
     p.OW = (int)d->ow; p.pad = d->pad; p.tw_log2 = w.tw_log2; p.th_log2 = w.th_log2; p.tiles_x = w.tiles_x;
     p.tiles_y = w.tiles_y; p.tiles_n = w.tiles_n; p.chunks = w.chunks; p.chunks_per_slice = w.cps; p.Ap = w.Ap;
     p.Bp = w.Bp;
-    p.l_scale = mod.x_scale; p.s_scale = mod.y_scale;
+    // operand modulation: per K-slice in the reduction when every slice lies inside one image (large images: chunks
+    // of 64 pixels, one image per chunk, and a slice length that divides the chunks of an image), else per staged
+    // element in the MOD instantiation of the main kernel
+    int slices_per_image = 0;
+    {
+        const int tn = kWgPix >> (w.tw_log2 + w.th_log2);
+        const int cpi = w.tiles_x * w.tiles_y;
+        if ((mod.x_scale || mod.y_scale) && !w.bx && tn == 1 && w.cps <= cpi && cpi % w.cps == 0)
+            slices_per_image = cpi / w.cps;
+    }
+    p.l_scale = slices_per_image ? nullptr : mod.x_scale;
+    p.s_scale = slices_per_image ? nullptr : mod.y_scale;
     if (!w.bx) {
         const int tw = 1 << w.tw_log2, th = 1 << w.th_log2, tn = kWgPix / (tw * th);
         const int ph = (d->kh == 1) ? th : (th - 1) * d->stride + d->kh;
@@ -2549,7 +2632,8 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const float*)workspace,
                        gw, (int)d->m, (int)d->c, w.Ap, w.Bp, w.taps, d->n > 0 ? w.slices : 0, d->w_stride_m,
-                       d->w_stride_c, alpha);
+                       d->w_stride_c, alpha, slices_per_image ? mod.x_scale : nullptr,
+                       slices_per_image ? mod.y_scale : nullptr, slices_per_image);
     return check_launch(who);
 }
 }  // namespace

@@ -18,6 +18,7 @@ MODCONV_CASES = [
     (3, 20, 12, 12, 24, 3, 1, 1, False),     # wgrad MODE 1
     (2, 3, 16, 16, 40, 3, 1, 1, False),      # wgrad MODE 2
     (1, 36, 32, 32, 70, 3, 1, 1, False),
+    (3, 36, 32, 32, 70, 3, 1, 1, False),     # wgrad: one image per pixel chunk -> factors applied per K-slice in the reduction
 ]
 
 

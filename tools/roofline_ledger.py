@@ -32,15 +32,20 @@ def _desc(arg):
 
 def work_of(name, a):
     """(class label, bound, algorithmic work: FLOPs for 'mfma', bytes for 'hbm')"""
-    if name.startswith("conv2d_") and name != "conv2d_workspace":
+    if (name.startswith("conv2d_") and name != "conv2d_workspace") or name.startswith("modconv2d_"):
         d = _desc(a[4] if name == "conv2d_fwd_bias_act_f32" else a[3])
         op = {"conv2d_fwd_f32": "fwd", "conv2d_fwd_bias_act_f32": "fwd+bias+lrelu", "conv2d_dgrad_f32": "dgrad",
-              "conv2d_wgrad_f32": "wgrad"}[name]
+              "conv2d_wgrad_f32": "wgrad", "modconv2d_fwd_f32": "fwd (modulated)", "modconv2d_dgrad_f32": "dgrad (modulated)",
+              "modconv2d_wgrad_f32": "wgrad (modulated)"}[name]
         width = "narrow(<=64ch)" if max(d.m if op.startswith("fwd") else d.c, 1) <= 64 else "wide"
-        if op == "wgrad":
+        if op.startswith("wgrad"):
             width = "narrow(<=32ch)" if (d.m <= 32 and d.c <= 32) else "wide"
-        label = "conv %dx%d s%d %-14s %s" % (d.kh, d.kw, d.stride, op, width)
+        label = "conv %dx%d s%d %-17s %s" % (d.kh, d.kw, d.stride, op, width)
         return label, "mfma", 2.0 * d.n * d.m * d.oh * d.ow * d.c * d.kh * d.kw
+    if name == "adam_multi_f32":
+        n = a[6]
+        numel = sum(a[4][i] for i in range(n))
+        return "adam (multi-tensor)", "hbm", 28.0 * numel
     if name == "gemm_f32":
         m, n, k = a[4], a[5], a[6]
         return "gemm (linear layers)", "mfma", 2.0 * m * n * k
