@@ -26,7 +26,7 @@ def main(dirs):
                     dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
     for k, cs in agg.items():
         m = {c: sum(v) / len(v) for c, v in cs.items()}
-        if m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) == 0 and not any(t in k[0] for t in ("blur", "elementwise", "copy", "reduce")):
+        if m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) == 0 and not any(t in k[0] for t in ("blur", "elementwise", "copy", "reduce", "conv_")):
             continue
         us = sum(dur[k]) / len(dur[k]) / 1e3 if dur[k] else 0.0
         gui = m.get("GRBM_GUI_ACTIVE", 0.0)
