@@ -820,6 +820,200 @@ __global__ __launch_bounds__(kBlock8) void conv_igemm_bx8_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------
+// fp32 3x3 stride-1 gather on 8 waves with LDS-DMA weights: 128 x 256-pixel tile, ONE 512-thread workgroup per CU.
+// conv_igemm_kernel<3,1,2,2,2,2,8> keeps the matrix pipe 80 % busy: each of its two workgroups per CU stops at two
+// barriers per 8-channel chunk, writes the chunk to LDS from registers in between, and the two drift into phase.
+// Here (the structure of conv_igemm_bx8_kernel, in exact fp32):
+//   * the weight tile of chunk k+1 goes global -> LDS by DMA (global_load_lds_dwordx4, 16 B per lane: two rows
+//     [tap][channel][128 m] of the re-laid weights per wave instruction, landing lane-linear in the other buffer):
+//     no registers, no ds_write pass;
+//   * the input patch of chunk k+1 (one position per thread, 8 channels) is loaded to registers before the MFMAs of
+//     chunk k and written to the other buffer in the middle of them;
+//   * ONE barrier per chunk (vmcnt(0) first: DMA data is ordered for other waves' ds_reads only by the issuer's
+//     vmcnt followed by a barrier the reader has passed);
+//   * the weight tile is shared by 8 waves instead of 4: half the L2 -> LDS weight traffic per MFMA.
+// MFMA operand order, accumulation order per output element and the epilogue are those of conv_igemm_kernel, so the
+// two kernels produce bit-identical results.  Selected with SAE_F8=1 (gather_plan): it measured 3 % SLOWER than the
+// 4-wave kernel and is kept as the recorded experiment the round-1 review asked for.
+// ------------------------------------------------------------------------------------------
+template <int MI, int NI, int WM, int WN, bool MOD = false>
+__global__ __launch_bounds__(kBlock8) void conv_igemm_f8_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ wp,
+                                                                float* __restrict__ y, const IgemmParams p) {
+    static_assert(WM * WN == 8, "8 waves per workgroup");
+    constexpr int T = 9, CK = 8;
+    constexpr int BM = 32 * MI * WM;
+    constexpr int BN = 32 * NI * WN;
+    constexpr int XCAP = 2 * BN;                            // patch positions (host-checked): one per thread
+    static_assert(XCAP == kBlock8, "one patch position per thread");
+    constexpr int A_FLOATS = T * CK * BM;                   // weight tile of one chunk
+    constexpr int A_INSTR = A_FLOATS / 4 / kWave;           // DMA instructions per chunk (64 16-byte cells each)
+    static_assert((A_FLOATS / 4) % kWave == 0 && BM % 4 == 0, "A tile is a whole number of wave DMAs");
+    __shared__ float As[2][A_FLOATS];
+    __shared__ float Xs[2][CK * XCAP];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wid / WN, wn = wid % WN;
+
+    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
+    const int TN = BN >> (p.tw_log2 + p.th_log2);
+    int bt = blockIdx.x;
+    if (p.xcd_order && (gridDim.x & 7) == 0) bt = (bt & 7) * (gridDim.x >> 3) + (bt >> 3);   // see conv_igemm_kernel
+    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
+    const int tiy = bt % p.tiles_y;
+    const int tin = bt / p.tiles_y;
+    const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
+    const int m0 = blockIdx.y * BM;
+
+    const int PH = TH + 2, PW = TW + 2;
+    const int IP = PH * PW;
+    const int CP = TN * IP;           // staged positions (<= XCAP, checked on the host)
+    const int HW = p.H * p.W;
+
+    int poff = -1;
+    [[maybe_unused]] int sidx = 0;    // in_scale row of this thread's patch position
+    if (tid < CP) {
+        const int pn = tid / IP;
+        const int rem = tid - pn * IP;
+        const int r = rem / PW;
+        const int c = rem - r * PW;
+        const int iy = oy0 - p.pad + r, ix = ox0 - p.pad + c;
+        if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            poff = pn * p.C * HW + iy * p.W + ix;
+            if constexpr (MOD) sidx = (n0 + pn) * p.C;
+        }
+    }
+
+    int pixbase[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int pp = (wn * NI + ni) * 32 + l31;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> p.tw_log2) & (TH - 1);
+        const int pn = pp >> (p.tw_log2 + p.th_log2);
+        pixbase[ni] = pn * IP + py * PW + px;
+    }
+    int tapoff[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) tapoff[t] = (t / 3) * PW + (t % 3);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    const float* xb = x + (int64_t)n0 * p.C * HW;
+    float xv[CK];
+    [[maybe_unused]] float sv[MOD ? CK : 1];
+
+    // lane's 16-byte cell of DMA instruction j: cell e = 64 j + lane = row (tap * CK + ch) * (BM / 4) + col4
+    auto dma_a = [&](int c0, int buf) {
+        for (int j = wid; j < A_INSTR; j += WM * WN) {
+            const int e = j * kWave + lane;
+            const int row = e / (BM / 4), col4 = e - row * (BM / 4);
+            const int tap = row / CK, ch = row - tap * CK;
+            const float* src = wp + ((int64_t)tap * p.Cp + c0 + ch) * p.Mp + m0 + col4 * 4;
+            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(&As[buf][j * kWave * 4]), 16, 0, 0);
+        }
+    };
+    auto load_x = [&](int c0) {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch) {
+            // branch-free: invalid positions read element 0 of the tile's first image and are zeroed in store_x
+            const bool ok = (c0 + ch) < p.C && poff >= 0;
+            xv[ch] = xb[ok ? (int64_t)(c0 + ch) * HW + poff : 0];
+            if constexpr (MOD) sv[ch] = p.in_scale[sidx + ((c0 + ch) < p.C ? c0 + ch : 0)];
+        }
+    };
+    auto store_x = [&](int c0, int buf) {
+        if (tid < CP) {
+#pragma unroll
+            for (int ch = 0; ch < CK; ++ch) {
+                float v = ((c0 + ch) < p.C && poff >= 0) ? xv[ch] : 0.0f;
+                if constexpr (MOD) v *= sv[ch];
+                Xs[buf][ch * XCAP + tid] = v;
+            }
+        }
+    };
+
+    const int c_begin = blockIdx.z * p.chunks_per_split * CK;
+    int c_end = c_begin + p.chunks_per_split * CK;
+    if (c_end > p.Cp) c_end = p.Cp;
+    dma_a(c_begin, 0);
+    load_x(c_begin);
+    store_x(c_begin, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA has landed
+    __syncthreads();
+    int buf = 0;
+    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
+        const bool more = c0 + CK < c_end;
+        if (more) {
+            dma_a(c0 + CK, buf ^ 1);         // lands in the other buffer under the MFMAs below
+            load_x(c0 + CK);
+        }
+        const float* Ac = As[buf];
+        const float* Xc = Xs[buf];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            // the LDS write of the next patch sits in the middle of the MFMA stream (same basic block: its ds_write
+            // instructions issue in the shadow of the matrix pipe)
+            if (t == 6 && more) store_x(c0 + CK, buf ^ 1);
+#pragma unroll
+            for (int kk = 0; kk < CK / 2; ++kk) {
+                const int ch = 2 * kk + half;
+                float a[MI], b[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[mi] = Ac[(t * CK + ch) * BM + (wm * MI + mi) * 32 + l31];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[ni] = Xc[ch * XCAP + pixbase[ni] + tapoff[t]];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) before the barrier: see the header comment
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int pp = (wn * NI + ni) * 32 + l31;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> p.tw_log2) & (TH - 1);
+        const int pn = pp >> (p.tw_log2 + p.th_log2);
+        const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
+        if (n < p.N && oy < p.OH && ox < p.OW) {
+            float* yb = y + (int64_t)blockIdx.z * p.slab_stride +
+                        ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < p.M) {
+                        float v = acc[mi][ni][r];
+                        if (p.act) {
+                            if (p.bias) v += p.bias[m];
+                            v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
+                        }
+                        yb[(int64_t)m * p.YH * p.YW] = v;
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // stride-2 transposed gather ("tr"): out[m][o] = sum_{c,k : o + pad = 2 i + k} wp[k][c][m] * in[c][i]
 // 3x3 taps only.  N-tiles of a wave = the 4 parity classes of the same 32 q positions.
 // ------------------------------------------------------------------------------------------
@@ -1247,6 +1441,7 @@ struct WgradParams {
     const float* l_scale;
     const float* s_scale;
     int zmask;            // always 0 (see IgemmParams)
+    int xcd_order;        // 1: XCD-aware workgroup order (see conv_wgrad_kernel)
 };
 
 constexpr int kWgPix = 64;
@@ -1286,7 +1481,20 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int wa = PIXSPLIT ? 0 : wid / WB, wb = PIXSPLIT ? 0 : wid % WB;
-    const int b0 = blockIdx.x * BB, a0 = blockIdx.y * BA, slice = blockIdx.z;
+    // XCD-aware order: the (a, b) tiles of one pixel slice read the same pixels; workgroup ids go round the 8 XCDs
+    // (id % 8), so in launch order they sit behind 8 different L2s and each fetches its own copy.  Re-labelled so that
+    // all tiles of a slice share an XCD and are dispatched together (needs slices % 8 == 0).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_order && (gridDim.z & 7) == 0) {
+        const int mn = gridDim.x * gridDim.y;
+        const int lin = bx + gridDim.x * (by + gridDim.y * bz);
+        const int j = lin >> 3;
+        const int tile = j % mn;
+        bz = (j / mn) * 8 + (lin & 7);
+        bx = tile % gridDim.x;
+        by = tile / gridDim.x;
+    }
+    const int b0 = bx * BB, a0 = by * BA, slice = bz;
 
     const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
     const int TN = PK >> (p.tw_log2 + p.th_log2);
@@ -2133,6 +2341,7 @@ struct GatherPlan {
     FwdShape sh; int Mp, Cp, taps; int tw_log2, th_log2, tiles_x, tiles_y, tiles_n; int ksplit, cps;
     bool bx;   // bf16-split arithmetic (3x3 stride 1, 128x128 tile)
     bool bx8;  // ... on the 8-wave LDS-DMA kernel (128 x 256-pixel tile)
+    bool f8;   // exact fp32 on the 8-wave LDS-DMA kernel (conv_igemm_f8_kernel)
     int64_t wp_floats, out_floats4, ws_floats;
 };
 GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int stride, bool scatter) {
@@ -2148,6 +2357,21 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
         pick_tile(256, OH, OW, 32, &twl, &thl);
         const int tw8 = 1 << twl, th8 = 1 << thl, tn8 = 256 / (tw8 * th8);
         if (tn8 * (th8 + 2) * (tw8 + 2) <= 512) { g.bx8 = true; g.sh.bn = 256; }   // one patch position per thread
+    }
+    g.f8 = false;
+    // measured on MI355X (same box, tools/kb_subset.py): 121.9 vs 125.8 TFLOP/s at 128 -> 128 @256^2 B=16 and 126.4 vs 130.0
+    // at 512 -> 512 @64^2 for this kernel vs the 4-wave register-staged one: the fp32 matrix pipe is at its power-limited
+    // rate either way, and one workgroup per CU loses the overlap two independent workgroups give.  Off by default.
+    static const int f8_knob = [] { const char* e = getenv("SAE_F8"); return e ? atoi(e) : 0; }();
+    if (f8_knob && conv_math() == 0 && ks == 3 && stride == 1 && g.sh.cfg == 0 && !scatter) {
+        int twl, thl;
+        pick_tile(256, OH, OW, 32, &twl, &thl);
+        const int tw8 = 1 << twl, th8 = 1 << thl, tn8 = 256 / (tw8 * th8);
+        // one patch position per thread, and enough 256-pixel tiles to fill the chip once (small layers keep the
+        // 4-wave kernel with its split-K path)
+        const int64_t tiles = (int64_t)ceil_div(OW, tw8) * ceil_div(OH, th8) * ceil_div(N, tn8) * (g.Mp / 128);
+        static const int f8_min_tiles = [] { const char* e = getenv("SAE_F8_MIN_TILES"); return e ? atoi(e) : 256; }();   // tests: 1
+        if (tn8 * (th8 + 2) * (tw8 + 2) <= 512 && tiles >= f8_min_tiles) { g.f8 = true; g.sh.bn = 256; }
     }
     pick_tile(g.sh.bn, OH, OW, 32, &g.tw_log2, &g.th_log2);
     const int tw = 1 << g.tw_log2, th = 1 << g.th_log2, tn = g.sh.bn / (tw * th);
@@ -2197,6 +2421,11 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
     constexpr int CK = (KS == 1) ? 32 : 8;
     constexpr int CK2 = (KS == 1) ? 16 : 8;
     if constexpr (KS == 3 && S == 1) {
+        if (g.f8) {
+            if (p.in_scale) hipLaunchKernelGGL((conv_igemm_f8_kernel<2, 2, 2, 4, true>), grid, dim3(kBlock8), 0, s, x, wp, y, p);
+            else hipLaunchKernelGGL((conv_igemm_f8_kernel<2, 2, 2, 4, false>), grid, dim3(kBlock8), 0, s, x, wp, y, p);
+            return SAE_OK;
+        }
         if (g.bx8) {
             hipLaunchKernelGGL((conv_igemm_bx8_kernel<2, 2, 2, 4>), grid, dim3(kBlock8), 0, s, x,
                                reinterpret_cast<const u32x4*>(wp), y, p);
@@ -2598,6 +2827,8 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
         if ((mod.x_scale || mod.y_scale) && !w.bx && tn == 1 && w.cps <= cpi && cpi % w.cps == 0)
             slices_per_image = cpi / w.cps;
     }
+    static const int xcd_knob = [] { const char* e = getenv("SAE_XCD_ORDER"); return e ? atoi(e) : 1; }();
+    p.xcd_order = xcd_knob;
     p.l_scale = slices_per_image ? nullptr : mod.x_scale;
     p.s_scale = slices_per_image ? nullptr : mod.y_scale;
     if (!w.bx) {
