@@ -78,26 +78,42 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
 
     const float* xp = x + plane * (int64_t)p.in_h * p.in_w;
     float* sp = strip[tr];
-    // all global loads of the strip are issued back to back into registers (NE per thread),
-    // then written to LDS: one load in flight per wave would leave HBM latency fully exposed
-    constexpr int NE = (SR * SW + TW - 1) / TW;
-    float staged[NE];
+    // all global loads of the strip are issued back to back into registers, then written to LDS: one load in flight
+    // per wave would leave HBM latency fully exposed.  The strip is fetched ROW-wise: lane tx takes column tx of each of
+    // the SR rows (one contiguous TW * 4-byte run per instruction, no per-element index division — the generic
+    // e -> (e / SW, e % SW) walk cost ~30 VALU instructions per output, more than the 16 FMAs of the filter), and the
+    // KW - 1 halo columns of all rows are gathered by NX more loads.
+    constexpr int XW = KW - 1;                               // halo columns right of the TW body
+    constexpr int NX = (XW * SR + TW - 1) / TW;              // loads per thread for them (1 at TW = 64)
+    float body[SR];
+    float halo[NX > 0 ? NX : 1];
+    const int ixb = ix0 + tx;
+    const bool col_ok = live && ixb >= 0 && ixb < p.in_w;
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int e = tx + i * TW;
-        const int r = e / SW, c = e - r * SW;
-        const int iy = iy0 + r, ix = ix0 + c;
+    for (int r = 0; r < SR; ++r) {
+        const int iy = iy0 + r;
         // branch-free: a load inside a divergent branch makes hipcc drain vmcnt at the join, which left two
         // loads in flight per wave; out-of-image elements read element 0 of the plane and are zeroed
-        const bool ok = live && e < SR * SW && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-        const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
-        staged[i] = ok ? v : 0.0f;
+        const bool ok = col_ok && iy >= 0 && iy < p.in_h;
+        const float v = xp[ok ? (int64_t)iy * p.in_w + ixb : 0];
+        body[r] = ok ? v : 0.0f;
     }
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
+    for (int i = 0; i < NX; ++i) {
         const int e = tx + i * TW;
-        const int r = e / SW, c = e - r * SW;
-        if (e < SR * SW) sp[r * SWP + c] = staged[i];
+        const int r = e / (XW > 0 ? XW : 1), c = TW + e - r * XW;
+        const int iy = iy0 + r, ix = ix0 + c;
+        const bool ok = live && e < XW * SR && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
+        halo[i] = ok ? v : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < SR; ++r) sp[r * SWP + tx] = body[r];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int e = tx + i * TW;
+        const int r = e / (XW > 0 ? XW : 1), c = TW + e - r * XW;
+        if (e < XW * SR) sp[r * SWP + c] = halo[i];
     }
     __syncthreads();
 
