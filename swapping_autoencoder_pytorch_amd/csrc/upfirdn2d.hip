@@ -215,7 +215,6 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
     constexpr int SR = ((RB - 1) * DOWN + KH - 1) / UP + 1;     // upfirdn2d_kernel.cu:54-55
     constexpr int SW = ((TW - 1) * DOWN + KW - 1) / UP + 1;
     constexpr int SWP = SW | 1;
-    constexpr int NE = (SR * SW + TW - 1) / TW;
     __shared__ float strip[NR][SR * SWP];
     __shared__ float taps[KH * KW];
 
@@ -241,21 +240,43 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
 
     const float* xp = x + plane * (int64_t)p.in_h * p.in_w;
     float* sp = strip[tr];
-    float staged[NE];
+    // row-wise staging as in blur_kernel: CB full TW-wide column blocks per row (lane tx takes column tx + b * TW),
+    // the SW - CB * TW remaining columns of all rows gathered by NX more loads; no per-element index division
+    constexpr int CB = SW / TW;
+    constexpr int XW = SW - CB * TW;
+    constexpr int NX = (XW * SR + TW - 1) / TW;
+    float body[SR][CB > 0 ? CB : 1];
+    float halo[NX > 0 ? NX : 1];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        const int e = tx + i * TW;
-        const int r = e / SW, c = e - r * SW;
-        const int iy = tile_in_y + r, ix = tile_in_x + c;
-        const bool ok = live && e < SR * SW && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;   // branch-free, see blur_kernel
-        const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
-        staged[i] = ok ? v : 0.0f;
+    for (int r = 0; r < SR; ++r) {
+        const int iy = tile_in_y + r;
+        const bool row_ok = live && iy >= 0 && iy < p.in_h;
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+            const int ix = tile_in_x + tx + b * TW;
+            const bool ok = row_ok && ix >= 0 && ix < p.in_w;   // branch-free, see blur_kernel
+            const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
+            body[r][b] = ok ? v : 0.0f;
+        }
     }
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
+    for (int i = 0; i < NX; ++i) {
         const int e = tx + i * TW;
-        const int r = e / SW, c = e - r * SW;
-        if (e < SR * SW) sp[r * SWP + c] = staged[i];
+        const int r = e / (XW > 0 ? XW : 1), c = CB * TW + e - r * XW;
+        const int iy = tile_in_y + r, ix = tile_in_x + c;
+        const bool ok = live && e < XW * SR && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
+        halo[i] = ok ? v : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < SR; ++r)
+#pragma unroll
+        for (int b = 0; b < CB; ++b) sp[r * SWP + tx + b * TW] = body[r][b];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int e = tx + i * TW;
+        const int r = e / (XW > 0 ? XW : 1), c = CB * TW + e - r * XW;
+        if (e < XW * SR) sp[r * SWP + c] = halo[i];
     }
     __syncthreads();
 
