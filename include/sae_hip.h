@@ -25,6 +25,9 @@
  *   sae_gemm_f32             <- F.linear and its backward       models/networks/stylegan2_layers.py:177,186
  *   sae_upsample2x_bilinear_{add,bwd}_f32
  *                            <- F.interpolate(bilinear x2) + residual   models/networks/generator.py:51-53
+ *   sae_l2_normalize_{,bwd_}f32 <- util.normalize                       util/util.py:18-22
+ *   sae_plane_affine_{,bwd_}f32 <- GeneratorModulation.forward           models/networks/generator.py:62-67
+ *   sae_softplus_mean_{,bwd_}f32 <- gan_loss                             models/networks/loss.py:10-16
  *   sae_adam_multi_f32       <- torch.optim.Adam(...).step()            optimizers/swapping_autoencoder_optimizer.py:34-42,77,95,107
  *
  * Conventions (what the reference's pybind layer did implicitly is explicit here):
@@ -253,6 +256,30 @@ int sae_upsample2x_bilinear_bwd_f32(const float* gy, float* gx, int64_t planes, 
 /* Residual merge y = alpha * (a + b): the (out + skip) / sqrt(2) of ResBlock (stylegan2_layers.py:689)
  * and of the generator's resolution-preserving block (generator.py:36) as one elementwise pass. */
 int sae_add_scale_f32(const float* a, const float* b, float* y, int64_t numel, float alpha, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small glue of the train step, one launch each way instead of a chain of ATen launches (csrc/glue.hip):
+ *   sae_l2_normalize_f32      y = x * rsqrt(sum_c x^2 + eps) over the channel axis of [outer][channels][inner]
+ *                             (util.normalize, util/util.py:18-22; inner = 1 for the [N, C] global code)
+ *   sae_l2_normalize_bwd_f32  gx = r * gy - r^3 * <gy, x>_c * x,  r = rsqrt(sum_c x^2 + eps)
+ *   sae_plane_affine_f32      y[p][i] = x[p][i] * a[p] + b[p] for p = (n, c) planes of hw elements
+ *                             (GeneratorModulation, models/networks/generator.py:62-67)
+ *   sae_plane_affine_bwd_f32  gx = g * a[p], ga[p] = sum_i g * x, gb[p] = sum_i g
+ *   sae_softplus_mean_f32     y[b] = mean_i softplus(sign * x[b][i])   (gan_loss, models/networks/loss.py:10-16;
+ *                             softplus with beta 1 and threshold 20 as F.softplus)
+ *   sae_softplus_mean_bwd_f32 gx[b][i] = gy[b] * sign * sigmoid(sign * x[b][i]) / inner
+ * ------------------------------------------------------------------------------------------ */
+int sae_l2_normalize_f32(const float* x, float* y, int64_t outer, int64_t channels, int64_t inner, float eps,
+                         sae_stream_t stream);
+int sae_l2_normalize_bwd_f32(const float* gy, const float* x, float* gx, int64_t outer, int64_t channels, int64_t inner,
+                             float eps, sae_stream_t stream);
+int sae_plane_affine_f32(const float* x, const float* a, const float* b, float* y, int64_t planes, int64_t hw,
+                         sae_stream_t stream);
+int sae_plane_affine_bwd_f32(const float* g, const float* x, const float* a, float* gx, float* ga, float* gb,
+                             int64_t planes, int64_t hw, sae_stream_t stream);
+int sae_softplus_mean_f32(const float* x, float* y, int64_t batch, int64_t inner, float sign, sae_stream_t stream);
+int sae_softplus_mean_bwd_f32(const float* gy, const float* x, float* gx, int64_t batch, int64_t inner, float sign,
+                              sae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-tensor Adam step: the update torch.optim.Adam applies to every parameter of a group

@@ -718,3 +718,95 @@ int oracle_modconv2d_wgrad_f32(const float* x, const float* gy, float* gw, const
     free(xs); free(gs);
     return rc;
 }
+
+/* ---- small glue (include/sae_hip.h, csrc/glue.hip).  util.normalize (util/util.py:18-22): v * rsqrt(sum(v^2, dim 1) + 1e-8);
+ * GeneratorModulation (generator.py:62-67): x * (1 * scale) + bias; gan_loss (loss.py:10-16): softplus(+-x).view(B,-1).mean(1).
+ * Evaluated in double; tests/test_glue.py pins each to the ATen expression the reference writes. */
+int oracle_l2_normalize_f32(const float* x, float* y, int64_t outer, int64_t channels, int64_t inner, float eps,
+                            sae_stream_t stream) {
+    (void)stream;
+    if (outer < 0 || channels < 1 || inner < 1 || (outer > 0 && (!x || !y))) return set_err("oracle_l2_normalize_f32: bad argument");
+    for (int64_t n = 0; n < outer; ++n)
+        for (int64_t j = 0; j < inner; ++j) {
+            double s = 0.0;
+            for (int64_t c = 0; c < channels; ++c) { double v = x[(n * channels + c) * inner + j]; s += v * v; }
+            const double r = 1.0 / sqrt(s + (double)eps);
+            for (int64_t c = 0; c < channels; ++c) y[(n * channels + c) * inner + j] = (float)(x[(n * channels + c) * inner + j] * r);
+        }
+    return SAE_OK;
+}
+
+int oracle_l2_normalize_bwd_f32(const float* gy, const float* x, float* gx, int64_t outer, int64_t channels, int64_t inner,
+                                float eps, sae_stream_t stream) {
+    (void)stream;
+    if (outer < 0 || channels < 1 || inner < 1 || (outer > 0 && (!gy || !x || !gx)))
+        return set_err("oracle_l2_normalize_bwd_f32: bad argument");
+    for (int64_t n = 0; n < outer; ++n)
+        for (int64_t j = 0; j < inner; ++j) {
+            double s = 0.0, d = 0.0;
+            for (int64_t c = 0; c < channels; ++c) {
+                const double v = x[(n * channels + c) * inner + j];
+                s += v * v;
+                d += (double)gy[(n * channels + c) * inner + j] * v;
+            }
+            const double r = 1.0 / sqrt(s + (double)eps);
+            for (int64_t c = 0; c < channels; ++c) {
+                const int64_t i = (n * channels + c) * inner + j;
+                gx[i] = (float)(r * gy[i] - r * r * r * d * x[i]);
+            }
+        }
+    return SAE_OK;
+}
+
+int oracle_plane_affine_f32(const float* x, const float* a, const float* b, float* y, int64_t planes, int64_t hw,
+                            sae_stream_t stream) {
+    (void)stream;
+    if (planes < 0 || hw < 1 || (planes > 0 && (!x || !a || !b || !y))) return set_err("oracle_plane_affine_f32: bad argument");
+    for (int64_t p = 0; p < planes; ++p)
+        for (int64_t i = 0; i < hw; ++i) y[p * hw + i] = (float)((double)x[p * hw + i] * (double)a[p] + (double)b[p]);
+    return SAE_OK;
+}
+
+int oracle_plane_affine_bwd_f32(const float* g, const float* x, const float* a, float* gx, float* ga, float* gb,
+                                int64_t planes, int64_t hw, sae_stream_t stream) {
+    (void)stream;
+    if (planes < 0 || hw < 1 || (planes > 0 && (!g || !x || !a || !gx || !ga || !gb)))
+        return set_err("oracle_plane_affine_bwd_f32: bad argument");
+    for (int64_t p = 0; p < planes; ++p) {
+        double sa = 0.0, sb = 0.0;
+        for (int64_t i = 0; i < hw; ++i) {
+            gx[p * hw + i] = (float)((double)g[p * hw + i] * (double)a[p]);
+            sa += (double)g[p * hw + i] * (double)x[p * hw + i];
+            sb += (double)g[p * hw + i];
+        }
+        ga[p] = (float)sa;
+        gb[p] = (float)sb;
+    }
+    return SAE_OK;
+}
+
+static double softplus_d(double v) { return v > 20.0 ? v : log1p(exp(v)); }
+
+int oracle_softplus_mean_f32(const float* x, float* y, int64_t batch, int64_t inner, float sign, sae_stream_t stream) {
+    (void)stream;
+    if (batch < 0 || inner < 1 || (batch > 0 && (!x || !y))) return set_err("oracle_softplus_mean_f32: bad argument");
+    for (int64_t b = 0; b < batch; ++b) {
+        double s = 0.0;
+        for (int64_t i = 0; i < inner; ++i) s += softplus_d((double)sign * (double)x[b * inner + i]);
+        y[b] = (float)(s / (double)inner);
+    }
+    return SAE_OK;
+}
+
+int oracle_softplus_mean_bwd_f32(const float* gy, const float* x, float* gx, int64_t batch, int64_t inner, float sign,
+                                 sae_stream_t stream) {
+    (void)stream;
+    if (batch < 0 || inner < 1 || (batch > 0 && (!gy || !x || !gx))) return set_err("oracle_softplus_mean_bwd_f32: bad argument");
+    for (int64_t b = 0; b < batch; ++b)
+        for (int64_t i = 0; i < inner; ++i) {
+            const double z = (double)sign * (double)x[b * inner + i];
+            const double dz = z > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-z));
+            gx[b * inner + i] = (float)((double)gy[b] * (double)sign * dz / (double)inner);
+        }
+    return SAE_OK;
+}

@@ -72,6 +72,12 @@ _SIGNATURES = {
     "modconv2d_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),
     "gemm_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _stream]),
     "add_scale_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _f32, _stream]),
+    "l2_normalize_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),
+    "l2_normalize_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),
+    "plane_affine_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _stream]),
+    "plane_affine_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _stream]),
+    "softplus_mean_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _f32, _stream]),
+    "softplus_mean_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _f32, _stream]),
     "adam_multi_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64, C.c_double,
                                  C.c_double, C.c_double, C.c_double, C.c_double, _stream]),
     "upsample2x_bilinear_add_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),

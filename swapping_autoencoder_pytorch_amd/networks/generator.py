@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from .. import util
 from ..stylegan2_layers import ConvLayer, EqualLinear, ModulatedConv2d, StyledConv, ToRGB
-from ..stylegan2_op import add_scale, linear, upsample2x_add
+from ..stylegan2_op import add_scale, linear, plane_affine, upsample2x_add
 from .base_network import BaseNetwork
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
@@ -72,7 +72,7 @@ class GeneratorModulation(torch.nn.Module):
                 sc, bi = self._projected
             else:
                 sc, bi = self.scale(style), self.bias(style)
-            return x * (1 * sc[:, :, None, None]) + bi[:, :, None, None]
+            return plane_affine(x, sc, bi)           # x * (1 * scale) + bias as one kernel
         style = F.interpolate(style, size=(x.size(2), x.size(3)), mode="bilinear", align_corners=False)
         return x * (1 * self.scale(style)) + self.bias(style)
 

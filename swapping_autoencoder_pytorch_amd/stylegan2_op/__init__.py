@@ -7,6 +7,7 @@ from .conv2d_gemm import conv2d, conv2d_bias_act, conv_transpose2d, input_grads_
 from .upsample import add_scale, upsample2x_add
 from .modulate import fusable, noise_bias_act, plane_scale
 from .crop import random_crop
+from .glue import l2_normalize, plane_affine, softplus_mean
 from .pad import ReflectionPad2d, reflect_pad
 
-__all__ = ["FusedLeakyReLU", "fused_leaky_relu", "upfirdn2d", "conv2d", "conv2d_bias_act", "conv_transpose2d", "input_grads_only", "linear", "modulated_conv2d", "upsample2x_add", "add_scale", "noise_bias_act", "plane_scale", "fusable", "random_crop", "reflect_pad", "ReflectionPad2d"]
+__all__ = ["FusedLeakyReLU", "fused_leaky_relu", "upfirdn2d", "conv2d", "conv2d_bias_act", "conv_transpose2d", "input_grads_only", "linear", "modulated_conv2d", "upsample2x_add", "add_scale", "noise_bias_act", "plane_scale", "fusable", "random_crop", "reflect_pad", "ReflectionPad2d", "l2_normalize", "plane_affine", "softplus_mean"]

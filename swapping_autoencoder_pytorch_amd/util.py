@@ -7,14 +7,14 @@ import argparse
 import torch
 
 from . import rng
-from .stylegan2_op import random_crop
+from .stylegan2_op import l2_normalize, random_crop
 
 
 def normalize(v):
     """L2-normalise over dim 1 (epsilon inside the rsqrt, as the reference)."""
     if isinstance(v, list):
         return [normalize(x) for x in v]
-    return v * torch.rsqrt(torch.sum(v ** 2, dim=1, keepdim=True) + 1e-8)
+    return l2_normalize(v, 1e-8)        # v * rsqrt(sum(v ** 2, dim=1, keepdim=True) + 1e-8) as one kernel
 
 
 def str2bool(v):

@@ -233,3 +233,48 @@ def modconv(lib, op, d, a, b, out_shape, x_scale=None, y_scale=None, wm_scale=No
     mod = ConvMod(*[(k.ptr if k is not None else None) for k in keep])
     lib.call(MOD_OPS[op], ba.ptr, bb.ptr, bo.ptr, C.byref(d), C.byref(mod), alpha, ws.ptr, n, _stream(device))
     return bo.numpy()
+
+
+def l2_normalize(lib, x, eps=1e-8, device=None):
+    outer, ch = x.shape[:2]
+    inner = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+    bx, by = _Buf(x, device), _out(x.shape, device)
+    lib.call("l2_normalize_f32", bx.ptr, by.ptr, outer, ch, inner, eps, _stream(device))
+    return by.numpy()
+
+
+def l2_normalize_bwd(lib, gy, x, eps=1e-8, device=None):
+    outer, ch = x.shape[:2]
+    inner = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
+    bg, bx, bo = _Buf(gy, device), _Buf(x, device), _out(x.shape, device)
+    lib.call("l2_normalize_bwd_f32", bg.ptr, bx.ptr, bo.ptr, outer, ch, inner, eps, _stream(device))
+    return bo.numpy()
+
+
+def plane_affine(lib, x, a, b, device=None):
+    planes, hw = int(np.prod(x.shape[:2])), int(np.prod(x.shape[2:]))
+    bx, ba, bb, by = _Buf(x, device), _Buf(a, device), _Buf(b, device), _out(x.shape, device)
+    lib.call("plane_affine_f32", bx.ptr, ba.ptr, bb.ptr, by.ptr, planes, hw, _stream(device))
+    return by.numpy()
+
+
+def plane_affine_bwd(lib, g, x, a, device=None):
+    planes, hw = int(np.prod(x.shape[:2])), int(np.prod(x.shape[2:]))
+    bg, bx, ba = _Buf(g, device), _Buf(x, device), _Buf(a, device)
+    bgx, bga, bgb = _out(x.shape, device), _out(a.shape, device), _out(a.shape, device)
+    lib.call("plane_affine_bwd_f32", bg.ptr, bx.ptr, ba.ptr, bgx.ptr, bga.ptr, bgb.ptr, planes, hw, _stream(device))
+    return bgx.numpy(), bga.numpy(), bgb.numpy()
+
+
+def softplus_mean(lib, x, sign, device=None):
+    batch, inner = x.shape[0], int(np.prod(x.shape[1:]))
+    bx, by = _Buf(x, device), _out((batch,), device)
+    lib.call("softplus_mean_f32", bx.ptr, by.ptr, batch, inner, sign, _stream(device))
+    return by.numpy()
+
+
+def softplus_mean_bwd(lib, gy, x, sign, device=None):
+    batch, inner = x.shape[0], int(np.prod(x.shape[1:]))
+    bg, bx, bo = _Buf(gy, device), _Buf(x, device), _out(x.shape, device)
+    lib.call("softplus_mean_bwd_f32", bg.ptr, bx.ptr, bo.ptr, batch, inner, sign, _stream(device))
+    return bo.numpy()
