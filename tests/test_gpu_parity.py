@@ -53,9 +53,16 @@ def test_micro_training_steps(_native_lib_loaded):
         # derivative changes from sqrt(2) to 0.2 sqrt(2), and D's gradient norms move by up to 1.5e-3 at step 0 (one unit
         # of 5120 ~ 1/sqrt(5120)); Adam(beta1 = 0) then separates the trajectories at the 1e-4 level in the losses.
         # Every recipe has such units (10 M leaky-ReLU inputs per step: the smallest |x| / rms is ~1e-8), so the
-        # tolerance states the size of that one-unit effect instead of pretending it cannot happen; the forward
-        # (step-0 losses) stays at 5e-6.
-        P.check_micro_steps(DEV, loss_tol=5e-6, grad_tol=5e-3, post_update_tol=2e-3)
+        # checks state the size of that one-unit effect instead of pretending it cannot happen: the forward of step 0
+        # (losses) stays at 5e-6, its gradient norms at the one-unit level, and the steps after the first Adam update
+        # — which turns the changed gradient signs of D's small entries into full +-lr moves — are only required to
+        # stay on the same trajectory to 2e-3 in the losses (measured 2.2e-4 / 2.0e-4 / 6.5e-4, profiles/r2_step_parity.json)
+        m = P.measure_micro_steps(DEV)
+        assert m["steps"][0]["max_loss_dev"] <= 5e-6, m["steps"][0]["loss_dev"]
+        assert m["steps"][0]["max_grad_norm_dev"] <= 5e-3, (m["steps"][0]["worst_grad"], m["steps"][0]["max_grad_norm_dev"])
+        for row in m["steps"][1:]:
+            assert row["max_loss_dev"] <= 2e-3, (row["step"], row["loss_dev"])
+        assert m["max_param_norm_dev_after"] <= 5e-2
 
 
 def test_cpu_tensor_is_refused():

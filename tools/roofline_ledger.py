@@ -71,6 +71,15 @@ def work_of(name, a):
         return "upsample x2 + residual", "hbm", 4.0 * a[3] * a[4] * a[5] * (1 + 4 + (4 if a[1] else 0))
     if name == "upsample2x_bilinear_bwd_f32":
         return "upsample x2 backward", "hbm", 4.0 * a[2] * a[3] * a[4] * 5
+    if name in ("l2_normalize_f32", "l2_normalize_bwd_f32"):
+        n = a[2 if name == "l2_normalize_f32" else 3] * a[3 if name == "l2_normalize_f32" else 4] * a[4 if name == "l2_normalize_f32" else 5]
+        return "l2 normalize (+bwd)", "hbm", 4.0 * n * (2 if name == "l2_normalize_f32" else 3)
+    if name in ("plane_affine_f32", "plane_affine_bwd_f32"):
+        n = a[4] * a[5] if name == "plane_affine_f32" else a[6] * a[7]
+        return "generator modulation (+bwd)", "hbm", 4.0 * n * (2 if name == "plane_affine_f32" else 3)
+    if name in ("softplus_mean_f32", "softplus_mean_bwd_f32"):
+        n = a[2] * a[3] if name == "softplus_mean_f32" else a[3] * a[4]
+        return "gan loss (+bwd)", "hbm", 8.0 * n
     if name in ("random_crop_f32", "random_crop_bwd_f32"):
         images, ch, h, w, crops, size = a[4:10]
         return name[:-4], "hbm", 4.0 * ch * (images * h * w + images * crops * size * size)
