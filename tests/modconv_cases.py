@@ -9,16 +9,16 @@ import abi_harness as H
 MODCONV_CASES = [
     (2, 8, 8, 8, 32, 3, 1, 1, False),        # several images per tile
     (3, 10, 4, 4, 70, 3, 1, 1, False),       # channel tails, 128-row tile
-    (1, 9, 36, 33, 130, 3, 1, 1, False),     # one image per tile (uniform factor path), M tail
+    (1, 9, 20, 33, 130, 3, 1, 1, False),     # one image per tile (uniform factor path), M tail
     (2, 40, 8, 8, 3, 1, 1, 0, False),        # ToRGB: 1x1, 3 output channels
     (2, 64, 8, 8, 40, 3, 1, 1, False),       # split-K
     (1, 70, 17, 17, 12, 3, 2, 0, True),      # transposed conv producing 70 channels ([C, M] weights)
-    (2, 72, 35, 67, 8, 3, 2, 0, True),       # transposed, strips, two images
+    (2, 40, 19, 35, 8, 3, 2, 0, True),       # transposed, strips (2^k + 1 grid), two images
     (2, 12, 9, 9, 20, 3, 2, 0, True),        # transposed, narrow tile
     (3, 20, 12, 12, 24, 3, 1, 1, False),     # wgrad MODE 1
     (2, 3, 16, 16, 40, 3, 1, 1, False),      # wgrad MODE 2
     (1, 36, 32, 32, 70, 3, 1, 1, False),
-    (3, 36, 32, 32, 70, 3, 1, 1, False),     # wgrad: one image per pixel chunk -> factors applied per K-slice in the reduction
+    (3, 20, 16, 32, 70, 3, 1, 1, False),     # wgrad: one image per pixel chunk -> factors applied per K-slice in the reduction
 ]
 
 
