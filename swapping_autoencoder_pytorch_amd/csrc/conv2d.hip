@@ -72,6 +72,36 @@ __global__ __launch_bounds__(kBlock) void conv_wprep_kernel(const float* __restr
 // ------------------------------------------------------------------------------------------
 // forward-type implicit GEMM (stride 1 or 2 gather)
 // ------------------------------------------------------------------------------------------
+// Profiling hook (tools/build_variant.sh ... -DSAE_CLOCK_PROBE, never in the product build): every workgroup of the
+// three fp32 MFMA kernels adds its duration in shader cycles (s_memtime) and in constant 100 MHz ticks (s_memrealtime)
+// to a device counter, from which tools/ab_conv.py --clock derives the shader clock the kernel actually ran at.
+#ifdef SAE_CLOCK_PROBE
+__device__ unsigned long long g_clock_probe[16];
+// [0] shader cycles, [1] 100 MHz ticks, [2] workgroups; phases of conv_igemm_kernel as seen by wave 0, in shader cycles:
+// [3] prologue, [4] MFMA phase, [5] wait at the barrier after it, [6] LDS stores, [7] wait at the second barrier,
+// [8] global-load issue, [9] epilogue
+#define SAE_CLOCK_BEGIN const unsigned long long cp_c0 = clock64(), cp_r0 = wall_clock64(); \
+    unsigned long long cp_t = cp_c0, cp_ph[7] = {0, 0, 0, 0, 0, 0, 0};
+#define SAE_CLOCK_PHASE(i) { const unsigned long long cp_n = clock64(); cp_ph[i] += cp_n - cp_t; cp_t = cp_n; }
+#define SAE_CLOCK_END                                                   \
+    if (threadIdx.x == 0) {                                             \
+        atomicAdd(&g_clock_probe[0], clock64() - cp_c0);                \
+        atomicAdd(&g_clock_probe[1], wall_clock64() - cp_r0);           \
+        atomicAdd(&g_clock_probe[2], 1ull);                             \
+        for (int cp_i = 0; cp_i < 7; ++cp_i) atomicAdd(&g_clock_probe[3 + cp_i], cp_ph[cp_i]); \
+    }
+#else
+#define SAE_CLOCK_BEGIN
+#define SAE_CLOCK_PHASE(i)
+#define SAE_CLOCK_END
+#endif
+
+// LDS operand reads of the gather kernels run this many (tap, channel pair) steps ahead of the MFMAs that use them
+#ifndef SAE_IGEMM_AHEAD
+#define SAE_IGEMM_AHEAD 1
+#endif
+constexpr int kIgemmAhead = SAE_IGEMM_AHEAD;
+
 struct IgemmParams {
     int N, C, H, W;       // input tensor; C = contraction channels
     int M, OH, OW;        // logical output grid, M = output channels
@@ -105,23 +135,38 @@ struct PatchCap {
 
 // MOD: the input is style-modulated while staged (IgemmParams::in_scale); a separate instantiation, so the
 // un-modulated kernels of E / D / Dpatch carry no trace of it
-template <int KS, int S, int MI, int NI, int WM, int WN, int CK, bool MOD = false>
+// QUAD (3x3 stride 1, rows a multiple of four floats wide, tiles at least 16 wide): the input patch is staged as
+// 16-byte quads aligned in memory -- the rows of the patch widened to [x0 - 4, x0 + TW + 4) -- CK channels' worth of quads
+// dealt out over the workgroup, so a chunk takes BN/64 dwordx4 loads and as many ds_write_b128 per thread instead of
+// 2.25 BN/32 dword ones.  A wave64 vector-memory instruction occupies the CU's address path for ~25-30 cycles whatever
+// its width (tools/probe/mfma_clock_probe.hip, profiles/r2_phase_clock_*.txt): the staging phase of a chunk is bound by the
+// NUMBER of such instructions, and the eight waves of a CU issue theirs at the same time.
+template <int KS, int S, int MI, int NI, int WM, int WN, int CK, bool MOD = false, bool QUAD = false>
 __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ wp,
                                                             float* __restrict__ y, const IgemmParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(!QUAD || (KS == 3 && S == 1), "quad staging: 3x3 stride 1");
     constexpr int T = KS * KS;
     constexpr int BM = 32 * MI * WM;
     constexpr int BN = 32 * NI * WN;
     constexpr int XCAP = PatchCap<KS, S, BN>::value;
-    constexpr int PPT = (XCAP + kBlock - 1) / kBlock;      // patch slots per thread per channel
+    constexpr int PPT = QUAD ? 1 : (XCAP + kBlock - 1) / kBlock;      // patch slots per thread per channel
+    constexpr int QCAP = BN / 2;                                      // QUAD: quads per channel accepted by the host
+    constexpr int QPT = QUAD ? (CK * QCAP + kBlock - 1) / kBlock : 1; // ... and quad slots per thread per chunk
     constexpr int A_VEC = T * CK * BM / 4;                  // float4 per A chunk
     constexpr int APT = (A_VEC + kBlock - 1) / kBlock;
+    // a channel row of Xs is XCAP patch floats + a 64-float dump area: threads whose slot lies beyond the patch store
+    // there, so no LDS store of the K loop is predicated (XROW = XCAP mod 64 keeps the bank pattern of the reads)
+    constexpr int XROW = XCAP + 64;
     __shared__ float As[T * CK * BM];
-    __shared__ float Xs[CK * XCAP];
+    __shared__ float Xs[CK * XROW];
 
+    SAE_CLOCK_BEGIN
     const int tid = threadIdx.x;
+    __builtin_assume(tid < kBlock);   // hipcc otherwise assumes up to 1024 and predicates the tail of the staging loops
     const int lane = tid & 63, wid = tid >> 6;
+    const int wid_u = __builtin_amdgcn_readfirstlane(wid);   // the same value, known to be wave-uniform
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wid / WN, wn = wid % WN;
 
@@ -142,14 +187,50 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
     const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
     const int HALFW = (PW + 1) >> 1;
-    const int RS = PW;
+    const int RS = QUAD ? TW + 8 : PW;
     const int IP = PH * RS;
     const int CP = TN * IP;           // staged floats per channel (<= XCAP, checked on the host)
     const int HW = p.H * p.W;
 
-    // per-thread patch slots: global offset relative to (image n0, channel 0) or -1
-    int poff[PPT];
-    int sidx[MOD ? PPT : 1];   // in_scale row of the slot's image (tiles that span several images only)
+    // per-thread patch slots.  pbyte: BYTE offset of the slot's input element relative to (image n0, channel 0);
+    // padding / out-of-tile slots read element 0 instead (always valid memory) and are zeroed on their way into LDS
+    // (pok), so that no global load of the K loop sits in a divergent branch and every load is the
+    // "uniform 64-bit base + 32-bit lane offset" form with loop-invariant lane offsets.  xdst: LDS index within a
+    // channel row (the dump area for slots beyond the patch).
+    unsigned pbyte[PPT];
+    bool pok[PPT];
+    int xdst[PPT];
+    bool wave_has[PPT];     // wave-uniform: some lane of this wave has a patch element in slot s (else the slot is skipped)
+    int sidx[MOD ? (QUAD ? QPT : PPT) : 1];   // in_scale row of the slot's image
+    // QUAD: slot k of a thread is quad j = tid + kBlock * k of the chunk: channel j / QN, quad j % QN of the patch
+    // (image, row, quad column); qbyte is relative to (image n0, channel c0) and includes the channel
+    unsigned qbyte[QPT];
+    bool qok[QPT];
+    int qdst[QPT], qch[QPT];
+    if constexpr (QUAD) {
+        const int RQ = RS >> 2;                 // quads per patch row
+        const int QI = PH * RQ, QN = TN * QI;   // quads per image, per channel (<= QCAP, checked on the host)
+#pragma unroll
+        for (int kq = 0; kq < QPT; ++kq) {
+            const int j = tid + kBlock * kq;
+            const int ch = j / QN;
+            const int q = j - ch * QN;
+            const int pn = q / QI;
+            const int rem = q - pn * QI;
+            const int r = rem / RQ;
+            const int qc = rem - r * RQ;
+            const int iy = oy0 - p.pad + r, ix = ox0 - 4 + 4 * qc;
+            const bool slot = ch < CK;
+            const bool in = slot && n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            qok[kq] = in;
+            qch[kq] = slot ? ch : CK - 1;
+            qbyte[kq] = in ? 4u * (unsigned)((pn * p.C + ch) * HW + iy * p.W + ix) : 0u;
+            qdst[kq] = slot ? ch * XROW + 4 * q : ((tid >> 4) & (CK - 1)) * XROW + XCAP + 4 * (tid & 15);
+            if constexpr (MOD) sidx[kq] = in ? (n0 + pn) * p.C + ch : 0;
+        }
+        pbyte[0] = 0; pok[0] = false; xdst[0] = 0; wave_has[0] = false;
+    } else {
+        qbyte[0] = 0; qok[0] = false; qdst[0] = 0; qch[0] = 0;
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
         const int e = tid + kBlock * s;
@@ -170,10 +251,26 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                 if constexpr (MOD) sidx[s] = (n0 + pn) * p.C;
             }
         }
-        poff[s] = off;
+        pok[s] = off >= 0;
+        pbyte[s] = off >= 0 ? 4u * (unsigned)off : 0u;
+        xdst[s] = e < CP ? e : XCAP + (tid & 63);
+        // (not for the stride-2 gather: measured 116 vs 121 TFLOP/s with the skip, its third slot is the only sparse one)
+        wave_has[s] = (KS == 3 && S == 2) || wid_u * kWave + kBlock * s < CP;
+    }
+    }
+    // weight staging: float4 e4 = tid + kBlock * i of the chunk's [tap][ch][m] block; its byte offset relative to
+    // (channel c0, column m0) of wp is loop-invariant
+    unsigned abyte[APT];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+        const int e4 = tid + kBlock * i;
+        const int row = e4 / (BM / 4);       // tap*CK + ch
+        const int col4 = e4 - row * (BM / 4);
+        const int tap = (row / CK) < T ? row / CK : 0, ch = row - (row / CK) * CK;
+        abyte[i] = 4u * (unsigned)((tap * p.Cp + ch) * p.Mp + col4 * 4);
     }
     const bool one_image = TN == 1;          // the whole tile lies in image n0: one (uniform) factor per channel
-    float sc[MOD ? CK : 1];                   // ... prefetched with the chunk
+    float sc[MOD ? (QUAD ? QPT : CK) : 1];   // ... prefetched with the chunk (QUAD: the factor of each quad slot)
 
     // per-lane LDS base of each N-tile pixel, and per-tap offsets
     int pixbase[NI];
@@ -183,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
         const int px = pp & (TW - 1);
         const int py = (pp >> p.tw_log2) & (TH - 1);
         const int pn = pp >> (p.tw_log2 + p.th_log2);
-        pixbase[ni] = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px;
+        pixbase[ni] = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px + (QUAD ? 4 - p.pad : 0);
     }
     int tapoff[T];
 #pragma unroll
@@ -201,16 +298,30 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
     const float* xb = x + (int64_t)n0 * p.C * HW;
-    float xv[CK][PPT];
+    float xv[QUAD ? 1 : CK][PPT] = {};
+    f32x4 xq[QPT];
     f32x4 av[APT];
 
     auto load_chunk = [&](int c0) {
+        if constexpr (QUAD) {
+            const char* xc = reinterpret_cast<const char*>(xb + (int64_t)c0 * HW);
 #pragma unroll
-        for (int ch = 0; ch < CK; ++ch) {
-            const bool ch_ok = (c0 + ch) < p.C;
-            const float* xc = xb + (int64_t)(c0 + ch) * HW;
+            for (int kq = 0; kq < QPT; ++kq) {
+                const bool ok = qok[kq] && c0 + qch[kq] < p.C;       // channels beyond C (last chunk): element 0, zeroed later
+                xq[kq] = *reinterpret_cast<const f32x4*>(xc + (ok ? qbyte[kq] : 0u));
+                if constexpr (MOD) sc[kq] = p.in_scale[ok ? sidx[kq] + c0 : 0];
+            }
+        } else {
 #pragma unroll
-            for (int s = 0; s < PPT; ++s) xv[ch][s] = (ch_ok && poff[s] >= 0) ? xc[poff[s]] : 0.0f;
+        for (int s = 0; s < PPT; ++s) {
+            if (!wave_has[s]) continue;
+#pragma unroll
+            for (int ch = 0; ch < CK; ++ch) {
+                // channels beyond C (last chunk) re-read channel C - 1 and are zeroed in store_chunk
+                const int cc = (c0 + ch) < p.C ? c0 + ch : p.C - 1;
+                const char* xc = reinterpret_cast<const char*>(xb + (int64_t)cc * HW);
+                xv[ch][s] = *reinterpret_cast<const float*>(xc + pbyte[s]);
+            }
         }
         if constexpr (MOD) {
             if (one_image) {
@@ -219,19 +330,26 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                 for (int ch = 0; ch < CK; ++ch) sc[ch] = srow[(c0 + ch) < p.C ? c0 + ch : 0];
             }
         }
+        }
+        const char* wb = reinterpret_cast<const char*>(wp + (int64_t)c0 * p.Mp + m0);
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int e4 = tid + kBlock * i;
-            if (e4 < A_VEC) {
-                const int row = e4 / (BM / 4);       // tap*CK + ch
-                const int col4 = e4 - row * (BM / 4);
-                const int tap = row / CK, ch = row - tap * CK;
-                av[i] = *reinterpret_cast<const f32x4*>(
-                    wp + ((int64_t)tap * p.Cp + c0 + ch) * p.Mp + m0 + col4 * 4);
-            }
+            if (e4 < A_VEC) av[i] = *reinterpret_cast<const f32x4*>(wb + abyte[i]);
         }
     };
     auto store_chunk = [&](int c0) {
+        if constexpr (QUAD) {
+#pragma unroll
+            for (int kq = 0; kq < QPT; ++kq) {
+                const bool ok = qok[kq] && c0 + qch[kq] < p.C;
+                f32x4 v = xq[kq];
+                if constexpr (MOD) v *= sc[kq];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
+                *reinterpret_cast<f32x4*>(Xs + qdst[kq]) = v;
+            }
+        } else {
         if constexpr (MOD) {
             if (one_image) {
 #pragma unroll
@@ -248,12 +366,15 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
             }
         }
 #pragma unroll
-        for (int ch = 0; ch < CK; ++ch)
+        for (int s = 0; s < PPT; ++s) {
+            if (!wave_has[s]) continue;
 #pragma unroll
-            for (int s = 0; s < PPT; ++s) {
-                const int e = tid + kBlock * s;
-                if (e < CP) Xs[ch * XCAP + e] = xv[ch][s];
+            for (int ch = 0; ch < CK; ++ch) {
+                const bool ch_ok = (c0 + ch) < p.C;
+                Xs[ch * XROW + xdst[s]] = (ch_ok && pok[s]) ? xv[ch][s] : 0.0f;
             }
+        }
+        }
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int e4 = tid + kBlock * i;
@@ -265,28 +386,46 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     int c_end = c_begin + p.chunks_per_split * CK;
     if (c_end > p.Cp) c_end = p.Cp;
     load_chunk(c_begin);
+    SAE_CLOCK_PHASE(0)
     for (int c0 = c_begin; c0 < c_end; c0 += CK) {
         __syncthreads();   // everyone finished reading the previous chunk
+        SAE_CLOCK_PHASE(2)
         store_chunk(c0);
+        SAE_CLOCK_PHASE(3)
         __syncthreads();
+        SAE_CLOCK_PHASE(4)
         if (c0 + CK < c_end) load_chunk(c0 + CK);   // in flight under the MFMAs below
+        SAE_CLOCK_PHASE(5)
+        // One step = one (tap, channel pair): MI x NI MFMAs on operands that were read from LDS kIgemmAhead steps
+        // earlier (a ring of register sets), so a wave's ds_reads are in flight under its own MFMAs instead of being
+        // waited for in front of each group.  The scheduling barriers keep the compiler from sinking the reads back
+        // to their first use; the accumulation order (tap-major, then channel pair) is unchanged.
+        constexpr int KK = CK / 2;
+        constexpr int NSTEP = T * KK;
+        constexpr int AH = kIgemmAhead, RING = AH + 1;
+        float ra[RING][MI], rb[RING][NI];
+        auto fetch = [&](int s, float (&a)[MI], float (&b)[NI]) {
+            const int t = s / KK, ch = 2 * (s % KK) + half;
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+            for (int mi = 0; mi < MI; ++mi) a[mi] = As[(t * CK + ch) * BM + (wm * MI + mi) * 32 + l31];
 #pragma unroll
-            for (int kk = 0; kk < CK / 2; ++kk) {
-                const int ch = 2 * kk + half;
-                float a[MI], b[NI];
+            for (int ni = 0; ni < NI; ++ni) b[ni] = Xs[ch * XROW + pixbase[ni] + tapoff[t]];
+        };
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a[mi] = As[(t * CK + ch) * BM + (wm * MI + mi) * 32 + l31];
+        for (int s = 0; s < AH; ++s) fetch(s, ra[s % RING], rb[s % RING]);
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) b[ni] = Xs[ch * XCAP + pixbase[ni] + tapoff[t]];
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + AH < NSTEP) fetch(s + AH, ra[(s + AH) % RING], rb[(s + AH) % RING]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-            }
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s % RING][mi], rb[s % RING][ni],
+                                                                       acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        SAE_CLOCK_PHASE(1)
     }
 
     // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
@@ -316,6 +455,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                 }
         }
     }
+    SAE_CLOCK_PHASE(6)
+    SAE_CLOCK_END
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2466,7 +2607,20 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
             } else {
                 return fail(SAE_EINVAL, "conv igemm: 128x256 tile is 3x3 stride-1 only");
             }
-        case 0: SAE_IGEMM(KS, S, 2, 2, 2, 2, CK); break;
+        case 0:
+            if constexpr (KS == 3 && S == 1) {
+                // quad staging (see conv_igemm_kernel): rows a multiple of 16 bytes, 16-byte aligned tensor, and the
+                // widened patch within 64 quads per channel (always for tiles >= 16 wide)
+                static const int quad_knob = [] { const char* e = getenv("SAE_IGEMM_QUAD"); return e ? atoi(e) : 1; }();
+                const int qn = tn * ph * ((tw + 8) / 4);
+                if (quad_knob && p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && qn <= sh.bn / 2 && p.pad <= 4) {
+                    if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 2, 2, 2, 2, 8, true, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    else hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 2, 2, 2, 2, 8, false, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    break;
+                }
+            }
+            SAE_IGEMM(KS, S, 2, 2, 2, 2, CK);
+            break;
         case 1: SAE_IGEMM(KS, S, 2, 2, 1, 4, CK); break;
         default:
             if constexpr (S == 1)
@@ -2876,3 +3030,15 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
     return check_launch(who);
 }
 }  // namespace
+
+#ifdef SAE_CLOCK_PROBE
+// profiling variant only: read (and optionally clear) the ten counters of g_clock_probe
+extern "C" int sae_debug_clock_probe(unsigned long long* host3, int reset) {
+    if (hipMemcpyFromSymbol(host3, HIP_SYMBOL(g_clock_probe), 80) != hipSuccess) return 1;
+    if (reset) {
+        const unsigned long long z[16] = {};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_clock_probe), z, 128) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

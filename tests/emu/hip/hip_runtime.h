@@ -341,6 +341,12 @@ static inline void __syncthreads() { hipemu::block_barrier(); }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
     std::memcpy((char*)(l) + (size) * hipemu::lane_id() + (off), (const void*)(g), (size))
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
+#define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#ifndef __clang__
+#define __builtin_assume(x) ((void)0)
+#endif
+#define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
 
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
