@@ -1599,23 +1599,31 @@ struct WgPatchCap {
 // MODE 2: MODE 1 with the B-tile lanes enumerating (channel, tap) pairs (C * taps <= 32: the RGB
 //         stems): one MFMA per k-pair instead of one per tap.
 // MOD: an operand is style-modulated while staged (WgradParams::l_scale / s_scale); a separate instantiation
-template <int KS, int S, int TA, int TB, int WA, int WB, int MODE, bool MOD = false>
+// WQ (stride 1, one image per 64-pixel chunk, rows of both tensors a multiple of four floats): both operands are staged as
+// aligned 16-byte quads -- a wave loads the 64 pixels of FOUR gy channels with one dwordx4 instruction, and the widened
+// x patch [x0 - 4, x0 + TW + 4) of one channel with one (3x3; 1x1: four channels) -- 20 (3x3) or 16 (1x1) vector-memory
+// instructions per wave and chunk instead of 64.  At one wave per SIMD the issue of those instructions is not hidden by
+// anything (profiles/r2_phase_clock_*.txt: 21 % of the kernel for 3x3, 54-61 % for 1x1).  LDS rows are 66 (S, 1x1 L) or
+// 162 (3x3 L) floats: 8-byte aligned for ds_write_b64 and conflict-free across the 32 channels of an MFMA operand read.
+template <int KS, int S, int TA, int TB, int WA, int WB, int MODE, bool MOD = false, bool WQ = false>
 __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restrict__ xl,
                                                             const float* __restrict__ gs,
                                                             float* __restrict__ slab, const WgradParams p) {
     constexpr bool PIXSPLIT = MODE == 1 || MODE == 2;
     constexpr bool PACKCT = MODE == 2;     // MODE 4 = MODE 0 with the operand double buffer forced on
     static_assert(PIXSPLIT ? (WA == 1 && WB == 1 && TA == 1 && TB == 1) : (WA * WB == 4), "wave arrangement");
+    static_assert(!WQ || (S == 1 && !PIXSPLIT && !MOD), "quad staging: stride 1, MODE 0 / 4, operands not modulated in the kernel");
     constexpr int T = KS * KS;
     constexpr int TT = PACKCT ? 1 : T;      // accumulator tap-tiles per (ta, tb)
     constexpr int BA = 32 * TA * WA, BB = 32 * TB * WB;
     constexpr int PK = kWgPix;
-    constexpr int SLD = PK + 1;
-    constexpr int LP = WgPatchCap<KS, S>::value;
+    constexpr int SLD = WQ ? PK + 2 : PK + 1;
+    constexpr int LP = WQ ? (KS == 1 ? PK + 2 : 162) : WgPatchCap<KS, S>::value;
     __shared__ float Ss[BA * SLD];
     __shared__ float Ls[BB * LP];
     __shared__ float red[PIXSPLIT ? 4 * 32 * 33 : 1];
 
+    SAE_CLOCK_BEGIN
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     // the wave index is wave-uniform: say so, or every per-wave base address lives in VGPRs
@@ -1641,7 +1649,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     const int TN = PK >> (p.tw_log2 + p.th_log2);
     const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
     const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
-    const int RS = PW;
+    const int RS = (WQ && KS == 3) ? TW + 8 : PW;      // WQ: patch rows widened to whole quads
     const int IP = PH * RS;
     const int CPs = TN * IP;
     const int HWl = p.H * p.W, HWs = p.OH * p.OW;
@@ -1684,8 +1692,15 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     constexpr int NS = BA / 4;
     constexpr int NLB = BB / 4;
     constexpr int LS = (KS == 1) ? 1 : (LP + kWave - 1) / kWave;
-    float sv[NS];
-    float lv[NLB][LS];
+    float sv[WQ ? 1 : NS];
+    float lv[WQ ? 1 : NLB][LS];
+    // WQ: S quads: lane = (channel sub-index cs = lane / 16, quad q = lane % 16), load i covers channels 16 i + 4 wid + cs;
+    // L quads (3x3): lane = quad of the widened patch, load j is channel wid + 4 j; (1x1): the S mapping
+    constexpr int NSQ = BA / 16;
+    constexpr int NLQ = (KS == 1) ? BB / 16 : BB / 4;
+    f32x4 sq[WQ ? NSQ : 1];
+    f32x4 lq[WQ ? NLQ : 1];
+    bool sq_ok = false, lq_ok = false;
     constexpr bool BRANCHFREE = KS == 3 && S == 2 && !PIXSPLIT;
     bool s_ok = false;      // validity of the prefetched chunk's elements (applied in store_chunk)
     int l_okmask = 0;
@@ -1721,6 +1736,46 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
                 }
             }
         }
+        if constexpr (WQ) {
+            const int q = lane & 15, cs = lane >> 4;
+            const int py = (4 * q) >> p.tw_log2, px = (4 * q) & (TW - 1);
+            {   // S: gy[n0][a0 + a][oy0 + py][ox0 + px .. + 3]
+                const int oy = oy0 + py, ox = ox0 + px;
+                sq_ok = oy < p.OH && ox < p.OW;
+                const char* sbase = reinterpret_cast<const char*>(gs + ((int64_t)n0 * p.M + a0) * HWs);
+                const unsigned pix = sq_ok ? (unsigned)(oy * p.OW + ox) : 0u;
+#pragma unroll
+                for (int i = 0; i < NSQ; ++i) {
+                    const int a = 16 * i + 4 * wid + cs;
+                    const unsigned off = (a0 + a < p.M) ? 4u * ((unsigned)(a * HWs) + pix) : 0u;
+                    sq[i] = *reinterpret_cast<const f32x4*>(sbase + off);
+                }
+            }
+            const char* lbase = reinterpret_cast<const char*>(xl + ((int64_t)n0 * p.C + b0) * HWl);
+            if constexpr (KS == 1) {   // L: x at the same pixels (1x1, stride 1, pad 0)
+                const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
+                lq_ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const unsigned pix = lq_ok ? (unsigned)(iy * p.W + ix) : 0u;
+#pragma unroll
+                for (int j = 0; j < NLQ; ++j) {
+                    const int b = 16 * j + 4 * wid + cs;
+                    const unsigned off = (b0 + b < p.C) ? 4u * ((unsigned)(b * HWl) + pix) : 0u;
+                    lq[j] = *reinterpret_cast<const f32x4*>(lbase + off);
+                }
+            } else {                   // L: quad `lane` of the widened patch of channel wid + 4 j
+                const int RQ = RS >> 2;
+                const int r = lane / RQ, qc = lane - r * RQ;
+                const int iy = oy0 - p.pad + r, ix = ox0 - 4 + 4 * qc;
+                lq_ok = r < PH && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                const unsigned pix = lq_ok ? (unsigned)(iy * p.W + ix) : 0u;
+#pragma unroll
+                for (int j = 0; j < NLQ; ++j) {
+                    const int b = wid + 4 * j;
+                    const unsigned off = (b0 + b < p.C) ? 4u * ((unsigned)(b * HWl) + pix) : 0u;
+                    lq[j] = *reinterpret_cast<const f32x4*>(lbase + off);
+                }
+            }
+        } else {
         // addressing: one wave-uniform 64-bit base per tensor + 32-bit (lane + channel) offsets,
         // so loads use the SGPR-base form and no per-channel pointer is kept in registers
         {
@@ -1780,8 +1835,41 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
                 }
             }
         }
+        }
     };
     auto store_chunk = [&]() {
+        if constexpr (WQ) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const int q = lane & 15, cs = lane >> 4;
+#pragma unroll
+            for (int i = 0; i < NSQ; ++i) {
+                const int a = 16 * i + 4 * wid + cs;
+                f32x4 v = sq[i];
+                const bool ok = sq_ok && a0 + a < p.M;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
+                float* dst = Ss + a * SLD + 4 * q;
+                *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
+                *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < NLQ; ++j) {
+                const int b = (KS == 1) ? 16 * j + 4 * wid + cs : wid + 4 * j;
+                f32x4 v = lq[j];
+                const bool ok = lq_ok && b0 + b < p.C;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
+                // 3x3: lanes beyond the patch (r >= PH) have lq_ok false and still own a distinct slot < 64 quads = 256
+                // floats: keep them inside the row by folding onto the last quad slots of the row's spare space
+                const int slot = (KS == 1) ? 4 * q : 4 * lane;
+                if (KS == 1 || 4 * lane + 3 < LP) {
+                    float* dst = Ls + b * LP + slot;
+                    *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
+                    *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
+                }
+            }
+            return;
+        }
         if (MOD && p.s_scale) {        // modulated S operand: factor of (image of this lane's pixel, channel a)
             if (TN == 1) {
 #pragma unroll
@@ -1831,11 +1919,16 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     };
 
     if (ch_begin < ch_end) load_chunk(ch_begin);
+    SAE_CLOCK_PHASE(0)
     for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
         __syncthreads();   // previous chunk fully consumed
+        SAE_CLOCK_PHASE(2)
         store_chunk();
+        SAE_CLOCK_PHASE(3)
         __syncthreads();
+        SAE_CLOCK_PHASE(4)
         if (chunk + 1 < ch_end) load_chunk(chunk + 1);   // in flight under the MFMAs below
+        SAE_CLOCK_PHASE(5)
 
         // ---- MFMA over the 64 pixels, two per instruction.  The LDS operands of k-pair i+1 are
         // fetched into a second register set before the MFMAs of k-pair i issue (explicit
@@ -1849,7 +1942,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
             const int px = pk & (TW - 1);
             const int py = (pk >> p.tw_log2) & (TH - 1);
             const int pn = pk >> (p.tw_log2 + p.th_log2);
-            const int pbase = pn * IP + ((KS == 1) ? py * RS + px : py * S * RS + px * S);
+            const int pbase = pn * IP + ((KS == 1) ? py * RS + px : py * S * RS + px * S) + ((WQ && KS == 3) ? 4 - p.pad : 0);
 #pragma unroll
             for (int ta = 0; ta < TA; ++ta) a[ta] = Ss[((wa * TA + ta) * 32 + l31) * SLD + pk];
             if constexpr (PACKCT) {
@@ -1899,6 +1992,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
                 mma(a_cur, b_cur);
             }
         }
+        SAE_CLOCK_PHASE(1)
     }
 
     // ---- slab store: rows = a (m), cols = b (c)
@@ -1936,6 +2030,8 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
                     }
                 }
     }
+    SAE_CLOCK_PHASE(6)
+    SAE_CLOCK_END
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2805,9 +2901,13 @@ int64_t tr_ws(int cin, int mout) {
     return (int64_t)9 * round_up(cin, sh.ck) * round_up(mout, sh.bm);
 }
 
-template <int KS, int S, int TA, int TB, int WA, int WB, int MODE>
+template <int KS, int S, int TA, int TB, int WA, int WB, int MODE, bool WQ = false>
 void launch_wgrad(const float* x, const float* gy, float* slab, const WgradParams& p, const WgPlan& w, hipStream_t s) {
     const dim3 grid((unsigned)(w.Bp / w.sh.bb), (unsigned)(w.Ap / w.sh.ba), (unsigned)w.slices);
+    if constexpr (WQ) {
+        hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, TA, TB, WA, WB, MODE, false, true>), grid, dim3(kBlock), 0, s, x, gy, slab, p);
+        return;
+    }
     if (p.l_scale || p.s_scale)
         hipLaunchKernelGGL((conv_wgrad_kernel<KS, S, TA, TB, WA, WB, MODE, true>), grid, dim3(kBlock), 0, s, x, gy, slab, p);
     else
@@ -2992,6 +3092,12 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
         const int cap = (d->kh == 1) ? 65 : (d->stride == 1 ? 145 : 325);
         if (tn * ph * pw > cap) return fail(SAE_EINVAL, "%s: patch exceeds LDS cap", who);
     }
+    // quad staging (see conv_wgrad_kernel): stride 1, one image per 64-pixel chunk, rows of both tensors a multiple of 16
+    // bytes, 16-byte aligned tensors, factors (if any) applied per K-slice in the reduction
+    static const int wq_knob = [] { const char* e = getenv("SAE_WGRAD_QUAD"); return e ? atoi(e) : 1; }();
+    const bool wq = wq_knob && !w.bx && w.sh.mode == 0 && d->stride == 1 && (kWgPix >> (w.tw_log2 + w.th_log2)) == 1 &&
+                    d->ow % 4 == 0 && d->w % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0 &&
+                    !p.l_scale && !p.s_scale && (d->kh == 3 ? d->pad <= 4 : d->pad == 0);
     if (d->n > 0 && w.bx) {
         WgBxParams q{};
         q.N = p.N; q.C = p.C; q.H = p.H; q.W = p.W; q.M = p.M; q.OH = p.OH; q.OW = p.OW; q.pad = p.pad;
@@ -3010,14 +3116,20 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
             else launch_wgrad<1, 2, 1, 1, 1, 1, 2>(x, gy, workspace, p, w, s);
         } else if (w.sh.mode == 1) {
             launch_wgrad<3, 1, 1, 1, 1, 1, 1>(x, gy, workspace, p, w, s);
-        } else if (d->kh == 3 && d->stride == 1) launch_wgrad<3, 1, 1, 1, 2, 2, 0>(x, gy, workspace, p, w, s);
+        } else if (d->kh == 3 && d->stride == 1) {
+            if (wq) launch_wgrad<3, 1, 1, 1, 2, 2, 0, true>(x, gy, workspace, p, w, s);
+            else launch_wgrad<3, 1, 1, 1, 2, 2, 0>(x, gy, workspace, p, w, s);
+        }
         else if (d->kh == 3) {
             // operand double buffer: 497 of 512 registers, no spill; 77.7 vs 68.6 TFLOP/s measured
             static const int db_knob = [] { const char* e = getenv("SAE_WGRAD_S2_DB"); return e ? atoi(e) : 1; }();
             if (db_knob) launch_wgrad<3, 2, 1, 1, 4, 1, 4>(x, gy, workspace, p, w, s);
             else launch_wgrad<3, 2, 1, 1, 4, 1, 0>(x, gy, workspace, p, w, s);
         }
-        else if (d->stride == 1) launch_wgrad<1, 1, 2, 2, 2, 2, 0>(x, gy, workspace, p, w, s);
+        else if (d->stride == 1) {
+            if (wq) launch_wgrad<1, 1, 2, 2, 2, 2, 0, true>(x, gy, workspace, p, w, s);
+            else launch_wgrad<1, 1, 2, 2, 2, 2, 0>(x, gy, workspace, p, w, s);
+        }
         else launch_wgrad<1, 2, 2, 2, 2, 2, 0>(x, gy, workspace, p, w, s);
     }
     const int64_t total = (int64_t)w.taps * d->m * d->c;

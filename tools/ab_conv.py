@@ -63,16 +63,16 @@ def clock_mode():
     buf = (C.c_ulonglong * 10)()
     stream = lambda: torch.cuda.current_stream(dev).cuda_stream
     print("%-20s %-6s %9s %9s %9s %9s   %s" % ("shape", "op", "TFLOP/s", "of 157.3", "MHz", "of peak@MHz",
-          "wave-0 time of conv_igemm_kernel: prologue | MFMA | barrier | LDS stores | barrier | load issue | epilogue (%)"))
+          "wave-0 time of conv_igemm_kernel / conv_wgrad_kernel: prologue | MFMA | barrier | LDS stores | barrier | load issue | epilogue (%)"))
     for (n, c, h, w, m, k, s, p, tag) in SHAPES:
         d = H.conv_desc(n, c, h, w, m, k, s, p)
         x = torch.randn(n, c, h, w, device=dev)
         wt = torch.randn(m, c, k, k, device=dev)
         gy = torch.randn(n, m, d.oh, d.ow, device=dev)
         flops = 2.0 * n * m * d.oh * d.ow * c * k * k
-        for op, oname in [(0, "fwd"), (1, "dgrad")]:
-            a, b = [(x, wt), (gy, wt)][op]
-            o = torch.empty([(n, m, d.oh, d.ow), (n, c, h, w)][op], device=dev)
+        for op, oname in [(0, "fwd"), (1, "dgrad"), (2, "wgrad")]:
+            a, b = [(x, wt), (gy, wt), (x, gy)][op]
+            o = torch.empty([(n, m, d.oh, d.ow), (n, c, h, w), (m, c, k, k)][op], device=dev)
             nws = lib.query("conv2d_workspace", C.byref(d), op)
             ws = torch.empty(max(nws, 1), device=dev)
             fn = lambda: lib.call(H.OPS[op], a.data_ptr(), b.data_ptr(), o.data_ptr(), C.byref(d), 1.0, ws.data_ptr(), nws,

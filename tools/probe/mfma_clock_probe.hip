@@ -199,6 +199,74 @@ __global__ __launch_bounds__(256) void probe_pipe(const float* __restrict__ src,
     }
 }
 
+// the 128 x 256 tile as a software pipeline at one wave per SIMD: 8 MFMAs per (tap, channel pair) step on 128
+// accumulator registers, per chunk and thread 9 dwordx4 weight loads + 4 dwordx4 activation-quad loads and as many
+// ds_write_b128, two LDS buffers, one barrier per chunk.  SPREAD: staging instructions per step (1 or 2)
+template <int SPREAD>
+__global__ __launch_bounds__(256) void probe_wide(const float* __restrict__ src, const float* __restrict__ wsrc,
+                                                  float* __restrict__ sink, long long span, int chunks,
+                                                  unsigned long long* __restrict__ clk) {
+    constexpr int CK = 8, ASZ = 9 * CK * 128, XSZ = CK * 416, NSTEP = 36, NA = 9, NX = 4, NITEM = NA + NX;
+    __shared__ float As[2][ASZ];
+    __shared__ float Xs[2][XSZ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned smask = (unsigned)span - 1u;
+    const unsigned long long c0 = clock64(), r0 = wall_clock64();
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    for (int i = tid; i < 2 * ASZ; i += 256) As[0][i] = 1e-3f * (float)(i & 15);
+    for (int i = tid; i < 2 * XSZ; i += 256) Xs[0][i] = 1e-3f * (float)(i & 7);
+    __syncthreads();
+    f32x4 st[NITEM];
+    for (int i = 0; i < NITEM; ++i) st[i] = f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f};
+    auto gload = [&](int c, int item) {
+        if (item < NA) st[item] = *reinterpret_cast<const f32x4*>(wsrc + (((unsigned)c * ASZ + (item * 256 + tid) * 4) & (kWeights - 1)));
+        else st[item] = *reinterpret_cast<const f32x4*>(src + ((((unsigned)c * gridDim.x + blockIdx.x) * 4096u + (item - NA) * 1024 + tid * 4) & smask));
+    };
+    auto lwrite = [&](int buf, int item) {
+        if (item < NA) *reinterpret_cast<f32x4*>(&As[buf][4 * (tid + 256 * item)]) = st[item];
+        else *reinterpret_cast<f32x4*>(&Xs[buf][(4 * (tid + 256 * (item - NA))) % (XSZ - 4)]) = st[item];
+    };
+    float ra[2][2], rb[2][4];
+    for (int c = 0; c < chunks; ++c) {
+        const int cur = c & 1;
+        auto fetch = [&](int s, float (&a)[2], float (&b)[4]) {
+            const int row = (s * 128 + (lane & 31)) % (ASZ - 32);
+            a[0] = As[cur][row]; a[1] = As[cur][row + 32];
+            const int xb = (s * 8 + lane) % (XSZ - 140);
+            b[0] = Xs[cur][xb]; b[1] = Xs[cur][xb + 40]; b[2] = Xs[cur][xb + 80]; b[3] = Xs[cur][xb + 120];
+        };
+        fetch(0, ra[0], rb[0]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + 1 < NSTEP) fetch(s + 1, ra[(s + 1) & 1], rb[(s + 1) & 1]);
+#pragma unroll
+            for (int q = 0; q < SPREAD; ++q) {
+                const int j = SPREAD * s + q;
+                if (j < NITEM) lwrite(cur ^ 1, j);
+                else if (j < 2 * NITEM) gload(c + 2, j - NITEM);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi * 4 + ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s & 1][mi], rb[s & 1][ni], acc[mi * 4 + ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+    float keep = 0.0f;
+    for (int i = 0; i < 8; ++i) keep += acc[i][0] + acc[i][7] + acc[i][15];
+    for (int i = 0; i < NITEM; ++i) keep += st[i][0] + st[i][3];
+    if (keep == 12345.678f) sink[0] = keep;
+    if (tid == 0) {
+        atomicAdd(&clk[0], clock64() - c0);
+        atomicAdd(&clk[1], wall_clock64() - r0);
+    }
+}
+
 template <typename K>
 static void run(const char* name, K kernel, int mfma_per_chunk, const float* src, const float* wsrc, float* sink,
                 long long span, int blocks, int chunks, unsigned long long* clk, int launches) {
@@ -238,6 +306,8 @@ int main(int argc, char** argv) {
     run("mode 1 (+ LDS reads)        ", probe<1>, 144, src, wsrc, sink, span, blocks, chunks, clk, n);
     run("mode 2 (+ staging, 2 barr.) ", probe<2>, 144, src, wsrc, sink, span, blocks, chunks, clk, n);
     run("mode 5 (mode 2, odd slots late)", probe<5>, 144, src, wsrc, sink, span, blocks, chunks, clk, n);
+    run("wide 128x256, 1 staging instr/step", probe_wide<1>, 288, src, wsrc, sink, span, 256, chunks, clk, n);
+    run("wide 128x256, 2 staging instr/step", probe_wide<2>, 288, src, wsrc, sink, span, 256, chunks, clk, n);
     run("pipe CK8 loads+writes+barrier", probe_pipe<8, 7>, 144, src, wsrc, sink, span, blocks, chunks, clk, n);
     run("pipe CK8 barrier only        ", probe_pipe<8, 4>, 144, src, wsrc, sink, span, blocks, chunks, clk, n);
     run("pipe CK8 writes+barrier      ", probe_pipe<8, 6>, 144, src, wsrc, sink, span, blocks, chunks, clk, n);
