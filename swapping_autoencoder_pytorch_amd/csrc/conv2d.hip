@@ -135,8 +135,8 @@ struct PatchCap {
 
 // MOD: the input is style-modulated while staged (IgemmParams::in_scale); a separate instantiation, so the
 // un-modulated kernels of E / D / Dpatch carry no trace of it
-// QUAD (3x3 stride 1, rows a multiple of four floats wide, tiles at least 16 wide): the input patch is staged as
-// 16-byte quads aligned in memory -- the rows of the patch widened to [x0 - 4, x0 + TW + 4) -- CK channels' worth of quads
+// QUAD (stride 1, rows a multiple of four floats wide; 3x3: tiles at least 16 wide, 1x1: pad 0): the input patch is staged
+// as 16-byte quads aligned in memory -- 3x3: the rows of the patch widened to [x0 - 4, x0 + TW + 4) -- CK channels' worth of quads
 // dealt out over the workgroup, so a chunk takes BN/64 dwordx4 loads and as many ds_write_b128 per thread instead of
 // 2.25 BN/32 dword ones.  A wave64 vector-memory instruction occupies the CU's address path for ~25-30 cycles whatever
 // its width (tools/probe/mfma_clock_probe.hip, profiles/r2_phase_clock_*.txt): the staging phase of a chunk is bound by the
@@ -146,13 +146,14 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                                                             const float* __restrict__ wp,
                                                             float* __restrict__ y, const IgemmParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(!QUAD || (KS == 3 && S == 1), "quad staging: 3x3 stride 1");
+    static_assert(!QUAD || S == 1, "quad staging: stride 1");
+    constexpr int XQ0 = (KS == 3) ? 4 : 0;      // QUAD: columns added on either side of the tile
     constexpr int T = KS * KS;
     constexpr int BM = 32 * MI * WM;
     constexpr int BN = 32 * NI * WN;
     constexpr int XCAP = PatchCap<KS, S, BN>::value;
     constexpr int PPT = QUAD ? 1 : (XCAP + kBlock - 1) / kBlock;      // patch slots per thread per channel
-    constexpr int QCAP = BN / 2;                                      // QUAD: quads per channel accepted by the host
+    constexpr int QCAP = (KS == 3) ? BN / 2 : BN / 4;                 // QUAD: quads per channel accepted by the host
     constexpr int QPT = QUAD ? (CK * QCAP + kBlock - 1) / kBlock : 1; // ... and quad slots per thread per chunk
     constexpr int A_VEC = T * CK * BM / 4;                  // float4 per A chunk
     constexpr int APT = (A_VEC + kBlock - 1) / kBlock;
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
     const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
     const int HALFW = (PW + 1) >> 1;
-    const int RS = QUAD ? TW + 8 : PW;
+    const int RS = QUAD ? TW + 2 * XQ0 : PW;
     const int IP = PH * RS;
     const int CP = TN * IP;           // staged floats per channel (<= XCAP, checked on the host)
     const int HW = p.H * p.W;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
             const int rem = q - pn * QI;
             const int r = rem / RQ;
             const int qc = rem - r * RQ;
-            const int iy = oy0 - p.pad + r, ix = ox0 - 4 + 4 * qc;
+            const int iy = oy0 - p.pad + r, ix = ox0 - XQ0 + 4 * qc - (KS == 1 ? p.pad : 0);
             const bool slot = ch < CK;
             const bool in = slot && n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             qok[kq] = in;
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
         const int px = pp & (TW - 1);
         const int py = (pp >> p.tw_log2) & (TH - 1);
         const int pn = pp >> (p.tw_log2 + p.th_log2);
-        pixbase[ni] = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px + (QUAD ? 4 - p.pad : 0);
+        pixbase[ni] = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px + ((QUAD && KS == 3) ? 4 - p.pad : 0);
     }
     int tapoff[T];
 #pragma unroll
@@ -2683,6 +2684,9 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
             return SAE_OK;
         }
     }
+    // 1x1 stride 1, pad 0 with quad staging: the tile's own pixels, rows a multiple of 16 bytes (tw >= 4 always is)
+    static const int quad1_knob = [] { const char* e = getenv("SAE_IGEMM_QUAD"); return e ? atoi(e) : 1; }();
+    const bool quad1 = quad1_knob && KS == 1 && S == 1 && p.pad == 0 && p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     switch (sh.cfg) {
 #define SAE_IGEMM(...)                                                                                          \
     do {                                                                                                        \
@@ -2715,9 +2719,25 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
                     break;
                 }
             }
+            if constexpr (KS == 1 && S == 1) {
+                if (quad1) {
+                    if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<1, 1, 2, 2, 2, 2, 32, true, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    else hipLaunchKernelGGL((conv_igemm_kernel<1, 1, 2, 2, 2, 2, 32, false, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    break;
+                }
+            }
             SAE_IGEMM(KS, S, 2, 2, 2, 2, CK);
             break;
-        case 1: SAE_IGEMM(KS, S, 2, 2, 1, 4, CK); break;
+        case 1:
+            if constexpr (KS == 1 && S == 1) {
+                if (quad1) {
+                    if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<1, 1, 2, 2, 1, 4, 32, true, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    else hipLaunchKernelGGL((conv_igemm_kernel<1, 1, 2, 2, 1, 4, 32, false, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    break;
+                }
+            }
+            SAE_IGEMM(KS, S, 2, 2, 1, 4, CK);
+            break;
         default:
             if constexpr (S == 1)
                 SAE_IGEMM(KS, 1, 1, 4, 1, 4, CK2);
