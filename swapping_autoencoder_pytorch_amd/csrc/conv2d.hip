@@ -1606,6 +1606,10 @@ struct WgPatchCap {
 // instructions per wave and chunk instead of 64.  At one wave per SIMD the issue of those instructions is not hidden by
 // anything (profiles/r2_phase_clock_*.txt: 21 % of the kernel for 3x3, 54-61 % for 1x1).  LDS rows are 66 (S, 1x1 L) or
 // 162 (3x3 L) floats: 8-byte aligned for ds_write_b64 and conflict-free across the 32 channels of an MFMA operand read.
+// Stride 2 (3x3, pad 0): the x rows are 2^k + 1 floats, so the patch [2 x0, 2 x0 + 2 TW] is fetched as quads that are only
+// 4-byte aligned (global_load_dwordx4 takes them, tools/probe/unaligned_x4_probe.hip) -- 85 quads per channel, two loads
+// per channel and wave instead of six; a quad that would run past the end of its row is fetched from W - 4 and shifted,
+// so nothing is read outside the tensor.  24 instead of 80 vector-memory instructions per wave and chunk.
 template <int KS, int S, int TA, int TB, int WA, int WB, int MODE, bool MOD = false, bool WQ = false>
 __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restrict__ xl,
                                                             const float* __restrict__ gs,
@@ -1613,13 +1617,13 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     constexpr bool PIXSPLIT = MODE == 1 || MODE == 2;
     constexpr bool PACKCT = MODE == 2;     // MODE 4 = MODE 0 with the operand double buffer forced on
     static_assert(PIXSPLIT ? (WA == 1 && WB == 1 && TA == 1 && TB == 1) : (WA * WB == 4), "wave arrangement");
-    static_assert(!WQ || (S == 1 && !PIXSPLIT && !MOD), "quad staging: stride 1, MODE 0 / 4, operands not modulated in the kernel");
+    static_assert(!WQ || (!PIXSPLIT && !MOD && (S == 1 || KS == 3)), "quad staging: MODE 0 / 4, operands not modulated in the kernel");
     constexpr int T = KS * KS;
     constexpr int TT = PACKCT ? 1 : T;      // accumulator tap-tiles per (ta, tb)
     constexpr int BA = 32 * TA * WA, BB = 32 * TB * WB;
     constexpr int PK = kWgPix;
     constexpr int SLD = WQ ? PK + 2 : PK + 1;
-    constexpr int LP = WQ ? (KS == 1 ? PK + 2 : 162) : WgPatchCap<KS, S>::value;
+    constexpr int LP = WQ ? (KS == 1 ? PK + 2 : (S == 1 ? 162 : 342)) : WgPatchCap<KS, S>::value;
     __shared__ float Ss[BA * SLD];
     __shared__ float Ls[BB * LP];
     __shared__ float red[PIXSPLIT ? 4 * 32 * 33 : 1];
@@ -1650,7 +1654,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     const int TN = PK >> (p.tw_log2 + p.th_log2);
     const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
     const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
-    const int RS = (WQ && KS == 3) ? TW + 8 : PW;      // WQ: patch rows widened to whole quads
+    const int RS = (WQ && KS == 3) ? (S == 1 ? TW + 8 : ((PW + 3) >> 2) << 2) : PW;      // WQ: patch rows widened to whole quads
     const int IP = PH * RS;
     const int CPs = TN * IP;
     const int HWl = p.H * p.W, HWs = p.OH * p.OW;
@@ -1698,10 +1702,12 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
     // WQ: S quads: lane = (channel sub-index cs = lane / 16, quad q = lane % 16), load i covers channels 16 i + 4 wid + cs;
     // L quads (3x3): lane = quad of the widened patch, load j is channel wid + 4 j; (1x1): the S mapping
     constexpr int NSQ = BA / 16;
-    constexpr int NLQ = (KS == 1) ? BB / 16 : BB / 4;
+    constexpr int NLQ = (KS == 1) ? BB / 16 : (S == 1 ? BB / 4 : BB / 2);   // stride 2: two loads per channel
     f32x4 sq[WQ ? NSQ : 1];
     f32x4 lq[WQ ? NLQ : 1];
     bool sq_ok = false, lq_ok = false;
+    [[maybe_unused]] bool lq_ok2 = false;          // stride 2: validity of the second quad of a channel
+    [[maybe_unused]] int lq_sh[2] = {0, 0};        // ... and how far each was moved left to stay inside its row
     constexpr bool BRANCHFREE = KS == 3 && S == 2 && !PIXSPLIT;
     bool s_ok = false;      // validity of the prefetched chunk's elements (applied in store_chunk)
     int l_okmask = 0;
@@ -1762,6 +1768,27 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
                     const int b = 16 * j + 4 * wid + cs;
                     const unsigned off = (b0 + b < p.C) ? 4u * ((unsigned)(b * HWl) + pix) : 0u;
                     lq[j] = *reinterpret_cast<const f32x4*>(lbase + off);
+                }
+            } else if constexpr (S == 2) {   // L: quads lane, lane + 64 of the patch of channel wid + 4 j (pad 0)
+                const int RQ = RS >> 2;
+                unsigned pix[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int qi = lane + 64 * h;
+                    const int r = qi / RQ, qc = qi - r * RQ;
+                    const int iy = oy0 * 2 + r, ix = ox0 * 2 + 4 * qc;
+                    const bool ok = r < PH && iy < p.H && ix < p.W;
+                    const int ixc = ix + 4 <= p.W ? ix : p.W - 4;       // keep the quad inside its row
+                    lq_sh[h] = ok ? ix - ixc : 0;
+                    pix[h] = ok ? (unsigned)(iy * p.W + ixc) : 0u;
+                    if (h == 0) lq_ok = ok; else lq_ok2 = ok;
+                }
+#pragma unroll
+                for (int j = 0; j < NLQ; ++j) {
+                    const int b = wid + 4 * (j >> 1);
+                    const unsigned off = (b0 + b < p.C) ? 4u * ((unsigned)(b * HWl) + pix[j & 1]) : 0u;
+                    struct __attribute__((packed, aligned(4))) U4 { f32x4 v; };     // 4-byte aligned quad
+                    lq[j] = reinterpret_cast<const U4*>(lbase + off)->v;
                 }
             } else {                   // L: quad `lane` of the widened patch of channel wid + 4 j
                 const int RQ = RS >> 2;
@@ -1853,6 +1880,29 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
                 *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
                 *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
             }
+            if constexpr (KS == 3 && S == 2) {
+#pragma unroll
+                for (int j = 0; j < NLQ; ++j) {
+                    const int b = wid + 4 * (j >> 1);
+                    const int sh = lq_sh[j & 1];
+                    const f32x4 u = lq[j];
+                    // a quad fetched `sh` floats to the left of its place: drop the first sh, the tail lies beyond the row
+                    f32x4 v = u;
+                    if (sh == 1) v = f32x4{u[1], u[2], u[3], 0.0f};
+                    if (sh == 2) v = f32x4{u[2], u[3], 0.0f, 0.0f};
+                    if (sh == 3) v = f32x4{u[3], 0.0f, 0.0f, 0.0f};
+                    const bool ok = ((j & 1) ? lq_ok2 : lq_ok) && b0 + b < p.C;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
+                    const int slot = 4 * (lane + 64 * (j & 1));
+                    if (slot + 3 < LP) {
+                        float* dst = Ls + b * LP + slot;
+                        *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
+                        *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int j = 0; j < NLQ; ++j) {
                 const int b = (KS == 1) ? 16 * j + 4 * wid + cs : wid + 4 * j;
@@ -1943,7 +1993,7 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
             const int px = pk & (TW - 1);
             const int py = (pk >> p.tw_log2) & (TH - 1);
             const int pn = pk >> (p.tw_log2 + p.th_log2);
-            const int pbase = pn * IP + ((KS == 1) ? py * RS + px : py * S * RS + px * S) + ((WQ && KS == 3) ? 4 - p.pad : 0);
+            const int pbase = pn * IP + ((KS == 1) ? py * RS + px : py * S * RS + px * S) + ((WQ && KS == 3 && S == 1) ? 4 - p.pad : 0);
 #pragma unroll
             for (int ta = 0; ta < TA; ++ta) a[ta] = Ss[((wa * TA + ta) * 32 + l31) * SLD + pk];
             if constexpr (PACKCT) {
@@ -3118,6 +3168,10 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
     const bool wq = wq_knob && !w.bx && w.sh.mode == 0 && d->stride == 1 && (kWgPix >> (w.tw_log2 + w.th_log2)) == 1 &&
                     d->ow % 4 == 0 && d->w % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0 &&
                     !p.l_scale && !p.s_scale && (d->kh == 3 ? d->pad <= 4 : d->pad == 0);
+    // ... stride 2 (3x3, pad 0): gy rows a multiple of 16 bytes, x rows of any width >= 4 (4-byte aligned quads)
+    const bool wq2 = wq_knob && !w.bx && w.sh.mode == 0 && d->kh == 3 && d->stride == 2 && d->pad == 0 &&
+                     (kWgPix >> (w.tw_log2 + w.th_log2)) == 1 && d->ow % 4 == 0 && d->w >= 4 &&
+                     (reinterpret_cast<uintptr_t>(gy) & 15) == 0 && !p.l_scale && !p.s_scale;
     if (d->n > 0 && w.bx) {
         WgBxParams q{};
         q.N = p.N; q.C = p.C; q.H = p.H; q.W = p.W; q.M = p.M; q.OH = p.OH; q.OW = p.OW; q.pad = p.pad;
@@ -3143,7 +3197,8 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
         else if (d->kh == 3) {
             // operand double buffer: 497 of 512 registers, no spill; 77.7 vs 68.6 TFLOP/s measured
             static const int db_knob = [] { const char* e = getenv("SAE_WGRAD_S2_DB"); return e ? atoi(e) : 1; }();
-            if (db_knob) launch_wgrad<3, 2, 1, 1, 4, 1, 4>(x, gy, workspace, p, w, s);
+            if (wq2) launch_wgrad<3, 2, 1, 1, 4, 1, 4, true>(x, gy, workspace, p, w, s);
+            else if (db_knob) launch_wgrad<3, 2, 1, 1, 4, 1, 4>(x, gy, workspace, p, w, s);
             else launch_wgrad<3, 2, 1, 1, 4, 1, 0>(x, gy, workspace, p, w, s);
         }
         else if (d->stride == 1) {
