@@ -146,14 +146,14 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                                                             const float* __restrict__ wp,
                                                             float* __restrict__ y, const IgemmParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(!QUAD || S == 1, "quad staging: stride 1");
+    static_assert(!QUAD || S == 1 || KS == 3, "quad staging: stride 1, or 3x3 stride 2");
     constexpr int XQ0 = (KS == 3) ? 4 : 0;      // QUAD: columns added on either side of the tile
     constexpr int T = KS * KS;
     constexpr int BM = 32 * MI * WM;
     constexpr int BN = 32 * NI * WN;
     constexpr int XCAP = PatchCap<KS, S, BN>::value;
     constexpr int PPT = QUAD ? 1 : (XCAP + kBlock - 1) / kBlock;      // patch slots per thread per channel
-    constexpr int QCAP = (KS == 3) ? BN / 2 : BN / 4;                 // QUAD: quads per channel accepted by the host
+    constexpr int QCAP = (S == 2) ? 5 * BN / 4 : (KS == 3) ? BN / 2 : BN / 4;   // QUAD: quads per channel accepted by the host
     constexpr int QPT = QUAD ? (CK * QCAP + kBlock - 1) / kBlock : 1; // ... and quad slots per thread per chunk
     constexpr int A_VEC = T * CK * BM / 4;                  // float4 per A chunk
     constexpr int APT = (A_VEC + kBlock - 1) / kBlock;
@@ -187,8 +187,10 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
 
     const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
     const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
-    const int HALFW = (PW + 1) >> 1;
-    const int RS = QUAD ? TW + 2 * XQ0 : PW;
+    // QUAD, stride 2 (pad 0): rows widened to whole quads starting at column 2 x0 (4-byte aligned quads, see the wgrad
+    // kernel), kept de-interleaved in LDS like the dword path: even columns, then odd columns
+    const int RS = QUAD ? (S == 2 ? ((PW + 3) >> 2) << 2 : TW + 2 * XQ0) : PW;
+    const int HALFW = (QUAD && S == 2) ? RS >> 1 : (PW + 1) >> 1;
     const int IP = PH * RS;
     const int CP = TN * IP;           // staged floats per channel (<= XCAP, checked on the host)
     const int HW = p.H * p.W;
@@ -208,6 +210,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     unsigned qbyte[QPT];
     bool qok[QPT];
     int qdst[QPT], qch[QPT];
+    [[maybe_unused]] int qdst2[(QUAD && S == 2) ? QPT : 1];   // stride 2: LDS index of the quad's odd columns
+    [[maybe_unused]] int qsh[(QUAD && S == 2) ? QPT : 1];     // ... and how far the quad was moved left to stay inside its row
     if constexpr (QUAD) {
         const int RQ = RS >> 2;                 // quads per patch row
         const int QI = PH * RQ, QN = TN * QI;   // quads per image, per channel (<= QCAP, checked on the host)
@@ -220,13 +224,23 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
             const int rem = q - pn * QI;
             const int r = rem / RQ;
             const int qc = rem - r * RQ;
-            const int iy = oy0 - p.pad + r, ix = ox0 - XQ0 + 4 * qc - (KS == 1 ? p.pad : 0);
+            const int iy = oy0 * S - p.pad + r, ix = (S == 2) ? ox0 * 2 + 4 * qc : ox0 - XQ0 + 4 * qc - (KS == 1 ? p.pad : 0);
             const bool slot = ch < CK;
             const bool in = slot && n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             qok[kq] = in;
             qch[kq] = slot ? ch : CK - 1;
-            qbyte[kq] = in ? 4u * (unsigned)((pn * p.C + ch) * HW + iy * p.W + ix) : 0u;
-            qdst[kq] = slot ? ch * XROW + 4 * q : ((tid >> 4) & (CK - 1)) * XROW + XCAP + 4 * (tid & 15);
+            if constexpr (S == 2) {
+                const int ixc = ix + 4 <= p.W ? ix : p.W - 4;      // a quad that would run past its row is fetched from W - 4
+                qsh[kq] = in ? ix - ixc : 0;
+                qbyte[kq] = in ? 4u * (unsigned)((pn * p.C + ch) * HW + iy * p.W + ixc) : 0u;
+                const int d0 = slot ? ch * XROW + pn * IP + r * RS + 2 * qc
+                                    : ((tid >> 3) & (CK - 1)) * XROW + XCAP + 2 * (tid & 7);
+                qdst[kq] = d0;
+                qdst2[kq] = slot ? d0 + HALFW : d0 + 32;
+            } else {
+                qbyte[kq] = in ? 4u * (unsigned)((pn * p.C + ch) * HW + iy * p.W + ix) : 0u;
+                qdst[kq] = slot ? ch * XROW + 4 * q : ((tid >> 4) & (CK - 1)) * XROW + XCAP + 4 * (tid & 15);
+            }
             if constexpr (MOD) sidx[kq] = in ? (n0 + pn) * p.C + ch : 0;
         }
         pbyte[0] = 0; pok[0] = false; xdst[0] = 0; wave_has[0] = false;
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
         const int px = pp & (TW - 1);
         const int py = (pp >> p.tw_log2) & (TH - 1);
         const int pn = pp >> (p.tw_log2 + p.th_log2);
-        pixbase[ni] = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px + ((QUAD && KS == 3) ? 4 - p.pad : 0);
+        pixbase[ni] = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px + ((QUAD && KS == 3 && S == 1) ? 4 - p.pad : 0);
     }
     int tapoff[T];
 #pragma unroll
@@ -309,7 +323,12 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
 #pragma unroll
             for (int kq = 0; kq < QPT; ++kq) {
                 const bool ok = qok[kq] && c0 + qch[kq] < p.C;       // channels beyond C (last chunk): element 0, zeroed later
-                xq[kq] = *reinterpret_cast<const f32x4*>(xc + (ok ? qbyte[kq] : 0u));
+                if constexpr (S == 2) {
+                    struct __attribute__((packed, aligned(4))) U4 { f32x4 v; };     // 4-byte aligned quad
+                    xq[kq] = reinterpret_cast<const U4*>(xc + (ok ? qbyte[kq] : 0u))->v;
+                } else {
+                    xq[kq] = *reinterpret_cast<const f32x4*>(xc + (ok ? qbyte[kq] : 0u));
+                }
                 if constexpr (MOD) sc[kq] = p.in_scale[ok ? sidx[kq] + c0 : 0];
             }
         } else {
@@ -348,7 +367,18 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                 if constexpr (MOD) v *= sc[kq];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
-                *reinterpret_cast<f32x4*>(Xs + qdst[kq]) = v;
+                if constexpr (S == 2) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const int sh = qsh[kq];      // fetched sh floats to the left of its place: the tail lies beyond the row
+                    const f32x4 u = v;
+                    if (sh == 1) v = f32x4{u[1], u[2], u[3], 0.0f};
+                    if (sh == 2) v = f32x4{u[2], u[3], 0.0f, 0.0f};
+                    if (sh == 3) v = f32x4{u[3], 0.0f, 0.0f, 0.0f};
+                    *reinterpret_cast<f32x2*>(Xs + qdst[kq]) = f32x2{v[0], v[2]};      // even columns
+                    *reinterpret_cast<f32x2*>(Xs + qdst2[kq]) = f32x2{v[1], v[3]};     // odd columns
+                } else {
+                    *reinterpret_cast<f32x4*>(Xs + qdst[kq]) = v;
+                }
             }
         } else {
         if constexpr (MOD) {
@@ -395,7 +425,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
         SAE_CLOCK_PHASE(3)
         __syncthreads();
         SAE_CLOCK_PHASE(4)
-        if (c0 + CK < c_end) load_chunk(c0 + CK);   // in flight under the MFMAs below
+        // in flight under the MFMAs below (issuing them one per MFMA step instead measured the same or slower)
+        if (c0 + CK < c_end) load_chunk(c0 + CK);
         SAE_CLOCK_PHASE(5)
         // One step = one (tap, channel pair): MI x NI MFMAs on operands that were read from LDS kIgemmAhead steps
         // earlier (a ring of register sets), so a wave's ds_reads are in flight under its own MFMAs instead of being
@@ -1181,21 +1212,26 @@ struct TrParams {
     TrRegion reg[3];
 };
 
+// WM x WN = 4 or 8 waves.  The 8-wave form (128 rows x 128 q positions) halves the weight traffic per MFMA -- a tap of the
+// transposed problem feeds only one of the four output parity classes, so the 128 x 64q tile needs twice the weight bytes
+// per MFMA of the forward gather, and the issue of those loads was 33-39 % of the kernel (profiles/r2_phase_clock_*.txt).
 template <int MI, int WM, int WN, int CK, bool MOD = false>
-__global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_tr_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ wp,
                                                                float* __restrict__ y, const TrParams p) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
+    constexpr int NT = 64 * WM * WN;
     constexpr int T = 9;
     constexpr int BM = 32 * MI * WM;
     constexpr int BQ = 32 * WN;                  // q positions per workgroup
     constexpr int XCAP = (25 * BQ) / 16;         // (TW+1)(TH+1)/(TW*TH) <= 25/16 for TW,TH >= 4
-    constexpr int PPT = (XCAP + kBlock - 1) / kBlock;
+    constexpr int PPT = (XCAP + NT - 1) / NT;
     constexpr int A_VEC = T * CK * BM / 4;
-    constexpr int APT = (A_VEC + kBlock - 1) / kBlock;
+    constexpr int APT = (A_VEC + NT - 1) / NT;
     __shared__ float As[T * CK * BM];
     __shared__ float Xs[CK * XCAP];
 
+    SAE_CLOCK_BEGIN
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -1225,7 +1261,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
     int sidx[MOD ? PPT : 1];   // in_scale row of the slot's image (tiles that span several images only)
 #pragma unroll
     for (int s = 0; s < PPT; ++s) {
-        const int e = tid + kBlock * s;
+        const int e = tid + NT * s;
         int off = -1;
         if constexpr (MOD) sidx[s] = 0;
         if (e < CP) {
@@ -1288,7 +1324,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
         }
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
-            const int e4 = tid + kBlock * i;
+            const int e4 = tid + NT * i;
             if (e4 < A_VEC) {
                 const int row = e4 / (BM / 4);
                 const int col4 = e4 - row * (BM / 4);
@@ -1318,22 +1354,27 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
         for (int ch = 0; ch < CK; ++ch)
 #pragma unroll
             for (int s = 0; s < PPT; ++s) {
-                const int e = tid + kBlock * s;
+                const int e = tid + NT * s;
                 if (e < CP) Xs[ch * XCAP + e] = xv[ch][s];
             }
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
-            const int e4 = tid + kBlock * i;
+            const int e4 = tid + NT * i;
             if (e4 < A_VEC) *reinterpret_cast<f32x4*>(As + e4 * 4) = av[i];
         }
     };
 
     load_chunk(0);
+    SAE_CLOCK_PHASE(0)
     for (int c0 = 0; c0 < p.Cp; c0 += CK) {
         __syncthreads();
+        SAE_CLOCK_PHASE(2)
         store_chunk(c0);
+        SAE_CLOCK_PHASE(3)
         __syncthreads();
+        SAE_CLOCK_PHASE(4)
         if (c0 + CK < p.Cp) load_chunk(c0 + CK);
+        SAE_CLOCK_PHASE(5)
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int cls = ((t / 3) & 1) * 2 + ((t % 3) & 1);   // parity class fed by this tap
@@ -1352,6 +1393,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
                 }
             }
         }
+        SAE_CLOCK_PHASE(1)
     }
 
     const int n = n0 + pn, qy = qy0 + py, qx = qx0 + px;
@@ -1383,6 +1425,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_tr_kernel(const float* __re
             }
         }
     }
+    SAE_CLOCK_PHASE(6)
+    SAE_CLOCK_END
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2532,12 +2576,16 @@ void pick_tile(int bn, int oh, int ow, int max_tw, int* tw_log2, int* th_log2) {
     *th_log2 = ilog2_ceil(th);
 }
 
-struct TrShape { int cfg; int bm, bq; int ck; };   // cfg 0: 128 x 64q, 1: 64 x 128q, 2: 32 x 128q, 3: 64 x 128q with 16-channel chunks
+struct TrShape { int cfg; int bm, bq; int ck; };   // cfg 0: 128 x 64q, 1: 64 x 128q, 2: 32 x 128q, 3: 64 x 128q with 16-channel chunks,
+                                                      // 4: 128 x 128q on 8 waves
 TrShape tr_shape(int mout) {
     TrShape s{};
     s.ck = 8;
     static const int cfg_knob = [] { const char* e = getenv("SAE_TR_CFG"); return e ? atoi(e) : -1; }();
     if (mout > 32 && cfg_knob == 3) { s.cfg = 3; s.bm = 64; s.bq = 128; s.ck = 16; }
+    // (cfg 4, one 8-wave workgroup per CU, measured 73-93 TFLOP/s against 92-104 for two independent 4-wave workgroups:
+    // the second workgroup's MFMAs are what covers the staging phases; kept behind the knob)
+    else if (mout > 64 && cfg_knob == 4 && conv_math() == 0) { s.cfg = 4; s.bm = 128; s.bq = 128; }
     else if (mout > 64 && cfg_knob != 1) { s.cfg = 0; s.bm = 128; s.bq = 64; }
     else if (mout > 32) { s.cfg = 1; s.bm = 64; s.bq = 128; }
     else { s.cfg = 2; s.bm = 32; s.bq = 128; }
@@ -2769,6 +2817,15 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
                     break;
                 }
             }
+            if constexpr (KS == 3 && S == 2) {
+                // stride 2, pad 0: 4-byte aligned quads from column 2 x0 on, (2 tw + 4) / 4 per row
+                const int qn2 = tn * ph * ((pw + 3) / 4);
+                if (quad1_knob && p.pad == 0 && p.W >= 4 && qn2 <= 5 * sh.bn / 4) {
+                    if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<3, 2, 2, 2, 2, 2, 8, true, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    else hipLaunchKernelGGL((conv_igemm_kernel<3, 2, 2, 2, 2, 2, 8, false, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    break;
+                }
+            }
             if constexpr (KS == 1 && S == 1) {
                 if (quad1) {
                     if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<1, 1, 2, 2, 2, 2, 32, true, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
@@ -2957,6 +3014,10 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
         switch (sh.cfg) {
             case 3: SAE_TR(2, 1, 4, 16); break;
             case 0: SAE_TR(2, 2, 2, CK); break;
+            case 4:
+                if (p.in_scale) hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 4, CK, true>), grid, dim3(512), 0, s, x, ws, y, p);
+                else hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 4, CK, false>), grid, dim3(512), 0, s, x, ws, y, p);
+                break;
             case 1: SAE_TR(2, 1, 4, CK); break;
             default: SAE_TR(1, 1, 4, CK); break;
         }

@@ -55,7 +55,7 @@ CONV_SMALL = [
     # second tile column, two images of one 16 x 8 tile each with a channel tail, dgrad (pad 2) of a valid conv
     (1, 12, 20, 36, 70, 3, 1, 0, False), (2, 20, 16, 16, 130, 3, 1, 1, False), (1, 70, 10, 16, 9, 3, 1, 0, False),
     # stride-2 wgrad with 4-byte aligned quads: one partial 32-wide tile per row, the last quad of a row shifted left
-    (2, 20, 21, 41, 40, 3, 2, 0, False),
+    (2, 20, 21, 41, 40, 3, 2, 0, False), (2, 12, 21, 41, 70, 3, 2, 0, False),
 ]
 
 # 3x3 stride-1 launches that take the 128x128 tile (the bf16x6 split-arithmetic kernel when
