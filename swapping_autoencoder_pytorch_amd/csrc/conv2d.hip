@@ -125,6 +125,7 @@ struct IgemmParams {
     // (lgkmcnt) and would serialise the ds_read pipeline of the MFMA loop
     int zmask;
     int xcd_order;          // 1: XCD-aware tile order (see conv_igemm_kernel)
+    int vec_store;          // 1: LDS-transposed dwordx4 epilogue (see conv_igemm_kernel)
 };
 
 template <int KS, int S, int BN>
@@ -460,6 +461,56 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
         SAE_CLOCK_PHASE(1)
     }
 
+    // Vector epilogue (IgemmParams::vec_store; output rows a multiple of four floats, 16-byte aligned, no scatter): the
+    // accumulators go through LDS once, 32 * WM rows at a time, and leave as dwordx4 stores of four consecutive pixels --
+    // 16 instead of 64 vector-memory instructions per wave and tile (the eight waves of a CU reach their epilogues
+    // together, and a wave64 store occupies the address path as long as a load does).
+    constexpr int LDC = BN + 4;
+    constexpr bool VEC_OK = T * CK * BM >= 32 * WM * LDC;     // the weight buffer holds one pass
+    if constexpr (VEC_OK) {
+        if (p.vec_store) {
+            constexpr int QROW = BN / 4;                        // quads per tile row
+            constexpr int VPT = 32 * WM * QROW / kBlock;        // quads per thread per pass
+            float* Cs = As;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                __syncthreads();       // the K loop's (or the previous pass's) readers are done with As
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + (wn * NI + ni) * 32 + l31] = acc[mi][ni][r];
+                __syncthreads();
+#pragma unroll
+                for (int v = 0; v < VPT; ++v) {
+                    const int qi = tid + kBlock * v;
+                    const int row = qi / QROW, qx = qi - row * QROW;
+                    const int m = m0 + ((row >> 5) * MI + mi) * 32 + (row & 31);
+                    const int pp = 4 * qx;
+                    const int px = pp & (TW - 1);
+                    const int py = (pp >> p.tw_log2) & (TH - 1);
+                    const int pn = pp >> (p.tw_log2 + p.th_log2);
+                    const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
+                    if (m < p.M && n < p.N && oy < p.OH && ox < p.OW) {
+                        f32x4 c = *reinterpret_cast<const f32x4*>(Cs + row * LDC + 4 * qx);
+                        if (p.act) {   // bias + leaky-ReLU of the following FusedLeakyReLU, fused_bias_act_kernel.cu:30,47
+                            const float bv = p.bias ? p.bias[m] : 0.0f;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float t = c[e] + bv;
+                                c[e] = ((t > 0.0f) ? t : t * p.act_slope) * p.act_scale;
+                            }
+                        }
+                        *reinterpret_cast<f32x4*>(y + (int64_t)blockIdx.z * p.slab_stride +
+                                                  (((int64_t)n * p.M + m) * p.YH + oy) * p.YW + ox) = c;
+                    }
+                }
+            }
+            SAE_CLOCK_PHASE(6)
+            SAE_CLOCK_END
+            return;
+        }
+    }
     // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
@@ -2909,6 +2960,10 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     p.xcd_order = xcd_knob;
     if (g.ksplit == 1) { p.bias = ep.bias; p.act = ep.act; p.act_slope = ep.slope; p.act_scale = ep.scale; }
     float* out = (g.ksplit > 1) ? ws + g.wp_floats : y;
+    static const int vec_knob = [] { const char* e = getenv("SAE_IGEMM_VEC_STORE"); return e ? atoi(e) : 1; }();
+    // measured (tools/ab_conv.py): +2.5 % with K loops of 64 chunks (512 channels), -1 % with 16 or 32: long loops only
+    p.vec_store = vec_knob && oys == 1 && oxs == 1 && OW % 4 == 0 && YW % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                  (vec_knob > 1 || g.cps >= 48);
     int rc;
     if (ks == 3 && stride == 1) rc = launch_igemm<3, 1>(x, ws, out, p, g, s);
     else if (ks == 3) rc = launch_igemm<3, 2>(x, ws, out, p, g, s);
