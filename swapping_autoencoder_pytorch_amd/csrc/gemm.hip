@@ -96,31 +96,7 @@ __global__ __launch_bounds__(kBlock) void gemm64_kernel(const float* __restrict_
     }
 }
 
-// the two halves of stage_panel for one wave (64 lanes, ROWS = 32): global -> registers, registers -> LDS
-__device__ __forceinline__ void panel_load(float (&v)[16], const float* __restrict__ src, int64_t row0, int64_t rows,
-                                           int64_t k0, int64_t kmax, int64_t s_row, int64_t s_k, int lane) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int e = lane + i * kWave;
-        int r, kk;
-        if (s_k == 1) { r = e / kKc; kk = e - r * kKc; } else { kk = e / 32; r = e - kk * 32; }
-        v[i] = (row0 + r < rows && k0 + kk < kmax) ? src[(row0 + r) * s_row + (k0 + kk) * s_k] : 0.0f;
-    }
-}
-__device__ __forceinline__ void panel_store(float* dst, const float (&v)[16], int64_t s_k, int lane) {
-    constexpr int LD = 33;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int e = lane + i * kWave;
-        int r, kk;
-        if (s_k == 1) { r = e / kKc; kk = e - r * kKc; } else { kk = e / 32; r = e - kk * 32; }
-        dst[kk * LD + r] = v[i];
-    }
-}
-
-// 32x32 output tile per workgroup; the 4 waves take K chunks round-robin and reduce through LDS.  The loads of a wave run
-// two chunks ahead of its MFMAs (three register sets): these launches are 16 workgroups of a long K loop, and with the
-// load -> LDS -> MFMA chain serialised every chunk cost a full memory latency (36 us per call, 54 calls per iteration).
+// 32x32 output tile per workgroup; the 4 waves take K chunks round-robin and reduce through LDS.
 __global__ __launch_bounds__(kBlock) void gemm32_splitk_kernel(const float* __restrict__ a,
                                                                const float* __restrict__ b,
                                                                const float* __restrict__ bias,
@@ -138,15 +114,10 @@ __global__ __launch_bounds__(kBlock) void gemm32_splitk_kernel(const float* __re
     const int64_t nchunks = ceil_div64(p.k, kKc);
     // every wave runs the same number of iterations so the (wave-private) staging never diverges
     const int64_t iters = ceil_div64(nchunks, 4);
-    float ra[3][16], rb[3][16];
-    auto load = [&](int64_t it, float (&va)[16], float (&vb)[16]) {
-        const int64_t k0 = (it * 4 + wid) * kKc;   // may be >= k: loads zeros
-        panel_load(va, a, i0, p.m, k0, p.k, p.a_si, p.a_sk, lane);
-        panel_load(vb, b, j0, p.n, k0, p.k, p.b_sj, p.b_sk, lane);
-    };
-    auto step = [&](const float (&va)[16], const float (&vb)[16]) {
-        panel_store(As[wid], va, p.a_sk, lane);
-        panel_store(Bs[wid], vb, p.b_sk, lane);
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t k0 = (it * 4 + wid) * kKc;   // may be >= k: stages zeros
+        stage_panel<BT, LD, kWave>(As[wid], a, i0, p.m, k0, p.k, p.a_si, p.a_sk, lane);
+        stage_panel<BT, LD, kWave>(Bs[wid], b, j0, p.n, k0, p.k, p.b_sj, p.b_sk, lane);
         __syncthreads();
 #pragma unroll
         for (int kp = 0; kp < kKc / 2; ++kp) {
@@ -155,20 +126,6 @@ __global__ __launch_bounds__(kBlock) void gemm32_splitk_kernel(const float* __re
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
         }
         __syncthreads();
-    };
-    load(0, ra[0], rb[0]);
-    load(1, ra[1], rb[1]);
-    for (int64_t it = 0; it < iters; it += 3) {
-        load(it + 2, ra[2], rb[2]);
-        step(ra[0], rb[0]);
-        if (it + 1 < iters) {
-            load(it + 3, ra[0], rb[0]);
-            step(ra[1], rb[1]);
-        }
-        if (it + 2 < iters) {
-            load(it + 4, ra[1], rb[1]);
-            step(ra[2], rb[2]);
-        }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wid][((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l31] = acc[r];
