@@ -2839,6 +2839,9 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
     // 1x1 stride 1, pad 0 with quad staging: the tile's own pixels, rows a multiple of 16 bytes (tw >= 4 always is)
     static const int quad1_knob = [] { const char* e = getenv("SAE_IGEMM_QUAD"); return e ? atoi(e) : 1; }();
     const bool quad1 = quad1_knob && KS == 1 && S == 1 && p.pad == 0 && p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    // 3x3 stride 1 on the 256-pixel tiles (64 x 256, 32 x 256): quad staging when the widened patch fits 128 quads
+    const bool quad3w = quad1_knob && KS == 3 && S == 1 && sh.bn == 256 && p.W % 4 == 0 && p.pad <= 4 &&
+                        (reinterpret_cast<uintptr_t>(x) & 15) == 0 && tn * ph * ((tw + 8) / 4) <= 128;
     switch (sh.cfg) {
 #define SAE_IGEMM(...)                                                                                          \
     do {                                                                                                        \
@@ -2847,6 +2850,11 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
     } while (0)
         case 4:
             if constexpr (KS == 3 && S == 1) {
+                if (quad3w) {
+                    if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 1, 2, 1, 4, 8, true, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    else hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 1, 2, 1, 4, 8, false, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    break;
+                }
                 SAE_IGEMM(3, 1, 1, 2, 1, 4, 8);
                 break;
             } else {
@@ -2890,6 +2898,13 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
             SAE_IGEMM(KS, S, 2, 2, 2, 2, CK);
             break;
         case 1:
+            if constexpr (KS == 3 && S == 1) {
+                if (quad3w) {
+                    if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 2, 2, 1, 4, 8, true, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    else hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 2, 2, 1, 4, 8, false, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
+                    break;
+                }
+            }
             if constexpr (KS == 1 && S == 1) {
                 if (quad1) {
                     if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<1, 1, 2, 2, 1, 4, 32, true, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
