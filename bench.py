@@ -12,7 +12,7 @@ penalty on every 16th discriminator iteration (the default K = 16 contains exact
 value = N * B * K / t   (whole-job images per second; B images per GPU -> weak scaling).
 
 Also reported on the same JSON line:
-  roofline     – dominant kernel (3x3 stride-1 implicit-GEMM conv, conv_igemm_kernel<3,1,2,2,2,2,8,false>):
+  roofline     – dominant kernel (3x3 stride-1 implicit-GEMM conv, conv_igemm_kernel<3,1,2,2,2,2,8,false,true>):
                  algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
                  launch stream inside the timed region, against the fp32 MFMA peak (157.3 TFLOP/s);
   cpu_baseline – the reference's CPU path (ATen on all host cores, restated in oracle/aten_cpu_path.py and pinned
@@ -29,12 +29,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
-# HBM-side traffic of the dominant kernel from the PMC passes (profiles/r2_pmc_f32.txt: separate rocprofv3 --pmc runs of
+# HBM-side traffic of the dominant kernel from the PMC passes (profiles/r2_pmc_f32_quad.txt: separate rocprofv3 --pmc runs of
 # tools/pmc_kernels.py; reads = TCC_EA0_RDREQ x 128 B — FETCH_SIZE tallies those 128-byte requests at 64 B, the x2
 # correction of the guide, confirmed here on a 1 GiB copy — writes = TCC_EA0_WRREQ x 64 B) on its reference launch,
-# 128 -> 128 3x3 @256x256 B=16 = 309.24 GFLOP, 1073.7 MB algorithmic (x + y): 642.6 MB read + 536.9 MB written.
+# 128 -> 128 3x3 @256x256 B=16 = 309.24 GFLOP, 1073.7 MB algorithmic (x + y): 634.6 MB read + 536.9 MB written.
 # Counters cannot be read inside a timed run; the figure is scaled to the average launch of the timed region by FLOPs.
-PMC_DOMINANT_F32 = {"gflop": 309.24, "read_bytes": 5.02e6 * 128, "write_bytes": 8.389e6 * 64, "algorithmic_bytes": 1073.7e6}
+PMC_DOMINANT_F32 = {"gflop": 309.24, "read_bytes": 4.958e6 * 128, "write_bytes": 8.389e6 * 64, "algorithmic_bytes": 1073.7e6}
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # same table, dense bf16 matrix; the bf16x6 arithmetic spends 6 bf16 products
                                       # (20/3 with the zero-padded ninth tap) per fp32 product
 FLOPS_PER_IMAGE = {"church256": 1.815e12, "bedroom256": 1.815e12, "ffhq512": 3.91e12, "ffhq1024": 6.08e12}
@@ -59,7 +59,7 @@ def parse():
 
 class DominantKernelTimer:
     """Brackets every launch of the dominant kernel (3x3 stride-1 gather with > 64 output
-    channels = conv_igemm_kernel<3,1,2,2,2,2,8,false>, reached from conv2d forward and stride-1 dgrad)
+    channels = conv_igemm_kernel<3,1,2,2,2,2,8,false,true>, reached from conv2d forward and stride-1 dgrad)
     with HIP events on the launch stream; durations are read after the final synchronise."""
 
     def __init__(self):
@@ -133,12 +133,12 @@ class DominantKernelTimer:
             note += "; peak = 2500 TFLOP/s dense bf16 / 6 split products per fp32 product"
         else:
             peak = MFMA_F32_PEAK_TFLOPS
-            kernel = "conv_igemm_kernel<3,1,2,2,2,2,8,false>"
+            kernel = "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"
         traffic = None
         if conv_math == "f32":
             scale = (fl / n / 1e9) / PMC_DOMINANT_F32["gflop"]
             traffic = round((PMC_DOMINANT_F32["read_bytes"] + PMC_DOMINANT_F32["write_bytes"]) * scale)
-            note += ("; traffic = HBM-side bytes per average launch from the PMC passes (profiles/r2_pmc_f32.txt: %.0f MB read + "
+            note += ("; traffic = HBM-side bytes per average launch from the PMC passes (profiles/r2_pmc_f32_quad.txt: %.0f MB read + "
                      "%.0f MB written per 309 GFLOP reference launch against %.0f MB algorithmic), scaled by FLOPs"
                      % (PMC_DOMINANT_F32["read_bytes"] / 1e6, PMC_DOMINANT_F32["write_bytes"] / 1e6,
                         PMC_DOMINANT_F32["algorithmic_bytes"] / 1e6))
