@@ -2698,6 +2698,18 @@ WgPlan wg_plan(const sae_conv2d_desc* d) {
     if (slices > w.chunks) slices = w.chunks;
     if (slices < 1) slices = 1;
     w.cps = ceil_div(w.chunks, slices);
+    // keep a K slice inside one image where the images are large (>= 32 chunks of 64 pixels): the factors of a
+    // style-modulated operand can then be applied per slice in the reduction and the main kernel stays the plain
+    // (quad-staged) one.  Costs more, smaller slabs only for the generator's 512-channel 64 x 64 layers (4 -> 8 / 16 slices).
+    if (w.sh.mode == 0 && !w.bx && tn == 1) {
+        const int cpi = w.tiles_x * w.tiles_y;
+        // (batches of at most 16 images only: the generator's; for D / Dpatch at 24 ... 384 images 40 slabs of 9 MB cost
+        // more, and moving cps to a divisor of the image breaks the one-workgroup-per-CU balance: 26.9 -> 30.6 ms measured)
+        if (cpi >= 32 && w.tiles_n <= 16) {
+            if (w.cps > cpi) w.cps = cpi;
+            else while (cpi % w.cps != 0) --w.cps;
+        }
+    }
     w.slices = ceil_div(w.chunks, w.cps);
     return w;
 }
