@@ -2762,8 +2762,8 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
     }
     g.f8 = false;
     // measured on MI355X (same box, tools/kb_subset.py): 121.9 vs 125.8 TFLOP/s at 128 -> 128 @256^2 B=16 and 126.4 vs 130.0
-    // at 512 -> 512 @64^2 for this kernel vs the 4-wave register-staged one: the fp32 matrix pipe is at its power-limited
-    // rate either way, and one workgroup per CU loses the overlap two independent workgroups give.  Off by default.
+    // at 512 -> 512 @64^2 for this kernel vs the 4-wave register-staged one: one workgroup per CU loses the overlap two
+    // independent workgroups give (their MFMAs are what covers each other's staging phases).  Off by default.
     static const int f8_knob = [] { const char* e = getenv("SAE_F8"); return e ? atoi(e) : 0; }();
     if (f8_knob && conv_math() == 0 && ks == 3 && stride == 1 && g.sh.cfg == 0 && !scatter) {
         int twl, thl;
