@@ -1,0 +1,37 @@
+"""The quad-staged gather / weight-gradient kernels and the LDS-transposed epilogue (csrc/conv2d.hip) change
+how operands reach LDS and how results leave the registers, not the arithmetic or its order: their results must be
+BIT-identical to the dword-staged kernels.  Two subprocesses (the knobs are read once per process), on the emulator and on
+the GPU."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(which, **env):
+    e = dict(os.environ, SAE_CONV_MATH="f32", SAE_CONV_THIN="0", **env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "quad_worker.py"), which], cwd=ROOT, env=e,
+                         capture_output=True, text=True, timeout=1800)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "quad-done" in out.stdout
+    return [l for l in out.stdout.splitlines() if l.startswith("(")]
+
+
+def _compare(which):
+    quad = _run(which, SAE_IGEMM_QUAD="1", SAE_WGRAD_QUAD="1", SAE_IGEMM_VEC_STORE="2")
+    plain = _run(which, SAE_IGEMM_QUAD="0", SAE_WGRAD_QUAD="0", SAE_IGEMM_VEC_STORE="0")
+    assert len(quad) == len(plain) and len(quad) > 0
+    diff = [(a, b) for a, b in zip(quad, plain) if a != b]
+    assert not diff, diff[:4]
+
+
+def test_quad_staging_is_bit_identical_on_the_emulator():
+    _compare("emu")
+
+
+@pytest.mark.gpu
+def test_quad_staging_is_bit_identical_on_the_gpu():
+    _compare("gpu")
