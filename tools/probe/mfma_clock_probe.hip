@@ -267,6 +267,68 @@ __global__ __launch_bounds__(256) void probe_wide(const float* __restrict__ src,
     }
 }
 
+// mode 6: the chunk's weights go global -> LDS by DMA (global_load_lds_dwordx4: no registers, no ds_write), activations
+// through registers as 2 dwordx4; ONE LDS buffer, so the DMA is issued after the barrier that ends the MFMA phase and waited
+// for before the next one -- its latency is exposed to this workgroup and has to be covered by the others.  ~70 registers
+// per wave: launched with three workgroups per CU.
+__global__ __launch_bounds__(256) void probe_dma(const float* __restrict__ src, const float* __restrict__ wsrc,
+                                                 float* __restrict__ sink, long long span, int chunks,
+                                                 unsigned long long* __restrict__ clk) {
+    constexpr int ASZ = 9 * 8 * 128, XSZ = 8 * 288;
+    __shared__ float As[ASZ];
+    __shared__ float Xs[XSZ];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned smask = (unsigned)span - 1u;
+    const unsigned long long c0 = clock64(), r0 = wall_clock64();
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    for (int i = tid; i < ASZ; i += 256) As[i] = 1e-3f * (float)(i & 15);
+    for (int i = tid; i < XSZ; i += 256) Xs[i] = 1e-3f * (float)(i & 7);
+    __syncthreads();
+    f32x4 xq[2] = {f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f}, f32x4{1e-3f, 2e-3f, 3e-3f, 4e-3f}};
+    float ra[2][2], rb[2][2];
+    for (int c = 0; c < chunks; ++c) {
+        // activations of the next chunk: in flight under the MFMAs
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            xq[i] = *reinterpret_cast<const f32x4*>(src + ((((unsigned)c * gridDim.x + blockIdx.x) * 2048u + i * 1024 + tid * 4) & smask));
+        auto fetch = [&](int s, float (&a)[2], float (&b)[2]) {
+            const int row = (s * 128 + (lane & 31)) % (ASZ - 32);
+            a[0] = As[row]; a[1] = As[row + 32];
+            b[0] = Xs[(s * 8 + lane) % (XSZ - 40)]; b[1] = Xs[(s * 8 + lane) % (XSZ - 40) + 33];
+        };
+        fetch(0, ra[0], rb[0]);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            if (s + 1 < 36) fetch(s + 1, ra[(s + 1) & 1], rb[(s + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s & 1][0], rb[s & 1][0], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s & 1][0], rb[s & 1][1], acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s & 1][1], rb[s & 1][0], acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s & 1][1], rb[s & 1][1], acc[3], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // weights of the next chunk straight into LDS: 9 x 256 lanes x 16 bytes
+        for (int j = wid; j < 36; j += 4)
+            __builtin_amdgcn_global_load_lds(wsrc + (((unsigned)c * ASZ + (j * 64 + lane) * 4) & (kWeights - 1)),
+                                             (__attribute__((address_space(3))) void*)(&As[j * 256]), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Xs[(4 * (tid + 256 * i)) % (XSZ - 4)]) = xq[i];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    float keep = 0.0f;
+    for (int i = 0; i < 4; ++i) keep += acc[i][0] + acc[i][7] + acc[i][15];
+    if (keep == 12345.678f) sink[0] = keep;
+    if (tid == 0) {
+        atomicAdd(&clk[0], clock64() - c0);
+        atomicAdd(&clk[1], wall_clock64() - r0);
+    }
+}
+
 template <typename K>
 static void run(const char* name, K kernel, int mfma_per_chunk, const float* src, const float* wsrc, float* sink,
                 long long span, int blocks, int chunks, unsigned long long* clk, int launches) {
@@ -306,6 +368,8 @@ int main(int argc, char** argv) {
     run("mode 1 (+ LDS reads)        ", probe<1>, 144, src, wsrc, sink, span, blocks, chunks, clk, n);
     run("mode 2 (+ staging, 2 barr.) ", probe<2>, 144, src, wsrc, sink, span, blocks, chunks, clk, n);
     run("mode 5 (mode 2, odd slots late)", probe<5>, 144, src, wsrc, sink, span, blocks, chunks, clk, n);
+    run("mode 6 (weights by LDS-DMA, 3 workgroups/CU)", probe_dma, 144, src, wsrc, sink, span, 768, chunks, clk, n);
+    run("mode 6 (weights by LDS-DMA, 2 workgroups/CU)", probe_dma, 144, src, wsrc, sink, span, 512, chunks, clk, n);
     run("wide 128x256, 1 staging instr/step", probe_wide<1>, 288, src, wsrc, sink, span, 256, chunks, clk, n);
     run("wide 128x256, 2 staging instr/step", probe_wide<2>, 288, src, wsrc, sink, span, 256, chunks, clk, n);
     run("pipe CK8 loads+writes+barrier", probe_pipe<8, 7>, 144, src, wsrc, sink, span, blocks, chunks, clk, n);
