@@ -45,3 +45,16 @@ def test_under_a_launcher_it_is_the_worker(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "8")
     monkeypatch.setenv("RANK", "3")
     assert bench.self_launch_command(_args(bench, ["--gpus", "8"]), ["--gpus", "8"]) is None
+
+
+def test_dominant_kernel_filter_follows_the_dispatch_rule():
+    """bench.py counts a launch towards `roofline` only when the library runs it on the named instantiation
+    (csrc/conv2d.hip fwd_shape / launch_igemm): 128 x 128 tile, quad staging."""
+    import bench
+    f = bench._runs_quad_main_kernel
+    assert f(128, 256, 256, 256, 1)            # D 128 -> 128 @ 256^2
+    assert f(512, 16, 16, 16, 1)               # 512 @ 16^2: one 16 x 8 tile per image half
+    assert not f(512, 8, 8, 8, 1)              # 8 x 8 images: two per tile, 80 quads per channel -> dword staging
+    assert not f(64, 256, 256, 256, 1)         # 64 output channels: the 64 x 256 tile
+    assert not f(128, 258, 256, 256, 0)        # reflection-padded rows (258 floats): dword staging
+    assert not f(409, 64, 64, 64, 1)           # 409 channels pad 8 % less on the 64-row tile
