@@ -9,6 +9,8 @@ The adjoint of an (up, down, pad) call with taps k is an upfirdn2d call with fli
 (up, down) exchanged and the pads of upfirdn2d.py:116-121; its adjoint is the forward call again,
 so two Function classes close the chain at any order.
 """
+import weakref
+
 import torch
 from torch.autograd import Function
 
@@ -53,6 +55,27 @@ def _adjoint_pad(in_hw, out_hw, taps_hw, up, down, pad):
     return (gx0, gx1, gy0, gy1)
 
 
+_FLIPPED = {}
+
+
+def _flipped(kernel):
+    """The taps flipped in both directions (upfirdn2d.py:119 of the reference flips them in every backward call: 52
+    `aten::flip` launches per iteration).  The FIR taps are module buffers that never change: one flip per buffer object,
+    re-done if the buffer is modified in place; entries die with their tensor (weak reference, identity checked, so a
+    recycled address or id cannot alias another tensor's taps)."""
+    entry = _FLIPPED.get(id(kernel))
+    if entry is not None and entry[0]() is kernel and entry[1] == kernel._version:
+        return entry[2]
+    if len(_FLIPPED) > 64:
+        for k in [k for k, e in _FLIPPED.items() if e[0]() is None]:
+            del _FLIPPED[k]
+        if len(_FLIPPED) > 64:
+            _FLIPPED.clear()
+    out = torch.flip(kernel, [0, 1])
+    _FLIPPED[id(kernel)] = (weakref.ref(kernel), kernel._version, out)
+    return out
+
+
 class UpFirDn2d(Function):
     @staticmethod
     def forward(ctx, input, kernel, up, down, pad):
@@ -78,7 +101,7 @@ class UpFirDn2dBackward(Function):
     def forward(ctx, grad_output, kernel, up, down, pad, in_hw, out_hw):
         ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         g_pad = _adjoint_pad(in_hw, out_hw, tuple(kernel.shape), up, down, pad)
-        flipped = torch.flip(kernel, [0, 1])
+        flipped = _flipped(kernel)
         grad_input = _run(grad_output, flipped, down, up, g_pad)   # (up, down) exchanged
         assert tuple(grad_input.shape[2:]) == tuple(in_hw), (grad_input.shape, in_hw)
         ctx.save_for_backward(kernel)
