@@ -512,6 +512,14 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
         }
     }
     // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
+    float bv[MI][16];        // bias of the rows this lane holds (fetched once, not per pixel tile)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            bv[mi][r] = (p.act && p.bias && m < p.M) ? p.bias[m] : 0.0f;
+        }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
         const int pp = (wn * NI + ni) * 32 + l31;
@@ -530,7 +538,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                     if (m < p.M) {
                         float v = acc[mi][ni][r];
                         if (p.act) {   // bias + leaky-ReLU of the following FusedLeakyReLU, fused_bias_act_kernel.cu:30,47
-                            if (p.bias) v += p.bias[m];
+                            v += bv[mi][r];
                             v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
                         }
                         yb[(int64_t)m * p.YH * p.YW] = v;
@@ -3080,7 +3088,9 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     static const int vec_knob = [] { const char* e = getenv("SAE_IGEMM_VEC_STORE"); return e ? atoi(e) : 1; }();
     // measured (tools/ab_conv.py): +2.5 % with K loops of 64 chunks (512 channels), -1 % with 16 or 32: long loops only
     p.vec_store = vec_knob && oys == 1 && oxs == 1 && OW % 4 == 0 && YW % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
-                  (vec_knob > 1 || g.cps >= 48);
+                  (vec_knob > 1 || g.cps >= 48 || ep.act);   // with the fused bias + leaky-ReLU also for short loops: the scalar
+                                                             // epilogue fetches the bias per element (tools/instep_gap.py: 122.6 vs
+                                                             // 127.9 TFLOP/s at 128 -> 128 @256^2, 129.0 vs 131.8 at 256 @128^2)
     int rc;
     if (ks == 3 && stride == 1) rc = launch_igemm<3, 1>(x, ws, out, p, g, s);
     else if (ks == 3) rc = launch_igemm<3, 2>(x, ws, out, p, g, s);
