@@ -41,6 +41,23 @@
 namespace sae {
 namespace {
 
+// Dispatch knobs for A/B experiments exist only in builds with -DSAE_TUNING (tools/build_variant*.sh, the emulator of
+// tests/emu): the product library reads no environment variable besides SAE_CONV_MATH (sae_api.hip).
+#ifdef SAE_TUNING
+inline int tuning_knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+inline int tuning_knob(const char*, int dflt) { return dflt; }
+#endif
+// SAE_TRACE_DISPATCH=1 (tuning builds): one stderr line per launch decision the tests want to see
+#define SAE_TRACE(...)                                                         \
+    do {                                                                       \
+        static const int trace_knob = tuning_knob("SAE_TRACE_DISPATCH", 0);    \
+        if (trace_knob) { fprintf(stderr, "sae-dispatch " __VA_ARGS__); fputc('\n', stderr); } \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------
 // weight re-layout
 // ------------------------------------------------------------------------------------------
@@ -1265,6 +1282,7 @@ struct TrParams {
     int pad;
     const float* in_scale;  // [N][C] or null: style modulation of the input, applied while staging (see IgemmParams)
     int zmask;              // always 0 (see IgemmParams)
+    int mtiles, main_items, strip_items;  // tr2: M tiles; (q tile, M tile) items of region 0 and of regions 1 + 2
     // main region + right / bottom strips, all in ONE launch (blockIdx.x runs through the regions):
     // launched one after the other the two thin strips cost a full K loop of latency each on a
     // nearly empty GPU
@@ -1484,6 +1502,297 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_tr_kernel(const float
             }
         }
     }
+    SAE_CLOCK_PHASE(6)
+    SAE_CLOCK_END
+}
+
+// ------------------------------------------------------------------------------------------
+// transposed gather, second generation ("tr2"): 32*MI rows x 128 q positions, CK = 16 or 8 channels per chunk.
+//
+// Same arithmetic in the same order as conv_igemm_tr_kernel (8-channel sub-chunks, tap-major, channel pairs), so its
+// results are BIT-identical; what changes is how operands reach LDS and how results leave the registers:
+//  * the input patch rows are widened to whole 16-byte quads [qx0 - 4, qx0 + TW) (TW a multiple of 4, input rows a multiple
+//    of four floats wide) and a chunk's quads are dealt out over the workgroup: 3 dwordx4 per thread and 16-channel chunk
+//    instead of 8 dword loads per 8 channels.  With the 9 weight quads that is 12 vector-memory instructions per 144 MFMAs
+//    of a wave (13 per 72 before); their issue was 33-39 % of the kernel (profiles/r2_phase_clock_*.txt);
+//  * 1-D grid in XCD-aware order with the M tile as the FASTEST index: the workgroups that share an input patch (all M
+//    tiles of a q tile) and its spatial neighbours run at the same time behind the same L2 (the plain order read the
+//    input 6.1x from the fabric, profiles/r2_pmc_f32_quad.txt);
+//  * the epilogue goes through LDS wave by wave: a lane holds both x-classes of a q position, i.e. two adjacent output
+//    columns, so the four classes of a wave's 32 positions are two complete output rows of 64 consecutive columns; they
+//    leave as 4-byte aligned dwordx4 stores (32 per lane instead of 128 stride-2 dword stores that wrote every 64-byte
+//    line twice);
+//  * the style factors of a modulated launch are fetched once into LDS (tiles never span images then).
+// Tiles are TN x TH x TW positions with TN (TH + 1) (TW + 4) <= kTr2Cap, chosen per region on the host.
+// ------------------------------------------------------------------------------------------
+constexpr int kTr2Cap = 192;        // patch floats per channel
+constexpr int kTr2MaxC = 2048;      // style factors held in LDS (modulated launches)
+
+template <int MI, int CK, bool MOD = false>
+__global__ __launch_bounds__(kBlock, 2) void conv_igemm_tr2_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ wp,
+                                                                float* __restrict__ y, const TrParams p) {
+    static_assert(CK == 8 || CK == 16, "8- or 16-channel chunks");
+    constexpr int T = 9;
+    constexpr int BM = 32 * MI;
+    constexpr int XCAP = kTr2Cap;
+    constexpr int QCAP = XCAP / 4;
+    constexpr int QPT = (CK * QCAP + kBlock - 1) / kBlock;       // quad slots per thread per chunk
+    constexpr int A_VEC = T * CK * BM / 4;
+    constexpr int APT = (A_VEC + kBlock - 1) / kBlock;
+    constexpr int XS = CK * XCAP + 4 * kBlock;                   // + a dump area for the slots beyond the patch
+    constexpr int AS = T * CK * BM;
+    constexpr int CS = 4 * 8 * 128;                              // epilogue: 8 rows x 128 floats per wave and pass
+    constexpr int LDSF = (AS + XS > CS) ? AS + XS : CS;
+    __shared__ __attribute__((aligned(16))) float smem[LDSF];
+    __shared__ float Ss[MOD ? kTr2MaxC : 1];
+    float* As = smem;
+    float* Xs = smem + AS;
+
+    SAE_CLOCK_BEGIN
+    const int tid = threadIdx.x;
+    __builtin_assume(tid < kBlock);
+    const int lane = tid & 63, wn = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // Work items = (q tile, M tile), M tile fastest.  XCD k (= workgroup id % 8) takes the k-th contiguous eighth of the strip
+    // items and then the k-th contiguous eighth of the main region's: the thin strip tiles (one active wave, latency-bound
+    // K loop) run FIRST, next to main tiles on the same CUs, instead of alone on an emptying GPU at the end of the launch
+    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+    const int ps = (p.strip_items + 7) >> 3, pm = (p.main_items + 7) >> 3;
+    int wk;
+    if (slot < ps) {
+        wk = xcd * ps + slot;
+        if (wk >= p.strip_items) return;
+        wk += p.main_items;
+    } else {
+        wk = xcd * pm + slot - ps;
+        if (wk >= p.main_items) return;
+    }
+    const int mt = wk % p.mtiles;
+    int bt = wk / p.mtiles;
+    int ridx = 0;
+    if (bt >= p.reg[0].blocks) {
+        bt -= p.reg[0].blocks; ridx = 1;
+        if (bt >= p.reg[1].blocks) { bt -= p.reg[1].blocks; ridx = 2; }
+    }
+    const TrRegion g = p.reg[ridx];
+    const int TW = g.tw, TH = g.th, TN = g.tn;
+    const int tix = bt % g.tiles_x; bt /= g.tiles_x;
+    const int tiy = bt % g.tiles_y;
+    const int tin = bt / g.tiles_y;
+    const int qx0 = g.qx_base + tix * TW, qy0 = g.qy_base + tiy * TH, n0 = tin * TN;
+    const int m0 = mt * BM;
+
+    const int PH = TH + 1;                 // patch row r <-> input row qy0 - 1 + r
+    const int RS = ((TW + 3) & ~3) + 4;    // patch column c <-> input column qx0 - 4 + c (qx0 is a multiple of 4)
+    const int RQ = RS >> 2;
+    const int IP = PH * RS;
+    const int QI = PH * RQ, QN = TN * QI;  // quads per image, per channel
+    const int HW = p.IH * p.IW;
+
+    // quad slot k of a thread = quad j = tid + kBlock * k of the chunk: channel j / QN, quad j % QN of the patch.  Slots
+    // outside the image (zero padding) or beyond the chunk fetch element 0 and are zeroed / dumped at the LDS write, so the
+    // K loop has no divergent branch and every load is "uniform 64-bit base + loop-invariant 32-bit lane offset"
+    unsigned qbyte[QPT];
+    int qdst[QPT], qch[QPT];       // qch < 0: never valid
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+        const int j = tid + kBlock * k;
+        const int ch = j / QN;
+        const int q = j - ch * QN;
+        const int pn = q / QI;
+        const int rem = q - pn * QI;
+        const int r = rem / RQ;
+        const int qc = rem - r * RQ;
+        const int iy = qy0 - 1 + r, ix = qx0 - 4 + 4 * qc;
+        const bool slot = ch < CK;
+        const bool in = slot && n0 + pn < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
+        qbyte[k] = in ? 4u * (unsigned)((pn * p.C + ch) * HW + iy * p.IW + ix) : 0u;
+        qch[k] = in ? ch : -1;
+        qdst[k] = slot ? ch * XCAP + 4 * q : CK * XCAP + 4 * tid;
+    }
+    unsigned abyte[APT];
+#pragma unroll
+    for (int i = 0; i < APT; ++i) {
+        const int e4 = tid + kBlock * i;
+        const int row = e4 / (BM / 4);
+        const int col4 = e4 - row * (BM / 4);
+        const int tap = (row / CK) < T ? row / CK : 0, ch = row - (row / CK) * CK;
+        abyte[i] = 4u * (unsigned)((tap * p.Cp + ch) * p.Mp + col4 * 4);
+    }
+    if constexpr (MOD) {    // tiles of a modulated launch lie inside one image (host)
+        for (int c = tid; c < p.C; c += kBlock) Ss[c] = p.in_scale[(int64_t)n0 * p.C + c];
+    }
+
+    const int pp = wn * 32 + l31;
+    const int npos = TN * TH * TW;
+    const int pn_l = pp / (TW * TH);
+    const int prem = pp - pn_l * (TW * TH);
+    const int py = prem / TW;
+    const int px = prem - py * TW;
+    const int pixbase = pp < npos ? pn_l * IP + py * RS + px : 0;     // lanes beyond the tile compute on position 0
+    const bool wave_active = wn * 32 < npos;                          // (whole waves beyond it skip their MFMAs: strip tiles)
+    int tapoff[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const int ky = t / 3, kx = t % 3;
+        // tap k contributes from input index q - (k == 2 ? 1 : 0)
+        tapoff[t] = ((ky == 2) ? 0 : 1) * RS + ((kx == 2) ? 3 : 4);
+    }
+
+    f32x16 acc[MI][4];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int cl = 0; cl < 4; ++cl)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][cl][r] = 0.0f;
+
+    const float* xb = x + (int64_t)n0 * p.C * HW;
+    f32x4 xq[QPT];
+    f32x4 av[APT];
+
+    auto load_chunk = [&](int c0) {
+        const char* xc = reinterpret_cast<const char*>(xb + (int64_t)c0 * HW);
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const bool ok = qch[k] >= 0 && c0 + qch[k] < p.C;      // channels beyond C (last chunk): element 0, zeroed later
+            xq[k] = *reinterpret_cast<const f32x4*>(xc + (ok ? qbyte[k] : 0u));
+        }
+        const char* wb = reinterpret_cast<const char*>(wp + (int64_t)c0 * p.Mp + m0);
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e4 = tid + kBlock * i;
+            if (e4 < A_VEC) av[i] = *reinterpret_cast<const f32x4*>(wb + abyte[i]);
+        }
+    };
+    auto store_chunk = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const bool ok = qch[k] >= 0 && c0 + qch[k] < p.C;
+            f32x4 v = xq[k];
+            if constexpr (MOD) v *= Ss[ok ? c0 + qch[k] : 0];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
+            *reinterpret_cast<f32x4*>(Xs + qdst[k]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < APT; ++i) {
+            const int e4 = tid + kBlock * i;
+            if (e4 < A_VEC) *reinterpret_cast<f32x4*>(As + e4 * 4) = av[i];
+        }
+    };
+
+    load_chunk(0);
+    SAE_CLOCK_PHASE(0)
+    for (int c0 = 0; c0 < p.Cp; c0 += CK) {
+        __syncthreads();
+        SAE_CLOCK_PHASE(2)
+        store_chunk(c0);
+        SAE_CLOCK_PHASE(3)
+        __syncthreads();
+        SAE_CLOCK_PHASE(4)
+        if (c0 + CK < p.Cp) load_chunk(c0 + CK);
+        SAE_CLOCK_PHASE(5)
+        if (wave_active)
+#pragma unroll
+        for (int sub = 0; sub < CK / 8; ++sub)
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int cls = ((t / 3) & 1) * 2 + ((t % 3) & 1);   // parity class fed by this tap
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int ch = sub * 8 + 2 * kk + half;
+                    const float b = Xs[ch * XCAP + pixbase + tapoff[t]];
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) {
+                        const float a = As[(t * CK + ch) * BM + mi * 32 + l31];
+                        // cls is a compile-time constant after unrolling t
+                        if (cls == 0) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][0], 0, 0, 0);
+                        else if (cls == 1) acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][1], 0, 0, 0);
+                        else if (cls == 2) acc[mi][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][2], 0, 0, 0);
+                        else acc[mi][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][3], 0, 0, 0);
+                    }
+                }
+            }
+        SAE_CLOCK_PHASE(1)
+    }
+
+    // ---- epilogue.  Per pass a wave parks 8 rows (m) x [cy][32 positions][cx] in its own LDS block; lane (cy = bit 4,
+    // k = lane & 15) then owns the quad of positions 2k, 2k + 1 = four consecutive columns of output row 2 qy + cy - pad
+    // for rows m8 = 2 v + (lane >> 5).
+    __syncthreads();                  // every wave is done with As / Xs
+    if (!wave_active) return;
+    if (TW & 1) {                     // one-column strips: positions 2k, 2k + 1 are not neighbours; plain stores
+        const int n = n0 + pn_l, qy = qy0 + py, qx = qx0 + px;
+        if (pp < npos && n < p.N && qy < g.QH && qx < g.QW) {
+#pragma unroll
+            for (int cl = 0; cl < 4; ++cl) {
+                const int oy = 2 * qy + (cl >> 1) - p.pad;
+                const int ox = 2 * qx + (cl & 1) - p.pad;
+                if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
+                    float* yb = y + ((int64_t)n * p.M * p.OH + oy) * p.OW + ox;
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int m = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            if (m < p.M) yb[(int64_t)m * p.OH * p.OW] = acc[mi][cl][r];
+                        }
+                }
+            }
+        }
+        return;
+    }
+    float* Cw = smem + wn * (8 * 128);
+    const int ecy = (lane >> 4) & 1, ek = lane & 15;
+    const int epp = wn * 32 + 2 * ek;
+    const int epn = epp / (TW * TH);
+    const int eprem = epp - epn * (TW * TH);
+    const int epy = eprem / TW;
+    const int epx = eprem - epy * TW;                 // even; position 2k + 1 is its right neighbour (TW is even)
+    const int en = n0 + epn, eqy = qy0 + epy, eqx = qx0 + epx;
+    const int oy = 2 * eqy + ecy - p.pad;
+    const int ox = 2 * eqx - p.pad;
+    unsigned emask = 0;               // bit e: output column ox + e exists and belongs to this tile's region
+    if (epp < npos && en < p.N && eqy < g.QH && oy >= 0 && oy < p.OH) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (eqx + (e >> 1) < g.QW && ox + e >= 0 && ox + e < p.OW) emask |= 1u << e;
+    }
+    const int64_t plane = (int64_t)p.OH * p.OW;
+    float* yb = y + (int64_t)en * p.M * plane + (int64_t)oy * p.OW + ox;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    struct __attribute__((packed, aligned(4))) U4 { f32x4 v; };     // 4-byte aligned quad (rows are 2^k + 1 wide)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int cy = 0; cy < 2; ++cy)
+                    *reinterpret_cast<f32x2*>(Cw + (4 * half + i) * 128 + cy * 64 + 2 * l31) =
+                        f32x2{acc[mi][cy * 2][4 * j + i], acc[mi][cy * 2 + 1][4 * j + i]};
+            wave_sync();
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int m8 = 2 * v + half;
+                const f32x4 c = *reinterpret_cast<const f32x4*>(Cw + m8 * 128 + (lane & 31) * 4);
+                const int m = m0 + mi * 32 + 8 * j + m8;
+                if (m < p.M) {
+                    float* yp = yb + (int64_t)m * plane;
+                    if (emask == 15u) reinterpret_cast<U4*>(yp)->v = c;
+                    else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (emask & (1u << e)) yp[e] = c[e];
+                    }
+                }
+            }
+            wave_sync();
+        }
     SAE_CLOCK_PHASE(6)
     SAE_CLOCK_END
 }
@@ -3115,10 +3424,121 @@ int64_t gather_ws(int N, int cin, int mout, int OH, int OW, int ks, int stride, 
     return gather_plan(N, cin, mout, OH, OW, ks, stride, scatter).ws_floats;
 }
 
+// ---- tr2 (conv_igemm_tr2_kernel): exact fp32, input rows a multiple of four floats wide and 16-byte aligned
+#ifndef SAE_TR2_DEFAULT
+#define SAE_TR2_DEFAULT 1
+#endif
+struct Tr2Shape { int mi, bm, ck; };
+Tr2Shape tr2_shape(int mout) {
+    static const int knob = tuning_knob("SAE_TR2", SAE_TR2_DEFAULT);      // 0: conv_igemm_tr_kernel, 2: 8-channel chunks
+    Tr2Shape s{};
+    s.mi = mout > 32 ? 2 : 1;
+    s.bm = 32 * s.mi;
+    // 16-channel chunks for the 64-row tile (117.6 / 113.9 / 101.1 TFLOP/s on the three D shapes vs 118.0 / 112.3 / 99.3 with
+    // 8); the 32-row tile of the narrow layers keeps 8 (three workgroups per CU: 92.6 vs 84.4 at 64 -> 32 @129, B = 128)
+    s.ck = (knob == 2 || (knob == 1 && s.mi == 1)) ? 8 : 16;
+    return s;
+}
+bool tr2_eligible(const float* x, int N, int cin, int IH, int IW, int mout, bool modulated) {
+    static const int knob = tuning_knob("SAE_TR2", SAE_TR2_DEFAULT);
+    if (!knob || conv_math() != 0) return false;
+    if (IW % 4 != 0 || IW < 8 || !aligned16(x)) return false;
+    // in-step by shape (profiles/r3_tr2_by_shape.txt): 32-wide inputs and up gain (n = 16 modulated 128 -> 256 @257: 100.6 ->
+    // 114.9 TFLOP/s; 512 -> 512 @65: 84.3 -> 89.7), the 16- and 8-wide ones lose to the free-form tiles of
+    // conv_igemm_tr_kernel (their 2^k + 1 grids are mostly strip), except modulated ones (factors from LDS, not per slot)
+    if (knob == 1 && IW < (modulated ? 16 : 32)) return false;
+    if (modulated && cin > kTr2MaxC) return false;
+    // 32-bit byte offsets inside a tile's images (at most 128 of them)
+    if ((int64_t)(N < 128 ? N : 128) * cin * IH * IW * 4 >= ((int64_t)1 << 31)) return false;
+    (void)mout;
+    return true;
+}
+// tile of a region: TN x TH x TW positions, TW a multiple of 4 or the whole (narrow) region; fewest wave-tiles
+bool tr2_pick_tile(int qw, int qh, int N, bool one_image, TrRegion& g) {
+    double best = -1.0;
+    for (int tw = 128; tw >= 1; --tw) {
+        if (tw % 4 != 0 && !(tw == qw && qw < 32)) continue;
+        const int rs = ((tw + 3) & ~3) + 4;
+        for (int th = 1; th * tw <= 128; ++th) {
+            if (th > qh && th > 1) break;
+            int tn = 128 / (tw * th);
+            if (tn > N) tn = N;
+            if (one_image) tn = 1;
+            while (tn > 1 && tn * (th + 1) * rs > kTr2Cap) --tn;
+            if (tn * (th + 1) * rs > kTr2Cap) continue;
+            const int waves = ceil_div(tw * th * tn, 32);
+            const double cost = (double)ceil_div(qw, tw) * ceil_div(qh, th) * ceil_div(N, tn) * (1.5 + waves);
+            if (best < 0 || cost < best) { best = cost; g.tw = tw; g.th = th; g.tn = tn; }
+        }
+    }
+    return best >= 0;
+}
+int run_tr2(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int IH, int IW,
+            int mout, int OH, int OW, int pad, int64_t sm, int64_t sc, float alpha, hipStream_t s,
+            const float* in_scale, WScale wsc) {
+    const Tr2Shape sh = tr2_shape(mout);
+    const int Mp = round_up(mout, sh.bm), Cp = round_up(cin, sh.ck);
+    const int64_t need = (int64_t)9 * Cp * Mp;
+    if (!ws || ws_floats < need)
+        return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
+    run_wprep(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s, wsc);
+    TrParams p{};
+    p.in_scale = in_scale;
+    p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
+    const int QH = (OH + pad - 1) / 2 + 1, QW = (OW + pad - 1) / 2 + 1;
+    // main region (sides a multiple of 4) + right / bottom strips, as in run_tr
+    auto main_side = [](int q, int align) {
+        int t = 32;
+        while (t > q) t >>= 1;
+        const int m = (q / t) * t;
+        return (q - m > 0 && (q - m) * 4 <= t && m > 0 && m % align == 0) ? m : q;    // split only a thin remainder
+    };
+    const int QHm = main_side(QH, 1), QWm = main_side(QW, 4);   // the right strip starts on a quad boundary
+    struct Region { int y0, y1, x0, x1; };
+    Region regions[3];
+    int nreg = 0;
+    regions[nreg++] = {0, QHm, 0, QWm};
+    if (QWm < QW) regions[nreg++] = {0, QH, QWm, QW};
+    if (QHm < QH) regions[nreg++] = {QHm, QH, 0, QWm};
+    int total = 0;
+    for (int r = 0; r < 3; ++r) {
+        TrRegion& g = p.reg[r];
+        g = TrRegion{};
+        if (r >= nreg) { g.tw = g.th = g.tn = g.tiles_x = g.tiles_y = g.tiles_n = 1; continue; }
+        const int qh = regions[r].y1 - regions[r].y0, qw = regions[r].x1 - regions[r].x0;
+        g.qy_base = regions[r].y0; g.qx_base = regions[r].x0; g.QH = regions[r].y1; g.QW = regions[r].x1;
+        if (!tr2_pick_tile(qw, qh, N, in_scale != nullptr, g)) return fail(SAE_EINVAL, "conv tr2: no tile fits the LDS patch cap");
+        g.tiles_x = ceil_div(qw, g.tw);
+        g.tiles_y = ceil_div(qh, g.th);
+        g.tiles_n = ceil_div(N, g.tn);
+        g.blocks = g.tiles_x * g.tiles_y * g.tiles_n;
+        total += g.blocks;
+    }
+    p.mtiles = Mp / sh.bm;
+    p.main_items = p.reg[0].blocks * p.mtiles;
+    p.strip_items = (total - p.reg[0].blocks) * p.mtiles;
+    SAE_TRACE("tr2 mi=%d ck=%d mod=%d tiles=%d main=%dx%dx%d", sh.mi, sh.ck, in_scale ? 1 : 0, total, p.reg[0].tn, p.reg[0].th,
+              p.reg[0].tw);
+    const dim3 grid((unsigned)(8 * (ceil_div(p.main_items, 8) + ceil_div(p.strip_items, 8))));
+#define SAE_TR2(MI_, CK_)                                                                                              \
+    do {                                                                                                               \
+        if (in_scale) hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, true>), grid, dim3(kBlock), 0, s, x, ws, y, p);   \
+        else hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, false>), grid, dim3(kBlock), 0, s, x, ws, y, p);           \
+    } while (0)
+    if (sh.mi == 2 && sh.ck == 16) SAE_TR2(2, 16);
+    else if (sh.mi == 2) SAE_TR2(2, 8);
+    else if (sh.ck == 16) SAE_TR2(1, 16);
+    else SAE_TR2(1, 8);
+#undef SAE_TR2
+    return SAE_OK;
+}
+
 // stride-2 3x3 transposed gather producing `mout` channels (the large image) from `cin` channels
 int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int IH, int IW,
            int mout, int OH, int OW, int pad, int64_t sm, int64_t sc, float alpha, hipStream_t s,
            const float* in_scale = nullptr, WScale wsc = WScale{nullptr, nullptr}) {
+    if (tr2_eligible(x, N, cin, IH, IW, mout, in_scale != nullptr))
+        return run_tr2(x, w, y, ws, ws_floats, N, cin, IH, IW, mout, OH, OW, pad, sm, sc, alpha, s, in_scale, wsc);
     const TrShape sh = tr_shape(mout);
     constexpr int CK = 8;
     const int Mp = round_up(mout, sh.bm), Cp = round_up(cin, sh.ck);
@@ -3214,7 +3634,11 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
 int64_t tr_ws(int cin, int mout) {
     const TrShape sh = tr_shape(mout);
     if (conv_math() == 1 && sh.cfg == 0) return (int64_t)27 * round_up(mout, sh.bm) * (round_up(cin, 8) / 8) * 4;
-    return (int64_t)9 * round_up(cin, sh.ck) * round_up(mout, sh.bm);
+    // whichever of the two fp32 kernels the launch takes (tr2 needs the pointer alignment to decide)
+    const Tr2Shape s2 = tr2_shape(mout);
+    const int64_t a = (int64_t)9 * round_up(cin, sh.ck) * round_up(mout, sh.bm);
+    const int64_t b = (int64_t)9 * round_up(cin, s2.ck) * round_up(mout, s2.bm);
+    return a > b ? a : b;
 }
 
 template <int KS, int S, int TA, int TB, int WA, int WB, int MODE, bool WQ = false>

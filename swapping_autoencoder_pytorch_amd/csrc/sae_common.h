@@ -45,6 +45,13 @@ inline int ilog2_ceil(int64_t v) {  // smallest e with (1 << e) >= v, v >= 1
 // product block, fp32 accumulate (see conv2d.hip "bx"); set by sae_set_conv_math / SAE_CONV_MATH
 int conv_math();
 
+// Lanes of ONE wave exchanging data through LDS: the wave's LDS instructions execute in order, so nothing has to be waited
+// for; this only keeps the compiler from moving LDS accesses across the exchange point.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace sae

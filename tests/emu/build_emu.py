@@ -34,7 +34,7 @@ def build(force=False):
     if not force and not needs_build():
         return OUT
     cmd = [host_clang(), "-x", "c++", "-std=c++17", "-O2", "-fPIC", "-shared", "-nogpulib", "-Wno-unused-value", "-Wno-psabi",
-           "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+           "-DSAE_TUNING", "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     for s in sources():
         cmd += [s]
     cmd += ["-o", OUT]

@@ -341,6 +341,9 @@ static inline void __syncthreads() { hipemu::block_barrier(); }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) \
     std::memcpy((char*)(l) + (size) * hipemu::lane_id() + (off), (const void*)(g), (size))
 #define __builtin_amdgcn_s_waitcnt(imm) ((void)0)
+// wave-level LDS exchange: a rendezvous of the wave's live lanes (on the GPU the lanes run in lockstep)
+#define __builtin_amdgcn_wave_barrier() hipemu::wave_rendezvous(hipemu::my_wave())
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
 #ifndef __clang__
 #define __builtin_assume(x) ((void)0)

@@ -15,6 +15,8 @@ MODCONV_CASES = [
     (1, 70, 17, 17, 12, 3, 2, 0, True),      # transposed conv producing 70 channels ([C, M] weights)
     (2, 40, 19, 35, 8, 3, 2, 0, True),       # transposed, strips (2^k + 1 grid), two images
     (2, 12, 9, 9, 20, 3, 2, 0, True),        # transposed, narrow tile
+    (2, 40, 17, 33, 24, 3, 2, 0, True),      # transposed, quad-staged (tr2): 8 x 16 input, strips, M / channel tails
+    (1, 20, 9, 25, 40, 3, 2, 0, True),       # ... 32-row tile
     (3, 20, 12, 12, 24, 3, 1, 1, False),     # wgrad MODE 1
     (2, 3, 16, 16, 40, 3, 1, 1, False),      # wgrad MODE 2
     (1, 36, 32, 32, 70, 3, 1, 1, False),

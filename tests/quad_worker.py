@@ -18,7 +18,10 @@ from swapping_autoencoder_pytorch_amd.hip_lib import SaeLibrary  # noqa: E402
 # tails, valid padding), 1x1 s1, 3x3 s2 with 2^k + 1 wide rows (shifted last quad, partial tile), thin 1x1 layers excluded
 # (different arithmetic order by design, checked against the oracle in the kernel tests)
 EMU = [(2, 20, 16, 16, 130, 3, 1, 1), (1, 12, 20, 36, 70, 3, 1, 0), (3, 20, 12, 12, 24, 3, 1, 1), (1, 70, 16, 16, 70, 1, 1, 0),
-       (2, 12, 21, 41, 70, 3, 2, 0), (1, 6, 33, 33, 130, 3, 2, 0)]
+       (2, 12, 21, 41, 70, 3, 2, 0), (1, 6, 33, 33, 130, 3, 2, 0),
+       # stride-2 data gradient through conv_igemm_tr2_kernel (input rows a multiple of 4 wide): M / channel tails, strips,
+       # pad 1, 32-row tile, several images per tile
+       (2, 40, 17, 33, 20, 3, 2, 0), (1, 36, 16, 24, 12, 3, 2, 1), (3, 20, 17, 17, 40, 3, 2, 0), (1, 70, 9, 65, 9, 3, 2, 0)]
 GPU = EMU + [(4, 128, 64, 64, 128, 3, 1, 1), (2, 512, 32, 32, 512, 3, 1, 1), (8, 32, 64, 64, 32, 3, 1, 1), (4, 64, 65, 65, 128, 3, 2, 0),
              (4, 128, 64, 64, 256, 1, 1, 0), (2, 256, 129, 129, 512, 3, 2, 0)]
 

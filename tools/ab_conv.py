@@ -64,7 +64,10 @@ def clock_mode():
     stream = lambda: torch.cuda.current_stream(dev).cuda_stream
     print("%-20s %-6s %9s %9s %9s %9s   %s" % ("shape", "op", "TFLOP/s", "of 157.3", "MHz", "of peak@MHz",
           "wave-0 time of conv_igemm_kernel / conv_wgrad_kernel: prologue | MFMA | barrier | LDS stores | barrier | load issue | epilogue (%)"))
+    only = [a[2:] for a in sys.argv[1:] if a.startswith("--") and a != "--clock"]
     for (n, c, h, w, m, k, s, p, tag) in SHAPES:
+        if only and not any(o in tag for o in only):
+            continue
         d = H.conv_desc(n, c, h, w, m, k, s, p)
         x = torch.randn(n, c, h, w, device=dev)
         wt = torch.randn(m, c, k, k, device=dev)

@@ -63,6 +63,11 @@ def calibrate():
 
 
 if __name__ == "__main__":
+    if "--tr" in sys.argv:      # the transposed gather alone (stride-2 data gradient), plain and at the generator's batch
+        calibrate()
+        conv(16, 128, 257, 257, 256, 3, 2, 0, ops=(1,))
+        conv(16, 256, 129, 129, 512, 3, 2, 0, ops=(1,))
+        sys.exit(0)
     calibrate()
     conv(16, 128, 256, 256, 128, 3, 1, 1)          # igemm s1 / dgrad s1 / wgrad s1
     conv(16, 128, 257, 257, 256, 3, 2, 0)          # igemm s2 / tr / wgrad s2
