@@ -56,7 +56,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 1
+#define SAE_ABI_VERSION 3   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -96,6 +96,25 @@ int sae_upfirdn2d_f32(const float* x, const float* k, float* y,
                       int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y,
                       int32_t pad_x0, int32_t pad_x1, int32_t pad_y0, int32_t pad_y1,
                       sae_stream_t stream);
+
+/* upfirdn2d on planes (minor = 1, down = 1, up = 1 or 2 on both axes, at most 4 x 4 taps) with the elementwise work that
+ * FOLLOWS it in the backward pass of a ResBlock (stylegan2_layers.py:672-693) done on its way out, so that the tensor
+ * between the two never exists in HBM:
+ *     v = upfirdn2d(x, k, up, pad)                                     exactly sae_upfirdn2d_f32's value
+ *     if (accumulate) v += y                                           the sum of a forked gradient (autograd's add;
+ *                                                                      the block input feeds conv1 AND the skip path)
+ *     if (act_ref)  { v = (act_ref > 0 ? v : slope * v) * scale;       FusedLeakyReLUFunctionBackward, fused_act.py:32-41
+ *                     gb[c] = sum over planes p with p % channels == c and all pixels of v }   (grad_bias, :36-41)
+ *     y = v
+ * act_ref: output-shaped (the saved output of the activation whose backward this is) or NULL; gb [channels] and the
+ * workspace (sae_upfirdn2d_epilogue_workspace floats) are used with act_ref only; the bias-gradient reduction is
+ * two-stage and fixed-order (deterministic, no atomics). */
+int64_t sae_upfirdn2d_epilogue_workspace(int64_t major, int64_t out_h, int64_t out_w, int64_t channels, int32_t up);
+int sae_upfirdn2d_epilogue_f32(const float* x, const float* k, float* y, int64_t major, int64_t in_h, int64_t in_w,
+                               int32_t kh, int32_t kw, int32_t up, int32_t pad_x0, int32_t pad_x1, int32_t pad_y0,
+                               int32_t pad_y1, const float* act_ref, float slope, float scale, float* gb,
+                               int64_t channels, int32_t accumulate, float* workspace, int64_t workspace_floats,
+                               sae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * bias_act: y[i] = act'(x[i] + b[(i / step_b) % size_b]) * scale       fused_bias_act_kernel.cu:18-49

@@ -39,7 +39,7 @@ typedef struct sae_conv2d_desc {
 
 static __thread char g_err[256];
 
-int oracle_abi_version(void) { return 1; }
+int oracle_abi_version(void) { return 3; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
@@ -106,6 +106,56 @@ int oracle_upfirdn2d_f32(const float* x, const float* k, float* y,
                     y[((mj * out_h + oy) * out_w + ox) * minor + mn] = (float)v;
                 }
             }
+    return SAE_OK;
+}
+
+/* include/sae_hip.h sae_upfirdn2d_epilogue_f32: the K1 call above followed by what the backward pass of a ResBlock
+ * (stylegan2_layers.py:672-693) does next with its result -- autograd's sum of the two gradients of the block input
+ * (accumulate) and / or FusedLeakyReLUFunctionBackward (fused_act.py:32-41: grad_input = grad_output * (out > 0 ? 1 :
+ * slope) * scale in float, as fused_bias_act_kernel.cu:30,47 does; grad_bias = grad_input.sum over all but the channel
+ * axis, here in double).  The FIR value is rounded to float first, as the separate kernels would have stored it. */
+int64_t oracle_upfirdn2d_epilogue_workspace(int64_t major, int64_t out_h, int64_t out_w, int64_t channels, int32_t up) {
+    (void)major; (void)out_h; (void)out_w; (void)channels; (void)up;
+    return 0;
+}
+int oracle_upfirdn2d_f32(const float* x, const float* k, float* y, int64_t major, int64_t in_h, int64_t in_w, int64_t minor,
+                         int32_t kh, int32_t kw, int32_t up_x, int32_t up_y, int32_t down_x, int32_t down_y, int32_t pad_x0,
+                         int32_t pad_x1, int32_t pad_y0, int32_t pad_y1, sae_stream_t stream);
+int oracle_upfirdn2d_epilogue_f32(const float* x, const float* k, float* y, int64_t major, int64_t in_h, int64_t in_w,
+                                  int32_t kh, int32_t kw, int32_t up, int32_t pad_x0, int32_t pad_x1, int32_t pad_y0,
+                                  int32_t pad_y1, const float* act_ref, float slope, float scale, float* gb,
+                                  int64_t channels, int32_t accumulate, float* workspace, int64_t workspace_floats,
+                                  sae_stream_t stream) {
+    (void)workspace; (void)workspace_floats;
+    if (!x || !k || !y || (up != 1 && up != 2) || kh < 1 || kw < 1 || kh > 4 || kw > 4 ||
+        (act_ref && (!gb || channels < 1 || major % channels != 0))) {
+        snprintf(g_err, sizeof g_err, "oracle_upfirdn2d_epilogue_f32: bad argument");
+        return SAE_EINVAL;
+    }
+    const int64_t out_h = in_h * up + pad_y0 + pad_y1 - kh + 1, out_w = in_w * up + pad_x0 + pad_x1 - kw + 1;
+    if (out_h < 1 || out_w < 1) return SAE_EINVAL;
+    const int64_t hw = out_h * out_w;
+    float* t = (float*)malloc(sizeof(float) * (size_t)(major * hw > 0 ? major * hw : 1));
+    if (!t) return SAE_EWORKSPACE;
+    int rc = oracle_upfirdn2d_f32(x, k, t, major, in_h, in_w, 1, kh, kw, up, up, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, stream);
+    if (rc != SAE_OK) { free(t); return rc; }
+    double* acc = act_ref ? (double*)calloc((size_t)channels, sizeof(double)) : NULL;
+    for (int64_t p = 0; p < major; ++p)
+        for (int64_t i = 0; i < hw; ++i) {
+            float v = t[p * hw + i];
+            if (accumulate) v += y[p * hw + i];
+            if (act_ref) {
+                v = (act_ref[p * hw + i] > 0.0f) ? v : v * slope;
+                v *= scale;
+                acc[p % channels] += (double)v;
+            }
+            y[p * hw + i] = v;
+        }
+    if (act_ref) {
+        for (int64_t c = 0; c < channels; ++c) gb[c] = (float)acc[c];
+        free(acc);
+    }
+    free(t);
     return SAE_OK;
 }
 

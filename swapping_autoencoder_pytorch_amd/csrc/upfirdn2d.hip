@@ -34,6 +34,69 @@ __device__ __forceinline__ int floor_div_i(int a, int b) {  // upfirdn2d_kernel.
     return c;
 }
 
+// Elementwise work that FOLLOWS a K1 call in the backward pass of a ResBlock, done on the way out (EPI instantiations,
+// sae_upfirdn2d_epilogue_f32): the accumulation of a forked gradient (y += v, autograd's add) and / or the K2 backward
+// (fused_act.py:32-41) v = (act_ref > 0 ? v : slope v) scale with its bias-gradient partial sums -- the tensor between
+// the two ops is never written to or re-read from HBM.
+struct K1Epilogue {
+    const float* act_ref;    // output-shaped saved activation, or null
+    float* partial;          // [channels][outer * q] per-strip partial sums of the activated gradient (act_ref only)
+    float slope, scale;
+    int accumulate;
+    int channels;            // channel of plane p = p % channels
+    int64_t q_per_channel;   // outer * (row groups per plane * x tiles)
+};
+
+// The epilogue's own operands (the old value of y, the activation reference) are fetched together with the strip, long
+// before the FIR needs them: issued after the FIR they were a second, fully exposed round trip per block.
+template <int RB>
+struct K1Operands { float old[RB], ref[RB]; };
+
+template <int RB>
+__device__ __forceinline__ void k1_prefetch(const K1Epilogue& e, K1Operands<RB>& q, const float* yp, bool col_ok,
+                                            int oy0, int out_h, int out_w, int ox, int64_t plane, int64_t plane_elems) {
+    const float* rp = e.act_ref ? e.act_ref + plane * plane_elems : yp;
+#pragma unroll
+    for (int o = 0; o < RB; ++o) {
+        const int oy = oy0 + o;
+        const bool ok = col_ok && oy < out_h;
+        const int64_t idx = ok ? (int64_t)oy * out_w + ox : 0;       // branch-free (see blur_kernel): element 0 otherwise
+        q.old[o] = e.accumulate ? yp[idx] : 0.0f;
+        q.ref[o] = e.act_ref ? rp[idx] : 1.0f;
+    }
+}
+
+// v: the thread's RB outputs of column ox, rows oy0 ...; writes y and (act_ref) the strip's partial bias-gradient sum
+template <int TW, int RB>
+__device__ __forceinline__ void k1_epilogue(const K1Epilogue& e, const K1Operands<RB>& q, float (&v)[RB], float* yp,
+                                            bool col_ok, int oy0, int out_h, int out_w, int ox, int64_t plane, int strip_q,
+                                            int q_per_plane, bool live, int tx) {
+    float bsum = 0.0f;
+    if (col_ok) {
+#pragma unroll
+        for (int o = 0; o < RB; ++o) {
+            const int oy = oy0 + o;
+            if (oy < out_h) {
+                float t = v[o];
+                if (e.accumulate) t += q.old[o];
+                if (e.act_ref) {
+                    t = ((q.ref[o] > 0.0f) ? t : t * e.slope) * e.scale;
+                    bsum += t;
+                }
+                yp[(int64_t)oy * out_w + ox] = t;
+            }
+        }
+    }
+    if (e.act_ref) {       // strip sum over its TW lanes (consecutive lanes of one wave), fixed order
+#pragma unroll
+        for (int m = TW / 2; m >= 1; m >>= 1) bsum += __shfl_xor(bsum, m, 64);
+        if (live && tx == 0) {
+            const int64_t n = plane / e.channels, c = plane - n * e.channels;
+            e.partial[c * e.q_per_channel + n * q_per_plane + strip_q] = bsum;
+        }
+    }
+}
+
 struct BlurParams {
     int64_t planes;
     int in_h, in_w, out_h, out_w;
@@ -44,10 +107,10 @@ struct BlurParams {
     int64_t groups;        // planes * groups_per_plane
 };
 
-template <int KH, int KW, int TW, int RB>
+template <int KH, int KW, int TW, int RB, bool EPI = false>
 __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ x,
                                                       const float* __restrict__ k,
-                                                      float* __restrict__ y, const BlurParams p) {
+                                                      float* __restrict__ y, const BlurParams p, const K1Epilogue e) {
     constexpr int NR = kBlock / TW;          // thread rows per block
     constexpr int SR = RB + KH - 1;          // staged rows per strip
     constexpr int SW = TW + KW - 1;          // staged columns per strip
@@ -107,6 +170,10 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
         const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
         halo[i] = ok ? v : 0.0f;
     }
+    [[maybe_unused]] K1Operands<EPI ? RB : 1> eq;
+    if constexpr (EPI)
+        k1_prefetch<RB>(e, eq, y + plane * (int64_t)p.out_h * p.out_w, live && ox0 + tx < p.out_w, oy0, p.out_h, p.out_w,
+                        ox0 + tx, plane, (int64_t)p.out_h * p.out_w);
 #pragma unroll
     for (int r = 0; r < SR; ++r) sp[r * SWP + tx] = body[r];
 #pragma unroll
@@ -143,6 +210,12 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
     }
 
     const int ox = ox0 + tx;
+    if constexpr (EPI) {
+        const int gi = (int)(g - plane * p.groups_per_plane);
+        k1_epilogue<TW, RB>(e, eq, acc, y + plane * (int64_t)p.out_h * p.out_w, live && ox < p.out_w, oy0, p.out_h, p.out_w, ox,
+                            plane, gi * p.x_tiles + xt, p.groups_per_plane * p.x_tiles, live, tx);
+        return;
+    }
     if (live && ox < p.out_w) {
         float* yp = y + plane * (int64_t)p.out_h * p.out_w;
 #pragma unroll
@@ -208,9 +281,9 @@ struct UpDownParams {
     int64_t groups;
 };
 
-template <int UP, int DOWN, int KH, int KW, int TW, int RB>
+template <int UP, int DOWN, int KH, int KW, int TW, int RB, bool EPI = false>
 __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict__ x, const float* __restrict__ k,
-                                                        float* __restrict__ y, const UpDownParams p) {
+                                                        float* __restrict__ y, const UpDownParams p, const K1Epilogue e) {
     constexpr int NR = kBlock / TW;
     constexpr int SR = ((RB - 1) * DOWN + KH - 1) / UP + 1;     // upfirdn2d_kernel.cu:54-55
     constexpr int SW = ((TW - 1) * DOWN + KW - 1) / UP + 1;
@@ -268,6 +341,10 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
         const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
         halo[i] = ok ? v : 0.0f;
     }
+    [[maybe_unused]] K1Operands<EPI ? RB : 1> eq;
+    if constexpr (EPI)
+        k1_prefetch<RB>(e, eq, y + plane * (int64_t)p.out_h * p.out_w, live && ox0 + tx < p.out_w, oy0, p.out_h, p.out_w,
+                        ox0 + tx, plane, (int64_t)p.out_h * p.out_w);
 #pragma unroll
     for (int r = 0; r < SR; ++r)
 #pragma unroll
@@ -286,6 +363,7 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
     const int kx0 = (in_x + 1) * UP - mid_x - 1;
     const int ox = ox0 + tx;
     float* yp = y + plane * (int64_t)p.out_h * p.out_w;
+    [[maybe_unused]] float vo[RB];
 #pragma unroll
     for (int o = 0; o < RB; ++o) {
         const int mid_y = tile_mid_y + o * DOWN;
@@ -301,50 +379,88 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
                 if (ky < KH && kx < KW) v = fmaf(sp[(rel_y + yy) * SWP + rel_x + xx], taps[ky * KW + kx], v);
             }
         const int oy = oy0 + o;
-        if (live && ox < p.out_w && oy < p.out_h) yp[(int64_t)oy * p.out_w + ox] = v;
+        if constexpr (EPI) vo[o] = v;
+        else if (live && ox < p.out_w && oy < p.out_h) yp[(int64_t)oy * p.out_w + ox] = v;
+    }
+    if constexpr (EPI) {
+        const int gi = (int)(g - plane * p.groups_per_plane);
+        k1_epilogue<TW, RB>(e, eq, vo, yp, live && ox < p.out_w, oy0, p.out_h, p.out_w, ox, plane, gi * p.x_tiles + xt,
+                            p.groups_per_plane * p.x_tiles, live, tx);
     }
 }
 
-template <int UP, int DOWN, int TW, int RB>
-void launch_updown(const float* x, const float* k, float* y, UpDownParams p, hipStream_t s) {
+template <int UP, int DOWN, int TW, int RB, bool EPI = false>
+void launch_updown(const float* x, const float* k, float* y, UpDownParams p, hipStream_t s, K1Epilogue e = K1Epilogue{}) {
     constexpr int NR = kBlock / TW;
     p.groups_per_plane = ceil_div(p.out_h, RB);
     p.x_tiles = ceil_div(p.out_w, TW);
     p.groups = p.planes * p.groups_per_plane;
     const int64_t blocks = ceil_div64(p.groups, NR) * p.x_tiles;
-    hipLaunchKernelGGL((updown_kernel<UP, DOWN, 4, 4, TW, RB>), dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, p);
+    hipLaunchKernelGGL((updown_kernel<UP, DOWN, 4, 4, TW, RB, EPI>), dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, p, e);
 }
 
-template <int KH, int KW, int TW, int RB>
-void launch_blur(const float* x, const float* k, float* y, BlurParams p, hipStream_t s) {
+template <int KH, int KW, int TW, int RB, bool EPI = false>
+void launch_blur(const float* x, const float* k, float* y, BlurParams p, hipStream_t s, K1Epilogue e = K1Epilogue{}) {
     constexpr int NR = kBlock / TW;
     p.groups_per_plane = ceil_div(p.out_h, RB);
     p.x_tiles = ceil_div(p.out_w, TW);
     p.groups = p.planes * p.groups_per_plane;
     const int64_t blocks = ceil_div64(p.groups, NR) * p.x_tiles;
-    hipLaunchKernelGGL((blur_kernel<KH, KW, TW, RB>), dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, p);
+    hipLaunchKernelGGL((blur_kernel<KH, KW, TW, RB, EPI>), dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, p, e);
+}
+
+// tile of the planes kernels: width from the output width, rows per thread from the output height (blur: 8 rows per thread
+// on wide planes, 67 VGPRs -> 7 waves/SIMD, measured 3.5-4.0 TB/s vs 2.9-3.5 with 16 rows)
+struct K1Tile { int tw, rb; };
+inline K1Tile blur_tile(int out_w, int out_h) {
+    if (out_w > 32) return {64, out_h >= 16 ? 8 : 4};
+    if (out_w > 16) return {32, out_h >= 16 ? 16 : 4};
+    if (out_w > 8) return {16, out_h >= 16 ? 16 : 4};
+    return {8, 4};
+}
+inline K1Tile updown_tile(int out_w) { return out_w > 16 ? K1Tile{64, 8} : K1Tile{16, 4}; }
+
+template <bool EPI>
+void dispatch_blur44(const float* x, const float* k, float* y, const BlurParams& p, hipStream_t s, const K1Epilogue& e) {
+    const K1Tile t = blur_tile(p.out_w, p.out_h);
+    if (t.tw == 64 && t.rb == 8) launch_blur<4, 4, 64, 8, EPI>(x, k, y, p, s, e);
+    else if (t.tw == 64) launch_blur<4, 4, 64, 4, EPI>(x, k, y, p, s, e);
+    else if (t.tw == 32 && t.rb == 16) launch_blur<4, 4, 32, 16, EPI>(x, k, y, p, s, e);
+    else if (t.tw == 32) launch_blur<4, 4, 32, 4, EPI>(x, k, y, p, s, e);
+    else if (t.tw == 16 && t.rb == 16) launch_blur<4, 4, 16, 16, EPI>(x, k, y, p, s, e);
+    else if (t.tw == 16) launch_blur<4, 4, 16, 4, EPI>(x, k, y, p, s, e);
+    else launch_blur<4, 4, 8, 4, EPI>(x, k, y, p, s, e);
 }
 
 template <int KH, int KW>
 void dispatch_blur(const float* x, const float* k, float* y, const BlurParams& p, hipStream_t s) {
-    // tile width from the output width, rows-per-thread from the output height
-    // tuning knob (benchmarks only): SAE_BLUR_RB=16 selects 16 rows per thread for wide planes
-    static const int rb_knob = [] { const char* e = getenv("SAE_BLUR_RB"); return e ? atoi(e) : 0; }();
-    if (p.out_w > 32) {
-        // 8 rows per thread: 67 VGPRs -> 7 waves/SIMD; measured 3.5-4.0 TB/s vs 2.9-3.5 TB/s with 16 rows
-        // (fewer LDS reads per output but half the waves in flight) on 256x256..257x257 planes
-        if (p.out_h >= 16 && rb_knob != 16) launch_blur<KH, KW, 64, 8>(x, k, y, p, s);
-        else if (p.out_h >= 16) launch_blur<KH, KW, 64, 16>(x, k, y, p, s);
-        else launch_blur<KH, KW, 64, 4>(x, k, y, p, s);
-    } else if (p.out_w > 16) {
-        if (p.out_h >= 16) launch_blur<KH, KW, 32, 16>(x, k, y, p, s);
-        else launch_blur<KH, KW, 32, 4>(x, k, y, p, s);
-    } else if (p.out_w > 8) {
-        if (p.out_h >= 16) launch_blur<KH, KW, 16, 16>(x, k, y, p, s);
-        else launch_blur<KH, KW, 16, 4>(x, k, y, p, s);
-    } else {
-        launch_blur<KH, KW, 8, 4>(x, k, y, p, s);
-    }
+    const K1Tile t = blur_tile(p.out_w, p.out_h);
+    if (t.tw == 64 && t.rb == 8) launch_blur<KH, KW, 64, 8>(x, k, y, p, s);
+    else if (t.tw == 64) launch_blur<KH, KW, 64, 4>(x, k, y, p, s);
+    else if (t.tw == 32 && t.rb == 16) launch_blur<KH, KW, 32, 16>(x, k, y, p, s);
+    else if (t.tw == 32) launch_blur<KH, KW, 32, 4>(x, k, y, p, s);
+    else if (t.tw == 16 && t.rb == 16) launch_blur<KH, KW, 16, 16>(x, k, y, p, s);
+    else if (t.tw == 16) launch_blur<KH, KW, 16, 4>(x, k, y, p, s);
+    else launch_blur<KH, KW, 8, 4>(x, k, y, p, s);
+}
+
+// second stage of the fused bias gradient: gb[c] = sum_q partial[c][q], one wave per channel, fixed order
+__global__ __launch_bounds__(kBlock) void k1_bias_finalize_kernel(const float* __restrict__ partial, float* __restrict__ gb,
+                                                                  int64_t channels, int64_t q_count) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t c = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    float acc = 0.0f;
+    if (c < channels)
+        for (int64_t q = lane; q < q_count; q += kWave) acc += partial[c * q_count + q];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (c < channels && lane == 0) gb[c] = acc;
+}
+
+// partial sums per channel of an epilogue launch: outer * row groups per plane * x tiles
+inline int64_t k1_q_per_plane(int out_h, int out_w, bool x2) {
+    const K1Tile t = x2 ? updown_tile(out_w) : blur_tile(out_w, out_h);
+    return (int64_t)ceil_div(out_h, t.rb) * ceil_div(out_w, t.tw);
 }
 
 }  // namespace
@@ -389,7 +505,7 @@ extern "C" int sae_upfirdn2d_f32(const float* x, const float* k, float* y, int64
         p.planes = major;
         p.in_h = (int)in_h; p.in_w = (int)in_w; p.out_h = (int)out_h; p.out_w = (int)out_w;
         p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
-        const bool wide = out_w > 16;
+        const bool wide = updown_tile((int)out_w).tw == 64;
         if (down_x == 2) {
             if (wide) launch_updown<1, 2, 64, 8>(x, k, y, p, s); else launch_updown<1, 2, 16, 4>(x, k, y, p, s);
         } else {
@@ -407,4 +523,68 @@ extern "C" int sae_upfirdn2d_f32(const float* x, const float* k, float* y, int64
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(upfirdn2d_generic_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, g);
     return check_launch("sae_upfirdn2d_f32(generic)");
+}
+
+extern "C" int64_t sae_upfirdn2d_epilogue_workspace(int64_t major, int64_t out_h, int64_t out_w, int64_t channels,
+                                                    int32_t up) {
+    if (major < 1 || out_h < 1 || out_w < 1 || channels < 1 || major % channels != 0 || out_h > (1 << 24) || out_w > (1 << 24))
+        return 0;
+    return major * k1_q_per_plane((int)out_h, (int)out_w, up == 2);
+}
+
+extern "C" int sae_upfirdn2d_epilogue_f32(const float* x, const float* k, float* y, int64_t major, int64_t in_h, int64_t in_w,
+                                          int32_t kh, int32_t kw, int32_t up, int32_t pad_x0, int32_t pad_x1, int32_t pad_y0,
+                                          int32_t pad_y1, const float* act_ref, float slope, float scale, float* gb,
+                                          int64_t channels, int32_t accumulate, float* workspace, int64_t workspace_floats,
+                                          sae_stream_t stream) {
+    sae::clear_stale_error();
+    if ((up != 1 && up != 2) || kh < 1 || kw < 1 || kh > 4 || kw > 4)
+        return fail(SAE_EINVAL, "sae_upfirdn2d_epilogue_f32: up must be 1 or 2 and the taps at most 4 x 4 (up=%d, %dx%d)", up, kh, kw);
+    if (major < 0 || in_h < 1 || in_w < 1 || in_h > (1 << 24) || in_w > (1 << 24))
+        return fail(SAE_EINVAL, "sae_upfirdn2d_epilogue_f32: bad tensor size");
+    const int64_t out_h = in_h * up + pad_y0 + pad_y1 - kh + 1;
+    const int64_t out_w = in_w * up + pad_x0 + pad_x1 - kw + 1;
+    if (out_h < 1 || out_w < 1)
+        return fail(SAE_EINVAL, "sae_upfirdn2d_epilogue_f32: empty output (%lld x %lld)", (long long)out_h, (long long)out_w);
+    hipStream_t s = (hipStream_t)stream;
+    if (act_ref) {
+        if (!gb || channels < 1 || major % channels != 0)
+            return fail(SAE_EINVAL, "sae_upfirdn2d_epilogue_f32: act_ref needs gb and major = outer * channels");
+        if (major == 0) {
+            hipMemsetAsync(gb, 0, sizeof(float) * (size_t)channels, s);
+            return check_launch("sae_upfirdn2d_epilogue_f32(memset)");
+        }
+    }
+    if (major == 0) return SAE_OK;
+    if (!x || !k || !y) return fail(SAE_EINVAL, "sae_upfirdn2d_epilogue_f32: null tensor");
+    K1Epilogue e{};
+    e.act_ref = act_ref; e.slope = slope; e.scale = scale; e.accumulate = accumulate ? 1 : 0;
+    e.channels = act_ref ? (int)channels : 1;
+    const int64_t qpp = k1_q_per_plane((int)out_h, (int)out_w, up == 2);
+    if (act_ref) {
+        const int64_t need = major * qpp;
+        if (!workspace || workspace_floats < need)
+            return fail(SAE_EWORKSPACE, "sae_upfirdn2d_epilogue_f32: workspace %lld < %lld floats", (long long)workspace_floats,
+                        (long long)need);
+        e.partial = workspace;
+        e.q_per_channel = (major / channels) * qpp;
+    }
+    if (up == 1) {
+        BlurParams p{};
+        p.planes = major;
+        p.in_h = (int)in_h; p.in_w = (int)in_w; p.out_h = (int)out_h; p.out_w = (int)out_w;
+        p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
+        dispatch_blur44<true>(x, k, y, p, s, e);
+    } else {
+        UpDownParams p{};
+        p.planes = major;
+        p.in_h = (int)in_h; p.in_w = (int)in_w; p.out_h = (int)out_h; p.out_w = (int)out_w;
+        p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
+        if (updown_tile((int)out_w).tw == 64) launch_updown<2, 1, 64, 8, true>(x, k, y, p, s, e);
+        else launch_updown<2, 1, 16, 4, true>(x, k, y, p, s, e);
+    }
+    if (act_ref)
+        hipLaunchKernelGGL(k1_bias_finalize_kernel, dim3((unsigned)ceil_div64(channels, kBlock / kWave)), dim3(kBlock), 0, s,
+                           (const float*)workspace, gb, channels, e.q_per_channel);
+    return check_launch("sae_upfirdn2d_epilogue_f32");
 }

@@ -42,6 +42,8 @@ class ConvMod(C.Structure):
     _fields_ = [("x_scale", C.c_void_p), ("y_scale", C.c_void_p), ("wm_scale", C.c_void_p), ("wc_scale", C.c_void_p)]
 
 
+ABI_VERSION = 3      # include/sae_hip.h: SAE_ABI_VERSION
+
 _SIGNATURES = {
     "abi_version": (C.c_int, []),
     "last_error": (C.c_char_p, []),
@@ -49,6 +51,9 @@ _SIGNATURES = {
     "get_conv_math": (C.c_int, []),
     "upfirdn2d_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i32, _i32,
                                 _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _stream]),
+    "upfirdn2d_epilogue_workspace": (_i64, [_i64, _i64, _i64, _i64, _i32]),
+    "upfirdn2d_epilogue_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                         _f32p, _f32, _f32, _f32p, _i64, _i32, _f32p, _i64, _stream]),
     "bias_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _stream]),
     "bias_act_bwd_workspace": (_i64, [_i64, _i64, _i64]),
     "bias_act_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _f32, _f32, _stream]),
@@ -108,13 +113,18 @@ class SaeLibrary:
             import torch  # noqa: F401
         self._dll = C.CDLL(path)
         self._fn = {}
+        # the version check runs BEFORE the other symbols are bound: a stale prebuilt library then fails with this
+        # message instead of a bare AttributeError on the first entry point it lacks
+        ver = getattr(self._dll, prefix + "abi_version", None)
+        got = ver() if ver is not None else None
+        if got != ABI_VERSION:
+            raise SaeError("%s has ABI version %s, this package needs %d (include/sae_hip.h: SAE_ABI_VERSION) - "
+                           "rebuild it: python -c 'import __graft_entry__ as g; g.build()'" % (path, got, ABI_VERSION))
         for name, (restype, argtypes) in _SIGNATURES.items():
             fn = getattr(self._dll, prefix + name)
             fn.restype = restype
             fn.argtypes = argtypes
             self._fn[name] = fn
-        if self._fn["abi_version"]() != 1:
-            raise SaeError("ABI version mismatch in %s" % path)
 
     def last_error(self):
         msg = self._fn["last_error"]()

@@ -25,6 +25,8 @@ from .stylegan2_op import (FusedLeakyReLU, ReflectionPad2d, add_scale, conv2d, c
 
 # SAE_MODCONV_FUSED=0 (debug / A-B measurements): ModulatedConv2d takes the two-step path (x * s, then a plain conv)
 _FUSED_MODCONV = os.environ.get("SAE_MODCONV_FUSED", "1") != "0"
+# SAE_RESBLOCK_FUSED=0 (debug / A-B measurements): ResBlock runs module by module instead of as one autograd node
+_FUSED_RESBLOCK = os.environ.get("SAE_RESBLOCK_FUSED", "1") != "0"
 
 
 def make_kernel(k):
@@ -382,7 +384,38 @@ class ResBlock(nn.Module):
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=downsample, blur_kernel=blur_kernel,
                               activate=False, bias=False)
 
+        self._fused_cfg = None
+
+    def _fused_config(self):
+        """ResBlockConfig of the single-node path (stylegan2_op/resblock.py), or False when this block is not the plain
+        downsampling block of D / Dpatch (reflection-padded encoder blocks, the non-downsampling block, other taps)."""
+        if self._fused_cfg is None:
+            c1, c2, sk = self.conv1, self.conv2, self.skip
+            ok = (_FUSED_RESBLOCK and "Blur" in c2._modules and "Blur" in sk._modules and "RefPad" not in c1._modules
+                  and not c2.Blur.reflection and not sk.Blur.reflection
+                  and isinstance(c1._modules.get("Act"), FusedLeakyReLU) and isinstance(c2._modules.get("Act"), FusedLeakyReLU)
+                  and "Act" not in sk._modules and sk.Conv.bias is None
+                  and tuple(c1.Conv.weight.shape[2:]) == (3, 3) and c1.Conv.stride == 1 and c1.Conv.padding == 1
+                  and tuple(c2.Conv.weight.shape[2:]) == (3, 3) and c2.Conv.stride == 2 and c2.Conv.padding == 0
+                  and tuple(sk.Conv.weight.shape[2:]) == (1, 1) and sk.Conv.stride == 2
+                  and max(c2.Blur.kernel.shape) <= 4 and max(sk.Blur.kernel.shape) <= 4)
+            if ok:
+                from .stylegan2_op.resblock import ResBlockConfig
+                self._fused_cfg = ResBlockConfig(c2.Blur.kernel, c2.Blur.pad, sk.Blur.kernel, sk.Blur.pad, c1.Conv.scale,
+                                                 c2.Conv.scale, sk.Conv.scale, c1.Act.negative_slope, c1.Act.scale,
+                                                 c2.Act.negative_slope, c2.Act.scale, 1.0 / math.sqrt(2))
+            else:
+                self._fused_cfg = False
+        return self._fused_cfg
+
     def forward(self, input):
+        cfg = self._fused_config()
+        if cfg and input.shape[2] % 2 == 0 and input.shape[3] % 2 == 0:
+            from .stylegan2_op.resblock import resblock
+            # the Blur buffers may have moved (module.to(device)) since the config was made
+            cfg.taps2, cfg.taps_s = self.conv2.Blur.kernel, self.skip.Blur.kernel
+            return resblock(input, self.conv1.Conv.weight, self.conv1.Act.bias, self.conv2.Conv.weight, self.conv2.Act.bias,
+                            self.skip.Conv.weight, cfg)
         return add_scale(self.conv2(self.conv1(input)), self.skip(input), 1.0 / math.sqrt(2))
 
 

@@ -62,21 +62,27 @@ class FusedLeakyReLUFunction(Function):
         return grad_input, (grad_bias if has_bias else None), None, None
 
 
+def bias_act_bwd_raw(grad_output, out, negative_slope, scale):
+    """(grad_input, grad_bias) of the leaky-ReLU form in one pass (sae_bias_act_bwd_f32); no autograd."""
+    lib = hip_lib.get()
+    grad_output = grad_output.contiguous()
+    lib.check(grad_output, out)
+    step, size = _geometry(out)
+    grad_input = torch.empty_like(grad_output)
+    grad_bias = torch.empty(size, dtype=out.dtype, device=out.device)
+    n_ws = lib.query("bias_act_bwd_workspace", out.numel(), step, size)
+    ws = torch.empty(max(n_ws, 1), dtype=out.dtype, device=out.device)
+    lib.call("bias_act_bwd_f32", grad_output.data_ptr(), out.data_ptr(), grad_input.data_ptr(),
+             grad_bias.data_ptr(), ws.data_ptr(), n_ws, out.numel(), step, size, float(negative_slope),
+             float(scale), lib.stream(out))
+    return grad_input, grad_bias
+
+
 class FusedLeakyReLUFunctionBackward(Function):
     @staticmethod
     def forward(ctx, grad_output, out, negative_slope, scale):
         ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
-        lib = hip_lib.get()
-        grad_output = grad_output.contiguous()
-        lib.check(grad_output, out)
-        step, size = _geometry(out)
-        grad_input = torch.empty_like(grad_output)
-        grad_bias = torch.empty(size, dtype=out.dtype, device=out.device)
-        n_ws = lib.query("bias_act_bwd_workspace", out.numel(), step, size)
-        ws = torch.empty(max(n_ws, 1), dtype=out.dtype, device=out.device)
-        lib.call("bias_act_bwd_f32", grad_output.data_ptr(), out.data_ptr(), grad_input.data_ptr(),
-                 grad_bias.data_ptr(), ws.data_ptr(), n_ws, out.numel(), step, size, float(negative_slope),
-                 float(scale), lib.stream(out))
+        grad_input, grad_bias = bias_act_bwd_raw(grad_output, out, negative_slope, scale)
         ctx.save_for_backward(out)
         ctx.cfg = (negative_slope, scale)
         return grad_input, grad_bias

@@ -1,0 +1,172 @@
+"""The downsampling ResBlock of D / Dpatch as ONE autograd node with a hand-scheduled backward.
+
+Reference semantics: ``(conv2(conv1(x)) + skip(x)) / sqrt(2)`` with conv1 = 3x3 conv + FusedLeakyReLU, conv2 = Blur + 3x3
+stride-2 conv + FusedLeakyReLU, skip = Blur + 1x1 stride-2 conv (models/networks/stylegan2_layers.py:672-693 built from
+ConvLayer, :612-668).  The forward launches exactly the kernels the module-by-module path launches (bit-identical
+output).  What a single node buys is control over the BACKWARD, where autograd's op-by-op schedule pays full HBM passes
+for elementwise work between the kernels (profiles/r2_roofline_by_kernel_church256.txt: `bias_act backward` 10.2 ms,
+`aten::add_` 3.5 ms, `add_scale backward` 1.2 ms per iteration):
+
+* the backward of conv1's activation (fused_act.py:32-41) rides in the epilogue of the blur's backward
+  (sae_upfirdn2d_epilogue_f32): the gradient w.r.t. conv1's output is never written to or re-read from HBM;
+* the two gradients of the block input (conv1's data gradient and the skip path's) are summed inside the skip path's
+  last kernel (the x2 zero-insert FIR accumulates into conv1's data gradient) instead of by a separate ``add_``;
+* the 1/sqrt(2) of the residual merge is folded into the constants of the kernels that consume the output gradient
+  (conv2's activation backward, the skip conv's alpha) instead of a pass of its own.
+
+The node stays twice differentiable (the R1 penalty differentiates D and Dpatch twice, swapping_autoencoder_model.py:
+143-174): when backward runs with create_graph=True it re-expresses the block with the differentiable operators of this
+package and lets autograd differentiate that (one extra forward of the block, only on the lazy-R1 iterations).
+"""
+import math
+
+import torch
+from torch.autograd import Function
+
+from .. import hip_lib
+from . import conv2d_gemm as cg
+from .conv2d_gemm import _Flags, _Geom
+from .fused_act import bias_act_bwd_raw
+from .upfirdn2d import _adjoint_pad, _flipped, _run as _upfirdn_run, upfirdn2d
+from .upsample import add_scale
+
+
+class ResBlockConfig:
+    """Static description of one block: FIR taps (the Blur buffers), pads, equalised-lr scales, activation constants."""
+    __slots__ = ("taps2", "pad2", "taps_s", "pad_s", "alpha1", "alpha2", "alpha_s", "slope1", "scale1", "slope2", "scale2",
+                 "merge")
+
+    def __init__(self, taps2, pad2, taps_s, pad_s, alpha1, alpha2, alpha_s, slope1, scale1, slope2, scale2, merge):
+        self.taps2, self.pad2, self.taps_s, self.pad_s = taps2, tuple(pad2), taps_s, tuple(pad_s)
+        self.alpha1, self.alpha2, self.alpha_s = float(alpha1), float(alpha2), float(alpha_s)
+        self.slope1, self.scale1, self.slope2, self.scale2 = float(slope1), float(scale1), float(slope2), float(scale2)
+        self.merge = float(merge)
+
+
+def resblock_composed(x, w1, b1, w2, b2, ws, cfg):
+    """The block from the differentiable operators (what ResBlock.forward runs module by module)."""
+    a1 = cg.conv2d_bias_act(x, w1, b1, stride=1, padding=1, alpha=cfg.alpha1, negative_slope=cfg.slope1, scale=cfg.scale1)
+    a1b = upfirdn2d(a1, cfg.taps2, pad=cfg.pad2)
+    a2 = cg.conv2d_bias_act(a1b, w2, b2, stride=2, padding=0, alpha=cfg.alpha2, negative_slope=cfg.slope2, scale=cfg.scale2)
+    s0 = upfirdn2d(x, cfg.taps_s, down=2, pad=cfg.pad_s)
+    s1 = cg.conv2d(s0, ws, None, stride=1, padding=0, alpha=cfg.alpha_s)
+    return add_scale(a2, s1, cfg.merge)
+
+
+def _pad4(pad):
+    return (pad[0], pad[1], pad[0], pad[1])
+
+
+def _k1_epilogue(g, taps, up, pad4, act_ref=None, slope=0.0, scale=1.0, accumulate_into=None):
+    """sae_upfirdn2d_epilogue_f32 on an NCHW gradient.  Returns (y, grad_bias or None); `accumulate_into` is updated in
+    place and returned as y."""
+    lib = hip_lib.get()
+    g = g.contiguous()
+    lib.check(g, taps, act_ref, accumulate_into)
+    n, c, h, w = g.shape
+    kh, kw = taps.shape
+    oh = h * up + pad4[2] + pad4[3] - kh + 1
+    ow = w * up + pad4[0] + pad4[1] - kw + 1
+    if accumulate_into is not None:
+        if tuple(accumulate_into.shape) != (n, c, oh, ow):
+            raise hip_lib.SaeError("k1 epilogue: accumulation target %s, result (%d, %d, %d, %d)" % (
+                tuple(accumulate_into.shape), n, c, oh, ow))
+        y = accumulate_into
+    else:
+        y = torch.empty((n, c, oh, ow), dtype=g.dtype, device=g.device)
+    gb = ws = None
+    n_ws = 0
+    if act_ref is not None:
+        if tuple(act_ref.shape) != (n, c, oh, ow):
+            raise hip_lib.SaeError("k1 epilogue: activation reference %s, result (%d, %d, %d, %d)" % (
+                tuple(act_ref.shape), n, c, oh, ow))
+        n_ws = lib.query("upfirdn2d_epilogue_workspace", n * c, oh, ow, c, up)
+        ws = torch.empty(max(n_ws, 1), dtype=g.dtype, device=g.device)
+        gb = torch.empty(c, dtype=g.dtype, device=g.device)
+    lib.call("upfirdn2d_epilogue_f32", g.data_ptr(), taps.data_ptr(), y.data_ptr(), n * c, h, w, kh, kw, up,
+             pad4[0], pad4[1], pad4[2], pad4[3], hip_lib.ptr(act_ref), float(slope), float(scale), hip_lib.ptr(gb), c,
+             1 if accumulate_into is not None else 0, hip_lib.ptr(ws), n_ws, lib.stream(g))
+    return y, gb
+
+
+class ResBlockFunction(Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, ws, cfg):
+        ctx.set_materialize_grads(False)
+        n, c, h, w = x.shape
+        m = w2.shape[0]
+        g1 = _Geom(n, c, h, w, c, 3, 1, 1, False, cfg.alpha1)
+        a1 = cg._launch_fused(g1, x, w1, b1, cfg.slope1, cfg.scale1)
+        a1b = _upfirdn_run(a1, cfg.taps2, (1, 1), (1, 1), _pad4(cfg.pad2))
+        g2 = _Geom(n, c, a1b.shape[2], a1b.shape[3], m, 3, 2, 0, False, cfg.alpha2)
+        a2 = cg._launch_fused(g2, a1b, w2, b2, cfg.slope2, cfg.scale2)
+        s0 = _upfirdn_run(x, cfg.taps_s, (1, 1), (2, 2), _pad4(cfg.pad_s))
+        gs = _Geom(n, c, s0.shape[2], s0.shape[3], m, 1, 1, 0, False, cfg.alpha_s)
+        s1 = cg._fwd(s0, ws, gs)
+        if s1.shape != a2.shape:
+            raise hip_lib.SaeError("ResBlock: branches disagree, %s vs %s" % (tuple(a2.shape), tuple(s1.shape)))
+        lib = hip_lib.get()
+        out = torch.empty_like(a2)
+        lib.call("add_scale_f32", a2.data_ptr(), s1.data_ptr(), out.data_ptr(), a2.numel(), cfg.merge, lib.stream(a2))
+        ctx.cfg = cfg
+        ctx.geoms = (g1, g2, gs)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.save_for_backward(x, w1, b1, w2, b2, ws, a1, a1b, a2, s0)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, w1, b1, w2, b2, ws, a1, a1b, a2, s0 = ctx.saved_tensors
+        cfg = ctx.cfg
+        need = ctx.needs_input_grad
+        wflag = _Flags.weight_grads
+        if gout is None:     # undefined = zero: nothing for the activation, explicit zeros for the parameters
+            def z(i, t):
+                return torch.zeros_like(t) if (t is not None and need[i] and wflag) else None
+            return None, z(1, w1), z(2, b1), z(3, w2), z(4, b2), z(5, ws), None
+        if torch.is_grad_enabled():
+            # create_graph=True (the R1 penalty): differentiate the composition of differentiable operators
+            params = [w1, b1, w2, b2, ws]
+            wanted = [0] if need[0] else []
+            wanted += [i + 1 for i, t in enumerate(params) if t is not None and need[i + 1] and wflag]
+            inputs = [([x] + params)[i] for i in wanted]
+            with torch.enable_grad():
+                out = resblock_composed(x, w1, b1, w2, b2, ws, cfg)
+                grads = torch.autograd.grad(out, inputs, gout, create_graph=True, allow_unused=True)
+            res = [None] * 7
+            for i, g in zip(wanted, grads):
+                res[i] = g
+            return tuple(res)
+
+        g1, g2, gs = ctx.geoms
+        gout = gout.contiguous()
+        c = cfg.merge
+        need_w = [need[i] and wflag for i in range(7)]
+        # conv2 branch: activation backward with the merge factor folded into its scale, then dgrad / wgrad
+        gp2, gb2 = bias_act_bwd_raw(gout, a2, cfg.slope2, cfg.scale2 * c)
+        gw2 = cg._wgrad(a1b, gp2, g2) if need_w[3] else None
+        gb2 = gb2 if (ctx.has_bias[1] and need[4]) else None
+        g_a1b = cg._dgrad(gp2, w2, g2)
+        del gp2
+        # blur backward with conv1's activation backward (and its bias gradient) in the epilogue
+        pad2 = _pad4(cfg.pad2)
+        adj2 = _adjoint_pad(tuple(a1.shape[2:]), tuple(a1b.shape[2:]), tuple(cfg.taps2.shape), (1, 1), (1, 1), pad2)
+        gp1, gb1 = _k1_epilogue(g_a1b, _flipped(cfg.taps2), 1, adj2, act_ref=a1, slope=cfg.slope1, scale=cfg.scale1)
+        del g_a1b
+        gw1 = cg._wgrad(x, gp1, g1) if need_w[1] else None
+        gb1 = gb1 if (ctx.has_bias[0] and need[2]) else None
+        # skip branch (merge factor folded into alpha); its x2 zero-insert FIR accumulates into conv1's data gradient
+        gs_c = _Geom(gs.n, gs.c, gs.h, gs.w, gs.m, gs.k, gs.stride, gs.pad, gs.cm_layout, gs.alpha * c)
+        gws = cg._wgrad(s0, gout, gs_c) if need_w[5] else None
+        gx = None
+        if need[0]:
+            gx = cg._dgrad(gp1, w1, g1)
+            g_s0 = cg._dgrad(gout, ws, gs_c)
+            pad_s = _pad4(cfg.pad_s)
+            adj_s = _adjoint_pad(tuple(x.shape[2:]), tuple(s0.shape[2:]), tuple(cfg.taps_s.shape), (1, 1), (2, 2), pad_s)
+            _k1_epilogue(g_s0, _flipped(cfg.taps_s), 2, adj_s, accumulate_into=gx)
+        return gx, gw1, gb1, gw2, gb2, gws, None
+
+
+def resblock(x, w1, b1, w2, b2, ws, cfg):
+    return ResBlockFunction.apply(x, w1, b1, w2, b2, ws, cfg)

@@ -51,6 +51,23 @@ def upfirdn2d(lib, x, k, up=(1, 1), down=(1, 1), pad=(0, 0, 0, 0), device=None):
     return by.numpy()
 
 
+def upfirdn2d_epilogue(lib, x, k, up, pad, y_old=None, act_ref=None, channels=1, slope=0.2, scale=2 ** 0.5, device=None):
+    """sae_upfirdn2d_epilogue_f32 on planes x [major, ih, iw]: returns (y, gb or None).  y_old: accumulate into it."""
+    major, ih, iw = x.shape
+    kh, kw = k.shape
+    oh = ih * up + pad[2] + pad[3] - kh + 1
+    ow = iw * up + pad[0] + pad[1] - kw + 1
+    bx, bk = _Buf(x, device), _Buf(k, device)
+    by = _Buf(y_old, device) if y_old is not None else _out((major, oh, ow), device)
+    br = _Buf(act_ref, device) if act_ref is not None else None
+    n = lib.query("upfirdn2d_epilogue_workspace", major, oh, ow, channels, up) if act_ref is not None else 0
+    bgb, ws = _out((channels,), device), _out((max(n, 1),), device)
+    lib.call("upfirdn2d_epilogue_f32", bx.ptr, bk.ptr, by.ptr, major, ih, iw, kh, kw, up, pad[0], pad[1], pad[2], pad[3],
+             br.ptr if br else None, slope, scale, bgb.ptr if br else None, channels, 1 if y_old is not None else 0,
+             ws.ptr if br else None, n, _stream(device))
+    return by.numpy(), (bgb.numpy() if br else None)
+
+
 def bias_act(lib, x, b, ref, act=3, grad=0, alpha=0.2, scale=2 ** 0.5, device=None):
     step_b = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
     bx = _Buf(x, device)

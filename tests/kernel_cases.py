@@ -25,6 +25,16 @@ UPFIRDN_SMALL = [
     ((2, 257, 257, 1), (3, 3), (1, 1), (2, 2), (0, 0, 0, 0)),
 ]
 
+# sae_upfirdn2d_epilogue_f32: (outer, channels, ih, iw, taps, up, pad(x0,x1,y0,y1)) -- the backward of the ResBlock's blur
+# (4 taps, pad (2,2) forward -> pad (1,1) on the 2^k + 1 wide gradient), of the skip path's decimation (up 2), of the
+# encoder's 3-tap blur; tiny planes (several strips per wave), odd sizes, one channel
+K1_EPILOGUE = [
+    (2, 3, 17, 17, 4, 1, (1, 1, 1, 1)), (1, 2, 67, 70, 4, 1, (1, 1, 1, 1)), (3, 5, 9, 9, 3, 1, (2, 0, 2, 0)),
+    (4, 6, 5, 5, 4, 1, (1, 1, 1, 1)), (2, 4, 33, 33, 4, 1, (2, 2, 2, 2)), (1, 1, 40, 12, 2, 1, (0, 1, 0, 1)),
+    (2, 3, 8, 8, 4, 2, (2, 1, 2, 1)), (1, 5, 19, 35, 4, 2, (2, 1, 2, 1)), (3, 4, 4, 4, 3, 2, (2, 2, 2, 2)),
+    (2, 2, 32, 32, 4, 2, (2, 1, 2, 1)),
+]
+
 BIAS_ACT_SHAPES = [(2, 8, 16, 16), (3, 5, 7, 7), (4, 16), (2, 4, 33, 31), (2, 3, 32, 32), (5, 6, 20, 20)]
 
 # (n, c, h, w, m, k, stride, pad, weights stored [C,M,k,k])

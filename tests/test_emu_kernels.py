@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import abi_harness as H
-from kernel_cases import BIAS_ACT_SHAPES, CONV_BX, CONV_SMALL, GEMM_CASES, UPFIRDN_SMALL
+from kernel_cases import BIAS_ACT_SHAPES, CONV_BX, CONV_SMALL, GEMM_CASES, K1_EPILOGUE, UPFIRDN_SMALL
 
 TOL = 2e-5   # fp32 kernel vs double-accumulating oracle, relative to the output's max magnitude
 
@@ -21,6 +21,39 @@ def test_upfirdn2d(emu_lib, oracle_lib, case):
     assert a.shape == o.shape
     assert not np.isnan(a).any()
     assert H.rel_err(a, o) < TOL
+
+
+def k1_epilogue_case(lib, oracle_lib, case, device=None):
+    """Every epilogue combination of sae_upfirdn2d_epilogue_f32 against (a) the oracle's restatement and (b) the SAME
+    library's separate calls (upfirdn2d, then the add, then the K2 backward): the fused value must be bit-identical to the
+    unfused one -- the FIR sum is rounded to float before the elementwise work either way."""
+    outer, ch, ih, iw, taps, up, pad = case
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((outer * ch, ih, iw)).astype(np.float32)
+    k = rng.standard_normal((taps, taps)).astype(np.float32)
+    plain = H.upfirdn2d(lib, x[..., None], k, (up, up), (1, 1), pad, device=device)[..., 0]
+    old = rng.standard_normal(plain.shape).astype(np.float32)
+    ref = rng.standard_normal(plain.shape).astype(np.float32)
+    for acc in (False, True):
+        for act in (False, True):
+            kw = dict(act_ref=ref if act else None, channels=ch)
+            y, gb = H.upfirdn2d_epilogue(lib, x, k, up, pad, y_old=old.copy() if acc else None, device=device, **kw)
+            yo, gbo = H.upfirdn2d_epilogue(oracle_lib, x, k, up, pad, y_old=old.copy() if acc else None, **kw)
+            assert not np.isnan(y).any()
+            assert H.rel_err(y, yo) < TOL, (acc, act)
+            want = plain + old if acc else plain
+            if act:
+                shaped = want.reshape(outer, ch, -1)
+                gx, gbs = H.bias_act_bwd(lib, shaped, ref.reshape(outer, ch, -1), device=device)
+                want = gx.reshape(want.shape)
+                assert np.allclose(gb, gbo, rtol=0, atol=2e-5 * np.abs(want).sum() / ch + 1e-6)
+                assert np.allclose(gb, gbs, rtol=0, atol=2e-5 * np.abs(want).sum() / ch + 1e-6)
+            assert np.array_equal(y, want), (acc, act)
+
+
+@pytest.mark.parametrize("case", K1_EPILOGUE, ids=str)
+def test_upfirdn2d_epilogue(emu_lib, oracle_lib, case):
+    k1_epilogue_case(emu_lib, oracle_lib, case)
 
 
 @pytest.mark.parametrize("shape", BIAS_ACT_SHAPES, ids=str)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import abi_harness as H
-from kernel_cases import CONV_BX, BIAS_ACT_SHAPES, CONV_GPU, GEMM_CASES, UPFIRDN_SMALL
+from kernel_cases import CONV_BX, BIAS_ACT_SHAPES, CONV_GPU, GEMM_CASES, K1_EPILOGUE, UPFIRDN_SMALL
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -40,6 +40,13 @@ def test_upfirdn2d(hip_lib, oracle_lib, case):
     o = H.upfirdn2d(oracle_lib, x, k, up, down, pad)
     assert a.shape == o.shape and not np.isnan(a).any()
     assert H.rel_err(a, o) < TOL
+
+
+@pytest.mark.parametrize("case", K1_EPILOGUE + [(2, 16, 129, 129, 4, 1, (1, 1, 1, 1)), (2, 8, 64, 64, 4, 2, (2, 1, 2, 1)),
+                                                  (300, 8, 5, 5, 4, 1, (1, 1, 1, 1))], ids=str)
+def test_upfirdn2d_epilogue(hip_lib, oracle_lib, case):
+    from test_emu_kernels import k1_epilogue_case
+    k1_epilogue_case(hip_lib, oracle_lib, case, device=DEV)
 
 
 @pytest.mark.parametrize("shape", BIAS_ACT_SHAPES + [(16, 128, 64, 64), (128, 32, 32, 32), (16, 512), (4, 7, 129, 129)], ids=str)

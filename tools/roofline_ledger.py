@@ -52,6 +52,13 @@ def work_of(name, a):
     if name == "gemm_f32":
         m, n, k = a[4], a[5], a[6]
         return "gemm (linear layers)", "mfma", 2.0 * m * n * k
+    if name == "upfirdn2d_epilogue_f32":
+        major, ih, iw, kh, kw, up, px0, px1, py0, py1 = a[3:13]
+        oh, ow = ih * up + py0 + py1 - kh + 1, iw * up + px0 + px1 - kw + 1
+        act, acc = bool(a[13]), bool(a[18])
+        kind = ("blur" if up == 1 else "zero-insert x2") + (" + accumulate" if acc else "") + (" + act backward" if act else "")
+        # algorithmic bytes: the FIR's input and output once, plus one read per fused operand (old y, activation reference)
+        return "upfirdn2d %s (fused epilogue)" % kind, "hbm", 4.0 * major * (ih * iw + oh * ow * (1 + int(act) + int(acc)))
     if name == "upfirdn2d_f32":
         major, ih, iw, minor, kh, kw, ux, uy, dx, dy, px0, px1, py0, py1 = a[3:17]
         oh = (ih * uy + py0 + py1 - kh + dy) // dy
