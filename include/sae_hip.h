@@ -45,7 +45,10 @@
  *     process-wide switch, the conv arithmetic of sae_set_conv_math() below (an atomic, meant to be chosen once
  *     at start-up: PyTorch runs backward on its own engine threads, so a per-thread setting would not reach the
  *     dgrad / wgrad calls; a conv call that races with a switch may see either value, and fails with
- *     SAE_EWORKSPACE rather than misbehaving if its workspace was sized for the other one).
+ *     SAE_EWORKSPACE rather than misbehaving if its workspace was sized for the other one).  The product build
+ *     reads ONE environment variable, SAE_CONV_MATH (the initial value of that switch, once).  Kernel-selection
+ *     knobs for A/B measurements and the recorded-experiment kernels exist only in builds with -DSAE_TUNING
+ *     (tools/build_variant*.sh, tests/tuning, tests/emu); `strings libsae_hip.so | grep ^SAE_` shows the product has none.
  */
 #ifndef SAE_HIP_H
 #define SAE_HIP_H

@@ -1082,8 +1082,8 @@ __global__ __launch_bounds__(kBlock8) void conv_igemm_bx8_kernel(const float* __
 //     vmcnt followed by a barrier the reader has passed);
 //   * the weight tile is shared by 8 waves instead of 4: half the L2 -> LDS weight traffic per MFMA.
 // MFMA operand order, accumulation order per output element and the epilogue are those of conv_igemm_kernel, so the
-// two kernels produce bit-identical results.  Selected with SAE_F8=1 (gather_plan): it measured 3 % SLOWER than the
-// 4-wave kernel and is kept as the recorded experiment the round-1 review asked for.
+// two kernels produce bit-identical results.  It measured 3 % SLOWER than the 4-wave kernel: a recorded experiment, compiled
+// only into tuning builds (-DSAE_TUNING, selected there with SAE_F8=1); the product library does not contain it.
 // ------------------------------------------------------------------------------------------
 template <int MI, int NI, int WM, int WN, bool MOD = false>
 __global__ __launch_bounds__(kBlock8) void conv_igemm_f8_kernel(const float* __restrict__ x,
@@ -1277,7 +1277,7 @@ struct TrRegion {
 struct TrParams {
     int N, C, IH, IW;     // input tensor (the small, "y side" image)
     int M, OH, OW;        // output tensor (the large, "x side" image)
-    int debug_skip_store;   // profiling aid (SAE_TR_NOSTORE): results are NOT written
+    int debug_skip_store;   // profiling aid of tuning builds (SAE_TR_NOSTORE): results are NOT written; ignored by the product
     int Cp, Mp;
     int pad;
     const float* in_scale;  // [N][C] or null: style modulation of the input, applied while staging (see IgemmParams)
@@ -1474,6 +1474,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_tr_kernel(const float
     }
 
     const int n = n0 + pn, qy = qy0 + py, qx = qx0 + px;
+#ifdef SAE_TUNING
     if (p.debug_skip_store) {   // keep the accumulators alive without the store traffic
         float keep = 0.0f;
 #pragma unroll
@@ -1483,6 +1484,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_tr_kernel(const float
         if (keep == 12345.678f) y[0] = keep;
         return;
     }
+#endif
     if (lane_ok && n < p.N && qy < g.QH && qx < g.QW) {   // q beyond this launch's region belongs to another launch
         // (pairing the two x-classes of a lane into one 4-byte-aligned 8-byte store was measured
         // slower, 87 vs 94 TFLOP/s: the rows are 2^k + 1 wide, so half of those stores are misaligned)
@@ -2911,8 +2913,8 @@ struct FwdShape { int cfg; int bm, bn; int ck; };   // cfg 0: 128x128, 1: 64x256
 FwdShape fwd_shape(int mout, int ks, int stride) {
     FwdShape s{};
     // tuning knob (benchmarks only): SAE_IGEMM_WIDE=1 gives 3x3 stride-1 layers a 128 x 256 tile
-    static const int wide_knob = [] { const char* e = getenv("SAE_IGEMM_WIDE"); return e ? atoi(e) : 0; }();
-    static const int bx_s2_knob = [] { const char* e = getenv("SAE_BX_S2"); return e ? atoi(e) : 1; }();
+    static const int wide_knob = tuning_knob("SAE_IGEMM_WIDE", 0);
+    static const int bx_s2_knob = tuning_knob("SAE_BX_S2", 1);
     if (mout > 64 && wide_knob && ks == 3 && stride == 1) { s.cfg = 3; s.bm = 128; s.bn = 256; }
     else if (mout > 32 && ks == 3 && stride == 2 && conv_math() == 1 && bx_s2_knob) { s.cfg = 6; s.bm = 64; s.bn = 128; }   // bf16x6 stride 2
     else if (mout > 64 && round_up(mout, 64) * 100 >= round_up(mout, 128) * 92) { s.cfg = 0; s.bm = 128; s.bn = 128; }
@@ -2922,7 +2924,7 @@ FwdShape fwd_shape(int mout, int ks, int stride) {
         // narrow layers (M <= 32).  a 32 x 256 tile at three workgroups per CU
         // (SAE_IGEMM_NARROW=0, tuning knob: 32 x 512 at one)
         // measured on 32->32 3x3 @128x128 B=128: 104 TFLOP/s (32 x 256) vs 81 (32 x 512)
-        static const int narrow_knob = [] { const char* e = getenv("SAE_IGEMM_NARROW"); return e ? atoi(e) : 1; }();
+        static const int narrow_knob = tuning_knob("SAE_IGEMM_NARROW", 1);
         if (narrow_knob && ks == 3 && stride == 1) { s.cfg = 4; s.bm = 32; s.bn = 256; }
         else { s.cfg = 2; s.bm = 32; s.bn = 512; }
     }
@@ -2949,7 +2951,7 @@ struct TrShape { int cfg; int bm, bq; int ck; };   // cfg 0: 128 x 64q, 1: 64 x 
 TrShape tr_shape(int mout) {
     TrShape s{};
     s.ck = 8;
-    static const int cfg_knob = [] { const char* e = getenv("SAE_TR_CFG"); return e ? atoi(e) : -1; }();
+    static const int cfg_knob = tuning_knob("SAE_TR_CFG", -1);
     if (mout > 32 && cfg_knob == 3) { s.cfg = 3; s.bm = 64; s.bq = 128; s.ck = 16; }
     // (cfg 4, one 8-wave workgroup per CU, measured 73-93 TFLOP/s against 92-104 for two independent 4-wave workgroups:
     // the second workgroup's MFMAs are what covers the staging phases; kept behind the knob)
@@ -3070,7 +3072,7 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
     g.Cp = round_up(cin, g.sh.ck);
     g.taps = ks * ks;
     g.bx8 = false;
-    static const int bx8_knob = [] { const char* e = getenv("SAE_BX8"); return e ? atoi(e) : 1; }();
+    static const int bx8_knob = tuning_knob("SAE_BX8", 1);
     if (bx8_knob && conv_math() == 1 && ks == 3 && stride == 1 && g.sh.cfg == 0) {
         int twl, thl;
         pick_tile(256, OH, OW, 32, &twl, &thl);
@@ -3081,7 +3083,11 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
     // measured on MI355X (same box, tools/kb_subset.py): 121.9 vs 125.8 TFLOP/s at 128 -> 128 @256^2 B=16 and 126.4 vs 130.0
     // at 512 -> 512 @64^2 for this kernel vs the 4-wave register-staged one: one workgroup per CU loses the overlap two
     // independent workgroups give (their MFMAs are what covers each other's staging phases).  Off by default.
-    static const int f8_knob = [] { const char* e = getenv("SAE_F8"); return e ? atoi(e) : 0; }();
+#ifdef SAE_TUNING      // the product build does not contain the kernel
+    static const int f8_knob = tuning_knob("SAE_F8", 0);
+#else
+    constexpr int f8_knob = 0;
+#endif
     if (f8_knob && conv_math() == 0 && ks == 3 && stride == 1 && g.sh.cfg == 0 && !scatter) {
         int twl, thl;
         pick_tile(256, OH, OW, 32, &twl, &thl);
@@ -3089,7 +3095,7 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
         // one patch position per thread, and enough 256-pixel tiles to fill the chip once (small layers keep the
         // 4-wave kernel with its split-K path)
         const int64_t tiles = (int64_t)ceil_div(OW, tw8) * ceil_div(OH, th8) * ceil_div(N, tn8) * (g.Mp / 128);
-        static const int f8_min_tiles = [] { const char* e = getenv("SAE_F8_MIN_TILES"); return e ? atoi(e) : 256; }();   // tests: 1
+        static const int f8_min_tiles = tuning_knob("SAE_F8_MIN_TILES", 256);   // tests: 1
         if (tn8 * (th8 + 2) * (tw8 + 2) <= 512 && tiles >= f8_min_tiles) { g.f8 = true; g.sh.bn = 256; }
     }
     pick_tile(g.sh.bn, OH, OW, 32, &g.tw_log2, &g.th_log2);
@@ -3115,7 +3121,7 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
     g.wp_floats = (int64_t)g.taps * g.Cp * g.Mp;
     // bf16x6: the 128-row tile (8-wave or 4-wave kernel) and, on the 4-wave kernel, the 64- and 32-row tiles of the
     // narrow layers (cfg 1: 64 x 256, cfg 4: 32 x 256)
-    static const int bx_narrow_knob = [] { const char* e = getenv("SAE_BX_NARROW"); return e ? atoi(e) : 1; }();
+    static const int bx_narrow_knob = tuning_knob("SAE_BX_NARROW", 1);
     g.bx = conv_math() == 1 && ks == 3 && stride == 1 &&
            (g.sh.cfg == 0 || (bx_narrow_knob && (g.sh.cfg == 1 || g.sh.cfg == 4)));
     if (conv_math() == 1 && ks == 3 && stride == 2 && g.sh.cfg == 6) g.bx = true;
@@ -3140,11 +3146,13 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
     constexpr int CK = (KS == 1) ? 32 : 8;
     constexpr int CK2 = (KS == 1) ? 16 : 8;
     if constexpr (KS == 3 && S == 1) {
+#ifdef SAE_TUNING
         if (g.f8) {
             if (p.in_scale) hipLaunchKernelGGL((conv_igemm_f8_kernel<2, 2, 2, 4, true>), grid, dim3(kBlock8), 0, s, x, wp, y, p);
             else hipLaunchKernelGGL((conv_igemm_f8_kernel<2, 2, 2, 4, false>), grid, dim3(kBlock8), 0, s, x, wp, y, p);
             return SAE_OK;
         }
+#endif
         if (g.bx8) {
             hipLaunchKernelGGL((conv_igemm_bx8_kernel<2, 2, 2, 4>), grid, dim3(kBlock8), 0, s, x,
                                reinterpret_cast<const u32x4*>(wp), y, p);
@@ -3166,7 +3174,7 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
         }
     }
     // 1x1 stride 1, pad 0 with quad staging: the tile's own pixels, rows a multiple of 16 bytes (tw >= 4 always is)
-    static const int quad1_knob = [] { const char* e = getenv("SAE_IGEMM_QUAD"); return e ? atoi(e) : 1; }();
+    static const int quad1_knob = tuning_knob("SAE_IGEMM_QUAD", 1);
     const bool quad1 = quad1_knob && KS == 1 && S == 1 && p.pad == 0 && p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     // 3x3 stride 1 on the 256-pixel tiles (64 x 256, 32 x 256): quad staging when the widened patch fits 128 quads
     const bool quad3w = quad1_knob && KS == 3 && S == 1 && sh.bn == 256 && p.W % 4 == 0 && p.pad <= 4 &&
@@ -3200,7 +3208,7 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
             if constexpr (KS == 3 && S == 1) {
                 // quad staging (see conv_igemm_kernel): rows a multiple of 16 bytes, 16-byte aligned tensor, and the
                 // widened patch within 64 quads per channel (always for tiles >= 16 wide)
-                static const int quad_knob = [] { const char* e = getenv("SAE_IGEMM_QUAD"); return e ? atoi(e) : 1; }();
+                static const int quad_knob = tuning_knob("SAE_IGEMM_QUAD", 1);
                 const int qn = tn * ph * ((tw + 8) / 4);
                 if (quad_knob && p.W % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && qn <= sh.bn / 2 && p.pad <= 4) {
                     if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 2, 2, 2, 2, 8, true, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
@@ -3364,7 +3372,7 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     if (!ws || ws_floats < g.ws_floats)
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)g.ws_floats);
     // thin 1x1 layers (at most four channels on one side, e.g. FromRGB / ToRGB): streamed, see conv1x1_thin_kernel
-    static const int thin_knob = [] { const char* e = getenv("SAE_CONV_THIN"); return e ? atoi(e) : 1; }();
+    static const int thin_knob = tuning_knob("SAE_CONV_THIN", 1);
     if (thin_knob && ks == 1 && stride == 1 && pad == 0 && oys == 1 && oxs == 1 && (cin <= 4 || mout <= 4) &&
         H == OH && W == OW && YH == OH && YW == OW && ((int64_t)H * W) % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && N <= 65535) {
@@ -3390,11 +3398,11 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     p.oys = oys; p.oxs = oxs; p.Cp = g.Cp; p.Mp = g.Mp; p.pad = pad;
     p.slab_stride = g.out_floats4;
     p.in_scale = in_scale;
-    static const int xcd_knob = [] { const char* e = getenv("SAE_XCD_ORDER"); return e ? atoi(e) : 1; }();
+    static const int xcd_knob = tuning_knob("SAE_XCD_ORDER", 1);
     p.xcd_order = xcd_knob;
     if (g.ksplit == 1) { p.bias = ep.bias; p.act = ep.act; p.act_slope = ep.slope; p.act_scale = ep.scale; }
     float* out = (g.ksplit > 1) ? ws + g.wp_floats : y;
-    static const int vec_knob = [] { const char* e = getenv("SAE_IGEMM_VEC_STORE"); return e ? atoi(e) : 1; }();
+    static const int vec_knob = tuning_knob("SAE_IGEMM_VEC_STORE", 1);
     // measured (tools/ab_conv.py): +2.5 % with K loops of 64 chunks (512 channels), -1 % with 16 or 32: long loops only
     p.vec_store = vec_knob && oys == 1 && oxs == 1 && OW % 4 == 0 && YW % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                   (vec_knob > 1 || g.cps >= 48 || ep.act);   // with the fused bias + leaky-ReLU also for short loops: the scalar
@@ -3554,7 +3562,7 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
     TrParams p{};
     p.in_scale = in_scale;
     p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
-    static const int nostore_knob = [] { const char* e = getenv("SAE_TR_NOSTORE"); return e ? atoi(e) : 0; }();
+    static const int nostore_knob = tuning_knob("SAE_TR_NOSTORE", 0);
     p.debug_skip_store = nostore_knob;
     const int QH = (OH + pad - 1) / 2 + 1, QW = (OW + pad - 1) / 2 + 1;
     // The transposed problems of this network have 2^k + 1 wide q grids (129, 65, 33, ...): one
@@ -3821,7 +3829,7 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
         if ((mod.x_scale || mod.y_scale) && !w.bx && tn == 1 && w.cps <= cpi && cpi % w.cps == 0)
             slices_per_image = cpi / w.cps;
     }
-    static const int xcd_knob = [] { const char* e = getenv("SAE_XCD_ORDER"); return e ? atoi(e) : 1; }();
+    static const int xcd_knob = tuning_knob("SAE_XCD_ORDER", 1);
     p.xcd_order = xcd_knob;
     p.l_scale = slices_per_image ? nullptr : mod.x_scale;
     p.s_scale = slices_per_image ? nullptr : mod.y_scale;
@@ -3834,7 +3842,7 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
     }
     // quad staging (see conv_wgrad_kernel): stride 1, one image per 64-pixel chunk, rows of both tensors a multiple of 16
     // bytes, 16-byte aligned tensors, factors (if any) applied per K-slice in the reduction
-    static const int wq_knob = [] { const char* e = getenv("SAE_WGRAD_QUAD"); return e ? atoi(e) : 1; }();
+    static const int wq_knob = tuning_knob("SAE_WGRAD_QUAD", 1);
     const bool wq = wq_knob && !w.bx && w.sh.mode == 0 && d->stride == 1 && (kWgPix >> (w.tw_log2 + w.th_log2)) == 1 &&
                     d->ow % 4 == 0 && d->w % 4 == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy)) & 15) == 0 &&
                     !p.l_scale && !p.s_scale && (d->kh == 3 ? d->pad <= 4 : d->pad == 0);
@@ -3866,7 +3874,7 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
         }
         else if (d->kh == 3) {
             // operand double buffer: 497 of 512 registers, no spill; 77.7 vs 68.6 TFLOP/s measured
-            static const int db_knob = [] { const char* e = getenv("SAE_WGRAD_S2_DB"); return e ? atoi(e) : 1; }();
+            static const int db_knob = tuning_knob("SAE_WGRAD_S2_DB", 1);
             if (wq2) launch_wgrad<3, 2, 1, 1, 4, 1, 4, true>(x, gy, workspace, p, w, s);
             else if (db_knob) launch_wgrad<3, 2, 1, 1, 4, 1, 4>(x, gy, workspace, p, w, s);
             else launch_wgrad<3, 2, 1, 1, 4, 1, 0>(x, gy, workspace, p, w, s);

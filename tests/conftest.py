@@ -22,6 +22,10 @@ def _hip_library_is_current():
     from swapping_autoencoder_pytorch_amd.csrc import build as hip_build
     if not hip_build.up_to_date() and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         hip_build.build()
+    # ... and the -DSAE_TUNING build of the same sources the GPU bit-identity tests load (tests/tuning)
+    from tuning import build_tuning
+    if not build_tuning.up_to_date() and build_tuning.hipcc():
+        build_tuning.build()
     yield
 
 

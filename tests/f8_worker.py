@@ -24,8 +24,9 @@ def main(which):
         from emu import build_emu
         lib, dev = SaeLibrary(build_emu.build(), prefix="sae_", device_only=False), None
     else:
-        from swapping_autoencoder_pytorch_amd import hip_lib
-        lib, dev = hip_lib.get(), "cuda:0"
+        # the tuning build of the same kernel sources (tests/tuning): the product library does not contain this kernel
+        from tuning import build_tuning
+        lib, dev = SaeLibrary(build_tuning.build()), "cuda:0"
     rng = np.random.default_rng(23)
     for n, c, h, w, m, p, cm in CASES:
         d = H.conv_desc(n, c, h, w, m, 3, 1, p, cm)

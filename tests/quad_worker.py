@@ -31,8 +31,9 @@ def main(which):
         from emu import build_emu
         lib, dev, cases = SaeLibrary(build_emu.build(), prefix="sae_", device_only=False), None, EMU
     else:
-        from swapping_autoencoder_pytorch_amd import hip_lib
-        lib, dev, cases = hip_lib.get(), "cuda:0", GPU
+        # the tuning build of the same kernel sources (tests/tuning): the product library has no dispatch knobs
+        from tuning import build_tuning
+        lib, dev, cases = SaeLibrary(build_tuning.build()), "cuda:0", GPU
     rng = np.random.default_rng(5)
     for n, c, h, w, m, k, s, p in cases:
         d = H.conv_desc(n, c, h, w, m, k, s, p)
