@@ -2,7 +2,8 @@
 
 The reference ships a dormant ``DataPrefetcher`` (data/__init__.py:52-82: one batch ahead, a side CUDA stream,
 ``wait_stream`` on hand-over) and feeds the step from a ``torch.utils.data.DataLoader`` (:96-104).  This is its
-MI355X counterpart, active by default in the native loop: batches are staged through PINNED host buffers and
+MI355X counterpart; the drop-in runner wraps the reference's loader in it whenever the run uses a GPU
+(dropin.PrefetchedLoader / wrap_dataloader): batches are staged through PINNED host buffers and
 copied on a dedicated HIP stream ``depth`` batches ahead, so the 12.6 MB of a 256x256 B=16 batch (0.2 ms over PCIe
 Gen5) never sits on the step's critical path; the consumer stream waits on the copy's event only, and the device
 buffers are tied to the consumer stream with ``record_stream`` so the caching allocator cannot recycle them early.

@@ -18,7 +18,10 @@ Besides the pre-seeding the runner
   * offers ``--dataset_mode synthetic``: ``data.synthetic_dataset.SyntheticDataset`` (uniform [-1, 1] images of
     ``--crop_size``, the data contract of data/base_dataset.py:136-141) so the loop runs without a dataset on disk,
   * substitutes fused_adam.FusedAdam for ``torch.optim.Adam`` inside this process (same constructor, update rule and
-    state_dict; ``SAE_DROPIN_ADAM=0`` keeps ATen's).
+    state_dict; ``SAE_DROPIN_ADAM=0`` keeps ATen's),
+  * wraps the loader ``data.create_dataset`` returns (data/__init__.py:81-129) in ``PrefetchedLoader`` when the run uses
+    a GPU: batches are staged into device memory two steps ahead on a side stream (data_prefetch.DevicePrefetcher, the
+    counterpart of the DataPrefetcher the reference keeps commented out; ``SAE_DROPIN_PREFETCH=0`` turns it off).
 
 Multi-GPU: the reference drives ``nn.DataParallel`` from one process (models/__init__.py:80) and addresses its
 device as the literal ``'cuda:0'`` (models/__init__.py:79, base_model.py:13, swapping_autoencoder_model.py:48).
@@ -49,9 +52,18 @@ def pin_rank_device(environ=None, reexec=True):
     if env.get(_PINNED_FLAG) == "1":
         return env.get("HIP_VISIBLE_DEVICES")
     local_rank = int(env.get("LOCAL_RANK", "0"))
-    visible = [d for d in env.get("HIP_VISIBLE_DEVICES", "").split(",") if d != ""]
-    mine = visible[local_rank] if local_rank < len(visible) else str(local_rank)
+    # the user's own restriction of the node's GPUs: HIP_VISIBLE_DEVICES, else CUDA_VISIBLE_DEVICES (the HIP runtime
+    # honours both, in that order).  ROCR_VISIBLE_DEVICES acts one level below (it renumbers what HIP sees), so HIP
+    # indices are relative to it and it is left alone.
+    spec = env.get("HIP_VISIBLE_DEVICES")
+    if spec is None or spec == "":
+        spec = env.get("CUDA_VISIBLE_DEVICES", "")
+    visible = [d for d in spec.split(",") if d != ""]
+    if visible and local_rank >= len(visible):
+        raise RuntimeError("LOCAL_RANK %d but only %d visible device(s) (%s)" % (local_rank, len(visible), spec))
+    mine = visible[local_rank] if visible else str(local_rank)
     env["HIP_VISIBLE_DEVICES"] = mine
+    env.pop("CUDA_VISIBLE_DEVICES", None)      # one source of truth: a stale list here would contradict the pin
     env[_PINNED_FLAG] = "1"
     torch = sys.modules.get("torch")
     if reexec and torch is not None and torch.cuda.is_initialized():
@@ -72,6 +84,18 @@ class _Inert:
         return lambda *args, **kwargs: True
 
 
+class _MissingDataPackage(types.ModuleType):
+    """Stand-in for a package the reference's real datasets need (lmdb, cv2): importing it succeeds, so that
+    ``data/*`` modules load, but USING it fails with the package's name instead of an AttributeError deep in a loader."""
+
+    def __getattr__(self, item):
+        if item.startswith("__"):
+            raise AttributeError(item)
+        raise ImportError("the reference's dataset code needs the `%s` package, which is not installed in this environment "
+                          "(the drop-in runner only stood in for its import); install it or use --dataset_mode synthetic"
+                          % self.__name__)
+
+
 class _Stub(types.ModuleType):
     """Import-only stand-in: any attribute is an inert class (enough for ``import x`` / ``from x import Y`` /
     ``class Z(x.Y)`` at module top level and for objects that are constructed but never do real work)."""
@@ -85,6 +109,9 @@ class _Stub(types.ModuleType):
 OPTIONAL_DEPENDENCIES = ("torchvision", "torchvision.transforms", "torchvision.transforms.functional",
                          "torchvision.models", "torchvision.datasets", "dominate", "dominate.tags", "func_timeout",
                          "visdom", "GPUtil", "cv2", "lmdb")
+
+
+DATA_PATH_DEPENDENCIES = ("cv2", "lmdb")     # used by the real LSUN / FFHQ datasets: stubbed for import only
 
 
 def install_missing_dependency_stubs():
@@ -102,7 +129,7 @@ def install_missing_dependency_stubs():
                     continue
             except (ImportError, ValueError):
                 pass
-        m = _Stub(name)
+        m = (_MissingDataPackage if root in DATA_PATH_DEPENDENCIES else _Stub)(name)
         m.__path__ = []
         sys.modules[name] = m
         stubbed.append(name)
@@ -147,6 +174,64 @@ def inject_synthetic_dataset():
     mod.SyntheticDataset = SyntheticDataset
     sys.modules["data.synthetic_dataset"] = mod
     return mod
+
+
+class PrefetchedLoader:
+    """The reference's ``ConfigurableDataLoader`` (data/__init__.py:81-129) with its batches staged into GPU memory
+    ``depth`` steps ahead by data_prefetch.DevicePrefetcher -- the working counterpart of the ``DataPrefetcher`` the
+    reference keeps commented out (data/__init__.py:52-78,97).  train.py:22-28 then receives ``real_A`` already
+    device-resident (``.cuda()`` / ``.to(device)`` in the model are no-ops).  Everything else (len, set_phase,
+    underlying_dataset, ...) is the wrapped loader's; a change of phase or a new ``iter()`` restarts the staging."""
+
+    def __init__(self, inner, device="cuda:0", depth=2):
+        self.__dict__["_inner"] = inner
+        self.__dict__["_device"] = device
+        self.__dict__["_depth"] = depth
+        self.__dict__["_prefetcher"] = None
+
+    def __getattr__(self, name):
+        return getattr(self.__dict__["_inner"], name)
+
+    def __setattr__(self, name, value):
+        setattr(self.__dict__["_inner"], name, value)
+
+    def __len__(self):
+        return len(self._inner)
+
+    def _pull(self):
+        inner = self._inner
+        while True:
+            try:
+                yield next(inner)
+            except StopIteration:
+                return
+
+    def set_phase(self, target_phase):
+        if self._inner.phase != target_phase:
+            self.__dict__["_prefetcher"] = None       # staged batches of the old phase are dropped
+        self._inner.set_phase(target_phase)
+
+    def __iter__(self):
+        iter(self._inner)
+        self.__dict__["_prefetcher"] = None
+        return self
+
+    def __next__(self):
+        if self.__dict__["_prefetcher"] is None:
+            from .data_prefetch import DevicePrefetcher
+            self.__dict__["_prefetcher"] = DevicePrefetcher(self._pull(), device=self._device, depth=self._depth)
+        return next(self.__dict__["_prefetcher"])
+
+
+def wrap_dataloader(create_dataset):
+    """``data.create_dataset`` -> the same loader behind a PrefetchedLoader when the run uses a GPU."""
+    def create(opt):
+        loader = create_dataset(opt)
+        import torch
+        if int(getattr(opt, "num_gpus", 0)) > 0 and torch.cuda.is_available() and os.environ.get("SAE_DROPIN_PREFETCH", "1") != "0":
+            return PrefetchedLoader(loader, device="cuda:0")
+        return loader
+    return create
 
 
 def attach_gradient_allreduce(optimizer):
@@ -210,6 +295,8 @@ def main(argv=None):
         from .fused_adam import FusedAdam
         torch.optim.Adam = FusedAdam
     _init_distributed()
+    import data                 # the reference's package
+    data.create_dataset = wrap_dataloader(data.create_dataset)
     import optimizers           # the reference's package (imports its models on the pre-seeded layers)
     _create = optimizers.create_optimizer
     optimizers.create_optimizer = lambda opt, model: attach_gradient_allreduce(_create(opt, model))

@@ -32,7 +32,9 @@ def _prepare():
 def train_end_to_end(ckpt_dir):
     """python train.py ... : option parser, data loader, model, optimizer, loss log, checkpoint."""
     import runpy
-    _prepare()
+    dropin = _prepare()
+    import data
+    data.create_dataset = dropin.wrap_dataloader(data.create_dataset)    # as dropin.main does; a pass-through without a GPU
     sys.argv = ["train.py", "--name", "dropin_e2e", "--total_nimgs", "24", "--checkpoints_dir", ckpt_dir, "--print_freq", "8",
                 "--display_freq", "100000", "--save_freq", "100000", "--evaluation_freq", "100000"] + MICRO_ARGV
     runpy.run_path(os.path.join(REF, "train.py"), run_name="__main__")

@@ -1,0 +1,66 @@
+"""`python -m swapping_autoencoder_pytorch_amd.dropin ROOT train.py ...` on a stand-in reference tree written by
+tests/standin_tree.py (the reference checkout does not exist on the GPU box): pre-seeding of the reference's import names,
+stubs for absent third-party packages, FusedAdam substitution, the synthetic dataset, the device prefetcher around the
+reference-style loader, optimiser steps incl. the R1 double backward.  GPU: the real library on cuda:0 (what north_star's
+"drops into train.py unchanged" means on hardware); CPU: the same tree on the oracle back end (pass-through loader)."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+import standin_tree
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--dataset_mode", "synthetic", "--batch_size", "4", "--crop_size", "32", "--steps", "4"]
+
+
+def _report(out):
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert "Training finished." in out.stdout
+    line = [l for l in out.stdout.splitlines() if l.startswith("STANDIN-REPORT ")][-1]
+    return json.loads(line[len("STANDIN-REPORT "):])
+
+
+def _common_checks(rep):
+    assert rep["convlayer"] == "swapping_autoencoder_pytorch_amd.stylegan2_layers"          # pre-seeded layer library
+    assert rep["upfirdn2d"].startswith("swapping_autoencoder_pytorch_amd.stylegan2_op")       # ... and operators
+    assert rep["adam"] == "swapping_autoencoder_pytorch_amd.fused_adam.FusedAdam"             # torch.optim.Adam substituted
+    assert rep["dataset"] == "SyntheticDataset"
+    expected = sorted(n for n in ("dominate", "visdom", "lmdb") if importlib.util.find_spec(n) is None)
+    assert rep["stubbed"] == expected
+    assert rep["params_moved"] == rep["params"] and rep["params"] >= 10                       # every parameter was trained
+    assert len(rep["losses"]) == 4 and "D_R1" in rep["losses"][1] and "D_R1" in rep["losses"][3]
+    for l in rep["losses"]:
+        assert all(v == v and abs(v) < 1e6 for v in l.values()), l
+
+
+def test_dropin_runner_on_the_standin_tree_oracle_backend(tmp_path):
+    standin_tree.write(str(tmp_path / "ref"))
+    code = ("import os, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "from swapping_autoencoder_pytorch_amd import dropin, hip_lib\n"
+            "from swapping_autoencoder_pytorch_amd.hip_lib import SaeLibrary\n"
+            "hip_lib._LIB = SaeLibrary(os.path.join(%r, 'oracle', 'libsae_oracle.so'), prefix='oracle_', device_only=False)\n"
+            "dropin.main([%r, 'train.py', '--num_gpus', '0'] + %r)\n" % (ROOT, ROOT, str(tmp_path / "ref"), ARGS))
+    out = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    rep = _report(out)
+    _common_checks(rep)
+    assert rep["loader"] == "ConfigurableDataLoader"          # no GPU: the prefetch wrapper is a pass-through
+    assert set(rep["batch_devices"]) == {"cpu"}
+
+
+@pytest.mark.gpu
+def test_dropin_runner_on_the_standin_tree_real_library_gpu(tmp_path):
+    standin_tree.write(str(tmp_path / "ref"))
+    out = subprocess.run([sys.executable, "-m", "swapping_autoencoder_pytorch_amd.dropin", str(tmp_path / "ref"), "train.py",
+                          "--num_gpus", "1"] + ARGS, cwd=ROOT, capture_output=True, text=True, timeout=900,
+                         env=dict(os.environ, PYTHONPATH=ROOT))
+    rep = _report(out)
+    _common_checks(rep)
+    assert rep["maps"] == ["libsae_hip.so"]                   # the hipcc-built library is what ran; no oracle in the process
+    assert rep["param_device"] == "cuda:0"
+    assert rep["loader"] == "PrefetchedLoader"                # the reference-style loader behind the device prefetcher
+    assert set(rep["batch_devices"]) == {"cuda:0"}            # train.py received device-resident batches

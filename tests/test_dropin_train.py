@@ -24,6 +24,71 @@ def test_pin_rank_device_maps_local_rank_to_cuda0():
     assert pin_rank_device(env, reexec=False) == "6" and env["HIP_VISIBLE_DEVICES"] == "6"
 
 
+def test_pin_rank_device_honours_cuda_visible_devices():
+    from swapping_autoencoder_pytorch_amd.dropin import pin_rank_device
+    env = {"WORLD_SIZE": "4", "LOCAL_RANK": "1", "CUDA_VISIBLE_DEVICES": "4,5,6,7"}
+    assert pin_rank_device(env, reexec=False) == "5"
+    assert env["HIP_VISIBLE_DEVICES"] == "5" and "CUDA_VISIBLE_DEVICES" not in env
+    env = {"WORLD_SIZE": "4", "LOCAL_RANK": "3", "HIP_VISIBLE_DEVICES": "2,3", "CUDA_VISIBLE_DEVICES": "0,1,2,3"}
+    with pytest.raises(RuntimeError):          # more ranks than visible devices: refuse instead of landing on GPU 3
+        pin_rank_device(env, reexec=False)
+
+
+def test_data_path_stubs_fail_with_the_package_name():
+    from swapping_autoencoder_pytorch_amd.dropin import _MissingDataPackage
+    m = _MissingDataPackage("lmdb")
+    with pytest.raises(ImportError, match="lmdb"):
+        m.open("x")
+
+
+def test_prefetched_loader_delegates_and_restarts(monkeypatch):
+    """PrefetchedLoader around a reference-style loader (data/__init__.py:81-129), with the staging object replaced by a
+    recorder (no GPU here): attribute / len delegation, lazy start, restart on set_phase and iter(), StopIteration."""
+    from swapping_autoencoder_pytorch_amd import data_prefetch, dropin
+
+    class Loader:
+        def __init__(self):
+            self.phase, self.items, self.length, self.underlying_dataset = "train", iter(range(5)), 5, "ds"
+
+        def set_phase(self, phase):
+            if phase != self.phase:
+                self.phase, self.items = phase, iter(range(100, 103))
+
+        def __iter__(self):
+            self.items = iter(range(5))
+            return self
+
+        def __len__(self):
+            return self.length
+
+        def __next__(self):
+            return next(self.items)
+
+    made = []
+
+    class Recorder:
+        def __init__(self, iterable, device, depth):
+            made.append((device, depth))
+            self.it = iter(iterable)
+
+        def __next__(self):
+            return next(self.it)
+
+    monkeypatch.setattr(data_prefetch, "DevicePrefetcher", Recorder)
+    pl = dropin.PrefetchedLoader(Loader(), device="cuda:0", depth=2)
+    assert len(pl) == 5 and pl.underlying_dataset == "ds" and pl.phase == "train" and made == []
+    assert [next(pl), next(pl)] == [0, 1] and made == [("cuda:0", 2)]
+    pl.set_phase("train")
+    assert next(pl) == 2 and len(made) == 1                   # same phase: staging continues
+    pl.set_phase("test")
+    assert [next(pl) for _ in range(3)] == [100, 101, 102] and len(made) == 2
+    with pytest.raises(StopIteration):
+        next(pl)
+    assert [x for x in pl] == [0, 1, 2, 3, 4] and len(made) == 3
+    pl.length = 7                                              # attribute writes reach the wrapped loader
+    assert len(pl) == 7
+
+
 def test_device_is_pinned_before_torch_is_imported():
     """The runner's entry point narrows HIP_VISIBLE_DEVICES before `import torch` happens at all (the HIP runtime
     reads the variable once, at initialisation)."""
