@@ -14,7 +14,10 @@ value = N * B * K / t   (whole-job images per second; B images per GPU -> weak s
 Also reported on the same JSON line:
   roofline     – dominant kernel (3x3 stride-1 implicit-GEMM conv, conv_igemm_kernel<3,1,2,2,2,2,8,false,true>):
                  algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
-                 launch stream inside the timed region, against the fp32 MFMA peak (157.3 TFLOP/s);
+                 launch stream inside the timed region, against the fp32 MFMA peak (157.3 TFLOP/s); `traffic` from the
+                 committed counter record profiles/r3_pmc_dominant.json (refused if it names another kernel);
+  roofline_by_kernel – the same event-timed fraction for the second-tier MFMA classes (stride-2 data gradient,
+                 stride-2 forward, both weight gradients) next to the dominant one;
   cpu_baseline – the reference's CPU path (ATen on all host cores, restated in oracle/aten_cpu_path.py and pinned
                  to the reference's own modules) timed on a bounded sample of the same workload: the image
                  discriminator forward + backward (rank 0, N = 1 only); the C oracle's rate rides along.
@@ -29,12 +32,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
-# HBM-side traffic of the dominant kernel from the PMC passes (profiles/r2_pmc_f32_quad.txt: separate rocprofv3 --pmc runs of
-# tools/pmc_kernels.py; reads = TCC_EA0_RDREQ x 128 B — FETCH_SIZE tallies those 128-byte requests at 64 B, the x2
-# correction of the guide, confirmed here on a 1 GiB copy — writes = TCC_EA0_WRREQ x 64 B) on its reference launch,
-# 128 -> 128 3x3 @256x256 B=16 = 309.24 GFLOP, 1073.7 MB algorithmic (x + y): 634.6 MB read + 536.9 MB written.
-# Counters cannot be read inside a timed run; the figure is scaled to the average launch of the timed region by FLOPs.
-PMC_DOMINANT_F32 = {"gflop": 309.24, "read_bytes": 4.958e6 * 128, "write_bytes": 8.389e6 * 64, "algorithmic_bytes": 1073.7e6}
+# HBM-side traffic of the dominant kernel: read from the committed counter summary (tools/run_pmc.sh -> tools/pmc_summary.py
+# --dominant-json): separate rocprofv3 --pmc passes over tools/pmc_kernels.py; reads = TCC_EA0_RDREQ x 128 B (FETCH_SIZE tallies
+# those 128-byte requests at 64 B, the x2 correction of the guide, confirmed on a 1 GiB copy in the same passes), writes =
+# TCC_EA0_WRREQ_64B x 64 B + the remaining write requests x 32 B, on the kernel's reference launch (128 -> 128 3x3 @256x256
+# B=16).  Counters cannot be read inside a timed run; the figure is scaled to the average launch of the timed region by FLOPs.
+PMC_DOMINANT_FILE = os.path.join(ROOT, "profiles", "r3_pmc_dominant.json")
+DOMINANT_KERNEL = "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"
+
+
+def load_pmc_dominant():
+    """The committed PMC record of the dominant kernel; refuses a record of another kernel (a stale file after a kernel
+    change must not silently describe the new one)."""
+    with open(PMC_DOMINANT_FILE) as f:
+        rec = json.load(f)
+    name = rec["kernel"].replace(" ", "")
+    if name != DOMINANT_KERNEL.replace(" ", ""):
+        raise SystemExit("bench.py: %s describes kernel %r, the timed dominant kernel is %r: re-run tools/run_pmc.sh and "
+                         "tools/pmc_summary.py --dominant-json" % (PMC_DOMINANT_FILE, rec["kernel"], DOMINANT_KERNEL))
+    return rec
+
+
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # same table, dense bf16 matrix; the bf16x6 arithmetic spends 6 bf16 products
                                       # (20/3 with the zero-padded ninth tap) per fp32 product
 FLOPS_PER_IMAGE = {"church256": 1.815e12, "bedroom256": 1.815e12, "ffhq512": 3.91e12, "ffhq1024": 6.08e12}
@@ -81,6 +99,17 @@ def _runs_quad_main_kernel(mout, in_w, out_h, out_w, pad):
     return in_w % 4 == 0 and pad <= 4 and tn * (th + 2) * ((tw + 8) // 4) <= 64
 
 
+# second-tier MFMA kernel classes reported next to the dominant one (roofline_by_kernel): the template each class runs
+KERNEL_CLASSES = {
+    "dominant": ("conv 3x3 s1 gather, 128 x 128 tile, quad staging (forward, fused bias+lrelu forward, s1 data gradient)",
+                 DOMINANT_KERNEL),
+    "s2_dgrad": ("conv 3x3 s2 data gradient / transposed conv (plain + modulated)", "conv_igemm_tr2_kernel<2,16,*> / conv_igemm_tr_kernel"),
+    "s2_fwd": ("conv 3x3 s2 forward gather (plain + modulated)", "conv_igemm_kernel<3,2,*>"),
+    "s1_wgrad": ("conv 3x3 s1 weight gradient (plain + modulated)", "conv_wgrad_kernel<3,1,*>"),
+    "s2_wgrad": ("conv 3x3 s2 weight gradient (plain + modulated)", "conv_wgrad_kernel<3,2,*>"),
+}
+
+
 class DominantKernelTimer:
     """Brackets every launch of the dominant kernel (the quad-staged 3x3 stride-1 gather on the 128 x 128 tile,
     conv_igemm_kernel<3,1,2,2,2,2,8,false,true>, reached from conv2d forward and stride-1 dgrad; _runs_quad_main_kernel
@@ -91,66 +120,69 @@ class DominantKernelTimer:
         self.records = []
         self.active = False
 
+    def classify(self, cg, op, geom, activation_factor):
+        """Class key of a conv launch, or None.  'dominant' is exactly the instantiation named above (un-modulated
+        activation, wide layer, quad-staged rows); the other classes are the 3x3 kernels the review tracks."""
+        if not self.active or geom.k != 3:
+            return None
+        if geom.stride == 1:
+            if op == cg.SAE_CONV_WGRAD:
+                return "s1_wgrad" if max(geom.m, geom.c) > 32 else None
+            if activation_factor:
+                return None
+            if op == cg.SAE_CONV_FWD and _runs_quad_main_kernel(geom.m, geom.w, geom.oh, geom.ow, geom.pad):
+                return "dominant"
+            if op == cg.SAE_CONV_DGRAD and _runs_quad_main_kernel(geom.c, geom.ow, geom.h, geom.w, 2 - geom.pad):
+                return "dominant"
+            return None
+        return {cg.SAE_CONV_FWD: "s2_fwd", cg.SAE_CONV_DGRAD: "s2_dgrad", cg.SAE_CONV_WGRAD: "s2_wgrad"}.get(op)
+
     def install(self):
         import torch
         from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as cg
         timer = self
+
+        def bracket(key, geom, call):
+            if key is None:
+                return call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = call()
+            e1.record()
+            timer.records.append((key, 2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9, e0, e1))
+            return out
+
         orig_launch = cg._launch
 
         def launch(name, op, geom, a, b, out_shape):
-            hit = timer.active and geom.k == 3 and geom.stride == 1 and (
-                (op == cg.SAE_CONV_FWD and _runs_quad_main_kernel(geom.m, geom.w, geom.oh, geom.ow, geom.pad)) or
-                (op == cg.SAE_CONV_DGRAD and _runs_quad_main_kernel(geom.c, geom.ow, geom.h, geom.w, 2 - geom.pad)))
-            if not hit:
-                return orig_launch(name, op, geom, a, b, out_shape)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_launch(name, op, geom, a, b, out_shape)
-            e1.record()
-            flops = 2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9
-            timer.records.append((flops, e0, e1))
-            return out
+            return bracket(timer.classify(cg, op, geom, False), geom, lambda: orig_launch(name, op, geom, a, b, out_shape))
 
         cg._launch = launch
         orig_fused = cg._launch_fused
 
         def launch_fused(geom, x, w, bias, slope, scale):     # forward with the fused bias + leaky-ReLU epilogue
-            if not (timer.active and geom.k == 3 and geom.stride == 1 and
-                    _runs_quad_main_kernel(geom.m, geom.w, geom.oh, geom.ow, geom.pad)):
-                return orig_fused(geom, x, w, bias, slope, scale)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_fused(geom, x, w, bias, slope, scale)
-            e1.record()
-            timer.records.append((2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9, e0, e1))
-            return out
+            return bracket(timer.classify(cg, cg.SAE_CONV_FWD, geom, False), geom,
+                           lambda: orig_fused(geom, x, w, bias, slope, scale))
 
         cg._launch_fused = launch_fused
         orig_mod = cg._launch_mod
 
         def launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_scale=None, wc_scale=None):
-            # a modulated-conv call whose ACTIVATION carries no factor runs the same kernel instantiation (weight
+            # a modulated-conv call whose ACTIVATION carries no factor runs the un-modulated kernel instantiation (weight
             # factors ride in the weight re-layout): the data gradient of the generator's plain modulated convs
-            hit = timer.active and geom.k == 3 and geom.stride == 1 and x_scale is None and y_scale is None and (
-                (op == cg.SAE_CONV_FWD and _runs_quad_main_kernel(geom.m, geom.w, geom.oh, geom.ow, geom.pad)) or
-                (op == cg.SAE_CONV_DGRAD and _runs_quad_main_kernel(geom.c, geom.ow, geom.h, geom.w, 2 - geom.pad)))
-            if not hit:
-                return orig_mod(name, op, geom, a, b, out_shape, x_scale, y_scale, wm_scale, wc_scale)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = orig_mod(name, op, geom, a, b, out_shape, x_scale, y_scale, wm_scale, wc_scale)
-            e1.record()
-            timer.records.append((2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9, e0, e1))
-            return out
+            key = timer.classify(cg, op, geom, x_scale is not None or y_scale is not None)
+            return bracket(key, geom, lambda: orig_mod(name, op, geom, a, b, out_shape, x_scale, y_scale, wm_scale, wc_scale))
 
         cg._launch_mod = launch_mod
 
-    def summary(self, conv_math="f32"):
-        if not self.records:
-            return None
-        ms = sum(e0.elapsed_time(e1) for _, e0, e1 in self.records)
-        fl = sum(f for f, _, _ in self.records)
-        n = len(self.records)
+    def summary(self, conv_math="f32", steps=1):
+        """(roofline of the dominant kernel, roofline_by_kernel list) from the event brackets of the timed region."""
+        dom = [r for r in self.records if r[0] == "dominant"]
+        if not dom:
+            return None, None
+        ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in dom)
+        fl = sum(f for _, f, _, _ in dom)
+        n = len(dom)
         achieved = fl / (ms * 1e-3) / 1e12
         note = "event bracket includes the <1% weight re-layout launch that precedes each conv"
         if conv_math == "bf16x6":
@@ -161,19 +193,32 @@ class DominantKernelTimer:
             note += "; peak = 2500 TFLOP/s dense bf16 / 6 split products per fp32 product"
         else:
             peak = MFMA_F32_PEAK_TFLOPS
-            kernel = "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"
+            kernel = DOMINANT_KERNEL
         traffic = None
         if conv_math == "f32":
-            scale = (fl / n / 1e9) / PMC_DOMINANT_F32["gflop"]
-            traffic = round((PMC_DOMINANT_F32["read_bytes"] + PMC_DOMINANT_F32["write_bytes"]) * scale)
-            note += ("; traffic = HBM-side bytes per average launch from the PMC passes (profiles/r2_pmc_f32_quad.txt: %.0f MB read + "
-                     "%.0f MB written per 309 GFLOP reference launch against %.0f MB algorithmic), scaled by FLOPs"
-                     % (PMC_DOMINANT_F32["read_bytes"] / 1e6, PMC_DOMINANT_F32["write_bytes"] / 1e6,
-                        PMC_DOMINANT_F32["algorithmic_bytes"] / 1e6))
-        return {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2),
+            pmc = load_pmc_dominant()
+            scale = (fl / n / 1e9) / pmc["gflop"]
+            traffic = round((pmc["read_bytes"] + pmc["write_bytes"]) * scale)
+            note += ("; traffic = HBM-side bytes per average launch from the PMC passes (%s: %.0f MB read + %.0f MB written per "
+                     "%.0f GFLOP reference launch against %.0f MB algorithmic), scaled by FLOPs"
+                     % (os.path.relpath(PMC_DOMINANT_FILE, ROOT), pmc["read_bytes"] / 1e6, pmc["write_bytes"] / 1e6, pmc["gflop"],
+                        pmc["algorithmic_bytes"] / 1e6))
+        roof = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2),
                 "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                 "traffic": traffic, "launches": n, "avg_launch_ms": round(ms / n, 4),
                 "avg_launch_gflop": round(fl / n / 1e9, 2), "note": note}
+        by_kernel = []
+        for key, (what, template) in KERNEL_CLASSES.items():
+            rec = [r for r in self.records if r[0] == key]
+            if not rec:
+                continue
+            kms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in rec)
+            kfl = sum(f for _, f, _, _ in rec)
+            by_kernel.append({"class": what, "kernel": template if conv_math == "f32" else "bf16x6 counterpart of " + template,
+                              "launches": len(rec), "ms_per_step": round(kms / steps, 3),
+                              "achieved": round(kfl / (kms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                              "frac": round(kfl / (kms * 1e-3) / 1e12 / peak, 4)})
+        return roof, by_kernel
 
 
 def cpu_baseline(preset, size, batch):
@@ -413,9 +458,10 @@ def main():
                 x = line["ms_r1_extra_max"] * 1e-3
                 t_norm = (dt - r1_in_window * x) / args.steps + x / every
                 line["value_r1_every_%d" % every] = round(world * batch / t_norm, 3)
-        roof = timer.summary(args.conv_math)
+        roof, by_kernel = timer.summary(args.conv_math, args.steps)
         if roof:
             line["roofline"] = roof
+            line["roofline_by_kernel"] = by_kernel
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.preset, size, batch)
         print(json.dumps(line), flush=True)

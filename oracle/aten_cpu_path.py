@@ -141,3 +141,79 @@ class DiscriminatorCPU(torch.nn.Module):
         total += 3.0 * self.final_conv.flops(n, h, w)[0]
         total += 3.0 * 2.0 * n * (self.head.lin1_w.numel() + self.head.lin2_w.numel())
         return total
+
+
+# ---- one upsampling block of the generator (models/networks/generator.py:39-53) on the same ATen path --------------------
+class ModulatedConvCPU(torch.nn.Module):
+    """ModulatedConv2d with a [N, style_dim] style (stylegan2_layers.py:209-325, `new_demodulation` branch :279-287): the
+    style modulates the INPUT (normalised over channels when demodulating), the weight is shared by the batch, repeated
+    and demodulated per output channel, and the conv runs grouped over the batch (:300-321) -- restated literally,
+    including the grouped conv_transpose2d + Blur of the upsampling form (:302-309)."""
+
+    def __init__(self, cin, cout, k, styledim, upsample=False):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(1, cout, cin, k, k))
+        self.mod_weight = torch.nn.Parameter(torch.randn(cin, styledim))      # modulation = EqualLinear(style_dim, cin, bias_init=1)
+        self.mod_bias = torch.nn.Parameter(torch.ones(cin))
+        self.cin, self.cout, self.k, self.upsample = cin, cout, k, upsample
+        self.scale = 1.0 / math.sqrt(cin * k * k)
+        self.mod_scale = 1.0 / math.sqrt(styledim)
+        self.register_buffer("blur", make_kernel([1, 3, 3, 1]) * 4)         # Blur(..., upsample_factor=2): taps * factor^2
+
+    def forward(self, x, style):
+        b, cin, h, w = x.shape
+        s = F.linear(style.view(b, -1), self.mod_weight * self.mod_scale, bias=self.mod_bias * 1.0)
+        s = s.view(b, cin, 1, 1)
+        s = s * torch.rsqrt(s.pow(2).mean([1], keepdim=True) + 1e-8)
+        x = x * s
+        weight = (self.scale * self.weight).repeat(b, 1, 1, 1, 1)
+        demod = torch.rsqrt(weight.pow(2).sum([2, 3, 4]) + 1e-8)
+        weight = weight * demod.view(b, self.cout, 1, 1, 1)
+        weight = weight.view(b * self.cout, cin, self.k, self.k)
+        if self.upsample:
+            x = x.view(1, b * cin, h, w)
+            weight = weight.view(b, self.cout, cin, self.k, self.k).transpose(1, 2).reshape(b * cin, self.cout, self.k, self.k)
+            out = F.conv_transpose2d(x, weight, padding=0, stride=2, groups=b)
+            out = out.view(b, self.cout, out.shape[2], out.shape[3])
+            p = (4 - 2) - (self.k - 1)
+            return upfirdn2d_native(out, self.blur, pad=((p + 1) // 2 + 1, p // 2 + 1))
+        x = x.view(1, b * cin, h, w)
+        out = F.conv2d(x, weight, padding=self.k // 2, groups=b)
+        return out.view(b, self.cout, out.shape[2], out.shape[3])
+
+
+class _Holder(torch.nn.Module):
+    def __init__(self, name, value):
+        super().__init__()
+        setattr(self, name, torch.nn.Parameter(value))
+
+
+class StyledConvCPU(torch.nn.Module):
+    """StyledConv (stylegan2_layers.py:367-405): modulated conv -> image + weight * noise (:351) -> FusedLeakyReLU."""
+
+    def __init__(self, cin, cout, k, styledim, upsample=False):
+        super().__init__()
+        self.conv = ModulatedConvCPU(cin, cout, k, styledim, upsample=upsample)
+        self.noise = _Holder("weight", torch.zeros(1))        # child modules, so that parameters() keeps the reference's order
+        self.activate = _Holder("bias", torch.zeros(cout))
+
+    def forward(self, x, style, noise):
+        out = self.conv(x, style)
+        out = out + self.noise.weight * noise
+        return fused_leaky_relu(out, self.activate.bias)
+
+
+class UpsamplingResnetBlockCPU(torch.nn.Module):
+    """generator.py:39-53 with use_noise=True and inch != outch; parameters in the reference module's own order."""
+
+    def __init__(self, inch, outch, styledim):
+        super().__init__()
+        self.conv1 = StyledConvCPU(inch, outch, 3, styledim, upsample=True)
+        self.conv2 = StyledConvCPU(outch, outch, 3, styledim, upsample=False)
+        self.skip = ConvLayerCPU(inch, outch, 1, activate=True, bias=True)
+
+    def forward(self, x, style, noise1, noise2):
+        skip = F.interpolate(self.skip(x), scale_factor=2, mode="bilinear", align_corners=False)
+        res = self.conv2(self.conv1(x, style, noise1), style, noise2)
+        return (skip + res) / math.sqrt(2)
+

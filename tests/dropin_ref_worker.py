@@ -97,7 +97,27 @@ def aten_cpu_path_pin():
     gm = torch.autograd.grad(ym.sum(), mp_)
     for a, b in zip(gr, gm):
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max() + 1e-12)
-    print("aten-cpu-path-pinned", err)
+    # one upsampling block of the generator, explicit noise maps
+    from models.networks.generator import UpsamplingResnetBlock
+    refb = UpsamplingResnetBlock(12, 8, 16, use_noise=True)
+    mineb = A.UpsamplingResnetBlockCPU(12, 8, 16)
+    rp, mp_ = list(refb.parameters()), list(mineb.parameters())
+    assert [tuple(a.shape) for a in rp] == [tuple(b.shape) for b in mp_], ([a.shape for a in rp], [b.shape for b in mp_])
+    with torch.no_grad():
+        for a, b in zip(rp, mp_):
+            a.copy_(torch.randn(a.shape) * (1.0 if a.dim() > 1 else 0.3))
+            b.copy_(a)
+    xb, st = torch.randn(3, 12, 8, 8), torch.randn(3, 16)
+    z1, z2 = torch.randn(3, 1, 16, 16), torch.randn(3, 1, 16, 16)
+    refb.conv1.noise.fixed_noise, refb.conv2.noise.fixed_noise = z1, z2
+    yr, ym = refb(xb, st), mineb(xb, st, z1, z2)
+    errb = float((yr - ym).abs().max() / yr.abs().max())
+    assert errb < 1e-5, errb
+    gr = torch.autograd.grad(yr.square().sum(), rp)
+    gm = torch.autograd.grad(ym.square().sum(), mp_)
+    for a, b in zip(gr, gm):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max() + 1e-12)
+    print("aten-cpu-path-pinned", err, errb)
 
 
 if __name__ == "__main__":

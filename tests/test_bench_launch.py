@@ -4,6 +4,8 @@ import importlib
 import os
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -58,3 +60,38 @@ def test_dominant_kernel_filter_follows_the_dispatch_rule():
     assert not f(64, 256, 256, 256, 1)         # 64 output channels: the 64 x 256 tile
     assert not f(128, 258, 256, 256, 0)        # reflection-padded rows (258 floats): dword staging
     assert not f(409, 64, 64, 64, 1)           # 409 channels pad 8 % less on the 64-row tile
+
+
+def test_pmc_record_of_another_kernel_is_refused(tmp_path, monkeypatch):
+    """roofline.traffic comes from the committed counter record of the dominant kernel; a record that names another kernel
+    (stale after a kernel change) stops the bench instead of describing the wrong kernel."""
+    import json
+    bench = _bench()
+    rec = bench.load_pmc_dominant()
+    assert rec["kernel"].replace(" ", "") == bench.DOMINANT_KERNEL and rec["read_bytes"] > 0 and rec["write_bytes"] > 0
+    assert 0.9 < (rec["read_bytes"] + rec["write_bytes"]) / rec["algorithmic_bytes"] < 3.0
+    other = tmp_path / "pmc.json"
+    other.write_text(json.dumps(dict(rec, kernel="conv_igemm_kernel<3,1,2,2,2,2,8,false,false>")))
+    monkeypatch.setattr(bench, "PMC_DOMINANT_FILE", str(other))
+    with pytest.raises(SystemExit):
+        bench.load_pmc_dominant()
+
+
+def test_kernel_class_of_a_launch():
+    """The event timer's classes (roofline_by_kernel) follow the library's dispatch: the dominant instantiation only for wide,
+    quad-staged, un-modulated 3x3 stride-1 gathers; the four second-tier classes by operation and stride."""
+    bench = _bench()
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as cg
+    t = bench.DominantKernelTimer()
+    t.active = True
+    g = cg._Geom(16, 128, 256, 256, 128, 3, 1, 1, False, 1.0)
+    assert t.classify(cg, cg.SAE_CONV_FWD, g, False) == "dominant" and t.classify(cg, cg.SAE_CONV_DGRAD, g, False) == "dominant"
+    assert t.classify(cg, cg.SAE_CONV_FWD, g, True) is None and t.classify(cg, cg.SAE_CONV_WGRAD, g, True) == "s1_wgrad"
+    narrow = cg._Geom(128, 32, 128, 128, 32, 3, 1, 1, False, 1.0)
+    assert t.classify(cg, cg.SAE_CONV_FWD, narrow, False) is None and t.classify(cg, cg.SAE_CONV_WGRAD, narrow, False) is None
+    s2 = cg._Geom(16, 128, 257, 257, 256, 3, 2, 0, False, 1.0)
+    assert [t.classify(cg, op, s2, False) for op in (cg.SAE_CONV_FWD, cg.SAE_CONV_DGRAD, cg.SAE_CONV_WGRAD)] == [
+        "s2_fwd", "s2_dgrad", "s2_wgrad"]
+    assert t.classify(cg, cg.SAE_CONV_FWD, cg._Geom(16, 128, 64, 64, 256, 1, 1, 0, False, 1.0), False) is None
+    t.active = False
+    assert t.classify(cg, cg.SAE_CONV_FWD, g, False) is None

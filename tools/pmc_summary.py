@@ -14,7 +14,42 @@ def short(n):
     return re.sub(r"\(.*", "", n)[:60]
 
 
+DOMINANT = "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"
+# tools/pmc_kernels.py's reference launch of it: 128 -> 128 3x3 @256x256, B = 16 (forward and stride-1 data gradient)
+DOMINANT_REF = {"gflop": 2.0 * 16 * 128 * 256 * 256 * 128 * 9 / 1e9, "algorithmic_bytes": 2.0 * 16 * 128 * 256 * 256 * 4,
+                "launch": "128 -> 128 3x3 stride 1 @256x256, B = 16 (tools/pmc_kernels.py)"}
+
+
+def dominant_record(agg, source):
+    """bench.py's roofline.traffic record: request-level HBM-side traffic of the dominant kernel's reference launch."""
+    rows = [m for k, m in agg.items() if k[0].replace(" ", "").startswith(DOMINANT)]
+    if not rows:
+        raise SystemExit("pmc_summary: no %s launch in the passes" % DOMINANT)
+    need = ("TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")
+    rows = [{c: sum(v) / len(v) for c, v in m.items()} for m in rows]
+    rows = [m for m in rows if all(c in m for c in need)]
+    if not rows:
+        raise SystemExit("pmc_summary: the passes lack %s" % (need,))
+    m = {c: sum(r[c] for r in rows) / len(rows) for c in need + ("TCC_EA0_RDREQ_32B_sum",) if all(c in r for r in rows)}
+    rd32 = m.get("TCC_EA0_RDREQ_32B_sum", 0.0)
+    rec = dict(DOMINANT_REF)
+    rec.update({"kernel": DOMINANT, "read_requests": m["TCC_EA0_RDREQ_sum"], "read_requests_32B": rd32,
+                "read_bytes": (m["TCC_EA0_RDREQ_sum"] - rd32) * 128 + rd32 * 32,
+                "write_requests": m["TCC_EA0_WRREQ_sum"], "write_requests_64B": m["TCC_EA0_WRREQ_64B_sum"],
+                "write_bytes": m["TCC_EA0_WRREQ_64B_sum"] * 64 + (m["TCC_EA0_WRREQ_sum"] - m["TCC_EA0_WRREQ_64B_sum"]) * 32,
+                "source": source,
+                "method": "rocprofv3 --pmc, one counter set per run, kernel trace only; TCC_EA0_RDREQ x 128 B (32-byte requests "
+                          "x 32 B), TCC_EA0_WRREQ_64B x 64 B + other write requests x 32 B; mean over the launches of the passes"})
+    rec["traffic_over_algorithmic"] = round((rec["read_bytes"] + rec["write_bytes"]) / rec["algorithmic_bytes"], 3)
+    return rec
+
+
 def main(dirs):
+    out_json = None
+    if "--dominant-json" in dirs:
+        i = dirs.index("--dominant-json")
+        out_json = dirs[i + 1]
+        dirs = dirs[:i] + dirs[i + 2:]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     for d in dirs:
@@ -37,6 +72,11 @@ def main(dirs):
             line += "  FETCH=%.1f MB (as reported)  WRITE=%.1f MB" % (m.get("FETCH_SIZE", 0) * 1024 / 1e6, m.get("WRITE_SIZE", 0) * 1024 / 1e6)
         print(line)
         print("   " + "  ".join("%s=%.4g" % (c, v) for c, v in sorted(m.items())))
+    if out_json:
+        import json
+        with open(out_json, "w") as f:
+            json.dump(dominant_record(agg, "tools/run_pmc.sh passes " + " ".join(dirs)), f, indent=1)
+            f.write("\n")
 
 
 if __name__ == "__main__":

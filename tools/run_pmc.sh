@@ -15,7 +15,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $root/$out/D --
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_MISS_sum TCC_HIT_sum --kernel-trace --output-format csv -d $root/$out/E -- python $root/tools/pmc_kernels.py > $root/$out/E.log 2>&1
 rocprofv3 --pmc TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_REQ_sum --kernel-trace --output-format csv -d $root/$out/F -- python $root/tools/pmc_kernels.py > $root/$out/F.log 2>&1
 cd $root
-python tools/pmc_summary.py $out/A $out/B $out/C $out/D $out/E $out/F > $out/summary.txt 2>&1
+python tools/pmc_summary.py $out/A $out/B $out/C $out/D $out/E $out/F --dominant-json $out/pmc_dominant.json > $out/summary.txt 2>&1
 # keep only the summary and the logs (the raw csv / db files are large)
 find $out -name "*.csv" -size +2M -delete; find $out -name "*.db" -delete
 tail -60 $out/summary.txt
