@@ -70,6 +70,9 @@ def parse():
                     help="arithmetic of the 3x3 conv kernels for the reported value (include/sae_hip.h: sae_set_conv_math)")
     ap.add_argument("--alt-steps", type=int, default=8,
                     help="steps of the extra measurement with the OTHER conv arithmetic (0 = skip); reported as alt_conv_math")
+    ap.add_argument("--force-allreduce", action="store_true",
+                    help="with --gpus 1: run the multi-GPU gradient path (buckets, grad-ready hooks, asynchronous RCCL "
+                         "all-reduce, per-bucket Adam) on the single rank -- the cost of that machinery, NOT a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
@@ -154,8 +157,8 @@ class DominantKernelTimer:
 
         orig_launch = cg._launch
 
-        def launch(name, op, geom, a, b, out_shape):
-            return bracket(timer.classify(cg, op, geom, False), geom, lambda: orig_launch(name, op, geom, a, b, out_shape))
+        def launch(name, op, geom, a, b, out_shape, out=None):
+            return bracket(timer.classify(cg, op, geom, False), geom, lambda: orig_launch(name, op, geom, a, b, out_shape, out=out))
 
         cg._launch = launch
         orig_fused = cg._launch_fused
@@ -336,6 +339,14 @@ def main():
         raise SystemExit("bench.py: --gpus %d but only %d device(s) are visible" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     launched = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)    # torch.distributed.run, any N
+    if args.force_allreduce:
+        if world != 1:
+            raise SystemExit("bench.py: --force-allreduce is the single-rank rehearsal of the multi-GPU gradient path")
+        os.environ["SAE_FORCE_ALLREDUCE"] = "1"         # grad_allreduce.GradAllReducer: stay enabled at world size 1
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if not launched:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            launched = True
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -436,6 +447,9 @@ def main():
                                    "every 16th D iteration" % (args.preset, size, size, batch),
                        "global_batch": world * batch, "parallelism": "dp%d" % world, "conv_math": args.conv_math},
         }
+        if args.force_allreduce:
+            line["config"]["force_allreduce"] = ("single-rank rehearsal of the multi-GPU gradient path: %d + %d buckets all-reduced over "
+                                                 "RCCL per iteration" % (len(optimizer.reducer_D.buckets), len(optimizer.reducer_G.buckets)))
         if alt:
             line["alt_conv_math"] = alt
         if per_image:

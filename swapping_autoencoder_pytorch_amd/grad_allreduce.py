@@ -16,7 +16,11 @@ replicate / scatter / gather / reduce_add through GPU 0 on every call).  Design 
 * ``finish()`` waits, scales by 1/world and scatters the averaged values back into ``.grad``;
   ``finish_into(optimizer)`` instead hands every completed bucket to the multi-tensor Adam kernel, which reads
   the summed gradients in place (fused_adam.FusedAdam).  Parameters that received no gradient in this pass
-  contribute zeros to the collective (its shape stays identical on all ranks) and are skipped by the update.
+  contribute zeros to the collective (its shape stays identical on all ranks) and are skipped by the update;
+* gradients as bucket views: while a reducer is armed, the weight-gradient kernels of the convolutions write their
+  result STRAIGHT into the parameter's slot of the flat bucket (``claim_destination``, used by
+  stylegan2_op/conv2d_gemm.py): autograd then adopts that view as ``.grad`` and the grad-ready hook has nothing to
+  copy.  Slots start on 256-byte boundaries so that the kernels' and Adam's 16-byte accesses stay aligned.
 
 With world_size == 1 (or torch.distributed not initialised) every method is a no-op."""
 import os
@@ -25,6 +29,22 @@ import torch
 import torch.distributed as dist
 
 BUCKET_BYTES = 32 * 1024 * 1024
+SLOT_ALIGN = 64          # floats: every parameter's slot starts on a 256-byte boundary
+
+# data_ptr of a parameter -> its slot in an armed reducer's flat bucket, handed out ONCE per backward pass
+_DESTINATIONS = {}
+
+
+def claim_destination(weight):
+    """For a weight-gradient producer: the bucket slot (shaped like `weight`) the gradient of `weight` should be written
+    into, or None.  One-shot: a parameter used twice in a graph gets the slot for its first gradient only, the second is
+    accumulated into it by autograd as usual."""
+    if not _DESTINATIONS:
+        return None
+    slot = _DESTINATIONS.pop(weight.data_ptr(), None)
+    if slot is None or slot.numel() != weight.numel():
+        return None
+    return slot.view(weight.shape)
 
 
 class _Bucket:
@@ -57,7 +77,7 @@ class GradAllReducer:
                 cur = _Bucket()
             cur.offsets.append(cur.numel)
             cur.params.append(p)
-            cur.numel += p.numel()
+            cur.numel += (p.numel() + SLOT_ALIGN - 1) // SLOT_ALIGN * SLOT_ALIGN
             self._where[p] = (len(self.buckets), len(cur.params) - 1)
         if cur.numel:
             self.buckets.append(cur)
@@ -76,6 +96,9 @@ class GradAllReducer:
             b.pending = len(b.params)
             b.work = None
             b.flat.zero_()
+            for p, off in zip(b.params, b.offsets):
+                if p.dim() == 4 and p.is_contiguous():       # conv weights: their wgrad kernels can write into the slot
+                    _DESTINATIONS[p.data_ptr()] = b.flat[off:off + p.numel()]
 
     def _on_grad(self, p):
         if not self.armed:
@@ -83,10 +106,17 @@ class GradAllReducer:
         bi, pi = self._where[p]
         b = self.buckets[bi]
         off = b.offsets[pi]
-        b.flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        slot = b.flat[off:off + p.numel()]
+        if p.grad.data_ptr() != slot.data_ptr():          # (a conv weight's gradient was produced in place: nothing to copy)
+            slot.copy_(p.grad.reshape(-1))
         b.pending -= 1
         if b.pending == 0:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _release_destinations(self):
+        for b in self.buckets:
+            for p in b.params:
+                _DESTINATIONS.pop(p.data_ptr(), None)
 
     def _launch_stragglers(self):
         """Buckets whose last gradient never arrived (some parameter got no gradient in this pass) still take part
@@ -103,13 +133,14 @@ class GradAllReducer:
         if not self.enabled or not self.armed:
             return
         self.armed = False
+        self._release_destinations()
         inv = 1.0 / self.world
         self._launch_stragglers()
         for b in self.buckets:
             b.work.wait()
             b.flat.mul_(inv)
             for p, off in zip(b.params, b.offsets):
-                if p.grad is not None:
+                if p.grad is not None and p.grad.data_ptr() != b.flat[off:off + 1].data_ptr():
                     p.grad.copy_(b.flat[off:off + p.numel()].view_as(p.grad))
             b.work = None
 
@@ -122,6 +153,7 @@ class GradAllReducer:
             optimizer.step()
             return
         self.armed = False
+        self._release_destinations()
         inv = 1.0 / self.world
         self._launch_stragglers()
         for b in self.buckets:

@@ -71,15 +71,16 @@ class _Geom:
         return d
 
 
-def _launch(name, op, geom, a, b, out_shape):
+def _launch(name, op, geom, a, b, out_shape, out=None):
     lib = hip_lib.get()
     a = a.contiguous()
     b = b.contiguous()
-    lib.check(a, b)
+    lib.check(a, b, out)
     d = geom.desc()
     n_ws = lib.query("conv2d_workspace", C.byref(d), op)
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=a.device)
-    out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
+    if out is None or tuple(out.shape) != tuple(out_shape):
+        out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
     lib.call(name, a.data_ptr(), b.data_ptr(), out.data_ptr(), C.byref(d), geom.alpha, ws.data_ptr(), n_ws,
              lib.stream(a))
     return out
@@ -108,8 +109,18 @@ def _dgrad(gy, w, g):
     return _launch("conv2d_dgrad_f32", SAE_CONV_DGRAD, g, gy, w, (g.n, g.c, g.h, g.w))
 
 
-def _wgrad(x, gy, g):
-    return _launch("conv2d_wgrad_f32", SAE_CONV_WGRAD, g, x, gy, g.weight_shape())
+def _wgrad(x, gy, g, out=None):
+    return _launch("conv2d_wgrad_f32", SAE_CONV_WGRAD, g, x, gy, g.weight_shape(), out=out)
+
+
+def weight_grad(x, gy, geom, weight):
+    """The weight gradient inside a backward pass: a differentiable node when the pass builds a graph (create_graph=True);
+    otherwise the bare kernel, writing straight into the parameter's slot of an armed gradient bucket when there is one
+    (grad_allreduce.claim_destination: the all-reduce then needs no gradient -> bucket copy)."""
+    if torch.is_grad_enabled():
+        return ConvWeightGrad.apply(x, gy, geom)
+    from ..grad_allreduce import claim_destination
+    return _wgrad(x, gy, geom, out=claim_destination(weight))
 
 
 def _zero_param_grad(ctx, index, param):
@@ -137,7 +148,7 @@ class ConvForward(Function):
             return None, _zero_param_grad(ctx, 1, ctx.saved_tensors[1]), None
         x, w = ctx.saved_tensors
         gx = ConvDataGrad.apply(gy, w, ctx.geom) if ctx.needs_input_grad[0] else None
-        gw = ConvWeightGrad.apply(x, gy, ctx.geom) if (ctx.needs_input_grad[1] and _Flags.weight_grads) else None
+        gw = weight_grad(x, gy, ctx.geom, w) if (ctx.needs_input_grad[1] and _Flags.weight_grads) else None
         return gx, gw, None
 
 
@@ -207,7 +218,7 @@ class ConvBiasAct(Function):
         geom, slope, scale, has_bias = ctx.cfg
         g_pre, g_bias = FusedLeakyReLUFunctionBackward.apply(gout, out, slope, scale)
         gx = ConvDataGrad.apply(g_pre, w, geom) if ctx.needs_input_grad[0] else None
-        gw = ConvWeightGrad.apply(x, g_pre, geom) if (ctx.needs_input_grad[1] and _Flags.weight_grads) else None
+        gw = weight_grad(x, g_pre, geom, w) if (ctx.needs_input_grad[1] and _Flags.weight_grads) else None
         gb = g_bias if (has_bias and ctx.needs_input_grad[2]) else None
         return gx, gw, gb, None, None, None
 

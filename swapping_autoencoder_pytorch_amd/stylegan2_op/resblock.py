@@ -144,7 +144,7 @@ class ResBlockFunction(Function):
         need_w = [need[i] and wflag for i in range(7)]
         # conv2 branch: activation backward with the merge factor folded into its scale, then dgrad / wgrad
         gp2, gb2 = bias_act_bwd_raw(gout, a2, cfg.slope2, cfg.scale2 * c)
-        gw2 = cg._wgrad(a1b, gp2, g2) if need_w[3] else None
+        gw2 = cg.weight_grad(a1b, gp2, g2, w2) if need_w[3] else None
         gb2 = gb2 if (ctx.has_bias[1] and need[4]) else None
         g_a1b = cg._dgrad(gp2, w2, g2)
         del gp2
@@ -153,11 +153,11 @@ class ResBlockFunction(Function):
         adj2 = _adjoint_pad(tuple(a1.shape[2:]), tuple(a1b.shape[2:]), tuple(cfg.taps2.shape), (1, 1), (1, 1), pad2)
         gp1, gb1 = _k1_epilogue(g_a1b, _flipped(cfg.taps2), 1, adj2, act_ref=a1, slope=cfg.slope1, scale=cfg.scale1)
         del g_a1b
-        gw1 = cg._wgrad(x, gp1, g1) if need_w[1] else None
+        gw1 = cg.weight_grad(x, gp1, g1, w1) if need_w[1] else None
         gb1 = gb1 if (ctx.has_bias[0] and need[2]) else None
         # skip branch (merge factor folded into alpha); its x2 zero-insert FIR accumulates into conv1's data gradient
         gs_c = _Geom(gs.n, gs.c, gs.h, gs.w, gs.m, gs.k, gs.stride, gs.pad, gs.cm_layout, gs.alpha * c)
-        gws = cg._wgrad(s0, gout, gs_c) if need_w[5] else None
+        gws = cg.weight_grad(s0, gout, gs_c, ws) if need_w[5] else None
         gx = None
         if need[0]:
             gx = cg._dgrad(gp1, w1, g1)

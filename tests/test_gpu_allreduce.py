@@ -34,9 +34,15 @@ for it in range(2):                                        # twice: hooks re-arm
     for p in params: p.grad = None
     red.arm()
     net(x).square().mean().backward()
+    # gradients as bucket views: the conv weight gradients were written by their kernels straight into the flat buckets
+    in_place = sum(int(p.grad.data_ptr() == red.buckets[red._where[p][0]].flat[red.buckets[red._where[p][0]].offsets[red._where[p][1]]:].data_ptr())
+                   for p in params if p.dim() == 4)
+    assert in_place == sum(1 for p in params if p.dim() == 4), in_place
     red.finish()
     for p, w in zip(params, want):
         assert torch.equal(p.grad, w), (it, p.shape)
+    for b in red.buckets:                                  # slots start on 256-byte boundaries
+        assert all(off %% 64 == 0 for off in b.offsets)
 torch.cuda.synchronize()
 dist.destroy_process_group()
 print("ALLREDUCE_OK")

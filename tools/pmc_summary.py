@@ -22,9 +22,11 @@ DOMINANT_REF = {"gflop": 2.0 * 16 * 128 * 256 * 256 * 128 * 9 / 1e9, "algorithmi
 
 def dominant_record(agg, source):
     """bench.py's roofline.traffic record: request-level HBM-side traffic of the dominant kernel's reference launch."""
-    rows = [m for k, m in agg.items() if k[0].replace(" ", "").startswith(DOMINANT)]
-    if not rows:
+    keys = [k for k in agg if k[0].replace(" ", "").startswith(DOMINANT)]
+    if not keys:
         raise SystemExit("pmc_summary: no %s launch in the passes" % DOMINANT)
+    biggest = max(int(k[1]) for k in keys)          # the reference launch (the split-K tail runs the same template on a small grid)
+    rows = [agg[k] for k in keys if int(k[1]) == biggest]
     need = ("TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum")
     rows = [{c: sum(v) / len(v) for c, v in m.items()} for m in rows]
     rows = [m for m in rows if all(c in m for c in need)]
