@@ -12,7 +12,7 @@ penalty on every 16th discriminator iteration (the default K = 16 contains exact
 value = N * B * K / t   (whole-job images per second; B images per GPU -> weak scaling).
 
 Also reported on the same JSON line:
-  roofline     – dominant kernel (3x3 stride-1 implicit-GEMM conv, conv_igemm_kernel<3,1,2,2,2,2,8,false,true>):
+  roofline     – dominant kernel (3x3 stride-1 implicit-GEMM conv, conv_igemm_kernel<3,1,2,2,1,4,8,false,true>):
                  algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
                  launch stream inside the timed region, against the fp32 MFMA peak (157.3 TFLOP/s); `traffic` from the
                  committed counter record profiles/r3_pmc_dominant.json (refused if it names another kernel);
@@ -38,7 +38,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, 
 # TCC_EA0_WRREQ_64B x 64 B + the remaining write requests x 32 B, on the kernel's reference launch (128 -> 128 3x3 @256x256
 # B=16).  Counters cannot be read inside a timed run; the figure is scaled to the average launch of the timed region by FLOPs.
 PMC_DOMINANT_FILE = os.path.join(ROOT, "profiles", "r3_pmc_dominant.json")
-DOMINANT_KERNEL = "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"
+DOMINANT_KERNEL = "conv_igemm_kernel<3,1,2,2,1,4,8,false,true>"
 
 
 def load_pmc_dominant():
@@ -78,11 +78,12 @@ def parse():
     return ap.parse_args()
 
 
-def _runs_quad_main_kernel(mout, in_w, out_h, out_w, pad):
-    """True when csrc/conv2d.hip dispatches a 3x3 stride-1 gather producing `mout` channels on an out_h x out_w grid from
-    rows of in_w floats to conv_igemm_kernel<3,1,2,2,2,2,8,false,true> (fwd_shape(): the 128 x 128 tile unless a 64-row
-    tile pads the channels 8 % less; launch_igemm(): quad staging when the rows are a multiple of four floats and the
-    widened patch of the tile pick_tile() chooses is at most 64 quads per channel)."""
+def _quad_gather_tile(mout, in_w, out_h, out_w, pad):
+    """Which quad-staged instantiation csrc/conv2d.hip dispatches a wide exact-fp32 3x3 stride-1 gather to -- "64x256"
+    (conv_igemm_kernel<3,1,2,2,1,4,8,false,true>), "128x128" (<3,1,2,2,2,2,8,false,true>) or None -- for a launch producing
+    `mout` channels on an out_h x out_w grid from rows of in_w floats.  Mirrors fwd_shape() (maps at least 128 wide take
+    the 64-row tile; otherwise the 128-row tile unless a 64-row tile pads the channels 8 % less), pick_tile() and the quad
+    conditions of launch_igemm() (rows a multiple of four floats, the widened patch within the tile's quad budget)."""
     def up(v, q):
         return (v + q - 1) // q * q
 
@@ -91,21 +92,26 @@ def _runs_quad_main_kernel(mout, in_w, out_h, out_w, pad):
         while p < v:
             p *= 2
         return p
-    if mout <= 64 or up(mout, 64) * 100 < up(mout, 128) * 92:
-        return False
+    if mout <= 64:
+        return None
+    tile64 = out_w >= 128 or up(mout, 64) * 100 < up(mout, 128) * 92
+    bn = 256 if tile64 else 128
     tw = min(max(pow2(out_w), 4), 32)
     th = max(pow2(out_h), 4)
-    while tw * th > 128:
+    while tw * th > bn:
         th //= 2
     th = max(th, 1)
-    tn = 128 // (tw * th)
-    return in_w % 4 == 0 and pad <= 4 and tn * (th + 2) * ((tw + 8) // 4) <= 64
+    tn = bn // (tw * th)
+    if in_w % 4 != 0 or pad > 4 or tn * (th + 2) * ((tw + 8) // 4) > bn // 2:
+        return None
+    return "64x256" if tile64 else "128x128"
 
 
 # second-tier MFMA kernel classes reported next to the dominant one (roofline_by_kernel): the template each class runs
 KERNEL_CLASSES = {
-    "dominant": ("conv 3x3 s1 gather, 128 x 128 tile, quad staging (forward, fused bias+lrelu forward, s1 data gradient)",
-                 DOMINANT_KERNEL),
+    "dominant": ("conv 3x3 s1 gather on maps >= 128 wide: 64 x 256 tile, quad staging (forward, fused bias+lrelu forward, s1 data "
+                 "gradient)", DOMINANT_KERNEL),
+    "s1_gather_128": ("conv 3x3 s1 gather on smaller maps: 128 x 128 tile, quad staging", "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"),
     "s2_dgrad": ("conv 3x3 s2 data gradient / transposed conv (plain + modulated)", "conv_igemm_tr2_kernel<2,16,*> / conv_igemm_tr_kernel"),
     "s2_fwd": ("conv 3x3 s2 forward gather (plain + modulated)", "conv_igemm_kernel<3,2,*>"),
     "s1_wgrad": ("conv 3x3 s1 weight gradient (plain + modulated)", "conv_wgrad_kernel<3,1,*>"),
@@ -114,10 +120,11 @@ KERNEL_CLASSES = {
 
 
 class DominantKernelTimer:
-    """Brackets every launch of the dominant kernel (the quad-staged 3x3 stride-1 gather on the 128 x 128 tile,
-    conv_igemm_kernel<3,1,2,2,2,2,8,false,true>, reached from conv2d forward and stride-1 dgrad; _runs_quad_main_kernel
-    repeats the library's dispatch rule so that exactly that instantiation is counted) with HIP events on the launch
-    stream; durations are read after the final synchronise."""
+    """Brackets every launch of the dominant kernel (the quad-staged 3x3 stride-1 gather on the 64 x 256 tile,
+    conv_igemm_kernel<3,1,2,2,1,4,8,false,true>: the wide layers on maps at least 128 wide, reached from conv2d forward and
+    stride-1 dgrad; _quad_gather_tile repeats the library's dispatch rule so that exactly that instantiation is counted)
+    and of the second-tier MFMA classes with HIP events on the launch stream; durations are read after the final
+    synchronise."""
 
     def __init__(self):
         self.records = []
@@ -133,11 +140,12 @@ class DominantKernelTimer:
                 return "s1_wgrad" if max(geom.m, geom.c) > 32 else None
             if activation_factor:
                 return None
-            if op == cg.SAE_CONV_FWD and _runs_quad_main_kernel(geom.m, geom.w, geom.oh, geom.ow, geom.pad):
-                return "dominant"
-            if op == cg.SAE_CONV_DGRAD and _runs_quad_main_kernel(geom.c, geom.ow, geom.h, geom.w, 2 - geom.pad):
-                return "dominant"
-            return None
+            tile = None
+            if op == cg.SAE_CONV_FWD:
+                tile = _quad_gather_tile(geom.m, geom.w, geom.oh, geom.ow, geom.pad)
+            elif op == cg.SAE_CONV_DGRAD:
+                tile = _quad_gather_tile(geom.c, geom.ow, geom.h, geom.w, 2 - geom.pad)
+            return {"64x256": "dominant", "128x128": "s1_gather_128"}.get(tile)
         return {cg.SAE_CONV_FWD: "s2_fwd", cg.SAE_CONV_DGRAD: "s2_dgrad", cg.SAE_CONV_WGRAD: "s2_wgrad"}.get(op)
 
     def install(self):
@@ -180,7 +188,9 @@ class DominantKernelTimer:
 
     def summary(self, conv_math="f32", steps=1):
         """(roofline of the dominant kernel, roofline_by_kernel list) from the event brackets of the timed region."""
-        dom = [r for r in self.records if r[0] == "dominant"]
+        # (bf16x6 keeps one tile for all wide layers: both exact-fp32 gather classes are its dominant kernel)
+        dom_keys = ("dominant",) if conv_math == "f32" else ("dominant", "s1_gather_128")
+        dom = [r for r in self.records if r[0] in dom_keys]
         if not dom:
             return None, None
         ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in dom)

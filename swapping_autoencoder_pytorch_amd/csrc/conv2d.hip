@@ -195,13 +195,25 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     // XCD k the k-th CONTIGUOUS eighth of the tile list puts a tile and its spatial neighbours (which share halo rows
     // and the 128-byte lines the halo columns straddle) behind the same L2, in flight at about the same time; in plain
     // order every XCD fetched its own copy: 1.56 GB from the fabric for 0.54 GB of input (profiles/r2_pmc_f32.txt)
+    // With several M tiles (gridDim.y > 1) the M tile is the FASTEST index of the re-labelled order: the workgroups that
+    // read the same input patch run together behind one L2 (in launch order they are gridDim.x workgroups apart and each
+    // fetched its own copy from HBM: 1138 MB read for 537 MB of input with two M tiles, profiles/r3_pmc_f32.txt).
     int bt = blockIdx.x;
-    if (p.xcd_order && (gridDim.x & 7) == 0) bt = (bt & 7) * (gridDim.x >> 3) + (bt >> 3);
+    int mt = blockIdx.y;
+    if (p.xcd_order) {
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {
+            const int lin = blockIdx.x + gridDim.x * blockIdx.y;           // dispatch order: x fastest
+            const int wk = (lin & 7) * (total >> 3) + (lin >> 3);
+            mt = wk % gridDim.y;
+            bt = wk / gridDim.y;
+        }
+    }
     const int tix = bt % p.tiles_x; bt /= p.tiles_x;
     const int tiy = bt % p.tiles_y;
     const int tin = bt / p.tiles_y;
     const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
-    const int m0 = blockIdx.y * BM;
+    const int m0 = mt * BM;
 
     const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
     const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
@@ -2910,14 +2922,20 @@ inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
 
 // tile shape of a forward-type launch producing `mout` channels
 struct FwdShape { int cfg; int bm, bn; int ck; };   // cfg 0: 128x128, 1: 64x256, 2: 32x512
-FwdShape fwd_shape(int mout, int ks, int stride) {
+FwdShape fwd_shape(int mout, int ks, int stride, int ow) {
     FwdShape s{};
     // tuning knob (benchmarks only): SAE_IGEMM_WIDE=1 gives 3x3 stride-1 layers a 128 x 256 tile
     static const int wide_knob = tuning_knob("SAE_IGEMM_WIDE", 0);
+    // exact fp32, 3x3 stride 1, maps at least 128 wide: the 64 x 256 tile for wide layers too -- a 32 x 8 pixel tile has less
+    // halo and 30 % less staging traffic per MFMA than 128 x 128 on 16 x 8 pixels (9 instead of 11 vector-memory instructions
+    // per chunk); same-box A/B (tools/ab_conv.py): 128 -> 128 @256^2 128.1 -> 130.9 TFLOP/s, 256 -> 256 @128^2 131.5 -> 136.1;
+    // at 64^2 and below (long K loops, few tiles) the 128-row tile stays ahead by up to 1 %.  Bit-identical results.
+    static const int prefer64_knob = tuning_knob("SAE_IGEMM_PREFER64", 1);
+    const bool wide_map_64 = prefer64_knob && conv_math() == 0 && ks == 3 && stride == 1 && ow >= 128;
     static const int bx_s2_knob = tuning_knob("SAE_BX_S2", 1);
     if (mout > 64 && wide_knob && ks == 3 && stride == 1) { s.cfg = 3; s.bm = 128; s.bn = 256; }
     else if (mout > 32 && ks == 3 && stride == 2 && conv_math() == 1 && bx_s2_knob) { s.cfg = 6; s.bm = 64; s.bn = 128; }   // bf16x6 stride 2
-    else if (mout > 64 && round_up(mout, 64) * 100 >= round_up(mout, 128) * 92) { s.cfg = 0; s.bm = 128; s.bn = 128; }
+    else if (mout > 64 && round_up(mout, 64) * 100 >= round_up(mout, 128) * 92 && !wide_map_64) { s.cfg = 0; s.bm = 128; s.bn = 128; }
     else if (mout > 64) { s.cfg = 1; s.bm = 64; s.bn = 256; }    // e.g. 409 -> 448 instead of 512 padded rows
     else if (mout > 32 || stride == 2) { s.cfg = 1; s.bm = 64; s.bn = 256; }
     else {
@@ -3067,7 +3085,7 @@ struct GatherPlan {
 };
 GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int stride, bool scatter) {
     GatherPlan g{};
-    g.sh = fwd_shape(mout, ks, stride);
+    g.sh = fwd_shape(mout, ks, stride, OW);
     g.Mp = round_up(mout, g.sh.bm);
     g.Cp = round_up(cin, g.sh.ck);
     g.taps = ks * ks;

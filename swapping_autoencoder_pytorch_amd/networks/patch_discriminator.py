@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import util
-from ..stylegan2_layers import ConvLayer, EqualLinear, ResBlock
+from ..stylegan2_layers import ConvLayer, EqualLinear, ResBlock, run_sequence
 from .base_network import BaseNetwork
 
 
@@ -66,7 +66,7 @@ class StyleGAN2PatchDiscriminator(BasePatchDiscriminator):
         else:
             b, t = patches.size(0), patches.size(1)
             flat = patches
-        feats = self.convs(flat)
+        feats = run_sequence(self.convs, flat)
         feats = feats.view(b, t, *feats.shape[1:])
         if aggregate:
             feats = feats.mean(1, keepdim=True).expand(-1, t, -1, -1, -1)

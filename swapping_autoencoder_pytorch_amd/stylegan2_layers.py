@@ -341,6 +341,18 @@ class ConvLayer(nn.Sequential):
         super().__init__(OrderedDict(layers))
         self._activated = activate
 
+    def _stem_config(self):
+        """StemConfig when this layer is a plain activated stride-1 conv (no blur, no reflection pad, FusedLeakyReLU with a
+        bias, size-preserving padding), else None."""
+        if not _FUSED_RESBLOCK or len(self._modules) != 2 or not isinstance(self._modules.get("Act"), FusedLeakyReLU):
+            return None
+        conv = self.Conv
+        k = conv.weight.shape[2]
+        if conv.stride != 1 or k not in (1, 3) or conv.padding != k // 2 or conv.bias is not None:
+            return None
+        from .stylegan2_op.resblock import StemConfig
+        return StemConfig(k, conv.padding, conv.scale, self.Act.negative_slope, self.Act.scale)
+
     def forward(self, input):
         """Same result as running the children in order; the Conv -> Act pair is ONE kernel (the
         bias + leaky-ReLU sits in the conv's epilogue)."""
@@ -408,15 +420,39 @@ class ResBlock(nn.Module):
                 self._fused_cfg = False
         return self._fused_cfg
 
-    def forward(self, input):
+    def forward(self, input, stem=None):
+        """stem: an activated stride-1 ConvLayer whose output is this block's input (run_sequence): it is then evaluated
+        inside the block's autograd node, `input` being the stem's input."""
         cfg = self._fused_config()
         if cfg and input.shape[2] % 2 == 0 and input.shape[3] % 2 == 0:
             from .stylegan2_op.resblock import resblock
             # the Blur buffers may have moved (module.to(device)) since the config was made
             cfg.taps2, cfg.taps_s = self.conv2.Blur.kernel, self.skip.Blur.kernel
+            st = None if stem is None else (stem.Conv.weight, stem.Act.bias, stem._stem_config())
             return resblock(input, self.conv1.Conv.weight, self.conv1.Act.bias, self.conv2.Conv.weight, self.conv2.Act.bias,
-                            self.skip.Conv.weight, cfg)
+                            self.skip.Conv.weight, cfg, stem=st)
+        if stem is not None:
+            input = stem(input)
         return add_scale(self.conv2(self.conv1(input)), self.skip(input), 1.0 / math.sqrt(2))
+
+
+def run_sequence(seq, x):
+    """``seq(x)`` for an nn.Sequential of ConvLayers / ResBlocks (D's and Dpatch's ``convs``), except that an activated
+    stride-1 ConvLayer directly in front of a single-node ResBlock is evaluated inside that node (its activation's
+    backward then rides in the kernel that finishes the block's input gradient).  Same values either way."""
+    mods = list(seq.children())
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        if (isinstance(m, ConvLayer) and isinstance(nxt, ResBlock) and m._stem_config() and nxt._fused_config()
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.dim() == 4):
+            x = nxt(x, stem=m)
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
 
 
 class Discriminator(nn.Module):
@@ -447,8 +483,8 @@ class Discriminator(nn.Module):
         )
 
     def forward(self, input):
-        out = self.final_conv(self.convs(input))
+        out = self.final_conv(run_sequence(self.convs, input))
         return self.final_linear(out.view(out.shape[0], -1))
 
     def get_features(self, input):
-        return self.final_conv(self.convs(input))
+        return self.final_conv(run_sequence(self.convs, input))

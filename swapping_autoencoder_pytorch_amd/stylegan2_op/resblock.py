@@ -43,6 +43,20 @@ class ResBlockConfig:
         self.merge = float(merge)
 
 
+class StemConfig:
+    """The activated stride-1 ConvLayer in front of a block (D's FromRGB 1x1, Dpatch's 3x3 stem): its output is the block's
+    input, so the backward of ITS activation can ride in the kernel that finishes the block's input gradient."""
+    __slots__ = ("k", "pad", "alpha", "slope", "scale")
+
+    def __init__(self, k, pad, alpha, slope, scale):
+        self.k, self.pad, self.alpha, self.slope, self.scale = int(k), int(pad), float(alpha), float(slope), float(scale)
+
+
+def stem_composed(x, w0, b0, scfg):
+    return cg.conv2d_bias_act(x, w0, b0, stride=1, padding=scfg.pad, alpha=scfg.alpha, negative_slope=scfg.slope,
+                              scale=scfg.scale)
+
+
 def resblock_composed(x, w1, b1, w2, b2, ws, cfg):
     """The block from the differentiable operators (what ResBlock.forward runs module by module)."""
     a1 = cg.conv2d_bias_act(x, w1, b1, stride=1, padding=1, alpha=cfg.alpha1, negative_slope=cfg.slope1, scale=cfg.scale1)
@@ -90,17 +104,27 @@ def _k1_epilogue(g, taps, up, pad4, act_ref=None, slope=0.0, scale=1.0, accumula
 
 
 class ResBlockFunction(Function):
+    """forward(x, w1, b1, w2, b2, ws, cfg[, w0, b0, scfg]): with a stem (w0 given) `x` is the STEM's input and the block
+    runs on lrelu(conv(x, w0) + b0) * scale."""
+
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, ws, cfg):
+    def forward(ctx, x, w1, b1, w2, b2, ws, cfg, w0=None, b0=None, scfg=None):
         ctx.set_materialize_grads(False)
-        n, c, h, w = x.shape
+        a0 = g0 = None
+        xin = x
+        if w0 is not None:
+            n0, c0, h0, wd0 = x.shape
+            g0 = _Geom(n0, c0, h0, wd0, w0.shape[0], scfg.k, 1, scfg.pad, False, scfg.alpha)
+            a0 = cg._launch_fused(g0, x, w0, b0, scfg.slope, scfg.scale)
+            xin = a0
+        n, c, h, w = xin.shape
         m = w2.shape[0]
         g1 = _Geom(n, c, h, w, c, 3, 1, 1, False, cfg.alpha1)
-        a1 = cg._launch_fused(g1, x, w1, b1, cfg.slope1, cfg.scale1)
+        a1 = cg._launch_fused(g1, xin, w1, b1, cfg.slope1, cfg.scale1)
         a1b = _upfirdn_run(a1, cfg.taps2, (1, 1), (1, 1), _pad4(cfg.pad2))
         g2 = _Geom(n, c, a1b.shape[2], a1b.shape[3], m, 3, 2, 0, False, cfg.alpha2)
         a2 = cg._launch_fused(g2, a1b, w2, b2, cfg.slope2, cfg.scale2)
-        s0 = _upfirdn_run(x, cfg.taps_s, (1, 1), (2, 2), _pad4(cfg.pad_s))
+        s0 = _upfirdn_run(xin, cfg.taps_s, (1, 1), (2, 2), _pad4(cfg.pad_s))
         gs = _Geom(n, c, s0.shape[2], s0.shape[3], m, 1, 1, 0, False, cfg.alpha_s)
         s1 = cg._fwd(s0, ws, gs)
         if s1.shape != a2.shape:
@@ -108,40 +132,42 @@ class ResBlockFunction(Function):
         lib = hip_lib.get()
         out = torch.empty_like(a2)
         lib.call("add_scale_f32", a2.data_ptr(), s1.data_ptr(), out.data_ptr(), a2.numel(), cfg.merge, lib.stream(a2))
-        ctx.cfg = cfg
-        ctx.geoms = (g1, g2, gs)
-        ctx.has_bias = (b1 is not None, b2 is not None)
-        ctx.save_for_backward(x, w1, b1, w2, b2, ws, a1, a1b, a2, s0)
+        ctx.cfg, ctx.scfg = cfg, scfg
+        ctx.geoms = (g1, g2, gs, g0)
+        ctx.has_bias = (b1 is not None, b2 is not None, b0 is not None)
+        ctx.save_for_backward(x, w1, b1, w2, b2, ws, a1, a1b, a2, s0, w0, b0, a0)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        x, w1, b1, w2, b2, ws, a1, a1b, a2, s0 = ctx.saved_tensors
-        cfg = ctx.cfg
-        need = ctx.needs_input_grad
+        x, w1, b1, w2, b2, ws, a1, a1b, a2, s0, w0, b0, a0 = ctx.saved_tensors
+        cfg, scfg = ctx.cfg, ctx.scfg
+        nargs = len(ctx.needs_input_grad)                     # 7 without a stem, 10 with one
+        need = tuple(ctx.needs_input_grad) + (False,) * (10 - nargs)
         wflag = _Flags.weight_grads
+        stem = w0 is not None
         if gout is None:     # undefined = zero: nothing for the activation, explicit zeros for the parameters
             def z(i, t):
                 return torch.zeros_like(t) if (t is not None and need[i] and wflag) else None
-            return None, z(1, w1), z(2, b1), z(3, w2), z(4, b2), z(5, ws), None
+            return (None, z(1, w1), z(2, b1), z(3, w2), z(4, b2), z(5, ws), None, z(7, w0), z(8, b0), None)[:nargs]
         if torch.is_grad_enabled():
             # create_graph=True (the R1 penalty): differentiate the composition of differentiable operators
-            params = [w1, b1, w2, b2, ws]
-            wanted = [0] if need[0] else []
-            wanted += [i + 1 for i, t in enumerate(params) if t is not None and need[i + 1] and wflag]
-            inputs = [([x] + params)[i] for i in wanted]
+            slots = {0: x, 1: w1, 2: b1, 3: w2, 4: b2, 5: ws, 7: w0, 8: b0}
+            wanted = [i for i, t in slots.items() if t is not None and need[i] and (i == 0 or wflag)]
             with torch.enable_grad():
-                out = resblock_composed(x, w1, b1, w2, b2, ws, cfg)
-                grads = torch.autograd.grad(out, inputs, gout, create_graph=True, allow_unused=True)
-            res = [None] * 7
+                xin = stem_composed(x, w0, b0, scfg) if stem else x
+                out = resblock_composed(xin, w1, b1, w2, b2, ws, cfg)
+                grads = torch.autograd.grad(out, [slots[i] for i in wanted], gout, create_graph=True, allow_unused=True)
+            res = [None] * 10
             for i, g in zip(wanted, grads):
                 res[i] = g
-            return tuple(res)
+            return tuple(res[:nargs])
 
-        g1, g2, gs = ctx.geoms
+        g1, g2, gs, g0 = ctx.geoms
+        xin = a0 if stem else x
         gout = gout.contiguous()
         c = cfg.merge
-        need_w = [need[i] and wflag for i in range(7)]
+        need_w = [need[i] and wflag for i in range(10)]
         # conv2 branch: activation backward with the merge factor folded into its scale, then dgrad / wgrad
         gp2, gb2 = bias_act_bwd_raw(gout, a2, cfg.slope2, cfg.scale2 * c)
         gw2 = cg.weight_grad(a1b, gp2, g2, w2) if need_w[3] else None
@@ -153,20 +179,34 @@ class ResBlockFunction(Function):
         adj2 = _adjoint_pad(tuple(a1.shape[2:]), tuple(a1b.shape[2:]), tuple(cfg.taps2.shape), (1, 1), (1, 1), pad2)
         gp1, gb1 = _k1_epilogue(g_a1b, _flipped(cfg.taps2), 1, adj2, act_ref=a1, slope=cfg.slope1, scale=cfg.scale1)
         del g_a1b
-        gw1 = cg.weight_grad(x, gp1, g1, w1) if need_w[1] else None
+        gw1 = cg.weight_grad(xin, gp1, g1, w1) if need_w[1] else None
         gb1 = gb1 if (ctx.has_bias[0] and need[2]) else None
         # skip branch (merge factor folded into alpha); its x2 zero-insert FIR accumulates into conv1's data gradient
         gs_c = _Geom(gs.n, gs.c, gs.h, gs.w, gs.m, gs.k, gs.stride, gs.pad, gs.cm_layout, gs.alpha * c)
         gws = cg.weight_grad(s0, gout, gs_c, ws) if need_w[5] else None
-        gx = None
-        if need[0]:
-            gx = cg._dgrad(gp1, w1, g1)
+        gx = gw0 = gb0 = None
+        need_stem = stem and (need[0] or need_w[7] or (need[8] and wflag))
+        if need_stem or (not stem and need[0]):
+            gin = cg._dgrad(gp1, w1, g1)
             g_s0 = cg._dgrad(gout, ws, gs_c)
             pad_s = _pad4(cfg.pad_s)
-            adj_s = _adjoint_pad(tuple(x.shape[2:]), tuple(s0.shape[2:]), tuple(cfg.taps_s.shape), (1, 1), (2, 2), pad_s)
-            _k1_epilogue(g_s0, _flipped(cfg.taps_s), 2, adj_s, accumulate_into=gx)
-        return gx, gw1, gb1, gw2, gb2, gws, None
+            adj_s = _adjoint_pad(tuple(xin.shape[2:]), tuple(s0.shape[2:]), tuple(cfg.taps_s.shape), (1, 1), (2, 2), pad_s)
+            if stem:
+                # ... and, when the block's input is the stem's activation, that activation's backward on the same pass:
+                # `gin` leaves the kernel as the gradient w.r.t. the stem's PRE-activation, with the stem's bias gradient
+                gp0, gb0 = _k1_epilogue(g_s0, _flipped(cfg.taps_s), 2, adj_s, accumulate_into=gin, act_ref=a0, slope=scfg.slope,
+                                        scale=scfg.scale)
+                gb0 = gb0 if (ctx.has_bias[2] and need[8] and wflag) else None
+                gw0 = cg.weight_grad(x, gp0, g0, w0) if need_w[7] else None
+                gx = cg._dgrad(gp0, w0, g0) if need[0] else None
+            else:
+                _k1_epilogue(g_s0, _flipped(cfg.taps_s), 2, adj_s, accumulate_into=gin)
+                gx = gin
+        return (gx, gw1, gb1, gw2, gb2, gws, None, gw0, gb0, None)[:nargs]
 
 
-def resblock(x, w1, b1, w2, b2, ws, cfg):
-    return ResBlockFunction.apply(x, w1, b1, w2, b2, ws, cfg)
+def resblock(x, w1, b1, w2, b2, ws, cfg, stem=None):
+    """stem: None or (w0, b0, StemConfig) -- x is then the stem's input."""
+    if stem is None:
+        return ResBlockFunction.apply(x, w1, b1, w2, b2, ws, cfg)
+    return ResBlockFunction.apply(x, w1, b1, w2, b2, ws, cfg, stem[0], stem[1], stem[2])

@@ -51,15 +51,18 @@ def test_under_a_launcher_it_is_the_worker(monkeypatch):
 
 def test_dominant_kernel_filter_follows_the_dispatch_rule():
     """bench.py counts a launch towards `roofline` only when the library runs it on the named instantiation
-    (csrc/conv2d.hip fwd_shape / launch_igemm): 128 x 128 tile, quad staging."""
+    (csrc/conv2d.hip fwd_shape / launch_igemm): the quad-staged 64 x 256 tile that wide layers take on maps >= 128 wide;
+    the 128 x 128 tile of the smaller maps is its own class."""
     import bench
-    f = bench._runs_quad_main_kernel
-    assert f(128, 256, 256, 256, 1)            # D 128 -> 128 @ 256^2
-    assert f(512, 16, 16, 16, 1)               # 512 @ 16^2: one 16 x 8 tile per image half
-    assert not f(512, 8, 8, 8, 1)              # 8 x 8 images: two per tile, 80 quads per channel -> dword staging
-    assert not f(64, 256, 256, 256, 1)         # 64 output channels: the 64 x 256 tile
-    assert not f(128, 258, 256, 256, 0)        # reflection-padded rows (258 floats): dword staging
-    assert not f(409, 64, 64, 64, 1)           # 409 channels pad 8 % less on the 64-row tile
+    f = bench._quad_gather_tile
+    assert f(128, 256, 256, 256, 1) == "64x256"          # D 128 -> 128 @ 256^2
+    assert f(256, 128, 128, 128, 1) == "64x256"
+    assert f(512, 64, 64, 64, 1) == "128x128"            # under 128 wide: the 128-row tile
+    assert f(512, 16, 16, 16, 1) == "128x128"            # 512 @ 16^2: one 16 x 8 tile per image half
+    assert f(512, 8, 8, 8, 1) is None                    # 8 x 8 images: two per tile, 80 quads per channel -> dword staging
+    assert f(64, 256, 256, 256, 1) is None               # 64 output channels: a narrow layer
+    assert f(128, 258, 256, 256, 0) is None              # reflection-padded rows (258 floats): dword staging
+    assert f(409, 64, 64, 64, 1) == "64x256"             # 409 channels pad 8 % less on the 64-row tile
 
 
 def test_pmc_record_of_another_kernel_is_refused(tmp_path, monkeypatch):
@@ -86,6 +89,10 @@ def test_kernel_class_of_a_launch():
     t.active = True
     g = cg._Geom(16, 128, 256, 256, 128, 3, 1, 1, False, 1.0)
     assert t.classify(cg, cg.SAE_CONV_FWD, g, False) == "dominant" and t.classify(cg, cg.SAE_CONV_DGRAD, g, False) == "dominant"
+    small = cg._Geom(16, 512, 64, 64, 512, 3, 1, 1, False, 1.0)       # maps under 128 wide keep the 128 x 128 tile
+    assert t.classify(cg, cg.SAE_CONV_FWD, small, False) == "s1_gather_128"
+    assert bench._quad_gather_tile(409, 128, 128, 128, 1) == "64x256" and bench._quad_gather_tile(409, 64, 64, 64, 1) == "64x256"
+    assert bench._quad_gather_tile(128, 130, 128, 128, 1) is None          # rows not a multiple of four floats
     assert t.classify(cg, cg.SAE_CONV_FWD, g, True) is None and t.classify(cg, cg.SAE_CONV_WGRAD, g, True) == "s1_wgrad"
     narrow = cg._Geom(128, 32, 128, 128, 32, 3, 1, 1, False, 1.0)
     assert t.classify(cg, cg.SAE_CONV_FWD, narrow, False) is None and t.classify(cg, cg.SAE_CONV_WGRAD, narrow, False) is None

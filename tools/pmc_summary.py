@@ -14,7 +14,7 @@ def short(n):
     return re.sub(r"\(.*", "", n)[:60]
 
 
-DOMINANT = "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"
+DOMINANT = "conv_igemm_kernel<3,1,2,2,1,4,8,false,true>"
 # tools/pmc_kernels.py's reference launch of it: 128 -> 128 3x3 @256x256, B = 16 (forward and stride-1 data gradient)
 DOMINANT_REF = {"gflop": 2.0 * 16 * 128 * 256 * 256 * 128 * 9 / 1e9, "algorithmic_bytes": 2.0 * 16 * 128 * 256 * 256 * 4,
                 "launch": "128 -> 128 3x3 stride 1 @256x256, B = 16 (tools/pmc_kernels.py)"}
