@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 3   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32 */
+#define SAE_ABI_VERSION 4   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -218,6 +218,15 @@ int sae_conv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2
  *   y = lrelu_{act_slope}(alpha * conv(x, w) + bias[m]) * act_scale          (bias may be NULL)   */
 int sae_conv2d_fwd_bias_act_f32(const float* x, const float* w, const float* bias, float* y,
                                 const sae_conv2d_desc* d, float alpha, float act_slope, float act_scale,
+                                float* workspace, int64_t workspace_floats, sae_stream_t stream);
+
+/* Forward conv with the residual merge of a ResBlock on its way out (stylegan2_layers.py:689, `(out + skip) / sqrt(2)`; the
+ * skip path's 1x1 conv adds the main branch's output and scales):
+ *     y = (alpha * conv(x, w) + residual) * res_scale          residual: y-shaped, 16-byte aligned, never y itself
+ * Bit-identical to sae_conv2d_fwd_f32 followed by sae_add_scale_f32 (the fp32 accumulator is the value the separate call
+ * would have stored).  3x3 problems under SAE_CONV_MATH_F32 only.  Workspace: sae_conv2d_workspace(d, SAE_CONV_FWD). */
+int sae_conv2d_fwd_residual_f32(const float* x, const float* w, const float* residual, float* y,
+                                const sae_conv2d_desc* d, float alpha, float res_scale,
                                 float* workspace, int64_t workspace_floats, sae_stream_t stream);
 int sae_conv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d,
                          float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);

@@ -39,7 +39,7 @@ typedef struct sae_conv2d_desc {
 
 static __thread char g_err[256];
 
-int oracle_abi_version(void) { return 3; }
+int oracle_abi_version(void) { return 4; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
@@ -50,6 +50,11 @@ int oracle_set_conv_math(int32_t mode) {
     return 0;
 }
 int oracle_get_conv_math(void) { return g_conv_math; }
+
+static int set_err_early(const char* msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return SAE_EINVAL;
+}
 
 /* upfirdn2d_kernel.cu:18-26 */
 static inline int64_t floor_div(int64_t a, int64_t b) {
@@ -470,6 +475,20 @@ int oracle_conv2d_fwd_bias_act_f32(const float* x, const float* w, const float* 
     if (rc != SAE_OK) return rc;
     int64_t hw = d->oh * d->ow;
     return oracle_bias_act_f32(y, bias, NULL, y, d->n * d->m * hw, hw, d->m, 3, 0, act_slope, act_scale, stream);
+}
+
+/* include/sae_hip.h sae_conv2d_fwd_residual_f32: ResBlock's skip conv followed by the merge `(out + skip) / math.sqrt(2)`
+ * (stylegan2_layers.py:683-689): the conv as oracle_conv2d_fwd_f32 (double accumulation, rounded to float as the separate
+ * call would store it), then (conv + residual) * res_scale in float. */
+int oracle_conv2d_fwd_residual_f32(const float* x, const float* w, const float* residual, float* y, const sae_conv2d_desc* d,
+                                   float alpha, float res_scale, float* workspace, int64_t workspace_floats,
+                                   sae_stream_t stream) {
+    if (!residual) return set_err_early("oracle_conv2d_fwd_residual_f32: null residual");
+    int rc = oracle_conv2d_fwd_f32(x, w, y, d, alpha, workspace, workspace_floats, stream);
+    if (rc != SAE_OK) return rc;
+    const int64_t numel = d->n * d->m * d->oh * d->ow;
+    for (int64_t i = 0; i < numel; ++i) y[i] = (y[i] + residual[i]) * res_scale;
+    return SAE_OK;
 }
 
 /* (out + skip) / sqrt(2), stylegan2_layers.py:689 / generator.py:36, as alpha * (a + b) in float. */

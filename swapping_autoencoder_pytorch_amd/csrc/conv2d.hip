@@ -134,6 +134,10 @@ struct IgemmParams {
     const float* bias;
     float act_slope, act_scale;
     int act;
+    // fused residual merge (forward only): y = (acc + residual[same index as y]) * res_scale when residual != null -- the
+    // (out + skip) / sqrt(2) of a ResBlock (stylegan2_layers.py:689) done by the skip path's 1x1 conv on its way out
+    const float* residual;
+    float res_scale;
     // style modulation of the INPUT (ModulatedConv2d, stylegan2_layers.py:280-286): when non-null, x[n][c][..] is
     // multiplied by in_scale[n * C + c] on its way into LDS, so the modulated activation never exists in HBM
     const float* in_scale;
@@ -530,8 +534,9 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                                 c[e] = ((t > 0.0f) ? t : t * p.act_slope) * p.act_scale;
                             }
                         }
-                        *reinterpret_cast<f32x4*>(y + (int64_t)blockIdx.z * p.slab_stride +
-                                                  (((int64_t)n * p.M + m) * p.YH + oy) * p.YW + ox) = c;
+                        const int64_t yi = (((int64_t)n * p.M + m) * p.YH + oy) * p.YW + ox;
+                        if (p.residual) c = (c + *reinterpret_cast<const f32x4*>(p.residual + yi)) * p.res_scale;
+                        *reinterpret_cast<f32x4*>(y + (int64_t)blockIdx.z * p.slab_stride + yi) = c;
                     }
                 }
             }
@@ -570,6 +575,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                             v += bv[mi][r];
                             v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
                         }
+                        if (p.residual)     // (only with oys == oxs == 1 and no K split: y and residual share indices)
+                            v = (v + p.residual[((int64_t)n * p.M * p.YH + oy) * p.YW + ox + (int64_t)m * p.YH * p.YW]) * p.res_scale;
                         yb[(int64_t)m * p.YH * p.YW] = v;
                     }
                 }
@@ -3058,7 +3065,8 @@ __global__ __launch_bounds__(kBlock) void conv_splitk_reduce_kernel(const float*
                                                                     int64_t slab_stride, int ksplit,
                                                                     const float* __restrict__ bias, int act,
                                                                     float act_slope, float act_scale, int hw,
-                                                                    int channels) {
+                                                                    int channels, const float* __restrict__ residual,
+                                                                    float res_scale) {
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel4; i += (int64_t)gridDim.x * kBlock) {
         f32x4 acc = *reinterpret_cast<const f32x4*>(slab + i * 4);
         for (int s = 1; s < ksplit; ++s) acc += *reinterpret_cast<const f32x4*>(slab + s * slab_stride + i * 4);
@@ -3070,6 +3078,7 @@ __global__ __launch_bounds__(kBlock) void conv_splitk_reduce_kernel(const float*
                 acc[e] = ((v > 0.0f) ? v : v * act_slope) * act_scale;
             }
         }
+        if (residual) acc = (acc + *reinterpret_cast<const f32x4*>(residual + i * 4)) * res_scale;
         *reinterpret_cast<f32x4*>(y + i * 4) = acc;
     }
 }
@@ -3380,7 +3389,7 @@ __global__ __launch_bounds__(kBlock) void conv1x1_thin_kernel(const float* __res
 }
 
 // forward-type gather producing `mout` channels from `cin` channels
-struct Epilogue { const float* bias; int act; float slope, scale; };
+struct Epilogue { const float* bias; int act; float slope, scale; const float* residual = nullptr; float res_scale = 1.0f; };
 
 int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int H, int W,
                int mout, int OH, int OW, int YH, int YW, int oys, int oxs, int ks, int stride, int pad, int64_t sm,
@@ -3391,7 +3400,10 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)g.ws_floats);
     // thin 1x1 layers (at most four channels on one side, e.g. FromRGB / ToRGB): streamed, see conv1x1_thin_kernel
     static const int thin_knob = tuning_knob("SAE_CONV_THIN", 1);
-    if (thin_knob && ks == 1 && stride == 1 && pad == 0 && oys == 1 && oxs == 1 && (cin <= 4 || mout <= 4) &&
+    if (ep.residual && (oys != 1 || oxs != 1 || YH != OH || YW != OW || g.bx || (reinterpret_cast<uintptr_t>(ep.residual) & 15) != 0))
+        return fail(SAE_EINVAL, "conv2d: the fused residual needs a dense, 16-byte aligned output-shaped tensor and the "
+                                "exact-fp32 kernels");
+    if (thin_knob && !ep.residual && ks == 1 && stride == 1 && pad == 0 && oys == 1 && oxs == 1 && (cin <= 4 || mout <= 4) &&
         H == OH && W == OW && YH == OH && YW == OW && ((int64_t)H * W) % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && N <= 65535) {
         ThinParams t{};
@@ -3418,12 +3430,15 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     p.in_scale = in_scale;
     static const int xcd_knob = tuning_knob("SAE_XCD_ORDER", 1);
     p.xcd_order = xcd_knob;
-    if (g.ksplit == 1) { p.bias = ep.bias; p.act = ep.act; p.act_slope = ep.slope; p.act_scale = ep.scale; }
+    if (g.ksplit == 1) {
+        p.bias = ep.bias; p.act = ep.act; p.act_slope = ep.slope; p.act_scale = ep.scale;
+        p.residual = ep.residual; p.res_scale = ep.res_scale;
+    }
     float* out = (g.ksplit > 1) ? ws + g.wp_floats : y;
     static const int vec_knob = tuning_knob("SAE_IGEMM_VEC_STORE", 1);
     // measured (tools/ab_conv.py): +2.5 % with K loops of 64 chunks (512 channels), -1 % with 16 or 32: long loops only
     p.vec_store = vec_knob && oys == 1 && oxs == 1 && OW % 4 == 0 && YW % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
-                  (vec_knob > 1 || g.cps >= 48 || ep.act);   // with the fused bias + leaky-ReLU also for short loops: the scalar
+                  (vec_knob > 1 || g.cps >= 48 || ep.act || ep.residual);   // with a fused epilogue also for short loops: the scalar
                                                              // epilogue fetches the bias per element (tools/instep_gap.py: 122.6 vs
                                                              // 127.9 TFLOP/s at 128 -> 128 @256^2, 129.0 vs 131.8 at 256 @128^2)
     int rc;
@@ -3441,7 +3456,7 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
         if (n4 > 0)
             hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s,
                                (const float*)out, y, n4, g.out_floats4, g.ksplit, ep.bias, ep.act, ep.slope, ep.scale,
-                               OH * OW, mout);
+                               OH * OW, mout, ep.residual, ep.res_scale);
     }
     return SAE_OK;
 }
@@ -3747,6 +3762,25 @@ extern "C" int sae_conv2d_fwd_bias_act_f32(const float* x, const float* w, const
                         d->w_stride_m, d->w_stride_c, 0, alpha, s, Epilogue{bias, 1, act_slope, act_scale});
     if (rc != SAE_OK) return rc;
     return check_launch("sae_conv2d_fwd_bias_act_f32");
+}
+
+extern "C" int sae_conv2d_fwd_residual_f32(const float* x, const float* w, const float* residual, float* y,
+                                           const sae_conv2d_desc* d, float alpha, float res_scale, float* workspace,
+                                           int64_t workspace_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (!desc_ok(d, "sae_conv2d_fwd_residual_f32")) return SAE_EINVAL;
+    if (d->n == 0) return SAE_OK;
+    if (!x || !w || !y || !residual) return fail(SAE_EINVAL, "sae_conv2d_fwd_residual_f32: null tensor");
+    if (conv_math() != 0 && d->kh == 3)
+        return fail(SAE_EINVAL, "sae_conv2d_fwd_residual_f32: 3x3 convolutions fuse the residual under SAE_CONV_MATH_F32 only");
+    hipStream_t s = (hipStream_t)stream;
+    Epilogue ep{nullptr, 0, 0.0f, 1.0f};
+    ep.residual = residual; ep.res_scale = res_scale;
+    int rc = run_gather(x, w, y, workspace, workspace_floats, (int)d->n, (int)d->c, (int)d->h, (int)d->w, (int)d->m,
+                        (int)d->oh, (int)d->ow, (int)d->oh, (int)d->ow, 1, 1, d->kh, d->stride, d->pad,
+                        d->w_stride_m, d->w_stride_c, 0, alpha, s, ep);
+    if (rc != SAE_OK) return rc;
+    return check_launch("sae_conv2d_fwd_residual_f32");
 }
 
 namespace {

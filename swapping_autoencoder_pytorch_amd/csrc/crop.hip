@@ -84,20 +84,27 @@ __global__ __launch_bounds__(kBlock) void random_crop_bwd_kernel(const float* __
                                                                  const float* __restrict__ params,
                                                                  const float* __restrict__ lin,
                                                                  float* __restrict__ gx, const CropGeom q) {
+    // The crop geometry (candidate ranges, bilinear weights) depends on the pixel and the crop only: it is worked out once
+    // and applied to up to kCropCh channels at a time (images have 3); per channel the terms are added in the same
+    // (crop, row, column) order as before, so the result is unchanged.
+    constexpr int kCropCh = 4;
     const int64_t total = (int64_t)q.images * q.h * q.w;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int px = (int)(i % q.w);
         const int py = (int)((i / q.w) % q.h);
         const int b = (int)(i / ((int64_t)q.w * q.h));
-        for (int ch = 0; ch < q.channels; ++ch) {
-            float acc = 0.0f;
+        for (int ch0 = 0; ch0 < q.channels; ch0 += kCropCh) {
+            const int nch = q.channels - ch0 < kCropCh ? q.channels - ch0 : kCropCh;
+            float acc[kCropCh] = {0.0f, 0.0f, 0.0f, 0.0f};
             for (int kc = 0; kc < q.crops; ++kc) {
                 const int64_t k = (int64_t)b * q.crops + kc;
                 const float* pr = params + 5 * k;
                 int c_lo, c_hi, r_lo, r_hi;
                 crop_range((float)px, pr[0] * pr[1], pr[3], q.w, q.size, &c_lo, &c_hi);
+                if (c_lo > c_hi) continue;
                 crop_range((float)py, pr[2], pr[4], q.h, q.size, &r_lo, &r_hi);
-                const float* gp = gy + (k * q.channels + ch) * q.size * q.size;
+                const int64_t plane = (int64_t)q.size * q.size;
+                const float* gp = gy + (k * q.channels + ch0) * plane;
                 for (int r = r_lo; r <= r_hi; ++r) {
                     const float iy = crop_coord(lin[r], pr[2], pr[4], q.h);
                     const float fy = floorf(iy);
@@ -114,11 +121,16 @@ __global__ __launch_bounds__(kBlock) void random_crop_bwd_kernel(const float* __
                         if (x0 == px) wx = (fx + 1.0f) - ix;
                         else if (x0 + 1 == px) wx = ix - fx;
                         else continue;
-                        acc += gp[r * q.size + c] * (wx * wy);
+                        const float wgt = wx * wy;
+#pragma unroll
+                        for (int e = 0; e < kCropCh; ++e)
+                            if (e < nch) acc[e] += gp[e * plane + r * q.size + c] * wgt;
                     }
                 }
             }
-            gx[((int64_t)b * q.channels + ch) * q.h * q.w + (int64_t)py * q.w + px] = acc;
+#pragma unroll
+            for (int e = 0; e < kCropCh; ++e)
+                if (e < nch) gx[((int64_t)b * q.channels + ch0 + e) * q.h * q.w + (int64_t)py * q.w + px] = acc[e];
         }
     }
 }

@@ -42,7 +42,7 @@ class ConvMod(C.Structure):
     _fields_ = [("x_scale", C.c_void_p), ("y_scale", C.c_void_p), ("wm_scale", C.c_void_p), ("wc_scale", C.c_void_p)]
 
 
-ABI_VERSION = 3      # include/sae_hip.h: SAE_ABI_VERSION
+ABI_VERSION = 4      # include/sae_hip.h: SAE_ABI_VERSION
 
 _SIGNATURES = {
     "abi_version": (C.c_int, []),
@@ -70,6 +70,7 @@ _SIGNATURES = {
     "conv2d_fwd_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "conv2d_fwd_bias_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32, _f32, _f32p, _i64,
                                           _stream]),
+    "conv2d_fwd_residual_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32, _f32p, _i64, _stream]),
     "conv2d_dgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "conv2d_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "modconv2d_fwd_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),

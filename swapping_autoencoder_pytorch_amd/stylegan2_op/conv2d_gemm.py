@@ -101,6 +101,25 @@ def _launch_fused(geom, x, w, bias, slope, scale):
     return out
 
 
+def _launch_residual(geom, x, w, residual, res_scale):
+    """(alpha * conv(x, w) + residual) * res_scale in one kernel (sae_conv2d_fwd_residual_f32)."""
+    lib = hip_lib.get()
+    x = x.contiguous()
+    w = w.contiguous()
+    residual = residual.contiguous()
+    lib.check(x, w, residual)
+    if tuple(residual.shape) != (geom.n, geom.m, geom.oh, geom.ow):
+        raise hip_lib.SaeError("conv + residual: residual %s, output (%d, %d, %d, %d)" % (
+            tuple(residual.shape), geom.n, geom.m, geom.oh, geom.ow))
+    d = geom.desc()
+    n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
+    out = torch.empty_like(residual)
+    lib.call("conv2d_fwd_residual_f32", x.data_ptr(), w.data_ptr(), residual.data_ptr(), out.data_ptr(), C.byref(d), geom.alpha,
+             float(res_scale), ws.data_ptr(), n_ws, lib.stream(x))
+    return out
+
+
 def _fwd(x, w, g):
     return _launch("conv2d_fwd_f32", SAE_CONV_FWD, g, x, w, (g.n, g.m, g.oh, g.ow))
 

@@ -12,11 +12,14 @@ for elementwise work between the kernels (profiles/r2_roofline_by_kernel_church2
 * the two gradients of the block input (conv1's data gradient and the skip path's) are summed inside the skip path's
   last kernel (the x2 zero-insert FIR accumulates into conv1's data gradient) instead of by a separate ``add_``;
 * the 1/sqrt(2) of the residual merge is folded into the constants of the kernels that consume the output gradient
-  (conv2's activation backward, the skip conv's alpha) instead of a pass of its own.
+  (conv2's activation backward, the skip conv's alpha) instead of a pass of its own;
+* (forward) the merge itself rides in the skip path's 1x1 conv (sae_conv2d_fwd_residual_f32).
 
 The node stays twice differentiable (the R1 penalty differentiates D and Dpatch twice, swapping_autoencoder_model.py:
-143-174): when backward runs with create_graph=True it re-expresses the block with the differentiable operators of this
-package and lets autograd differentiate that (one extra forward of the block, only on the lazy-R1 iterations).
+143-174): when backward runs with create_graph=True and only the input gradient is wanted (the R1 pattern) it chains the
+package's differentiable backward operators on the saved activations -- what autograd does for the module-by-module path,
+no recomputation; with weight gradients in the graph it re-expresses the block with the differentiable forward operators
+and lets autograd differentiate that.
 """
 import math
 
@@ -103,6 +106,34 @@ def _k1_epilogue(g, taps, up, pad4, act_ref=None, slope=0.0, scale=1.0, accumula
     return y, gb
 
 
+def _input_grad_graph(ctx, gout, nargs, need):
+    """Differentiable input gradient of the block (and stem) from the saved activations: the operators autograd itself
+    would chain for the module-by-module path (FusedLeakyReLUFunctionBackward, ConvDataGrad, UpFirDn2dBackward)."""
+    from .fused_act import FusedLeakyReLUFunctionBackward
+    from .upfirdn2d import UpFirDn2dBackward
+    x, w1, b1, w2, b2, ws, a1, a1b, a2, s0, w0, b0, a0 = ctx.saved_tensors
+    cfg, scfg = ctx.cfg, ctx.scfg
+    g1, g2, gs, g0 = ctx.geoms
+    res = [None] * 10
+    if not need[0]:
+        return tuple(res[:nargs])
+    xin = a0 if w0 is not None else x
+    g = gout * cfg.merge
+    gp2, _ = FusedLeakyReLUFunctionBackward.apply(g, a2, cfg.slope2, cfg.scale2)
+    g_a1b = cg.ConvDataGrad.apply(gp2, w2, g2)
+    g_a1 = UpFirDn2dBackward.apply(g_a1b, cfg.taps2, (1, 1), (1, 1), _pad4(cfg.pad2), tuple(a1.shape[2:]), tuple(a1b.shape[2:]))
+    gp1, _ = FusedLeakyReLUFunctionBackward.apply(g_a1, a1, cfg.slope1, cfg.scale1)
+    gin = cg.ConvDataGrad.apply(gp1, w1, g1)
+    g_s0 = cg.ConvDataGrad.apply(g, ws, gs)
+    gin = gin + UpFirDn2dBackward.apply(g_s0, cfg.taps_s, (1, 1), (2, 2), _pad4(cfg.pad_s), tuple(xin.shape[2:]),
+                                        tuple(s0.shape[2:]))
+    if w0 is not None:
+        gp0, _ = FusedLeakyReLUFunctionBackward.apply(gin, a0, scfg.slope, scfg.scale)
+        gin = cg.ConvDataGrad.apply(gp0, w0, g0)
+    res[0] = gin
+    return tuple(res[:nargs])
+
+
 class ResBlockFunction(Function):
     """forward(x, w1, b1, w2, b2, ws, cfg[, w0, b0, scfg]): with a stem (w0 given) `x` is the STEM's input and the block
     runs on lrelu(conv(x, w0) + b0) * scale."""
@@ -126,12 +157,11 @@ class ResBlockFunction(Function):
         a2 = cg._launch_fused(g2, a1b, w2, b2, cfg.slope2, cfg.scale2)
         s0 = _upfirdn_run(xin, cfg.taps_s, (1, 1), (2, 2), _pad4(cfg.pad_s))
         gs = _Geom(n, c, s0.shape[2], s0.shape[3], m, 1, 1, 0, False, cfg.alpha_s)
-        s1 = cg._fwd(s0, ws, gs)
-        if s1.shape != a2.shape:
-            raise hip_lib.SaeError("ResBlock: branches disagree, %s vs %s" % (tuple(a2.shape), tuple(s1.shape)))
-        lib = hip_lib.get()
-        out = torch.empty_like(a2)
-        lib.call("add_scale_f32", a2.data_ptr(), s1.data_ptr(), out.data_ptr(), a2.numel(), cfg.merge, lib.stream(a2))
+        if (gs.n, gs.m, gs.oh, gs.ow) != tuple(a2.shape):
+            raise hip_lib.SaeError("ResBlock: branches disagree, %s vs %s" % (tuple(a2.shape), (gs.n, gs.m, gs.oh, gs.ow)))
+        # the skip path's 1x1 conv adds the main branch and applies 1 / sqrt(2) on its way out (no separate merge pass,
+        # the skip branch's own output never exists in HBM); bit-identical to conv, then add_scale
+        out = cg._launch_residual(gs, s0, ws, a2, cfg.merge)
         ctx.cfg, ctx.scfg = cfg, scfg
         ctx.geoms = (g1, g2, gs, g0)
         ctx.has_bias = (b1 is not None, b2 is not None, b0 is not None)
@@ -150,8 +180,15 @@ class ResBlockFunction(Function):
             def z(i, t):
                 return torch.zeros_like(t) if (t is not None and need[i] and wflag) else None
             return (None, z(1, w1), z(2, b1), z(3, w2), z(4, b2), z(5, ws), None, z(7, w0), z(8, b0), None)[:nargs]
+        if torch.is_grad_enabled() and not wflag:
+            # create_graph=True inside input_grads_only() -- the R1 penalty's first backward (swapping_autoencoder_model.py:
+            # 143-148): only the INPUT gradient is wanted.  It depends on the activations through the leaky-ReLU masks alone
+            # (piecewise constant), so the chain of differentiable backward operators on the SAVED activations is exact and
+            # nothing has to be recomputed; the graph it records reaches the weights and the incoming gradient.
+            return _input_grad_graph(ctx, gout, nargs, need)
         if torch.is_grad_enabled():
-            # create_graph=True (the R1 penalty): differentiate the composition of differentiable operators
+            # create_graph=True with weight gradients in the graph: differentiate the composition of differentiable
+            # operators (one extra forward of the block; no training path takes this branch)
             slots = {0: x, 1: w1, 2: b1, 3: w2, 4: b2, 5: ws, 7: w0, 8: b0}
             wanted = [i for i, t in slots.items() if t is not None and need[i] and (i == 0 or wflag)]
             with torch.enable_grad():

@@ -121,6 +121,14 @@ def conv_bias_act(lib, d, x, w, bias, alpha=1.0, slope=0.2, scale=2 ** 0.5, devi
     return bo.numpy()
 
 
+def conv_residual(lib, d, x, w, residual, alpha=1.0, res_scale=0.5, device=None):
+    nws = lib.query("conv2d_workspace", C.byref(d), 0)
+    bx, bw, br = _Buf(x, device), _Buf(w, device), _Buf(residual, device)
+    by, ws = _out(residual.shape, device), _out((max(nws, 1),), device)
+    lib.call("conv2d_fwd_residual_f32", bx.ptr, bw.ptr, br.ptr, by.ptr, C.byref(d), alpha, res_scale, ws.ptr, nws, _stream(device))
+    return by.numpy()
+
+
 def gemm(lib, a, b, bias, m, n, k, a_si, a_sk, b_sk, b_sj, alpha=1.0, device=None):
     ba, bb = _Buf(a, device), _Buf(b, device)
     bbias = _Buf(bias, device) if bias is not None else None

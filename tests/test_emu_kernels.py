@@ -184,6 +184,32 @@ def test_conv2d_bias_act(emu_lib, oracle_lib, case):
         assert H.rel_err(e, o) < TOL
 
 
+# sae_conv2d_fwd_residual_f32: 1x1 skip convs on every tile (128 / 64 / 32 rows, quad and dword staging, scalar and vector
+# epilogue, split-K), odd sizes, a 3x3 case; (n, c, h, w, m, k, stride, pad)
+CONV_RESIDUAL = [(2, 40, 8, 8, 70, 1, 1, 0), (1, 70, 16, 16, 130, 1, 1, 0), (2, 33, 7, 9, 20, 1, 1, 0), (1, 256, 4, 4, 40, 1, 1, 0),
+                 (3, 12, 12, 20, 24, 1, 1, 0), (1, 9, 20, 36, 70, 3, 1, 1), (2, 8, 9, 9, 32, 3, 2, 0)]
+
+
+def conv_residual_case(lib, oracle_lib, case, device=None):
+    """Against the oracle, and BIT-identical to the same library's conv followed by its add_scale."""
+    n, c, h, w, m, k, s, p = case
+    d = H.conv_desc(n, c, h, w, m, k, s, p)
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    wt = rng.standard_normal((m, c, k, k)).astype(np.float32)
+    res = rng.standard_normal((n, m, d.oh, d.ow)).astype(np.float32)
+    e = H.conv_residual(lib, d, x, wt, res, alpha=0.23, res_scale=0.7071, device=device)
+    o = H.conv_residual(oracle_lib, d, x, wt, res, alpha=0.23, res_scale=0.7071)
+    assert not np.isnan(e).any() and H.rel_err(e, o) < TOL
+    plain = H.conv(lib, 0, d, x, wt, res.shape, alpha=0.23, device=device)
+    assert np.array_equal(e, ((plain + res) * np.float32(0.7071)).astype(np.float32))
+
+
+@pytest.mark.parametrize("case", CONV_RESIDUAL, ids=str)
+def test_conv2d_residual(emu_lib, oracle_lib, case):
+    conv_residual_case(emu_lib, oracle_lib, case)
+
+
 GLUE_SHAPES = [(2, 5, 16, 16), (3, 8, 4, 8), (1, 70, 32, 36), (4, 3, 2, 2), (2, 600, 8, 8)]
 
 

@@ -42,6 +42,15 @@ def test_upfirdn2d(hip_lib, oracle_lib, case):
     assert H.rel_err(a, o) < TOL
 
 
+@pytest.mark.parametrize("case", [(4, 128, 64, 64, 256, 1, 1, 0), (2, 512, 16, 16, 512, 1, 1, 0), (8, 32, 64, 64, 64, 1, 1, 0),
+                                  (2, 128, 32, 32, 128, 3, 1, 1)], ids=str)
+def test_conv2d_residual(hip_lib, oracle_lib, case):
+    from test_emu_kernels import CONV_RESIDUAL, conv_residual_case
+    conv_residual_case(hip_lib, oracle_lib, case, device=DEV)
+    for small in CONV_RESIDUAL[:3]:
+        conv_residual_case(hip_lib, oracle_lib, small, device=DEV)
+
+
 @pytest.mark.parametrize("case", K1_EPILOGUE + [(2, 16, 129, 129, 4, 1, (1, 1, 1, 1)), (2, 8, 64, 64, 4, 2, (2, 1, 2, 1)),
                                                   (300, 8, 5, 5, 4, 1, (1, 1, 1, 1))], ids=str)
 def test_upfirdn2d_epilogue(hip_lib, oracle_lib, case):

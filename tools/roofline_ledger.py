@@ -34,8 +34,9 @@ def _desc(arg):
 def work_of(name, a):
     """(class label, bound, algorithmic work: FLOPs for 'mfma', bytes for 'hbm')"""
     if (name.startswith("conv2d_") and name != "conv2d_workspace") or name.startswith("modconv2d_"):
-        d = _desc(a[4] if name == "conv2d_fwd_bias_act_f32" else a[3])
-        op = {"conv2d_fwd_f32": "fwd", "conv2d_fwd_bias_act_f32": "fwd+bias+lrelu", "conv2d_dgrad_f32": "dgrad",
+        d = _desc(a[4] if name in ("conv2d_fwd_bias_act_f32", "conv2d_fwd_residual_f32") else a[3])
+        op = {"conv2d_fwd_f32": "fwd", "conv2d_fwd_bias_act_f32": "fwd+bias+lrelu", "conv2d_fwd_residual_f32": "fwd+residual",
+              "conv2d_dgrad_f32": "dgrad",
               "conv2d_wgrad_f32": "wgrad", "modconv2d_fwd_f32": "fwd (modulated)", "modconv2d_dgrad_f32": "dgrad (modulated)",
               "modconv2d_wgrad_f32": "wgrad (modulated)"}[name]
         width = "narrow(<=64ch)" if max(d.m if op.startswith("fwd") else d.c, 1) <= 64 else "wide"
