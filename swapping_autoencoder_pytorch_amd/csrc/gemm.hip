@@ -30,6 +30,47 @@ __device__ __forceinline__ void stage_panel(float* dst, const float* __restrict_
                                             int64_t k0, int64_t kmax, int64_t s_row, int64_t s_k, int t) {
     constexpr int NE = ROWS * kKc / NTHREADS;     // loads per thread, all issued before the LDS writes
     static_assert(ROWS * kKc % NTHREADS == 0, "panel must divide evenly");
+    // 16-byte loads whenever the unit-stride axis allows (panel fully inside the matrix, strides and base a multiple of four
+    // floats): a quarter of the vector-memory instructions -- the skinny products of the linear layers issue two loads per
+    // MFMA otherwise and are bound by exactly that
+    if constexpr (NE % 4 == 0) {
+        constexpr int NQ = NE / 4;
+        const bool inside = row0 + ROWS <= rows && k0 + kKc <= kmax && (reinterpret_cast<uintptr_t>(src) & 15) == 0;
+        if (inside && s_k == 1 && (s_row & 3) == 0 && (k0 & 3) == 0) {          // k contiguous: quads of four k
+            f32x4 q[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int e = t + i * NTHREADS;
+                const int r = e / (kKc / 4), kq = e - r * (kKc / 4);
+                q[i] = *reinterpret_cast<const f32x4*>(src + (row0 + r) * s_row + k0 + 4 * kq);
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int e = t + i * NTHREADS;
+                const int r = e / (kKc / 4), kq = e - r * (kKc / 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[(4 * kq + j) * LD + r] = q[i][j];
+            }
+            return;
+        }
+        if (inside && s_row == 1 && (s_k & 3) == 0 && (row0 & 3) == 0) {        // rows contiguous: quads of four rows
+            f32x4 q[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int e = t + i * NTHREADS;
+                const int kk = e / (ROWS / 4), rq = e - kk * (ROWS / 4);
+                q[i] = *reinterpret_cast<const f32x4*>(src + (row0 + 4 * rq) + (k0 + kk) * s_k);
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int e = t + i * NTHREADS;
+                const int kk = e / (ROWS / 4), rq = e - kk * (ROWS / 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dst[kk * LD + 4 * rq + j] = q[i][j];
+            }
+            return;
+        }
+    }
     float v[NE];
     if (s_k == 1) {   // k contiguous in memory: lanes walk k
 #pragma unroll

@@ -190,6 +190,10 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
 #pragma unroll
         for (int b = 0; b < KW; ++b) tap[a][b] = taps[a * KW + b];
 
+    // (measured and dropped, same-box A/B with tools/kb_k1.py: the rows accumulated in pairs as packed fp32, v_pk_fma_f32
+    // with the staged value broadcast against a pair of taps held in scalar registers -- 20 instead of 32 vector
+    // instructions per pair of outputs and 54 instead of 67 VGPRs, yet 3.13 vs 3.46 TB/s at 256^2 and 4.10 vs 4.33 at
+    // 257 -> 256: the kernel is not bound by its FMA issue)
     float acc[RB];
 #pragma unroll
     for (int o = 0; o < RB; ++o) acc[o] = 0.0f;

@@ -96,4 +96,6 @@ CONV_GPU = CONV_SMALL + [
     (3, 96, 4, 4, 48, 3, 1, 0, False),         # Dpatch final valid conv 4x4 -> 2x2
 ]
 
-GEMM_CASES = [(16, 40, 300), (128, 70, 64), (5, 3, 1000), (70, 130, 33), (33, 200, 513)]
+GEMM_CASES = [(16, 40, 300), (128, 70, 64), (5, 3, 1000), (70, 130, 33), (33, 200, 513),
+              # aligned shapes: the 16-byte staging loads of both orientations (64 x 64 tile and the split-K 32 x 32 tile)
+              (128, 256, 512), (64, 64, 96), (32, 128, 2048), (160, 96, 64)]

@@ -15,6 +15,8 @@ from swapping_autoencoder_pytorch_amd import hip_lib as L  # noqa: E402
 import abi_harness as H  # noqa: E402
 
 dev = torch.device("cuda:0")
+if os.environ.get("KB_LIBRARY"):        # A/B against a variant build (tools/variants/*.so); default: the product library
+    L._LIB = L.SaeLibrary(os.path.abspath(os.environ["KB_LIBRARY"]))
 lib = L.get()
 quick = "--quick" in sys.argv
 

@@ -52,6 +52,8 @@ def work_of(name, a):
         return "adam (multi-tensor)", "hbm", 28.0 * numel
     if name == "gemm_f32":
         m, n, k = a[4], a[5], a[6]
+        if BY_SHAPE:
+            return "gemm (linear layers) m%-5d n%-5d k%-5d" % (m, n, k), "mfma", 2.0 * m * n * k
         return "gemm (linear layers)", "mfma", 2.0 * m * n * k
     if name == "upfirdn2d_epilogue_f32":
         major, ih, iw, kh, kw, up, px0, px1, py0, py1 = a[3:13]
