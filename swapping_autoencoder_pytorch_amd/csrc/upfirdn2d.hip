@@ -97,6 +97,16 @@ __device__ __forceinline__ void k1_epilogue(const K1Epilogue& e, const K1Operand
     }
 }
 
+// XCD-aware workgroup order.  Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2; the
+// strips of neighbouring workgroups share halo rows (3 of 11 staged rows at 8 rows per thread) and the 128-byte lines that
+// straddle the 64-column tile boundaries of the 2^k + 1 wide rows, so in launch order every XCD fetched its own copy: 1102 MB
+// read from HBM for 537 MB of input (blur 256^2 -> 257^2, profiles/r3_pmc_f32.txt), i.e. the kernel sat at the HBM roof with
+// 1.6x its algorithmic traffic.  XCD k now takes the k-th contiguous eighth of the workgroup list.
+__device__ __forceinline__ int64_t k1_block_id() {
+    const int64_t per = gridDim.x >> 3;          // the host rounds the grid up to a multiple of 8
+    return (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+
 struct BlurParams {
     int64_t planes;
     int in_h, in_w, out_h, out_w;
@@ -105,6 +115,7 @@ struct BlurParams {
     int groups_per_plane;  // ceil(out_h / RB)
     int x_tiles;           // ceil(out_w / TW)
     int64_t groups;        // planes * groups_per_plane
+    int64_t blocks;        // workgroups that have work (the grid is rounded up to a multiple of 8, see k1_block_id)
 };
 
 template <int KH, int KW, int TW, int RB, bool EPI = false>
@@ -129,7 +140,8 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
         taps[threadIdx.x] = v;
     }
 
-    const int64_t bid = blockIdx.x;
+    const int64_t bid = k1_block_id();
+    if (bid >= p.blocks) return;                    // (whole workgroup: the grid's padding to a multiple of 8)
     const int xt = (int)(bid % p.x_tiles);
     const int64_t g = (bid / p.x_tiles) * NR + tr;  // strip (row group) handled by this thread row
     const bool live = g < p.groups;
@@ -283,6 +295,7 @@ struct UpDownParams {
     int kh, kw;
     int groups_per_plane, x_tiles;
     int64_t groups;
+    int64_t blocks;
 };
 
 template <int UP, int DOWN, int KH, int KW, int TW, int RB, bool EPI = false>
@@ -303,7 +316,8 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
         if (ky < p.kh && kx < p.kw) v = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
         taps[threadIdx.x] = v;
     }
-    const int64_t bid = blockIdx.x;
+    const int64_t bid = k1_block_id();
+    if (bid >= p.blocks) return;
     const int xt = (int)(bid % p.x_tiles);
     const int64_t g = (bid / p.x_tiles) * NR + tr;
     const bool live = g < p.groups;
@@ -399,8 +413,9 @@ void launch_updown(const float* x, const float* k, float* y, UpDownParams p, hip
     p.groups_per_plane = ceil_div(p.out_h, RB);
     p.x_tiles = ceil_div(p.out_w, TW);
     p.groups = p.planes * p.groups_per_plane;
-    const int64_t blocks = ceil_div64(p.groups, NR) * p.x_tiles;
-    hipLaunchKernelGGL((updown_kernel<UP, DOWN, 4, 4, TW, RB, EPI>), dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, p, e);
+    p.blocks = ceil_div64(p.groups, NR) * p.x_tiles;
+    hipLaunchKernelGGL((updown_kernel<UP, DOWN, 4, 4, TW, RB, EPI>), dim3((unsigned)((p.blocks + 7) / 8 * 8)), dim3(kBlock), 0, s,
+                       x, k, y, p, e);
 }
 
 template <int KH, int KW, int TW, int RB, bool EPI = false>
@@ -409,8 +424,9 @@ void launch_blur(const float* x, const float* k, float* y, BlurParams p, hipStre
     p.groups_per_plane = ceil_div(p.out_h, RB);
     p.x_tiles = ceil_div(p.out_w, TW);
     p.groups = p.planes * p.groups_per_plane;
-    const int64_t blocks = ceil_div64(p.groups, NR) * p.x_tiles;
-    hipLaunchKernelGGL((blur_kernel<KH, KW, TW, RB, EPI>), dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, p, e);
+    p.blocks = ceil_div64(p.groups, NR) * p.x_tiles;
+    hipLaunchKernelGGL((blur_kernel<KH, KW, TW, RB, EPI>), dim3((unsigned)((p.blocks + 7) / 8 * 8)), dim3(kBlock), 0, s, x, k, y,
+                       p, e);
 }
 
 // tile of the planes kernels: width from the output width, rows per thread from the output height (blur: 8 rows per thread
