@@ -3,8 +3,11 @@
 Stands where the reference constructs ``torch.optim.Adam(params, lr=..., betas=(beta1, beta2))``
 (optimizers/swapping_autoencoder_optimizer.py:34-42) and steps it (:77,:95,:107): same constructor arguments,
 same ``state_dict`` layout (``step`` / ``exp_avg`` / ``exp_avg_sq`` per parameter, so optimiser checkpoints move
-between the two), same update.  One call to ``step`` issues a handful of launches for the whole parameter list
-(226 tensors per group at the church preset) instead of ATen's per-tensor elementwise chains.
+between the two), same update rule.  Not bit-identical to ATen's: the kernel multiplies sqrt(v) by a host-computed
+1 / sqrt(bias_correction2) where torch divides by sqrt(bias_correction2) -- an ulp-level difference per step
+(tests/test_adam.py holds the two to 2e-7 relative over several steps).  One call to ``step`` issues a handful of
+launches for the whole parameter list (226 tensors per group at the church preset) instead of ATen's per-tensor
+elementwise chains.  The per-parameter step counters advance only after the launch was accepted.
 
 ``step(grad_views=..., grad_scale=...)`` lets the gradient all-reduce hand over its flat buckets directly: the
 kernel reads the summed gradients where RCCL left them and applies the 1 / world_size itself, which removes the
@@ -58,11 +61,10 @@ class FusedAdam(torch.optim.Optimizer):
                     raise hip_lib.SaeError("FusedAdam needs contiguous parameters")
                 g = g.contiguous()
                 st = self._state_of(p)
-                st["step"] += 1
                 lib.check(p, g, st["exp_avg"], st["exp_avg_sq"])
                 ps.append(p.data_ptr()); gs.append(g.data_ptr()); ms.append(st["exp_avg"].data_ptr())
-                vs.append(st["exp_avg_sq"].data_ptr()); ns.append(p.numel()); steps.append(int(st["step"].item()))
-                keep.append(g)
+                vs.append(st["exp_avg_sq"].data_ptr()); ns.append(p.numel()); steps.append(int(st["step"].item()) + 1)
+                keep.append((g, st))
             if not ps:
                 continue
             n = len(ps)
@@ -71,4 +73,6 @@ class FusedAdam(torch.optim.Optimizer):
             beta1, beta2 = group["betas"]
             lib.call("adam_multi_f32", arr_p, arr_g, arr_m, arr_v, arr_n, arr_s, n, float(group["lr"]), float(beta1),
                      float(beta2), float(group["eps"]), float(grad_scale), lib.stream(group["params"][0]))
+            for _, st in keep:           # the step counters advance only once the launch was accepted
+                st["step"] += 1
         return loss

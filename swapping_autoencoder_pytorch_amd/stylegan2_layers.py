@@ -229,6 +229,10 @@ class ModulatedConv2d(nn.Module):
             # ONE kernel per operation: style factor folded into the conv's operand staging, demodulation into its
             # weight re-layout (stylegan2_op.conv2d_gemm.ModulatedConv).  Under the bf16x6 arithmetic the operand
             # staging does not take activation factors yet: the two-step path below runs there.
+            # LIMITATION: this fused node is differentiable ONCE (ModulatedConv.backward is @once_differentiable); the
+            # two-step path below is closed under differentiation.  The train step never differentiates the generator
+            # twice (the R1 penalties touch D and Dpatch only); a second-order gradient through G needs
+            # SAE_MODCONV_FUSED=0 (or SAE_CONV_MATH=bf16x6), otherwise autograd raises.
             out = modulated_conv2d(input, s, self.weight[0], self._demod() if self.demodulate else None,
                                    padding=self.padding, alpha=self.scale, transposed=self.upsample)
             return self.blur(out) if self.upsample else out
