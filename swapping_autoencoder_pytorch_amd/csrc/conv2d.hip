@@ -1302,6 +1302,9 @@ struct TrParams {
     const float* in_scale;  // [N][C] or null: style modulation of the input, applied while staging (see IgemmParams)
     int zmask;              // always 0 (see IgemmParams)
     int mtiles, main_items, strip_items;  // tr2: M tiles; (q tile, M tile) items of region 0 and of regions 1 + 2
+    // conv_igemm_tr_kernel, split K (blockIdx.z): chunks per slice and the distance between the partial outputs
+    int chunks_per_split;
+    int64_t slab_stride;
     // main region + right / bottom strips, all in ONE launch (blockIdx.x runs through the regions):
     // launched one after the other the two thin strips cost a full K loop of latency each on a
     // nearly empty GPU
@@ -1460,16 +1463,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_tr_kernel(const float
         }
     };
 
-    load_chunk(0);
+    // split K over blockIdx.z (launches with few workgroups and long channel loops: the 4 x 4 ... 17 x 17 tails and the
+    // encoder's 1024-channel 7 x 7 layer); the partial outputs go to slabs that conv_splitk_reduce_kernel sums in fixed order
+    const int c_begin = blockIdx.z * p.chunks_per_split * CK;
+    int c_end = c_begin + p.chunks_per_split * CK;
+    if (c_end > p.Cp) c_end = p.Cp;
+    y += (int64_t)blockIdx.z * p.slab_stride;
+    load_chunk(c_begin);
     SAE_CLOCK_PHASE(0)
-    for (int c0 = 0; c0 < p.Cp; c0 += CK) {
+    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
         __syncthreads();
         SAE_CLOCK_PHASE(2)
         store_chunk(c0);
         SAE_CLOCK_PHASE(3)
         __syncthreads();
         SAE_CLOCK_PHASE(4)
-        if (c0 + CK < p.Cp) load_chunk(c0 + CK);
+        if (c0 + CK < c_end) load_chunk(c0 + CK);
         SAE_CLOCK_PHASE(5)
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -3574,6 +3583,97 @@ int run_tr2(const float* x, const float* w, float* y, float* ws, int64_t ws_floa
     return SAE_OK;
 }
 
+// q-grid decomposition of conv_igemm_tr_kernel: fills p.reg[], returns the number of q tiles (-1: no tile fits)
+int tr_plan_regions(TrParams& p, int N, int OH, int OW, int pad, int bq) {
+    const int QH = (OH + pad - 1) / 2 + 1, QW = (OW + pad - 1) / 2 + 1;
+    // The transposed problems of this network have 2^k + 1 wide q grids (129, 65, 33, ...): one
+    // launch with 32-wide tiles would spend 25 % (129) to 94 % (33) of its MFMAs on padding.  The
+    // grid is cut into a main region whose sides are multiples of the natural tile side plus thin
+    // right / bottom strips, each launched with its own best tile shape.  For the smallest grids (5 x 5, 9 x 9, 17 x 17:
+    // the 9 x 9 ... 33 x 33 maps of D / Dpatch) the strips are a large share of the work and free-form tiles over the WHOLE
+    // grid (e.g. five 5 x 5 grids per 128-position tile) can cost less: both decompositions are priced, the cheaper one runs.
+    auto main_side = [](int q) {
+        int t = 32;
+        while (t > q) t >>= 1;
+        const int m = (q / t) * t;
+        return (q - m > 0 && (q - m) * 4 <= t && m > 0) ? m : q;    // split only a thin remainder
+    };
+    struct Region { int y0, y1, x0, x1; };
+    // tile = tn x th x tw q-positions: fewest workgroups (each costs bq lanes of MFMA work), with a
+    // penalty for narrow rows (short global-memory runs: a 9-wide tile measured no faster than a
+    // 32-wide one with 12 % more workgroups)
+    auto plan = [&](const Region* regions, int nreg, TrRegion* out, double* cost_out) {
+        int total_blocks = 0;
+        double total_cost = 0.0;
+        for (int r = 0; r < 3; ++r) {
+            TrRegion& g = out[r];
+            g = TrRegion{};
+            if (r >= nreg) { g.tw = g.th = g.tn = g.tiles_x = g.tiles_y = g.tiles_n = 1; continue; }   // empty: blocks = 0
+            const int qh = regions[r].y1 - regions[r].y0, qw = regions[r].x1 - regions[r].x0;
+            g.qy_base = regions[r].y0; g.qx_base = regions[r].x0; g.QH = regions[r].y1; g.QW = regions[r].x1;
+            const int cap = (25 * bq) / 16;
+            double best = -1.0;
+            for (int tw = 1; tw <= 32; ++tw)
+                for (int th = 1; th * tw <= bq; ++th) {
+                    if (tw < 4 && tw < qw) continue;               // narrow tiles only for narrow strips
+                    int tn = bq / (tw * th);
+                    if (tn > N) tn = N;
+                    if (tn * (th + 1) * (tw + 1) > cap) continue;
+                    const double cost = (double)ceil_div(qw, tw) * ceil_div(qh, th) * ceil_div(N, tn) * (1.0 + 8.0 / (tw < qw ? tw : 32));
+                    if (best < 0 || cost < best) {
+                        best = cost; g.tw = tw; g.th = th; g.tn = tn;
+                    }
+                }
+            if (best < 0) return -1;
+            g.tiles_x = ceil_div(qw, g.tw);
+            g.tiles_y = ceil_div(qh, g.th);
+            g.tiles_n = ceil_div(N, g.tn);
+            g.blocks = g.tiles_x * g.tiles_y * g.tiles_n;
+            total_blocks += g.blocks;
+            total_cost += best;
+        }
+        *cost_out = total_cost;
+        return total_blocks;
+    };
+    const int QHm = main_side(QH), QWm = main_side(QW);
+    Region split[3];
+    int nsplit = 0;
+    split[nsplit++] = {0, QHm, 0, QWm};
+    if (QWm < QW) split[nsplit++] = {0, QH, QWm, QW};          // right strip (full height)
+    if (QHm < QH) split[nsplit++] = {QHm, QH, 0, QWm};          // bottom strip
+    double cost_split = 0.0;
+    const int blocks_split = plan(split, nsplit, p.reg, &cost_split);
+    static const int whole_knob = tuning_knob("SAE_TR_WHOLE", 1);
+    if (nsplit > 1 && whole_knob && QH <= 17 && QW <= 17) {
+        const Region whole[1] = {{0, QH, 0, QW}};
+        TrRegion alt[3];
+        double cost_whole = 0.0;
+        const int blocks_whole = plan(whole, 1, alt, &cost_whole);
+        if (blocks_whole > 0 && (blocks_split < 0 || cost_whole < cost_split || whole_knob == 2)) {
+            for (int r = 0; r < 3; ++r) p.reg[r] = alt[r];
+            return blocks_whole;
+        }
+    }
+    return blocks_split;
+}
+
+// K split of conv_igemm_tr_kernel (exact fp32 only): like the forward gather's, for launches that leave most CUs idle
+struct TrSplit { int ksplit, cps; int64_t out_floats4; };
+TrSplit tr_split(int total_blocks, int mtiles, int nchunks, int64_t numel, bool fp32_kernel) {
+    TrSplit t{1, nchunks, (numel + 3) / 4 * 4};
+    const int blocks = total_blocks * mtiles;
+    if (fp32_kernel && blocks < 192 && nchunks >= 16 && numel % 4 == 0) {
+        int k = 512 / (blocks > 0 ? blocks : 1);
+        if (k > 8) k = 8;
+        if (k > nchunks / 8) k = nchunks / 8;
+        if (k >= 2) {
+            t.cps = ceil_div(nchunks, k);
+            t.ksplit = ceil_div(nchunks, t.cps);
+        }
+    }
+    return t;
+}
+
 // stride-2 3x3 transposed gather producing `mout` channels (the large image) from `cin` channels
 int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int IH, int IW,
            int mout, int OH, int OW, int pad, int64_t sm, int64_t sc, float alpha, hipStream_t s,
@@ -3597,56 +3697,19 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
     p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
     static const int nostore_knob = tuning_knob("SAE_TR_NOSTORE", 0);
     p.debug_skip_store = nostore_knob;
-    const int QH = (OH + pad - 1) / 2 + 1, QW = (OW + pad - 1) / 2 + 1;
-    // The transposed problems of this network have 2^k + 1 wide q grids (129, 65, 33, ...): one
-    // launch with 32-wide tiles would spend 25 % (129) to 94 % (33) of its MFMAs on padding.  The
-    // grid is cut into a main region whose sides are multiples of the natural tile side plus thin
-    // right / bottom strips, each launched with its own best tile shape.
-    auto main_side = [](int q) {
-        int t = 32;
-        while (t > q) t >>= 1;
-        const int m = (q / t) * t;
-        return (q - m > 0 && (q - m) * 4 <= t && m > 0) ? m : q;    // split only a thin remainder
-    };
-    const int QHm = main_side(QH), QWm = main_side(QW);
-    struct Region { int y0, y1, x0, x1; };
-    Region regions[3];
-    int nreg = 0;
-    regions[nreg++] = {0, QHm, 0, QWm};
-    if (QWm < QW) regions[nreg++] = {0, QH, QWm, QW};          // right strip (full height)
-    if (QHm < QH) regions[nreg++] = {QHm, QH, 0, QWm};          // bottom strip
-    int total_blocks = 0;
-    for (int r = 0; r < 3; ++r) {
-        TrRegion& g = p.reg[r];
-        g = TrRegion{};
-        if (r >= nreg) { g.tw = g.th = g.tn = g.tiles_x = g.tiles_y = g.tiles_n = 1; continue; }   // empty: blocks = 0
-        const int qh = regions[r].y1 - regions[r].y0, qw = regions[r].x1 - regions[r].x0;
-        g.qy_base = regions[r].y0; g.qx_base = regions[r].x0; g.QH = regions[r].y1; g.QW = regions[r].x1;
-        // tile = tn x th x tw q-positions: fewest workgroups (each costs bq lanes of MFMA work), with a
-        // penalty for narrow rows (short global-memory runs: a 9-wide tile measured no faster than a
-        // 32-wide one with 12 % more workgroups)
-        const int cap = (25 * sh.bq) / 16;
-        double best = -1.0;
-        for (int tw = 1; tw <= 32; ++tw)
-            for (int th = 1; th * tw <= sh.bq; ++th) {
-                if (tw < 4 && tw < qw) continue;               // narrow tiles only for narrow strips
-                int tn = sh.bq / (tw * th);
-                if (tn > N) tn = N;
-                if (tn * (th + 1) * (tw + 1) > cap) continue;
-                const double cost = (double)ceil_div(qw, tw) * ceil_div(qh, th) * ceil_div(N, tn) * (1.0 + 8.0 / (tw < qw ? tw : 32));
-                if (best < 0 || cost < best) {
-                    best = cost; g.tw = tw; g.th = th; g.tn = tn;
-                }
-            }
-        if (best < 0) return fail(SAE_EINVAL, "conv tr: no tile fits the LDS patch cap");
-        g.tiles_x = ceil_div(qw, g.tw);
-        g.tiles_y = ceil_div(qh, g.th);
-        g.tiles_n = ceil_div(N, g.tn);
-        g.blocks = g.tiles_x * g.tiles_y * g.tiles_n;
-        total_blocks += g.blocks;
-    }
+    const int total_blocks = tr_plan_regions(p, N, OH, OW, pad, sh.bq);
+    if (total_blocks < 0) return fail(SAE_EINVAL, "conv tr: no tile fits the LDS patch cap");
+    const TrSplit sp = tr_split(total_blocks, Mp / sh.bm, Cp / sh.ck, (int64_t)N * mout * OH * OW, !bx);
+    if (sp.ksplit > 1 && ws_floats < need + (int64_t)sp.ksplit * sp.out_floats4)
+        return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats,
+                    (long long)(need + (int64_t)sp.ksplit * sp.out_floats4));
+    p.chunks_per_split = sp.cps;
+    p.slab_stride = sp.ksplit > 1 ? sp.out_floats4 : 0;
+    SAE_TRACE("tr cfg=%d tiles=%d ksplit=%d", sh.cfg, total_blocks, sp.ksplit);
+    float* const y_final = y;
+    if (sp.ksplit > 1) y = ws + need;
     {
-        const dim3 grid((unsigned)total_blocks, (unsigned)(Mp / sh.bm));
+        const dim3 grid((unsigned)total_blocks, (unsigned)(Mp / sh.bm), (unsigned)sp.ksplit);
         if (bx) {
             hipLaunchKernelGGL((conv_igemm_tr_bx_kernel<2, 2, 2>), grid, dim3(kBlock), 0, s, x,
                                reinterpret_cast<const u32x4*>(ws), y, p);
@@ -3669,16 +3732,31 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
         }
 #undef SAE_TR
     }
+    if (sp.ksplit > 1) {
+        const int64_t n4 = (int64_t)N * mout * OH * OW / 4;
+        int64_t blocks = ceil_div64(n4, kBlock);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const float*)y, y_final, n4,
+                           sp.out_floats4, sp.ksplit, (const float*)nullptr, 0, 0.0f, 1.0f, OH * OW, mout,
+                           (const float*)nullptr, 1.0f);
+    }
     return SAE_OK;
 }
 
-int64_t tr_ws(int cin, int mout) {
+int64_t tr_ws(int N, int cin, int mout, int OH, int OW, int pad) {
     const TrShape sh = tr_shape(mout);
     if (conv_math() == 1 && sh.cfg == 0) return (int64_t)27 * round_up(mout, sh.bm) * (round_up(cin, 8) / 8) * 4;
     // whichever of the two fp32 kernels the launch takes (tr2 needs the pointer alignment to decide)
     const Tr2Shape s2 = tr2_shape(mout);
-    const int64_t a = (int64_t)9 * round_up(cin, sh.ck) * round_up(mout, sh.bm);
+    int64_t a = (int64_t)9 * round_up(cin, sh.ck) * round_up(mout, sh.bm);
     const int64_t b = (int64_t)9 * round_up(cin, s2.ck) * round_up(mout, s2.bm);
+    TrParams p{};
+    const int total_blocks = tr_plan_regions(p, N, OH, OW, pad, sh.bq);
+    if (total_blocks > 0) {
+        const TrSplit sp = tr_split(total_blocks, round_up(mout, sh.bm) / sh.bm, round_up(cin, sh.ck) / sh.ck,
+                                    (int64_t)N * mout * OH * OW, true);
+        if (sp.ksplit > 1) a += (int64_t)sp.ksplit * sp.out_floats4;
+    }
     return a > b ? a : b;
 }
 
@@ -3708,7 +3786,7 @@ extern "C" int64_t sae_conv2d_workspace(const sae_conv2d_desc* d, int32_t op) {
         case SAE_CONV_DGRAD:
             if (d->stride == 1) return gather_ws((int)d->n, (int)d->m, (int)d->c, (int)d->h, (int)d->w, d->kh, 1, false);
             if (d->kh == 1) return gather_ws((int)d->n, (int)d->m, (int)d->c, (int)d->oh, (int)d->ow, 1, 1, true);
-            return tr_ws((int)d->m, (int)d->c);
+            return tr_ws((int)d->n, (int)d->m, (int)d->c, (int)d->h, (int)d->w, d->pad);
         case SAE_CONV_WGRAD: {
             const WgPlan w = wg_plan(d);
             return (int64_t)w.slices * w.taps * w.Ap * w.Bp;

@@ -55,6 +55,9 @@ CONV_SMALL = [
     # stride-2 dgrad / transposed conv producing > 64 channels: the class-split 128 x 128q transposed gather
     (1, 70, 17, 17, 12, 3, 2, 0, False), (2, 72, 35, 67, 8, 3, 2, 0, True), (1, 70, 10, 12, 20, 3, 2, 1, False),
     (1, 130, 9, 11, 6, 3, 2, 0, False),
+    # stride-2 dgrad with a long channel loop and few tiles: the K split of conv_igemm_tr_kernel (slabs + fixed-order reduce),
+    # also on a 7 x 7 -> 16 x 16 problem of the encoder's kind (pad 0, even input size) and with [C, M] weights
+    (1, 12, 17, 17, 136, 3, 2, 0, False), (2, 8, 16, 16, 160, 3, 2, 0, False), (1, 20, 9, 9, 200, 3, 2, 0, True),
     # fp32 wgrad with vectorised staging (OW % 16|32 == 0): 16- and 32-column tiles, valid padding, M/C tails
     (2, 40, 16, 16, 40, 3, 1, 1, False), (1, 36, 32, 32, 70, 3, 1, 1, False), (1, 33, 18, 34, 40, 3, 1, 0, False),
     (1, 130, 8, 64, 36, 3, 1, 1, False),

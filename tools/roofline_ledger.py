@@ -23,6 +23,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from swapping_autoencoder_pytorch_amd import hip_lib  # noqa: E402
 
+if os.environ.get("KB_LIBRARY"):        # A/B of dispatch knobs: a tuning build (tests/tuning, tools/variants) instead of the product library
+    hip_lib._LIB = hip_lib.SaeLibrary(os.path.abspath(os.environ["KB_LIBRARY"]))
+
 MFMA_PEAK, HBM_PEAK = 157.3e12, 8.0e12
 BY_SHAPE = False     # --by-shape: one row per conv geometry, with the time above 0.85 of the MFMA peak
 
