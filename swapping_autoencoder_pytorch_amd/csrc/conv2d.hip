@@ -507,6 +507,26 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
             float* Cs = As;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
+                // the residual of this pass is fetched BEFORE the LDS round trip (its addresses do not depend on it): issued
+                // after it, every store waited for its own load -- the 1x1 skip convs (K loops of 4-16 chunks) are all
+                // epilogue and ran at 44 TFLOP/s
+                f32x4 resq[VPT];
+                if (p.residual) {
+#pragma unroll
+                    for (int v = 0; v < VPT; ++v) {
+                        const int qi = tid + kBlock * v;
+                        const int row = qi / QROW, qx = qi - row * QROW;
+                        const int m = m0 + ((row >> 5) * MI + mi) * 32 + (row & 31);
+                        const int pp = 4 * qx;
+                        const int px = pp & (TW - 1);
+                        const int py = (pp >> p.tw_log2) & (TH - 1);
+                        const int pn = pp >> (p.tw_log2 + p.th_log2);
+                        const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
+                        const bool ok = m < p.M && n < p.N && oy < p.OH && ox < p.OW;
+                        const int64_t yi = ok ? (((int64_t)n * p.M + m) * p.YH + oy) * p.YW + ox : 0;
+                        resq[v] = *reinterpret_cast<const f32x4*>(p.residual + yi);
+                    }
+                }
                 __syncthreads();       // the K loop's (or the previous pass's) readers are done with As
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni)
@@ -535,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                             }
                         }
                         const int64_t yi = (((int64_t)n * p.M + m) * p.YH + oy) * p.YW + ox;
-                        if (p.residual) c = (c + *reinterpret_cast<const f32x4*>(p.residual + yi)) * p.res_scale;
+                        if (p.residual) c = (c + resq[v]) * p.res_scale;
                         *reinterpret_cast<f32x4*>(y + (int64_t)blockIdx.z * p.slab_stride + yi) = c;
                     }
                 }
@@ -565,7 +585,19 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
             float* yb = y + (int64_t)blockIdx.z * p.slab_stride +
                         ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi) {
+                // the 16 residual values of this accumulator tile are fetched together, branch-free (rows beyond M re-read
+                // row M - 1), before any of them is used: a load inside the store loop made every store wait for its own
+                // round trip (the 1x1 skip convs ran at 40 TFLOP/s)
+                float rv[16];
+                if (p.residual) {     // (only with oys == oxs == 1 and no K split: y and residual share indices)
+                    const float* rb = p.residual + ((int64_t)n * p.M * p.YH + oy) * p.YW + ox;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        rv[r] = rb[(int64_t)(m < p.M ? m : p.M - 1) * p.YH * p.YW];
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -575,11 +607,11 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                             v += bv[mi][r];
                             v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
                         }
-                        if (p.residual)     // (only with oys == oxs == 1 and no K split: y and residual share indices)
-                            v = (v + p.residual[((int64_t)n * p.M * p.YH + oy) * p.YW + ox + (int64_t)m * p.YH * p.YW]) * p.res_scale;
+                        if (p.residual) v = (v + rv[r]) * p.res_scale;
                         yb[(int64_t)m * p.YH * p.YW] = v;
                     }
                 }
+            }
         }
     }
     SAE_CLOCK_PHASE(6)
@@ -3662,7 +3694,8 @@ struct TrSplit { int ksplit, cps; int64_t out_floats4; };
 TrSplit tr_split(int total_blocks, int mtiles, int nchunks, int64_t numel, bool fp32_kernel) {
     TrSplit t{1, nchunks, (numel + 3) / 4 * 4};
     const int blocks = total_blocks * mtiles;
-    if (fp32_kernel && blocks < 192 && nchunks >= 16 && numel % 4 == 0) {
+    static const int split_knob = tuning_knob("SAE_TR_SPLITK", 1);     // 0: never (bit-identity comparisons against tr2)
+    if (split_knob && fp32_kernel && blocks < 192 && nchunks >= 16 && numel % 4 == 0) {
         int k = 512 / (blocks > 0 ? blocks : 1);
         if (k > 8) k = 8;
         if (k > nchunks / 8) k = nchunks / 8;

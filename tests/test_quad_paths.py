@@ -13,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(which, **env):
-    e = dict(os.environ, SAE_CONV_MATH="f32", SAE_CONV_THIN="0", SAE_TRACE_DISPATCH="1", **env)
+    # (SAE_TR_SPLITK=0: the K split of conv_igemm_tr_kernel changes the summation order by design)
+    e = dict(os.environ, SAE_CONV_MATH="f32", SAE_CONV_THIN="0", SAE_TRACE_DISPATCH="1", SAE_TR_SPLITK="0", **env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "quad_worker.py"), which], cwd=ROOT, env=e,
                          capture_output=True, text=True, timeout=1800)
     assert out.returncode == 0, out.stderr[-3000:]
