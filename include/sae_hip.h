@@ -224,7 +224,7 @@ int sae_conv2d_fwd_bias_act_f32(const float* x, const float* w, const float* bia
  * skip path's 1x1 conv adds the main branch's output and scales):
  *     y = (alpha * conv(x, w) + residual) * res_scale          residual: y-shaped, 16-byte aligned, never y itself
  * Bit-identical to sae_conv2d_fwd_f32 followed by sae_add_scale_f32 (the fp32 accumulator is the value the separate call
- * would have stored).  3x3 problems under SAE_CONV_MATH_F32 only.  Workspace: sae_conv2d_workspace(d, SAE_CONV_FWD). */
+ * would have stored).  1x1 convolutions only (kh = kw = 1, either stride).  Workspace: sae_conv2d_workspace(d, SAE_CONV_FWD). */
 int sae_conv2d_fwd_residual_f32(const float* x, const float* w, const float* residual, float* y,
                                 const sae_conv2d_desc* d, float alpha, float res_scale,
                                 float* workspace, int64_t workspace_floats, sae_stream_t stream);

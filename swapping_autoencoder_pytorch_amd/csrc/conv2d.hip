@@ -164,11 +164,17 @@ struct PatchCap {
 // its width (tools/probe/mfma_clock_probe.hip, profiles/r2_phase_clock_*.txt): the staging phase of a chunk is bound by the
 // NUMBER of such instructions, and the eight waves of a CU issue theirs at the same time.
 template <int KS, int S, int MI, int NI, int WM, int WN, int CK, bool MOD = false, bool QUAD = false>
+// (measured and dropped: __launch_bounds__(kBlock, 2) for the 64-accumulator tiles -- it brings the modulated stride-2
+// instantiations, 8 registers over budget, back to two waves per SIMD with 11-16 spilled registers; their time did not move
+// (5.16 ms per iteration either way) and the step got 0.7 % slower, the other instantiations' allocation changes with it)
 __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ wp,
                                                             float* __restrict__ y, const IgemmParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(!QUAD || S == 1 || KS == 3, "quad staging: stride 1, or 3x3 stride 2");
+    // the fused residual merge (IgemmParams::residual) is compiled into the 1x1 kernels only -- the skip convs are its one
+    // use, and one register more sent the stride-2 3x3 gather from two waves per SIMD to one (27.0 -> 31.2 ms per iteration)
+    constexpr bool RESIDUAL = KS == 1;
     constexpr int XQ0 = (KS == 3) ? 4 : 0;      // QUAD: columns added on either side of the tile
     constexpr int T = KS * KS;
     constexpr int BM = 32 * MI * WM;
@@ -182,8 +188,12 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     // a channel row of Xs is XCAP patch floats + a 64-float dump area: threads whose slot lies beyond the patch store
     // there, so no LDS store of the K loop is predicated (XROW = XCAP mod 64 keeps the bank pattern of the reads)
     constexpr int XROW = XCAP + 64;
-    __shared__ float As[T * CK * BM];
-    __shared__ float Xs[CK * XROW];
+    // one allocation: the LDS-transposed epilogue may use the whole of it (the weight tile alone is too small for the 1x1
+    // kernels' 32-channel chunks)
+    constexpr int AS = T * CK * BM, XS = CK * XROW;
+    __shared__ __attribute__((aligned(16))) float smem[AS + XS];
+    float* const As = smem;
+    float* const Xs = smem + AS;
 
     SAE_CLOCK_BEGIN
     const int tid = threadIdx.x;
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     // 16 instead of 64 vector-memory instructions per wave and tile (the eight waves of a CU reach their epilogues
     // together, and a wave64 store occupies the address path as long as a load does).
     constexpr int LDC = BN + 4;
-    constexpr bool VEC_OK = T * CK * BM >= 32 * WM * LDC;     // the weight buffer holds one pass
+    constexpr bool VEC_OK = AS + XS >= 32 * WM * LDC;         // the staging buffers hold one pass
     if constexpr (VEC_OK) {
         if (p.vec_store) {
             constexpr int QROW = BN / 4;                        // quads per tile row
@@ -510,8 +520,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                 // the residual of this pass is fetched BEFORE the LDS round trip (its addresses do not depend on it): issued
                 // after it, every store waited for its own load -- the 1x1 skip convs (K loops of 4-16 chunks) are all
                 // epilogue and ran at 44 TFLOP/s
-                f32x4 resq[VPT];
-                if (p.residual) {
+                [[maybe_unused]] f32x4 resq[RESIDUAL ? VPT : 1];
+                if (RESIDUAL && p.residual) {
 #pragma unroll
                     for (int v = 0; v < VPT; ++v) {
                         const int qi = tid + kBlock * v;
@@ -555,7 +565,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                             }
                         }
                         const int64_t yi = (((int64_t)n * p.M + m) * p.YH + oy) * p.YW + ox;
-                        if (p.residual) c = (c + resq[v]) * p.res_scale;
+                        if constexpr (RESIDUAL)
+                            if (p.residual) c = (c + resq[v]) * p.res_scale;
                         *reinterpret_cast<f32x4*>(y + (int64_t)blockIdx.z * p.slab_stride + yi) = c;
                     }
                 }
@@ -589,8 +600,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                 // the 16 residual values of this accumulator tile are fetched together, branch-free (rows beyond M re-read
                 // row M - 1), before any of them is used: a load inside the store loop made every store wait for its own
                 // round trip (the 1x1 skip convs ran at 40 TFLOP/s)
-                float rv[16];
-                if (p.residual) {     // (only with oys == oxs == 1 and no K split: y and residual share indices)
+                [[maybe_unused]] float rv[RESIDUAL ? 16 : 1];
+                if (RESIDUAL && p.residual) {     // (only with oys == oxs == 1 and no K split: y and residual share indices)
                     const float* rb = p.residual + ((int64_t)n * p.M * p.YH + oy) * p.YW + ox;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -607,7 +618,8 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                             v += bv[mi][r];
                             v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
                         }
-                        if (p.residual) v = (v + rv[r]) * p.res_scale;
+                        if constexpr (RESIDUAL)
+                            if (p.residual) v = (v + rv[r]) * p.res_scale;
                         yb[(int64_t)m * p.YH * p.YW] = v;
                     }
                 }
@@ -3477,11 +3489,13 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     }
     float* out = (g.ksplit > 1) ? ws + g.wp_floats : y;
     static const int vec_knob = tuning_knob("SAE_IGEMM_VEC_STORE", 1);
-    // measured (tools/ab_conv.py): +2.5 % with K loops of 64 chunks (512 channels), -1 % with 16 or 32: long loops only
+    // Round 2 measured +2.5 % with K loops of 64 chunks and -1 % with 16 or 32 on the 128 x 128 tile and enabled it for long
+    // loops (and fused bias + leaky-ReLU) only.  With the epilogue buffer spanning both staging areas (so that the 64 x 256
+    // tile and the 1x1 kernels have it at all) it wins for every K length (same-box A/B, tools/ab_conv.py tuning with
+    // SAE_IGEMM_VEC_STORE=1|3): 128 -> 128 @256^2 129.1 -> 131.0, 256 @128^2 134.4 -> 135.9, 1x1 128 -> 256 @256^2 83.6 -> 90.5
+    // TFLOP/s.  (knob 3 = the round-2 rule)
     p.vec_store = vec_knob && oys == 1 && oxs == 1 && OW % 4 == 0 && YW % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
-                  (vec_knob > 1 || g.cps >= 48 || ep.act || ep.residual);   // with a fused epilogue also for short loops: the scalar
-                                                             // epilogue fetches the bias per element (tools/instep_gap.py: 122.6 vs
-                                                             // 127.9 TFLOP/s at 128 -> 128 @256^2, 129.0 vs 131.8 at 256 @128^2)
+                  (vec_knob != 3 || g.cps >= 48 || ep.act || ep.residual);
     int rc;
     if (ks == 3 && stride == 1) rc = launch_igemm<3, 1>(x, ws, out, p, g, s);
     else if (ks == 3) rc = launch_igemm<3, 2>(x, ws, out, p, g, s);
@@ -3882,8 +3896,8 @@ extern "C" int sae_conv2d_fwd_residual_f32(const float* x, const float* w, const
     if (!desc_ok(d, "sae_conv2d_fwd_residual_f32")) return SAE_EINVAL;
     if (d->n == 0) return SAE_OK;
     if (!x || !w || !y || !residual) return fail(SAE_EINVAL, "sae_conv2d_fwd_residual_f32: null tensor");
-    if (conv_math() != 0 && d->kh == 3)
-        return fail(SAE_EINVAL, "sae_conv2d_fwd_residual_f32: 3x3 convolutions fuse the residual under SAE_CONV_MATH_F32 only");
+    if (d->kh != 1)
+        return fail(SAE_EINVAL, "sae_conv2d_fwd_residual_f32: 1x1 convolutions only (the skip path of a ResBlock)");
     hipStream_t s = (hipStream_t)stream;
     Epilogue ep{nullptr, 0, 0.0f, 1.0f};
     ep.residual = residual; ep.res_scale = res_scale;

@@ -185,9 +185,9 @@ def test_conv2d_bias_act(emu_lib, oracle_lib, case):
 
 
 # sae_conv2d_fwd_residual_f32: 1x1 skip convs on every tile (128 / 64 / 32 rows, quad and dword staging, scalar and vector
-# epilogue, split-K), odd sizes, a 3x3 case; (n, c, h, w, m, k, stride, pad)
+# epilogue, split-K), odd sizes, stride 2; (n, c, h, w, m, k, stride, pad)
 CONV_RESIDUAL = [(2, 40, 8, 8, 70, 1, 1, 0), (1, 70, 16, 16, 130, 1, 1, 0), (2, 33, 7, 9, 20, 1, 1, 0), (1, 256, 4, 4, 40, 1, 1, 0),
-                 (3, 12, 12, 20, 24, 1, 1, 0), (1, 9, 20, 36, 70, 3, 1, 1), (2, 8, 9, 9, 32, 3, 2, 0)]
+                 (3, 12, 12, 20, 24, 1, 1, 0), (2, 33, 7, 7, 130, 1, 2, 0), (1, 20, 15, 15, 36, 1, 2, 0)]
 
 
 def conv_residual_case(lib, oracle_lib, case, device=None):

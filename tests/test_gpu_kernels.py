@@ -43,7 +43,7 @@ def test_upfirdn2d(hip_lib, oracle_lib, case):
 
 
 @pytest.mark.parametrize("case", [(4, 128, 64, 64, 256, 1, 1, 0), (2, 512, 16, 16, 512, 1, 1, 0), (8, 32, 64, 64, 64, 1, 1, 0),
-                                  (2, 128, 32, 32, 128, 3, 1, 1)], ids=str)
+                                  (2, 128, 33, 33, 128, 1, 2, 0)], ids=str)
 def test_conv2d_residual(hip_lib, oracle_lib, case):
     from test_emu_kernels import CONV_RESIDUAL, conv_residual_case
     conv_residual_case(hip_lib, oracle_lib, case, device=DEV)

@@ -38,6 +38,10 @@ SHAPES = [  # n, c, h, w, m, k, s, p, tag
 def libpath(name):
     if name == "product":
         return L.DEFAULT_LIBRARY
+    if name == "tuning":       # the -DSAE_TUNING build of the current sources (environment knobs select the kernels)
+        return os.path.join(ROOT, "tests", "tuning", "libsae_hip_tuning.so")
+    if os.sep in name:
+        return os.path.abspath(name)
     return os.path.join(ROOT, "tools", "variants", name + ".so")
 
 
