@@ -29,7 +29,15 @@ def _common_checks(rep):
     assert rep["upfirdn2d"].startswith("swapping_autoencoder_pytorch_amd.stylegan2_op")       # ... and operators
     assert rep["adam"] == "swapping_autoencoder_pytorch_amd.fused_adam.FusedAdam"             # torch.optim.Adam substituted
     assert rep["dataset"] == "SyntheticDataset"
-    expected = sorted(n for n in ("dominate", "visdom", "lmdb") if importlib.util.find_spec(n) is None)
+    def natively_importable(name):
+        # (another test of this process may have left the runner's stand-in module behind: that is not the real package)
+        if type(sys.modules.get(name)).__name__ in ("_Stub", "_MissingDataPackage"):
+            return False
+        try:
+            return importlib.util.find_spec(name) is not None
+        except (ValueError, ImportError):
+            return False
+    expected = sorted(n for n in ("dominate", "visdom", "lmdb") if not natively_importable(n))
     assert rep["stubbed"] == expected
     assert rep["params_moved"] == rep["params"] and rep["params"] >= 10                       # every parameter was trained
     assert len(rep["losses"]) == 4 and "D_R1" in rep["losses"][1] and "D_R1" in rep["losses"][3]
