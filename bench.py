@@ -234,6 +234,42 @@ class DominantKernelTimer:
         return roof, by_kernel
 
 
+def cpu_baseline_config1(A, threads_hint):
+    """BASELINE.json configs[0], the reference's own CPU-runnable case, measured whole: 32 x 32, B = 4, one reconstruction
+    forward + backward (E -> G -> L1, gradients of every E and G parameter) through the ATen-CPU restatement of the
+    reference's StyleGAN2ResnetEncoder / StyleGAN2ResnetGenerator (oracle/aten_cpu_path.py, pinned to the unmodified
+    reference modules by tests/dropin_ref_worker.py::aten_cpu_path_pin).  No scaling: images per second of that pass."""
+    import torch
+    from swapping_autoencoder_pytorch_amd.options import make_options
+    opt = make_options("tiny32", batch_size=4, num_gpus=0)
+    torch.manual_seed(0)
+    enc, gen = A.EncoderCPU(opt), A.GeneratorCPU(opt)
+    params = list(enc.parameters()) + list(gen.parameters())
+    img = torch.rand(4, 3, 32, 32) * 2 - 1
+
+    def one_pass():
+        for p in params:
+            p.grad = None
+        (gen(*enc(img)) - img).abs().mean().backward()
+
+    best, sweep = None, []
+    for threads in sorted({1, 8, max(1, min(threads_hint, 32))}):
+        torch.set_num_threads(threads)
+        one_pass()
+        t0, reps = time.time(), 0
+        while reps < 3 or (time.time() - t0 < 2.0 and reps < 50):
+            one_pass()
+            reps += 1
+        dt = (time.time() - t0) / reps
+        sweep.append({"threads": threads, "ms": round(dt * 1e3, 1)})
+        if best is None or dt < best[1]:
+            best = (threads, dt)
+    threads, dt = best
+    return {"value": round(4 / dt, 3), "unit": "images/s", "cores": threads, "kind": "port", "ms_per_pass": round(dt * 1e3, 1),
+            "sample": "BASELINE.json configs[0]: E+G reconstruction forward+backward, 4 images 32x32, default channel widths "
+                      "(%d parameters), ATen CPU, best of %s" % (sum(p.numel() for p in params), sweep)}
+
+
 def cpu_baseline(preset, size, batch):
     """The reference's CPU code path timed on this host (rank 0, N = 1): the image discriminator forward + backward
     (weights trainable, input without gradient = the D(real) pass of a discriminator step) through ATen on all
@@ -286,6 +322,8 @@ def cpu_baseline(preset, size, batch):
            "sample": "image discriminator forward + backward, %d images %dx%d: %.2f TFLOP of conv work in %.2f s = %.2f "
                      "TFLOP/s, scaled by %.3f TFLOP/image of the full iteration" % (n, size, size, flops / 1e12, dt,
                                                                                   flops / dt / 1e12, per_image / 1e12)}
+
+    out["config1"] = cpu_baseline_config1(A, threads)
 
     so = os.path.join(ROOT, "oracle", "libsae_oracle.so")
     if not os.path.exists(so):

@@ -150,8 +150,9 @@ class ModulatedConvCPU(torch.nn.Module):
     and demodulated per output channel, and the conv runs grouped over the batch (:300-321) -- restated literally,
     including the grouped conv_transpose2d + Blur of the upsampling form (:302-309)."""
 
-    def __init__(self, cin, cout, k, styledim, upsample=False):
+    def __init__(self, cin, cout, k, styledim, upsample=False, demodulate=True):
         super().__init__()
+        self.demodulate = demodulate
         self.weight = torch.nn.Parameter(torch.randn(1, cout, cin, k, k))
         self.mod_weight = torch.nn.Parameter(torch.randn(cin, styledim))      # modulation = EqualLinear(style_dim, cin, bias_init=1)
         self.mod_bias = torch.nn.Parameter(torch.ones(cin))
@@ -164,11 +165,13 @@ class ModulatedConvCPU(torch.nn.Module):
         b, cin, h, w = x.shape
         s = F.linear(style.view(b, -1), self.mod_weight * self.mod_scale, bias=self.mod_bias * 1.0)
         s = s.view(b, cin, 1, 1)
-        s = s * torch.rsqrt(s.pow(2).mean([1], keepdim=True) + 1e-8)
+        if self.demodulate:
+            s = s * torch.rsqrt(s.pow(2).mean([1], keepdim=True) + 1e-8)
         x = x * s
         weight = (self.scale * self.weight).repeat(b, 1, 1, 1, 1)
-        demod = torch.rsqrt(weight.pow(2).sum([2, 3, 4]) + 1e-8)
-        weight = weight * demod.view(b, self.cout, 1, 1, 1)
+        if self.demodulate:
+            demod = torch.rsqrt(weight.pow(2).sum([2, 3, 4]) + 1e-8)
+            weight = weight * demod.view(b, self.cout, 1, 1, 1)
         weight = weight.view(b * self.cout, cin, self.k, self.k)
         if self.upsample:
             x = x.view(1, b * cin, h, w)
@@ -197,8 +200,10 @@ class StyledConvCPU(torch.nn.Module):
         self.noise = _Holder("weight", torch.zeros(1))        # child modules, so that parameters() keeps the reference's order
         self.activate = _Holder("bias", torch.zeros(cout))
 
-    def forward(self, x, style, noise):
+    def forward(self, x, style, noise=None):
         out = self.conv(x, style)
+        if noise is None:      # NoiseInjection.forward, stylegan2_layers.py:340-342: a fresh N(0, 1) map per call
+            noise = out.new_empty(out.shape[0], 1, out.shape[2], out.shape[3]).normal_()
         out = out + self.noise.weight * noise
         return fused_leaky_relu(out, self.activate.bias)
 
@@ -212,8 +217,183 @@ class UpsamplingResnetBlockCPU(torch.nn.Module):
         self.conv2 = StyledConvCPU(outch, outch, 3, styledim, upsample=False)
         self.skip = ConvLayerCPU(inch, outch, 1, activate=True, bias=True)
 
-    def forward(self, x, style, noise1, noise2):
+    def forward(self, x, style, noise1=None, noise2=None):
         skip = F.interpolate(self.skip(x), scale_factor=2, mode="bilinear", align_corners=False)
         res = self.conv2(self.conv1(x, style, noise1), style, noise2)
         return (skip + res) / math.sqrt(2)
+
+
+# ---- the encoder and the generator of the reconstruction path (BASELINE.json config 1: 32 x 32, B = 4, one reconstruction
+# forward + backward on the CPU) on the same ATen path; parameters in the reference modules' own order ----------------------
+def normalize(v):
+    """util/util.py:18-22"""
+    return v * torch.rsqrt(torch.sum(v ** 2, dim=1, keepdim=True) + 1e-8)
+
+
+class GenConvLayerCPU(torch.nn.Module):
+    """ConvLayer in full (stylegan2_layers.py:612-668): optional Blur (with its own reflection padding, :90-112) before a
+    stride-2 conv, or (reflection) padding before a stride-1 conv; conv bias only without activation; FusedLeakyReLU /
+    ScaledLeakyReLU after."""
+
+    def __init__(self, cin, cout, k, downsample=False, blur_kernel=(1, 3, 3, 1), bias=True, activate=True, pad=None,
+                 reflection_pad=False):
+        super().__init__()
+        self.k, self.downsample, self.activate, self.reflection = k, downsample, activate, reflection_pad
+        self.weight = torch.nn.Parameter(torch.randn(cout, cin, k, k))
+        self.scale = 1.0 / math.sqrt(cin * k * k)
+        self.conv_bias = torch.nn.Parameter(torch.zeros(cout)) if (bias and not activate) else None
+        self.act_bias = torch.nn.Parameter(torch.zeros(cout)) if (bias and activate) else None
+        if downsample:
+            if pad is None:
+                pad = (len(blur_kernel) - 2) + (k - 1)
+            self.blur_pad = ((pad + 1) // 2, pad // 2)
+            self.register_buffer("blur", make_kernel(list(blur_kernel)))
+            self.padding = 0
+        else:
+            self.padding = k // 2 if pad is None else pad
+
+    def forward(self, x):
+        if self.downsample:
+            p0, p1 = self.blur_pad
+            if self.reflection:
+                x = upfirdn2d_native(F.pad(x, (p0, p1, p0, p1), mode="reflect"), self.blur, pad=(0, 0))
+            else:
+                x = upfirdn2d_native(x, self.blur, pad=(p0, p1))
+            x = F.conv2d(x, self.weight * self.scale, bias=self.conv_bias, stride=2, padding=0)
+        else:
+            padding = self.padding
+            if self.reflection and padding > 0:
+                x = F.pad(x, (padding,) * 4, mode="reflect")
+                padding = 0
+            x = F.conv2d(x, self.weight * self.scale, bias=self.conv_bias, stride=1, padding=padding)
+        if self.activate:
+            if self.act_bias is not None:
+                return fused_leaky_relu(x, self.act_bias)
+            return F.leaky_relu(x, 0.2) * math.sqrt(2)          # ScaledLeakyReLU, stylegan2_layers.py:198-207
+        return x
+
+
+class GenResBlockCPU(torch.nn.Module):
+    """ResBlock (stylegan2_layers.py:672-693) with its blur taps / reflection padding options."""
+
+    def __init__(self, cin, cout, blur_kernel=(1, 3, 3, 1), reflection_pad=False):
+        super().__init__()
+        self.conv1 = GenConvLayerCPU(cin, cin, 3, reflection_pad=reflection_pad)
+        self.conv2 = GenConvLayerCPU(cin, cout, 3, downsample=True, blur_kernel=blur_kernel, reflection_pad=reflection_pad)
+        self.skip = GenConvLayerCPU(cin, cout, 1, downsample=True, blur_kernel=blur_kernel, activate=False, bias=False)
+
+    def forward(self, x):
+        return (self.conv2(self.conv1(x)) + self.skip(x)) / math.sqrt(2)
+
+
+class _LinearCPU(torch.nn.Module):
+    """EqualLinear without activation (stylegan2_layers.py:152-190)."""
+
+    def __init__(self, cin, cout, bias_init=0.0):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(cout, cin))
+        self.bias = torch.nn.Parameter(torch.full((cout,), float(bias_init)))
+        self.scale = 1.0 / math.sqrt(cin)
+
+    def forward(self, x):
+        return F.linear(x, self.weight * self.scale, bias=self.bias * 1.0)
+
+
+class EncoderCPU(torch.nn.Module):
+    """StyleGAN2ResnetEncoder (models/networks/encoder.py:31-114), forward without feature extraction."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        n_sp, n_gl = opt.netE_num_downsampling_sp, opt.netE_num_downsampling_gl
+        blur = (1, 2, 1) if opt.use_antialias else (1,)
+        self.FromRGB = GenConvLayerCPU(3, self.nc(0), 1)
+        self.DownToSpatialCode = torch.nn.ModuleList(
+            [GenResBlockCPU(self.nc(i), self.nc(i + 1), blur, reflection_pad=True) for i in range(n_sp)])
+        ch = self.nc(n_sp)
+        self.ToSpatialCode = torch.nn.ModuleList([GenConvLayerCPU(ch, ch, 1, activate=True, bias=True),
+                                                  GenConvLayerCPU(ch, opt.spatial_code_ch, 1, activate=False, bias=True)])
+        self.DownToGlobalCode = torch.nn.ModuleList(
+            [GenConvLayerCPU(self.nc(n_sp + i), self.nc(n_sp + i + 1), 3, blur_kernel=(1,), downsample=True, pad=0)
+             for i in range(n_gl)])
+        self.ToGlobalCode = _LinearCPU(self.nc(n_sp + n_gl), opt.global_code_ch)
+
+    def nc(self, idx):
+        nc = self.opt.netE_nc_steepness ** (5 + idx) * self.opt.netE_scale_capacity
+        return round(min(self.opt.global_code_ch, int(round(nc))))
+
+    def forward(self, x):
+        x = self.FromRGB(x)
+        for b in self.DownToSpatialCode:
+            x = b(x)
+        sp = x
+        for c in self.ToSpatialCode:
+            sp = c(sp)
+        for c in self.DownToGlobalCode:
+            x = c(x)
+        gl = self.ToGlobalCode(x.mean(dim=(2, 3)))
+        return normalize(sp), normalize(gl)
+
+
+class ResolutionPreservingResnetBlockCPU(torch.nn.Module):
+    """generator.py:23-36"""
+
+    def __init__(self, inch, outch, styledim):
+        super().__init__()
+        self.conv1 = StyledConvCPU(inch, outch, 3, styledim)
+        self.conv2 = StyledConvCPU(outch, outch, 3, styledim)
+        self.skip = GenConvLayerCPU(inch, outch, 1, activate=False, bias=False) if inch != outch else None
+
+    def forward(self, x, style):
+        skip = x if self.skip is None else self.skip(x)
+        return (skip + self.conv2(self.conv1(x, style), style)) / math.sqrt(2)
+
+
+class ToRGBCPU(torch.nn.Module):
+    """ToRGB with skip = None (stylegan2_layers.py:408-427): un-demodulated 1x1 modulated conv + bias."""
+
+    def __init__(self, cin, styledim):
+        super().__init__()
+        self.bias = torch.nn.Parameter(torch.zeros(1, 3, 1, 1))
+        self.conv = ModulatedConvCPU(cin, 3, 1, styledim, demodulate=False)
+
+    def forward(self, x, style):
+        return self.conv(x, style) + self.bias
+
+
+class GeneratorCPU(torch.nn.Module):
+    """StyleGAN2ResnetGenerator (models/networks/generator.py:70-186) with fresh noise maps per call."""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        sd = opt.global_code_ch + opt.num_classes
+        self.mod_scale = _LinearCPU(sd, opt.spatial_code_ch)          # GeneratorModulation: scale, bias (generator.py:56-67)
+        self.mod_bias = _LinearCPU(sd, opt.spatial_code_ch)
+        blocks, cin = [], opt.spatial_code_ch
+        for i in range(opt.netG_num_base_resnet_layers):
+            cout = max(opt.spatial_code_ch, round((i + 1) / opt.netG_num_base_resnet_layers * self.nf(0)))
+            blocks.append(ResolutionPreservingResnetBlockCPU(cin, cout, sd))
+            cin = cout
+        self.head = torch.nn.ModuleList(blocks)
+        ups = []
+        for j in range(opt.netE_num_downsampling_sp):
+            cout = self.nf(j + 1)
+            ups.append(UpsamplingResnetBlockCPU(cin, cout, sd))
+            cin = cout
+        self.ups = torch.nn.ModuleList(ups)
+        self.to_rgb = ToRGBCPU(cin, sd)
+
+    def nf(self, num_up):
+        ch = 128 * (2 ** (self.opt.netE_num_downsampling_sp - num_up))
+        return int(min(512, ch) * self.opt.netG_scale_capacity)
+
+    def forward(self, sp, gl):
+        sp, gl = normalize(sp), normalize(gl)
+        x = sp * (1 * self.mod_scale(gl)[:, :, None, None]) + self.mod_bias(gl)[:, :, None, None]
+        for b in self.head:
+            x = b(x, gl)
+        for b in self.ups:
+            x = b(x, gl)
+        return self.to_rgb(x, gl)
 
