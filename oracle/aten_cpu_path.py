@@ -202,6 +202,8 @@ class StyledConvCPU(torch.nn.Module):
 
     def forward(self, x, style, noise=None):
         out = self.conv(x, style)
+        if noise is None and getattr(self, "fixed_noise", None) is not None:      # :343-347, the fixed map
+            noise = self.fixed_noise.to(out.dtype)
         if noise is None:      # NoiseInjection.forward, stylegan2_layers.py:340-342: a fresh N(0, 1) map per call
             noise = out.new_empty(out.shape[0], 1, out.shape[2], out.shape[3]).normal_()
         out = out + self.noise.weight * noise

@@ -138,3 +138,54 @@ def test_generator_upsampling_block_128_to_256_vs_aten_restatement(conv_math):
 
     err_o, err_a = _grads_and_errors(ref64, ref32, ours, [x, style], run_ref, lambda m, i: m(i[0], i[1]), t)
     _check("UpsamplingResnetBlock 16x256x128x128 -> 16x128x256x256 vs ATen restatement in double (cuda:0)", conv_math, err_o, err_a)
+
+
+class _Reconstruction(torch.nn.Module):
+    """image -> E -> (spatial code, global code) -> G -> image: the reconstruction path of every training step
+    (swapping_autoencoder_model.py:96-101)"""
+
+    def __init__(self, enc, gen):
+        super().__init__()
+        self.E, self.G = enc, gen
+
+    def forward(self, x):
+        sp, gl = self.E(x)
+        return self.G(sp, gl)
+
+
+def test_encoder_generator_reconstruction_church256_b16_vs_aten_restatement(conv_math):
+    """The whole encoder and the whole generator at the BASELINE configuration (church256, B = 16, default widths): one
+    reconstruction, gradients of the input image and of all 100 parameter tensors of E and G, fixed noise maps."""
+    import aten_cpu_path as A
+    from swapping_autoencoder_pytorch_amd.networks.encoder import StyleGAN2ResnetEncoder
+    from swapping_autoencoder_pytorch_amd.networks.generator import StyleGAN2ResnetGenerator
+    from swapping_autoencoder_pytorch_amd.options import make_options
+    from swapping_autoencoder_pytorch_amd.stylegan2_layers import NoiseInjection
+    opt = make_options("church256", batch_size=16, num_gpus=1)
+    b = 16
+    ours = _Reconstruction(StyleGAN2ResnetEncoder(opt), StyleGAN2ResnetGenerator(opt)).to(DEV)
+    ref32 = _Reconstruction(A.EncoderCPU(opt), A.GeneratorCPU(opt)).to(DEV)
+    sp, dp = list(ref32.parameters()), list(ours.parameters())
+    assert [tuple(p.shape) for p in sp] == [tuple(p.shape) for p in dp]
+    g = torch.Generator().manual_seed(13)
+    with torch.no_grad():                 # the reference's own initialisation (N(0, 1) weights), biases / noise strengths made non-zero
+        for a_, b_ in zip(sp, dp):
+            v = torch.randn(a_.shape, generator=g) * (1.0 if a_.dim() > 1 and tuple(a_.shape) != (1, 3, 1, 1) else 0.2)
+            a_.copy_(v)
+            b_.copy_(v)
+    ref64 = _Reconstruction(A.EncoderCPU(opt), A.GeneratorCPU(opt)).to(DEV).double()
+    ref64.load_state_dict({k: v.double() for k, v in ref32.state_dict().items()})
+    x = (torch.rand(b, 3, 256, 256, generator=g) * 2 - 1).to(DEV)
+    with torch.no_grad():
+        ours(x[:1])                       # records every NoiseInjection's map size
+    mine_noise = [m for m in ours.modules() if isinstance(m, NoiseInjection)]
+    ref_noise = [[m for m in r.modules() if isinstance(m, A.StyledConvCPU)] for r in (ref32, ref64)]
+    assert len(mine_noise) == len(ref_noise[0]) == len(ref_noise[1]) > 0
+    for i, m in enumerate(mine_noise):
+        z = torch.randn(b, 1, m.image_size[2], m.image_size[3], generator=g).to(DEV)
+        m.fixed_noise = z
+        ref_noise[0][i].fixed_noise = z
+        ref_noise[1][i].fixed_noise = z
+    t = torch.randn(b, 3, 256, 256, generator=g).to(DEV)
+    err_o, err_a = _grads_and_errors(ref64, ref32, ours, [x], lambda m, i: m(i[0]), lambda m, i: m(i[0]), t)
+    _check("Encoder -> Generator reconstruction 16x3x256x256 vs ATen restatement in double (cuda:0)", conv_math, err_o, err_a)

@@ -1,0 +1,51 @@
+"""The package's whole encoder and generator (host modules over the C-ABI, oracle back end) against the ATen restatement of the
+reference's modules (oracle/aten_cpu_path.py, pinned to the reference in tests/dropin_ref_worker.py::aten_cpu_path_pin): one
+reconstruction, output and every parameter gradient, fixed noise maps.  The GPU form of this test at BASELINE size is
+tests/test_gpu_network_parity.py."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+from parity_common import backend
+
+
+def test_encoder_generator_reconstruction_matches_the_aten_restatement(oracle_lib):
+    import aten_cpu_path as A
+    from swapping_autoencoder_pytorch_amd.networks.encoder import StyleGAN2ResnetEncoder
+    from swapping_autoencoder_pytorch_amd.networks.generator import StyleGAN2ResnetGenerator
+    from swapping_autoencoder_pytorch_amd.options import make_options
+    from swapping_autoencoder_pytorch_amd.stylegan2_layers import NoiseInjection
+    opt = make_options("tiny32", batch_size=2, num_gpus=0, netE_scale_capacity=0.25, netG_scale_capacity=0.125,
+                       global_code_ch=64, spatial_code_ch=8)
+    torch.manual_seed(0)
+    with backend(oracle_lib):
+        enc, gen = StyleGAN2ResnetEncoder(opt), StyleGAN2ResnetGenerator(opt)
+        ref_enc, ref_gen = A.EncoderCPU(opt), A.GeneratorCPU(opt)
+        sp = list(ref_enc.parameters()) + list(ref_gen.parameters())
+        dp = list(enc.parameters()) + list(gen.parameters())
+        assert [tuple(p.shape) for p in sp] == [tuple(p.shape) for p in dp]
+        with torch.no_grad():
+            for a, b in zip(sp, dp):
+                v = torch.randn(a.shape) * (1.0 if a.dim() > 1 and tuple(a.shape) != (1, 3, 1, 1) else 0.2)
+                a.copy_(v)
+                b.copy_(v)
+        x = torch.rand(2, 3, 32, 32) * 2 - 1
+        with torch.no_grad():
+            gen(*enc(x[:1]))
+        mine = [m for m in gen.modules() if isinstance(m, NoiseInjection)]
+        theirs = [m for m in ref_gen.modules() if isinstance(m, A.StyledConvCPU)]
+        assert len(mine) == len(theirs) == 2 * (opt.netG_num_base_resnet_layers + opt.netE_num_downsampling_sp)
+        for m, r in zip(mine, theirs):
+            z = torch.randn(2, 1, m.image_size[2], m.image_size[3])
+            m.fixed_noise = z
+            r.fixed_noise = z
+        y, yr = gen(*enc(x)), ref_gen(*ref_enc(x))
+        assert float((y - yr).abs().max() / yr.abs().max()) < 1e-5
+        g1 = torch.autograd.grad((y - x).abs().mean(), dp)
+        g2 = torch.autograd.grad((yr - x).abs().mean(), sp)
+        for a, b in zip(g1, g2):
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max() + 1e-12)
