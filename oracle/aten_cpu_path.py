@@ -211,16 +211,16 @@ class StyledConvCPU(torch.nn.Module):
 
 
 class UpsamplingResnetBlockCPU(torch.nn.Module):
-    """generator.py:39-53 with use_noise=True and inch != outch; parameters in the reference module's own order."""
+    """generator.py:39-53 with use_noise=True; parameters in the reference module's own order."""
 
     def __init__(self, inch, outch, styledim):
         super().__init__()
         self.conv1 = StyledConvCPU(inch, outch, 3, styledim, upsample=True)
         self.conv2 = StyledConvCPU(outch, outch, 3, styledim, upsample=False)
-        self.skip = ConvLayerCPU(inch, outch, 1, activate=True, bias=True)
+        self.skip = ConvLayerCPU(inch, outch, 1, activate=True, bias=True) if inch != outch else None   # Identity, :48-49
 
     def forward(self, x, style, noise1=None, noise2=None):
-        skip = F.interpolate(self.skip(x), scale_factor=2, mode="bilinear", align_corners=False)
+        skip = F.interpolate(x if self.skip is None else self.skip(x), scale_factor=2, mode="bilinear", align_corners=False)
         res = self.conv2(self.conv1(x, style, noise1), style, noise2)
         return (skip + res) / math.sqrt(2)
 

@@ -5,6 +5,7 @@ tests/test_gpu_network_parity.py."""
 import os
 import sys
 
+import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,14 +14,15 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 from parity_common import backend
 
 
-def test_encoder_generator_reconstruction_matches_the_aten_restatement(oracle_lib):
+@pytest.mark.parametrize("n_sp", [2, 3])     # 3: an upsampling block with an Identity skip (generator.py:48-49)
+def test_encoder_generator_reconstruction_matches_the_aten_restatement(oracle_lib, n_sp):
     import aten_cpu_path as A
     from swapping_autoencoder_pytorch_amd.networks.encoder import StyleGAN2ResnetEncoder
     from swapping_autoencoder_pytorch_amd.networks.generator import StyleGAN2ResnetGenerator
     from swapping_autoencoder_pytorch_amd.options import make_options
     from swapping_autoencoder_pytorch_amd.stylegan2_layers import NoiseInjection
     opt = make_options("tiny32", batch_size=2, num_gpus=0, netE_scale_capacity=0.25, netG_scale_capacity=0.125,
-                       global_code_ch=64, spatial_code_ch=8)
+                       global_code_ch=64, spatial_code_ch=8, netE_num_downsampling_sp=n_sp)
     torch.manual_seed(0)
     with backend(oracle_lib):
         enc, gen = StyleGAN2ResnetEncoder(opt), StyleGAN2ResnetGenerator(opt)
