@@ -22,7 +22,8 @@ def test_encoder_generator_reconstruction_matches_the_aten_restatement(oracle_li
     from swapping_autoencoder_pytorch_amd.options import make_options
     from swapping_autoencoder_pytorch_amd.stylegan2_layers import NoiseInjection
     opt = make_options("tiny32", batch_size=2, num_gpus=0, netE_scale_capacity=0.25, netG_scale_capacity=0.125,
-                       global_code_ch=64, spatial_code_ch=8, netE_num_downsampling_sp=n_sp)
+                       global_code_ch=64, spatial_code_ch=8, netE_num_downsampling_sp=n_sp,
+                       netE_num_downsampling_gl=4 - n_sp)
     torch.manual_seed(0)
     with backend(oracle_lib):
         enc, gen = StyleGAN2ResnetEncoder(opt), StyleGAN2ResnetGenerator(opt)
