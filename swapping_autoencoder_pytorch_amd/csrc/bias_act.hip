@@ -150,16 +150,36 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_plane_kernel(
     if (threadIdx.x == 0) partial[c * nsplit + s] = t;
 }
 
-// Small channel planes (step_b < 256, including the [N, C] case step_b == 1): one thread per
-// (c, hw) column j walks the outer dimension; consecutive threads touch consecutive addresses.
-// partial[j] = sum_n gx[n][j],  j = c*step_b + hw.
+// Small channel planes (step_b < 256, including the [N, C] case step_b == 1): one thread per (c, hw) column j walks a
+// slice of the outer dimension; consecutive threads touch consecutive addresses.  The outer dimension is cut into
+// gridDim.y slices so that a few thousand workgroups are in flight (one slice left 24 workgroups on 256 CUs for the
+// 384 x [384, 4, 4] maps of the patch discriminator: 0.2 TB/s), four rows per step so that eight loads are in flight
+// per thread.   partial[(c * S + s) * step_b + hw] = sum over the slice's rows of gx[n][c][hw]
 __global__ __launch_bounds__(kBlock) void bias_act_bwd_column_kernel(
     const float* __restrict__ gy, const float* __restrict__ yref, float* __restrict__ gx,
-    float* __restrict__ partial, int64_t outer, int64_t cols, float alpha, float scale) {
+    float* __restrict__ partial, int64_t outer, int64_t cols, int64_t step_b, int rows_per_slice, float alpha, float scale) {
     const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (j >= cols) return;
+    const int64_t n0 = (int64_t)blockIdx.y * rows_per_slice;
+    int64_t n1 = n0 + rows_per_slice;
+    if (n1 > outer) n1 = outer;
     float acc = 0.0f;
-    for (int64_t n = 0; n < outer; ++n) {
+    int64_t n = n0;
+    for (; n + 4 <= n1; n += 4) {
+        float g[4], r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            g[u] = gy[(n + u) * cols + j];
+            r[u] = yref[(n + u) * cols + j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float o = ((r[u] > 0.0f) ? g[u] : g[u] * alpha) * scale;
+            gx[(n + u) * cols + j] = o;
+            acc += o;
+        }
+    }
+    for (; n < n1; ++n) {
         const int64_t i = n * cols + j;
         const float g = gy[i];
         const float r = yref[i];
@@ -167,27 +187,37 @@ __global__ __launch_bounds__(kBlock) void bias_act_bwd_column_kernel(
         gx[i] = o;
         acc += o;
     }
-    partial[j] = acc;
+    const int64_t c = j / step_b, hw = j - c * step_b;
+    partial[(c * gridDim.y + blockIdx.y) * step_b + hw] = acc;
 }
 
-// Second stage: gb[c] = sum_{q < Q} partial[c*Q + q], one wave per channel, fixed order.
+// Second stage: gb[c] = sum_{q < Q} partial[c*Q + q], one workgroup per channel, fixed order: thread t sums q = t, t + 256,
+// ... in four independent chains (one chain of Q / 64 dependent loads per wave took 50 us at the Q of a few thousand that
+// the fused K1 epilogue produces), then wave shuffles and one LDS round.
 __global__ __launch_bounds__(kBlock) void bias_grad_finalize_kernel(const float* __restrict__ partial,
                                                                      float* __restrict__ gb,
                                                                      int64_t size_b, int q_count) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t c = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    float acc = 0.0f;
-    if (c < size_b)
-        for (int q = lane; q < q_count; q += kWave) acc += partial[c * q_count + q];
-    acc = wave_sum(acc);
-    if (c < size_b && lane == 0) gb[c] = acc;
+    const int64_t c = blockIdx.x;
+    const float* pc = partial + c * q_count;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int q = threadIdx.x;
+    for (; q + 3 * kBlock < q_count; q += 4 * kBlock) {
+        a0 += pc[q];
+        a1 += pc[q + kBlock];
+        a2 += pc[q + 2 * kBlock];
+        a3 += pc[q + 3 * kBlock];
+    }
+    for (; q < q_count; q += kBlock) a0 += pc[q];
+    const float t = block_sum((a0 + a1) + (a2 + a3));
+    if (threadIdx.x == 0) gb[c] = t;
 }
 
 struct BwdPlan {
     bool column;        // small-plane kernel
     int vec;            // 4 or 1 (plane kernel)
     int chunks_per_plane;
-    int nsplit;
+    int nsplit;         // plane kernel: workgroups per channel; column kernel: slices of the outer dimension
+    int rows_per_slice; // column kernel
     int q_count;        // partials per channel
     int64_t outer;
 };
@@ -197,7 +227,15 @@ BwdPlan plan_bwd(int64_t numel, int64_t step_b, int64_t size_b, bool ptr_aligned
     p.outer = numel / (step_b * size_b);
     if (step_b < 256) {
         p.column = true;
-        p.q_count = (int)step_b;
+        // ~2048 workgroups, at least 8 rows per slice
+        const int64_t col_blocks = ceil_div64(step_b * size_b, kBlock);
+        int64_t slices = ceil_div64(2048, col_blocks);
+        if (slices > p.outer / 8) slices = p.outer / 8;
+        if (slices < 1) slices = 1;
+        if (slices > 512) slices = 512;
+        p.rows_per_slice = (int)ceil_div64(p.outer, slices);
+        p.nsplit = (int)ceil_div64(p.outer, p.rows_per_slice);
+        p.q_count = (int)step_b * p.nsplit;
         return p;
     }
     p.column = false;
@@ -286,8 +324,8 @@ extern "C" int sae_bias_act_bwd_f32(const float* gy, const float* y_ref, float* 
                     (long long)workspace_floats, (long long)need);
     if (p.column) {
         const int64_t cols = size_b * step_b;
-        hipLaunchKernelGGL(bias_act_bwd_column_kernel, dim3((unsigned)ceil_div64(cols, kBlock)), dim3(kBlock), 0,
-                           s, gy, y_ref, gx, workspace, p.outer, cols, alpha, scale);
+        hipLaunchKernelGGL(bias_act_bwd_column_kernel, dim3((unsigned)ceil_div64(cols, kBlock), (unsigned)p.nsplit),
+                           dim3(kBlock), 0, s, gy, y_ref, gx, workspace, p.outer, cols, step_b, p.rows_per_slice, alpha, scale);
     } else if (p.vec == 4) {
         hipLaunchKernelGGL((bias_act_bwd_plane_kernel<4>), dim3((unsigned)size_b, (unsigned)p.nsplit),
                            dim3(kBlock), 0, s, gy, y_ref, gx, workspace, p.outer, step_b, size_b,
@@ -297,8 +335,8 @@ extern "C" int sae_bias_act_bwd_f32(const float* gy, const float* y_ref, float* 
                            dim3(kBlock), 0, s, gy, y_ref, gx, workspace, p.outer, step_b, size_b,
                            p.chunks_per_plane, p.nsplit, alpha, scale);
     }
-    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((unsigned)ceil_div64(size_b, kBlock / kWave)),
-                       dim3(kBlock), 0, s, (const float*)workspace, gb, size_b, p.q_count);
+    hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3((unsigned)size_b), dim3(kBlock), 0, s, (const float*)workspace, gb,
+                       size_b, p.q_count);
     return check_launch("sae_bias_act_bwd_f32");
 }
 

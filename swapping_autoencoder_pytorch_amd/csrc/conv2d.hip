@@ -41,16 +41,7 @@
 namespace sae {
 namespace {
 
-// Dispatch knobs for A/B experiments exist only in builds with -DSAE_TUNING (tools/build_variant*.sh, the emulator of
-// tests/emu): the product library reads no environment variable besides SAE_CONV_MATH (sae_api.hip).
-#ifdef SAE_TUNING
-inline int tuning_knob(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-#else
-inline int tuning_knob(const char*, int dflt) { return dflt; }
-#endif
+// (tuning_knob: sae_common.h)
 // SAE_TRACE_DISPATCH=1 (tuning builds): one stderr line per launch decision the tests want to see
 #define SAE_TRACE(...)                                                         \
     do {                                                                       \

@@ -80,6 +80,12 @@ __device__ __forceinline__ void crop_range(float t, float mul, float off, int ex
     *lo = l; *hi = h;
 }
 
+// does the bilinear footprint of the output index with linspace value `lin` cover image coordinate t ?
+__device__ __forceinline__ bool crop_touches(float lin, float mul, float off, int extent, int t) {
+    const int i0 = (int)floorf(crop_coord(lin, mul, off, extent));
+    return i0 == t || i0 + 1 == t;
+}
+
 __global__ __launch_bounds__(kBlock) void random_crop_bwd_kernel(const float* __restrict__ gy,
                                                                  const float* __restrict__ params,
                                                                  const float* __restrict__ lin,
@@ -99,10 +105,27 @@ __global__ __launch_bounds__(kBlock) void random_crop_bwd_kernel(const float* __
             for (int kc = 0; kc < q.crops; ++kc) {
                 const int64_t k = (int64_t)b * q.crops + kc;
                 const float* pr = params + 5 * k;
+                // the window of the crop in the image, from the source coordinates of its first and last output index (the map is
+                // linear in the index): a pixel more than one column / row outside it (plus one of slack for the rounding of the
+                // ends) receives nothing from this crop.  The windows cover 2 - 6 % of the image, so this skips the range
+                // inversion below (four divisions) for almost every (pixel, crop) pair.
+                const float xa = crop_coord(lin[0] * pr[0], pr[1], pr[3], q.w), xb = crop_coord(lin[q.size - 1] * pr[0], pr[1], pr[3], q.w);
+                if ((float)px < floorf(fminf(xa, xb)) - 1.0f || (float)px > floorf(fmaxf(xa, xb)) + 2.0f) continue;
+                const float ya = crop_coord(lin[0], pr[2], pr[4], q.h), yb = crop_coord(lin[q.size - 1], pr[2], pr[4], q.h);
+                if ((float)py < floorf(fminf(ya, yb)) - 1.0f || (float)py > floorf(fmaxf(ya, yb)) + 2.0f) continue;
                 int c_lo, c_hi, r_lo, r_hi;
                 crop_range((float)px, pr[0] * pr[1], pr[3], q.w, q.size, &c_lo, &c_hi);
                 if (c_lo > c_hi) continue;
                 crop_range((float)py, pr[2], pr[4], q.h, q.size, &r_lo, &r_hi);
+                // the candidate ranges are the inverse map widened by two on each side; the map is monotonic, so the outputs
+                // that really touch the pixel are contiguous: trim the ends with the forward's own arithmetic before the
+                // double loop (it ran over ~100 candidate pairs for ~30 contributing ones, on the few waves whose pixels lie
+                // inside a crop window -- the kernel's critical path: 0.23 ms for 13 MB)
+                while (c_lo <= c_hi && !crop_touches(lin[c_lo] * pr[0], pr[1], pr[3], q.w, px)) ++c_lo;
+                while (c_hi >= c_lo && !crop_touches(lin[c_hi] * pr[0], pr[1], pr[3], q.w, px)) --c_hi;
+                if (c_lo > c_hi) continue;
+                while (r_lo <= r_hi && !crop_touches(lin[r_lo], pr[2], pr[4], q.h, py)) ++r_lo;
+                while (r_hi >= r_lo && !crop_touches(lin[r_hi], pr[2], pr[4], q.h, py)) --r_hi;
                 const int64_t plane = (int64_t)q.size * q.size;
                 const float* gp = gy + (k * q.channels + ch0) * plane;
                 for (int r = r_lo; r <= r_hi; ++r) {

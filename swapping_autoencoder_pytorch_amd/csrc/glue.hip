@@ -21,19 +21,30 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return v;
 }
 
+// sum over the workgroup, the same value in every thread (fixed order: wave shuffles, then the four wave sums)
+__device__ __forceinline__ float block_sum_f(float v) {
+    __shared__ float red[kBlock / kWave];
+    v = wave_sum_f(v);
+    __syncthreads();                // protects `red` against its previous use
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) t += red[w];
+    return t;
+}
+
 // x, y: [outer][C][inner]
 __global__ __launch_bounds__(kBlock) void l2_normalize_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               int64_t outer, int C, int64_t inner, float eps) {
-    if (inner == 1) {               // one wave per row
-        const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-        const int lane = threadIdx.x & 63;
-        if (row >= outer) return;
+    if (inner == 1) {               // one workgroup per row (one wave walked the 2048 channels of the global code in 19 us)
+        const int64_t row = blockIdx.x;
         const float* xr = x + row * C;
         float s = 0.0f;
-        for (int c = lane; c < C; c += kWave) s = fmaf(xr[c], xr[c], s);
-        s = wave_sum_f(s);
+        for (int c = threadIdx.x; c < C; c += kBlock) s = fmaf(xr[c], xr[c], s);
+        s = block_sum_f(s);
         const float r = (1.0f / sqrtf(s + eps));
-        for (int c = lane; c < C; c += kWave) y[row * C + c] = xr[c] * r;
+        for (int c = threadIdx.x; c < C; c += kBlock) y[row * C + c] = xr[c] * r;
         return;
     }
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -52,18 +63,16 @@ __global__ __launch_bounds__(kBlock) void l2_normalize_bwd_kernel(const float* _
                                                                   float* __restrict__ gx, int64_t outer, int C,
                                                                   int64_t inner, float eps) {
     if (inner == 1) {
-        const int64_t row = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-        const int lane = threadIdx.x & 63;
-        if (row >= outer) return;
+        const int64_t row = blockIdx.x;
         const float* xr = x + row * C;
         const float* gr = gy + row * C;
         float s = 0.0f, d = 0.0f;
-        for (int c = lane; c < C; c += kWave) { s = fmaf(xr[c], xr[c], s); d = fmaf(gr[c], xr[c], d); }
-        s = wave_sum_f(s);
-        d = wave_sum_f(d);
+        for (int c = threadIdx.x; c < C; c += kBlock) { s = fmaf(xr[c], xr[c], s); d = fmaf(gr[c], xr[c], d); }
+        s = block_sum_f(s);
+        d = block_sum_f(d);
         const float r = (1.0f / sqrtf(s + eps));
         const float k = r * r * r * d;
-        for (int c = lane; c < C; c += kWave) gx[row * C + c] = r * gr[c] - k * xr[c];
+        for (int c = threadIdx.x; c < C; c += kBlock) gx[row * C + c] = r * gr[c] - k * xr[c];
         return;
     }
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -152,11 +161,11 @@ using namespace sae;
 extern "C" int sae_l2_normalize_f32(const float* x, float* y, int64_t outer, int64_t channels, int64_t inner, float eps,
                                     sae_stream_t stream) {
     sae::clear_stale_error();
-    if (outer < 0 || channels < 1 || inner < 1 || channels >= ((int64_t)1 << 31))
+    if (outer < 0 || outer >= ((int64_t)1 << 31) || channels < 1 || inner < 1 || channels >= ((int64_t)1 << 31))
         return fail(SAE_EINVAL, "sae_l2_normalize_f32: bad shape");
     if (outer == 0) return SAE_OK;
     if (!x || !y) return fail(SAE_EINVAL, "sae_l2_normalize_f32: null tensor");
-    const unsigned blocks = inner == 1 ? blocks_for(outer, kBlock / kWave) : blocks_for(outer * inner, kBlock);
+    const unsigned blocks = inner == 1 ? (unsigned)outer : blocks_for(outer * inner, kBlock);
     hipLaunchKernelGGL(l2_normalize_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, x, y, outer, (int)channels,
                        inner, eps);
     return check_launch("sae_l2_normalize_f32");
@@ -165,11 +174,11 @@ extern "C" int sae_l2_normalize_f32(const float* x, float* y, int64_t outer, int
 extern "C" int sae_l2_normalize_bwd_f32(const float* gy, const float* x, float* gx, int64_t outer, int64_t channels,
                                         int64_t inner, float eps, sae_stream_t stream) {
     sae::clear_stale_error();
-    if (outer < 0 || channels < 1 || inner < 1 || channels >= ((int64_t)1 << 31))
+    if (outer < 0 || outer >= ((int64_t)1 << 31) || channels < 1 || inner < 1 || channels >= ((int64_t)1 << 31))
         return fail(SAE_EINVAL, "sae_l2_normalize_bwd_f32: bad shape");
     if (outer == 0) return SAE_OK;
     if (!gy || !x || !gx) return fail(SAE_EINVAL, "sae_l2_normalize_bwd_f32: null tensor");
-    const unsigned blocks = inner == 1 ? blocks_for(outer, kBlock / kWave) : blocks_for(outer * inner, kBlock);
+    const unsigned blocks = inner == 1 ? (unsigned)outer : blocks_for(outer * inner, kBlock);
     hipLaunchKernelGGL(l2_normalize_bwd_kernel, dim3(blocks), dim3(kBlock), 0, (hipStream_t)stream, gy, x, gx, outer,
                        (int)channels, inner, eps);
     return check_launch("sae_l2_normalize_bwd_f32");

@@ -123,13 +123,29 @@ __global__ __launch_bounds__(kBlock) void noise_bias_act_bwd_kernel(
     }
 }
 
-// gb[c] = sum_q partial_b[c*Q + q] (one wave per channel); block 0 additionally reduces all of partial_n
-// (channels * Q values, fixed order) into gw[0]
+// gb[c] = sum_q partial_b[c*Q + q] (one wave per channel); the LAST workgroup additionally reduces all of partial_n
+// (channels * Q values, fixed order, four independent chains per thread) into gw[0]
 __global__ __launch_bounds__(kBlock) void noise_bias_finalize_kernel(const double* __restrict__ partial_b,
                                                                      const double* __restrict__ partial_n,
                                                                      float* __restrict__ gb, float* __restrict__ gw,
                                                                      int channels, int q_count) {
     __shared__ double red[kBlock / kWave];
+    if (blockIdx.x == gridDim.x - 1) {       // its own workgroup: the channel sums do not wait behind it
+        if (!gw) return;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        const int total = channels * q_count;
+        int i = threadIdx.x;
+        for (; i + 3 * kBlock < total; i += 4 * kBlock) {
+            t0 += partial_n[i];
+            t1 += partial_n[i + kBlock];
+            t2 += partial_n[i + 2 * kBlock];
+            t3 += partial_n[i + 3 * kBlock];
+        }
+        for (; i < total; i += kBlock) t0 += partial_n[i];
+        const double t = block_sum_m((t0 + t1) + (t2 + t3), red);
+        if (threadIdx.x == 0) gw[0] = (float)t;
+        return;
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int c = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     double acc = 0.0;
@@ -137,13 +153,6 @@ __global__ __launch_bounds__(kBlock) void noise_bias_finalize_kernel(const doubl
         for (int q = lane; q < q_count; q += kWave) acc += partial_b[c * q_count + q];
     acc = wave_sum_m(acc);
     if (gb && c < channels && lane == 0) gb[c] = (float)acc;
-    if (blockIdx.x == 0 && gw) {
-        double t = 0.0;
-        const int total = channels * q_count;
-        for (int i = threadIdx.x; i < total; i += kBlock) t += partial_n[i];
-        t = block_sum_m(t, red);
-        if (threadIdx.x == 0) gw[0] = (float)t;
-    }
 }
 
 // one workgroup per (n, c) plane
@@ -254,7 +263,7 @@ extern "C" int sae_noise_bias_act_bwd_f32(const float* gy, const float* y_ref, c
     double* pn = pb + channels * nsplit;
     hipLaunchKernelGGL(noise_bias_act_bwd_kernel, dim3((unsigned)channels, (unsigned)nsplit), dim3(kBlock), 0, s, gy,
                        y_ref, noise, gx, pb, pn, outer, (int)hw, (int)channels, cpp, nsplit, alpha, scale);
-    hipLaunchKernelGGL(noise_bias_finalize_kernel, dim3((unsigned)ceil_div64(channels, kBlock / kWave)), dim3(kBlock),
+    hipLaunchKernelGGL(noise_bias_finalize_kernel, dim3((unsigned)ceil_div64(channels, kBlock / kWave) + 1), dim3(kBlock),
                        0, s, (const double*)pb, (const double*)pn, gbias, noise ? gnoise_weight : nullptr, (int)channels,
                        nsplit);
     return check_launch("sae_noise_bias_act_bwd_f32");

@@ -16,14 +16,40 @@ struct PadGeom {
 
 __device__ __forceinline__ int refl(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
+// Row-wise: a wave owns whole output rows (kPadRows at a time), its lanes the columns in runs of 64, four runs in flight.  The
+// (plane, row) split is one division per row and wave; the element-wise form spent three 64-bit divisions per 8 bytes moved
+// and sat at 2.3 TB/s (profiles/r3_roofline_by_shape_church256.txt) where the streaming kernels reach 5.
+constexpr int kPadRows = 2;
+
 __global__ __launch_bounds__(kBlock) void reflect_pad_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                              int64_t planes, const PadGeom q) {
-    const int64_t total = planes * q.oh * q.ow;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int ox = (int)(i % q.ow);
-        const int oy = (int)((i / q.ow) % q.oh);
-        const int64_t p = i / ((int64_t)q.ow * q.oh);
-        y[i] = x[(p * q.h + refl(oy - q.top, q.h)) * q.w + refl(ox - q.left, q.w)];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t rows = planes * q.oh;
+    const int64_t waves = (int64_t)gridDim.x * (kBlock / kWave);
+    for (int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kPadRows; row0 < rows;
+         row0 += waves * kPadRows) {
+#pragma unroll
+        for (int r = 0; r < kPadRows; ++r) {
+            const int64_t row = row0 + r;
+            if (row >= rows) break;
+            const int64_t p = row / q.oh;
+            const int oy = (int)(row - p * q.oh);
+            const float* src = x + (p * q.h + refl(oy - q.top, q.h)) * q.w;
+            float* dst = y + row * q.ow;
+            for (int ox0 = 0; ox0 < q.ow; ox0 += 4 * kWave) {
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ox = ox0 + u * kWave + lane;
+                    v[u] = src[ox < q.ow ? refl(ox - q.left, q.w) : 0];      // branch-free load, see upfirdn2d.hip
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int ox = ox0 + u * kWave + lane;
+                    if (ox < q.ow) dst[ox] = v[u];
+                }
+            }
+        }
     }
 }
 
@@ -38,21 +64,53 @@ __device__ __forceinline__ int pre_images(int i, int n, int before, int on, int 
     return cnt;
 }
 
+// row-wise like the forward; the row's pre-images are shared by the wave, the column's (one, except next to the border) per lane
 __global__ __launch_bounds__(kBlock) void reflect_pad_adj_kernel(const float* __restrict__ gy, float* __restrict__ gx,
                                                                  int64_t planes, const PadGeom q) {
-    const int64_t total = planes * q.h * q.w;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
-        const int px = (int)(i % q.w);
-        const int py = (int)((i / q.w) % q.h);
-        const int64_t p = i / ((int64_t)q.w * q.h);
-        int ys[3], xs[3];
-        const int ny = pre_images(py, q.h, q.top, q.oh, ys);
-        const int nx = pre_images(px, q.w, q.left, q.ow, xs);
-        const float* g = gy + p * q.oh * q.ow;
-        float acc = 0.0f;
-        for (int a = 0; a < ny; ++a)
-            for (int b = 0; b < nx; ++b) acc += g[(int64_t)ys[a] * q.ow + xs[b]];
-        gx[i] = acc;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t rows = planes * q.h;
+    const int64_t waves = (int64_t)gridDim.x * (kBlock / kWave);
+    for (int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * kPadRows; row0 < rows;
+         row0 += waves * kPadRows) {
+#pragma unroll
+        for (int r = 0; r < kPadRows; ++r) {
+            const int64_t row = row0 + r;
+            if (row >= rows) break;
+            const int64_t p = row / q.h;
+            const int py = (int)(row - p * q.h);
+            int ys[3];
+            const int ny = pre_images(py, q.h, q.top, q.oh, ys);
+            const float* g = gy + p * q.oh * q.ow;
+            float* dst = gx + row * q.w;
+            for (int px0 = 0; px0 < q.w; px0 += 4 * kWave) {
+                float acc[4];
+                // the direct pre-image (every element has one) is fetched branch-free for the four runs, the mirrored ones --
+                // border rows and the few border columns -- in a rarely taken branch; the terms are added in the order
+                // (row pre-image, column pre-image) of the element-wise form
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int px = px0 + u * kWave + lane;
+                    acc[u] = g[(int64_t)ys[0] * q.ow + (px < q.w ? px + q.left : 0)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int px = px0 + u * kWave + lane;
+                    if (px < q.w) {
+                        int xs[3];
+                        const int nx = pre_images(px, q.w, q.left, q.ow, xs);
+                        if (ny > 1 || nx > 1) {
+                            for (int a = 0; a < ny; ++a)
+                                for (int b = (a == 0 ? 1 : 0); b < nx; ++b) acc[u] += g[(int64_t)ys[a] * q.ow + xs[b]];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int px = px0 + u * kWave + lane;
+                    if (px < q.w) dst[px] = acc[u];
+                }
+            }
+        }
     }
 }
 
@@ -74,7 +132,7 @@ extern "C" int sae_reflect_pad_f32(const float* x, float* y, int64_t planes, int
     if (planes == 0) return SAE_OK;
     if (!x || !y) return fail(SAE_EINVAL, "sae_reflect_pad_f32: null tensor");
     const PadGeom q{(int)h, (int)w, (int)h + top + bottom, (int)w + left + right, left, top};
-    int64_t blocks = ceil_div64(planes * q.oh * q.ow, kBlock);
+    int64_t blocks = ceil_div64(planes * q.oh, (kBlock / kWave) * kPadRows);
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(reflect_pad_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, x, y, planes, q);
     return check_launch("sae_reflect_pad_f32");
@@ -88,7 +146,7 @@ extern "C" int sae_reflect_pad_adj_f32(const float* gy, float* gx, int64_t plane
     if (planes == 0) return SAE_OK;
     if (!gy || !gx) return fail(SAE_EINVAL, "sae_reflect_pad_adj_f32: null tensor");
     const PadGeom q{(int)h, (int)w, (int)h + top + bottom, (int)w + left + right, left, top};
-    int64_t blocks = ceil_div64(planes * h * w, kBlock);
+    int64_t blocks = ceil_div64(planes * h, (kBlock / kWave) * kPadRows);
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(reflect_pad_adj_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, gy, gx, planes,
                        q);

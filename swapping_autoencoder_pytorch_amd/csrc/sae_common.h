@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #include "sae_hip.h"
 
@@ -34,6 +35,17 @@ inline int check_launch(const char* what) {
 
 __host__ __device__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Dispatch knobs for A/B experiments exist only in builds with -DSAE_TUNING (tools/build_variant*.sh, the emulator of
+// tests/emu): the product library reads no environment variable besides SAE_CONV_MATH (sae_api.hip).
+#ifdef SAE_TUNING
+inline int tuning_knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+inline int tuning_knob(const char*, int dflt) { return dflt; }
+#endif
 
 inline int ilog2_ceil(int64_t v) {  // smallest e with (1 << e) >= v, v >= 1
     int e = 0;

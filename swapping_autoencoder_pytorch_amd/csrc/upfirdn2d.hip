@@ -49,11 +49,13 @@ struct K1Epilogue {
 
 // The epilogue's own operands (the old value of y, the activation reference) are fetched together with the strip, long
 // before the FIR needs them: issued after the FIR they were a second, fully exposed round trip per block.
-template <int RB>
-struct K1Operands { float old[RB], ref[RB]; };
+// ACC = false: instantiations that never accumulate (the blur + activation-backward pass of the ResBlock) do not carry the
+// `old` registers -- with the taps in scalar registers that takes the 64 x 8 blur from 84 to 60 VGPRs, 5 to 8 waves per SIMD.
+template <int RB, bool ACC = true>
+struct K1Operands { float old[ACC ? RB : 1], ref[RB]; };
 
-template <int RB>
-__device__ __forceinline__ void k1_prefetch(const K1Epilogue& e, K1Operands<RB>& q, const float* yp, bool col_ok,
+template <int RB, bool ACC = true>
+__device__ __forceinline__ void k1_prefetch(const K1Epilogue& e, K1Operands<RB, ACC>& q, const float* yp, bool col_ok,
                                             int oy0, int out_h, int out_w, int ox, int64_t plane, int64_t plane_elems) {
     const float* rp = e.act_ref ? e.act_ref + plane * plane_elems : yp;
 #pragma unroll
@@ -61,14 +63,14 @@ __device__ __forceinline__ void k1_prefetch(const K1Epilogue& e, K1Operands<RB>&
         const int oy = oy0 + o;
         const bool ok = col_ok && oy < out_h;
         const int64_t idx = ok ? (int64_t)oy * out_w + ox : 0;       // branch-free (see blur_kernel): element 0 otherwise
-        q.old[o] = e.accumulate ? yp[idx] : 0.0f;
+        if constexpr (ACC) q.old[o] = e.accumulate ? yp[idx] : 0.0f;
         q.ref[o] = e.act_ref ? rp[idx] : 1.0f;
     }
 }
 
 // v: the thread's RB outputs of column ox, rows oy0 ...; writes y and (act_ref) the strip's partial bias-gradient sum
-template <int TW, int RB>
-__device__ __forceinline__ void k1_epilogue(const K1Epilogue& e, const K1Operands<RB>& q, float (&v)[RB], float* yp,
+template <int TW, int RB, bool ACC = true>
+__device__ __forceinline__ void k1_epilogue(const K1Epilogue& e, const K1Operands<RB, ACC>& q, float (&v)[RB], float* yp,
                                             bool col_ok, int oy0, int out_h, int out_w, int ox, int64_t plane, int strip_q,
                                             int q_per_plane, bool live, int tx) {
     float bsum = 0.0f;
@@ -78,7 +80,9 @@ __device__ __forceinline__ void k1_epilogue(const K1Epilogue& e, const K1Operand
             const int oy = oy0 + o;
             if (oy < out_h) {
                 float t = v[o];
-                if (e.accumulate) t += q.old[o];
+                if constexpr (ACC) {
+                    if (e.accumulate) t += q.old[o];
+                }
                 if (e.act_ref) {
                     t = ((q.ref[o] > 0.0f) ? t : t * e.slope) * e.scale;
                     bsum += t;
@@ -116,43 +120,25 @@ struct BlurParams {
     int x_tiles;           // ceil(out_w / TW)
     int64_t groups;        // planes * groups_per_plane
     int64_t blocks;        // workgroups that have work (the grid is rounded up to a multiple of 8, see k1_block_id)
+    int main_per_unit;     // blur_tail_kernel: 64-column workgroups per unit of 32 row groups ((x_tiles - 1) * 8)
 };
 
-template <int KH, int KW, int TW, int RB, bool EPI = false>
-__global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ x,
-                                                      const float* __restrict__ k,
-                                                      float* __restrict__ y, const BlurParams p, const K1Epilogue e) {
-    constexpr int NR = kBlock / TW;          // thread rows per block
+// One strip: RB output rows by TW output columns starting at column ox0 of row group g (global index over all planes), staged
+// through the thread row's LDS strip `sp`.  `xt` is the strip's x-tile index in the epilogue's partial-sum layout.
+template <int KH, int KW, int TW, int RB, bool EPI, bool ACC = true>
+__device__ __forceinline__ void blur_strip(const float* __restrict__ x, float* __restrict__ y, const BlurParams& p,
+                                           const K1Epilogue& e, float* sp, const float* taps, const int tx, const int64_t g,
+                                           const int xt, const int ox0) {
     constexpr int SR = RB + KH - 1;          // staged rows per strip
     constexpr int SW = TW + KW - 1;          // staged columns per strip
     constexpr int SWP = SW | 1;              // odd row stride
-    __shared__ float strip[NR][SR * SWP];
-    __shared__ float taps[KH * KW];
-
-    const int tx = threadIdx.x % TW;
-    const int tr = threadIdx.x / TW;
-
-    // flipped taps, zero padded to the template size (upfirdn2d_kernel.cu:71-81)
-    if (threadIdx.x < KH * KW) {
-        const int ky = threadIdx.x / KW, kx = threadIdx.x % KW;
-        float v = 0.0f;
-        if (ky < p.kh && kx < p.kw) v = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
-        taps[threadIdx.x] = v;
-    }
-
-    const int64_t bid = k1_block_id();
-    if (bid >= p.blocks) return;                    // (whole workgroup: the grid's padding to a multiple of 8)
-    const int xt = (int)(bid % p.x_tiles);
-    const int64_t g = (bid / p.x_tiles) * NR + tr;  // strip (row group) handled by this thread row
     const bool live = g < p.groups;
     const int64_t plane = live ? g / p.groups_per_plane : 0;
     const int oy0 = live ? (int)(g - plane * p.groups_per_plane) * RB : 0;
-    const int ox0 = xt * TW;
     const int iy0 = oy0 - p.pad_y0;  // input row of staged row 0
     const int ix0 = ox0 - p.pad_x0;  // input column of staged column 0
 
     const float* xp = x + plane * (int64_t)p.in_h * p.in_w;
-    float* sp = strip[tr];
     // all global loads of the strip are issued back to back into registers, then written to LDS: one load in flight
     // per wave would leave HBM latency fully exposed.  The strip is fetched ROW-wise: lane tx takes column tx of each of
     // the SR rows (one contiguous TW * 4-byte run per instruction, no per-element index division — the generic
@@ -182,9 +168,9 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
         const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
         halo[i] = ok ? v : 0.0f;
     }
-    [[maybe_unused]] K1Operands<EPI ? RB : 1> eq;
+    [[maybe_unused]] K1Operands<EPI ? RB : 1, ACC> eq;
     if constexpr (EPI)
-        k1_prefetch<RB>(e, eq, y + plane * (int64_t)p.out_h * p.out_w, live && ox0 + tx < p.out_w, oy0, p.out_h, p.out_w,
+        k1_prefetch<RB, ACC>(e, eq, y + plane * (int64_t)p.out_h * p.out_w, live && ox0 + tx < p.out_w, oy0, p.out_h, p.out_w,
                         ox0 + tx, plane, (int64_t)p.out_h * p.out_w);
 #pragma unroll
     for (int r = 0; r < SR; ++r) sp[r * SWP + tx] = body[r];
@@ -200,7 +186,8 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
 #pragma unroll
     for (int a = 0; a < KH; ++a)
 #pragma unroll
-        for (int b = 0; b < KW; ++b) tap[a][b] = taps[a * KW + b];
+        for (int b = 0; b < KW; ++b)      // wave-uniform: kept in scalar registers (16 VGPRs less at 4 x 4 taps)
+            tap[a][b] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, taps[a * KW + b])));
 
     // (measured and dropped, same-box A/B with tools/kb_k1.py: the rows accumulated in pairs as packed fp32, v_pk_fma_f32
     // with the staged value broadcast against a pair of taps held in scalar registers -- 20 instead of 32 vector
@@ -228,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
     const int ox = ox0 + tx;
     if constexpr (EPI) {
         const int gi = (int)(g - plane * p.groups_per_plane);
-        k1_epilogue<TW, RB>(e, eq, acc, y + plane * (int64_t)p.out_h * p.out_w, live && ox < p.out_w, oy0, p.out_h, p.out_w, ox,
+        k1_epilogue<TW, RB, ACC>(e, eq, acc, y + plane * (int64_t)p.out_h * p.out_w, live && ox < p.out_w, oy0, p.out_h, p.out_w, ox,
                             plane, gi * p.x_tiles + xt, p.groups_per_plane * p.x_tiles, live, tx);
         return;
     }
@@ -239,6 +226,72 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
             const int oy = oy0 + o;
             if (oy < p.out_h) yp[(int64_t)oy * p.out_w + ox] = acc[o];
         }
+    }
+}
+
+template <int KH, int KW, int TW, int RB, bool EPI = false, bool ACC = true>
+__global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ x,
+                                                      const float* __restrict__ k,
+                                                      float* __restrict__ y, const BlurParams p, const K1Epilogue e) {
+    constexpr int NR = kBlock / TW;          // thread rows per block
+    constexpr int SR = RB + KH - 1;
+    constexpr int SWP = (TW + KW - 1) | 1;
+    __shared__ float strip[NR][SR * SWP];
+    __shared__ float taps[KH * KW];
+
+    const int tx = threadIdx.x % TW;
+    const int tr = threadIdx.x / TW;
+
+    // flipped taps, zero padded to the template size (upfirdn2d_kernel.cu:71-81)
+    if (threadIdx.x < KH * KW) {
+        const int ky = threadIdx.x / KW, kx = threadIdx.x % KW;
+        float v = 0.0f;
+        if (ky < p.kh && kx < p.kw) v = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+        taps[threadIdx.x] = v;
+    }
+
+    const int64_t bid = k1_block_id();
+    if (bid >= p.blocks) return;                    // (whole workgroup: the grid's padding to a multiple of 8)
+    const int xt = (int)(bid % p.x_tiles);
+    const int64_t g = (bid / p.x_tiles) * NR + tr;  // strip (row group) handled by this thread row
+    blur_strip<KH, KW, TW, RB, EPI, ACC>(x, y, p, e, strip[tr], taps, tx, g, xt, xt * TW);
+}
+
+// The 2^k + 1 wide outputs of the train step (65, 129, 257: every blur in front of a stride-2 conv) leave ONE column for the
+// last 64-column tile: a fifth, a third, half of the wavefronts ran with one live lane, and the kernel's rate followed the
+// live fraction (4.9 TB/s at 256 columns, 4.1 - 4.4 at 257, 3.7 at 129, 2.6 at 65: gpurun r3C by-shape ledger).  Here the
+// remainder columns (1 ... 8) of 32 row groups are packed into one workgroup of 8-lane thread rows, placed right behind the 64-column
+// workgroups of the same row groups (it re-reads the last columns of their input from the same XCD's L2):
+//   unit u = [ main_per_unit workgroups of 4 row groups x 64 columns | 1 workgroup of 32 row groups x 8 columns ]
+// The partial-sum layout of the epilogue is unchanged (the remainder is x tile x_tiles - 1).
+template <int KH, int KW, int RB, bool EPI = false, bool ACC = true>
+__global__ __launch_bounds__(kBlock) void blur_tail_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                           float* __restrict__ y, const BlurParams p, const K1Epilogue e) {
+    constexpr int SR = RB + KH - 1;
+    constexpr int SWP_M = (64 + KW - 1) | 1, SWP_T = (8 + KW - 1) | 1;
+    constexpr int LDS_M = (kBlock / 64) * SR * SWP_M, LDS_T = (kBlock / 8) * SR * SWP_T;
+    __shared__ float strips[LDS_M > LDS_T ? LDS_M : LDS_T];
+    __shared__ float taps[KH * KW];
+    if (threadIdx.x < KH * KW) {
+        const int ky = threadIdx.x / KW, kx = threadIdx.x % KW;
+        float v = 0.0f;
+        if (ky < p.kh && kx < p.kw) v = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
+        taps[threadIdx.x] = v;
+    }
+    const int64_t bid = k1_block_id();
+    if (bid >= p.blocks) return;
+    const int64_t unit = bid / (p.main_per_unit + 1);
+    const int r = (int)(bid - unit * (p.main_per_unit + 1));
+    if (r < p.main_per_unit) {
+        const int xm = p.x_tiles - 1;
+        const int xt = r % xm;
+        const int tr = threadIdx.x / 64;
+        const int64_t g = (unit * 8 + r / xm) * 4 + tr;
+        blur_strip<KH, KW, 64, RB, EPI, ACC>(x, y, p, e, strips + tr * SR * SWP_M, taps, threadIdx.x % 64, g, xt, xt * 64);
+    } else {
+        const int tr = threadIdx.x / 8;
+        blur_strip<KH, KW, 8, RB, EPI, ACC>(x, y, p, e, strips + tr * SR * SWP_T, taps, threadIdx.x % 8, unit * 32 + tr, p.x_tiles - 1,
+                                       (p.x_tiles - 1) * 64);
     }
 }
 
@@ -418,16 +471,30 @@ void launch_updown(const float* x, const float* k, float* y, UpDownParams p, hip
                        x, k, y, p, e);
 }
 
-template <int KH, int KW, int TW, int RB, bool EPI = false>
+template <int KH, int KW, int TW, int RB, bool EPI = false, bool ACC = true>
 void launch_blur(const float* x, const float* k, float* y, BlurParams p, hipStream_t s, K1Epilogue e = K1Epilogue{}) {
     constexpr int NR = kBlock / TW;
     p.groups_per_plane = ceil_div(p.out_h, RB);
     p.x_tiles = ceil_div(p.out_w, TW);
     p.groups = p.planes * p.groups_per_plane;
     p.blocks = ceil_div64(p.groups, NR) * p.x_tiles;
-    hipLaunchKernelGGL((blur_kernel<KH, KW, TW, RB, EPI>), dim3((unsigned)((p.blocks + 7) / 8 * 8)), dim3(kBlock), 0, s, x, k, y,
+    hipLaunchKernelGGL((blur_kernel<KH, KW, TW, RB, EPI, ACC>), dim3((unsigned)((p.blocks + 7) / 8 * 8)), dim3(kBlock), 0, s, x, k, y,
                        p, e);
 }
+
+template <int KH, int KW, int RB, bool EPI = false, bool ACC = true>
+void launch_blur_tail(const float* x, const float* k, float* y, BlurParams p, hipStream_t s, K1Epilogue e = K1Epilogue{}) {
+    p.groups_per_plane = ceil_div(p.out_h, RB);
+    p.x_tiles = ceil_div(p.out_w, 64);
+    p.groups = p.planes * p.groups_per_plane;
+    p.main_per_unit = (p.x_tiles - 1) * 8;
+    p.blocks = ceil_div64(p.groups, 32) * (p.main_per_unit + 1);
+    hipLaunchKernelGGL((blur_tail_kernel<KH, KW, RB, EPI, ACC>), dim3((unsigned)((p.blocks + 7) / 8 * 8)), dim3(kBlock), 0, s, x, k, y,
+                       p, e);
+}
+
+// 64-column tiles with a remainder of 1 ... 8 columns
+inline bool blur_has_tail(int out_w) { return out_w > 64 && out_w % 64 >= 1 && out_w % 64 <= 8; }
 
 // tile of the planes kernels: width from the output width, rows per thread from the output height (blur: 8 rows per thread
 // on wide planes, 67 VGPRs -> 7 waves/SIMD, measured 3.5-4.0 TB/s vs 2.9-3.5 with 16 rows)
@@ -443,7 +510,12 @@ inline K1Tile updown_tile(int out_w) { return out_w > 16 ? K1Tile{64, 8} : K1Til
 template <bool EPI>
 void dispatch_blur44(const float* x, const float* k, float* y, const BlurParams& p, hipStream_t s, const K1Epilogue& e) {
     const K1Tile t = blur_tile(p.out_w, p.out_h);
-    if (t.tw == 64 && t.rb == 8) launch_blur<4, 4, 64, 8, EPI>(x, k, y, p, s, e);
+    const bool tail = t.tw == 64 && t.rb == 8 && blur_has_tail(p.out_w) && tuning_knob("SAE_K1_TAIL", 1);
+    if (EPI && !e.accumulate && t.tw == 64 && t.rb == 8) {       // the train step's blur + activation backward: no `old` operand
+        if (tail) launch_blur_tail<4, 4, 8, EPI, false>(x, k, y, p, s, e);
+        else launch_blur<4, 4, 64, 8, EPI, false>(x, k, y, p, s, e);
+    } else if (tail) launch_blur_tail<4, 4, 8, EPI>(x, k, y, p, s, e);
+    else if (t.tw == 64 && t.rb == 8) launch_blur<4, 4, 64, 8, EPI>(x, k, y, p, s, e);
     else if (t.tw == 64) launch_blur<4, 4, 64, 4, EPI>(x, k, y, p, s, e);
     else if (t.tw == 32 && t.rb == 16) launch_blur<4, 4, 32, 16, EPI>(x, k, y, p, s, e);
     else if (t.tw == 32) launch_blur<4, 4, 32, 4, EPI>(x, k, y, p, s, e);
@@ -455,7 +527,8 @@ void dispatch_blur44(const float* x, const float* k, float* y, const BlurParams&
 template <int KH, int KW>
 void dispatch_blur(const float* x, const float* k, float* y, const BlurParams& p, hipStream_t s) {
     const K1Tile t = blur_tile(p.out_w, p.out_h);
-    if (t.tw == 64 && t.rb == 8) launch_blur<KH, KW, 64, 8>(x, k, y, p, s);
+    if (KH > 1 && t.tw == 64 && t.rb == 8 && blur_has_tail(p.out_w) && tuning_knob("SAE_K1_TAIL", 1)) launch_blur_tail<KH, KW, 8>(x, k, y, p, s);
+    else if (t.tw == 64 && t.rb == 8) launch_blur<KH, KW, 64, 8>(x, k, y, p, s);
     else if (t.tw == 64) launch_blur<KH, KW, 64, 4>(x, k, y, p, s);
     else if (t.tw == 32 && t.rb == 16) launch_blur<KH, KW, 32, 16>(x, k, y, p, s);
     else if (t.tw == 32) launch_blur<KH, KW, 32, 4>(x, k, y, p, s);
@@ -464,17 +537,34 @@ void dispatch_blur(const float* x, const float* k, float* y, const BlurParams& p
     else launch_blur<KH, KW, 8, 4>(x, k, y, p, s);
 }
 
-// second stage of the fused bias gradient: gb[c] = sum_q partial[c][q], one wave per channel, fixed order
+// second stage of the fused bias gradient: gb[c] = sum_q partial[c][q], one workgroup per channel, fixed order.  q runs to a
+// few thousand here (outer * strips per plane): one wave per channel walked them as a chain of q / 64 dependent loads, 50 us per
+// call and a fifth of the fused blur's time in the step (profiles/r3_step_church256_b16_f32_kernel_trace.txt); thread t now
+// sums q = t, t + 256, ... in four independent chains.
 __global__ __launch_bounds__(kBlock) void k1_bias_finalize_kernel(const float* __restrict__ partial, float* __restrict__ gb,
                                                                   int64_t channels, int64_t q_count) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t c = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    float acc = 0.0f;
-    if (c < channels)
-        for (int64_t q = lane; q < q_count; q += kWave) acc += partial[c * q_count + q];
+    __shared__ float red[kBlock / kWave];
+    const float* pc = partial + (int64_t)blockIdx.x * q_count;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int64_t q = threadIdx.x;
+    for (; q + 3 * kBlock < q_count; q += 4 * kBlock) {
+        a0 += pc[q];
+        a1 += pc[q + kBlock];
+        a2 += pc[q + 2 * kBlock];
+        a3 += pc[q + 3 * kBlock];
+    }
+    for (; q < q_count; q += kBlock) a0 += pc[q];
+    float acc = (a0 + a1) + (a2 + a3);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    if (c < channels && lane == 0) gb[c] = acc;
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) t += red[w];
+        gb[blockIdx.x] = t;
+    }
 }
 
 // partial sums per channel of an epilogue launch: outer * row groups per plane * x tiles
@@ -604,7 +694,7 @@ extern "C" int sae_upfirdn2d_epilogue_f32(const float* x, const float* k, float*
         else launch_updown<2, 1, 16, 4, true>(x, k, y, p, s, e);
     }
     if (act_ref)
-        hipLaunchKernelGGL(k1_bias_finalize_kernel, dim3((unsigned)ceil_div64(channels, kBlock / kWave)), dim3(kBlock), 0, s,
-                           (const float*)workspace, gb, channels, e.q_per_channel);
+        hipLaunchKernelGGL(k1_bias_finalize_kernel, dim3((unsigned)channels), dim3(kBlock), 0, s, (const float*)workspace, gb,
+                           channels, e.q_per_channel);
     return check_launch("sae_upfirdn2d_epilogue_f32");
 }

@@ -71,33 +71,56 @@ __global__ __launch_bounds__(kBlock) void upsample2x_add_kernel(const float* __r
 
 // adjoint: gx[i][j] = alpha * sum over the 4x4 output neighbourhood rows 2i-1..2i+2, cols
 // 2j-1..2j+2 (clamped to the image) with separable weights (1/4, 3/4, 3/4, 1/4).
+// A lane fetches the two middle columns (2j, 2j+1) of each of the four rows as one 8-byte load -- a wave reads 512
+// contiguous bytes per instruction -- and takes the outer two (2j-1, 2j+2) from its neighbours' registers; only the first and
+// last lane of a wave fetch theirs.  (Sixteen stride-2 dword loads per lane before: 4x the bytes through the L1 and 2.0 TB/s,
+// profiles/r3_roofline_by_shape_church256.txt.)  Consecutive lanes own consecutive input pixels of the flattened tensor;
+// where a row ends inside a wave the clamp, not the neighbour, supplies the outer column.
+template <typename IdxT>
 __global__ __launch_bounds__(kBlock) void upsample2x_bwd_kernel(const float* __restrict__ gy,
-                                                                float* __restrict__ gx, const Up2Params p) {
-    const int64_t per_plane = (int64_t)p.h * p.w;
-    const int64_t total = p.planes * per_plane;
+                                                                float* __restrict__ gx, const Up2Params p, IdxT total) {
+    const IdxT per_plane = (IdxT)p.h * (IdxT)p.w;
     const int oh = 2 * p.h, ow = 2 * p.w;
-    for (int64_t idx = (int64_t)blockIdx.x * kBlock + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * kBlock) {
-        const int64_t plane = idx / per_plane;
-        const int rem = (int)(idx - plane * per_plane);
+    const int lane = threadIdx.x & (kWave - 1);
+    // whole waves iterate together (the trip count is taken from the wave's first lane) so that the register exchange below
+    // always finds its neighbour
+    const IdxT stride = (IdxT)gridDim.x * kBlock;
+    for (IdxT base = (IdxT)blockIdx.x * kBlock + (threadIdx.x & ~(kWave - 1)); base < total; base += stride) {
+        const IdxT idx = base + lane;
+        const bool live = idx < total;
+        const IdxT ii = live ? idx : total - 1;
+        const IdxT plane = ii / per_plane;
+        const int rem = (int)(ii - plane * per_plane);
         const int i = rem / p.w, j = rem - i * p.w;
-        const float* gp = gy + plane * per_plane * 4;
-        const float wgt[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-        float acc = 0.0f;
+        const float* gp = gy + (int64_t)plane * per_plane * 4;
+        float2 mid[4];
+        float left[4], right[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             int yy = 2 * i - 1 + a;
             yy = yy < 0 ? 0 : (yy > oh - 1 ? oh - 1 : yy);
-            float row = 0.0f;
+            const float* rowp = gp + (int64_t)yy * ow;
+            mid[a] = *reinterpret_cast<const float2*>(rowp + 2 * j);
+            // the outer columns of the wave's end lanes (clamped to the row: reads the lane's own middle column at the border)
+            left[a] = (lane == 0) ? rowp[j > 0 ? 2 * j - 1 : 0] : 0.0f;
+            right[a] = (lane == kWave - 1) ? rowp[j < p.w - 1 ? 2 * j + 2 : ow - 1] : 0.0f;
+        }
+        float acc = 0.0f;
+        const float wgt[4] = {0.25f, 0.75f, 0.75f, 0.25f};
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                int xx = 2 * j - 1 + b;
-                xx = xx < 0 ? 0 : (xx > ow - 1 ? ow - 1 : xx);
-                row = fmaf(wgt[b], gp[(int64_t)yy * ow + xx], row);
-            }
+        for (int a = 0; a < 4; ++a) {
+            const float from_prev = __shfl(mid[a].y, lane > 0 ? lane - 1 : 0, kWave);
+            const float from_next = __shfl(mid[a].x, lane < kWave - 1 ? lane + 1 : kWave - 1, kWave);
+            const float l = (j == 0) ? mid[a].x : (lane == 0 ? left[a] : from_prev);
+            const float r = (j == p.w - 1) ? mid[a].y : (lane == kWave - 1 ? right[a] : from_next);
+            float row = 0.0f;
+            row = fmaf(wgt[0], l, row);
+            row = fmaf(wgt[1], mid[a].x, row);
+            row = fmaf(wgt[2], mid[a].y, row);
+            row = fmaf(wgt[3], r, row);
             acc = fmaf(wgt[a], row, acc);
         }
-        gx[idx] = p.alpha * acc;
+        if (live) gx[idx] = p.alpha * acc;
     }
 }
 
@@ -131,8 +154,14 @@ extern "C" int sae_upsample2x_bilinear_bwd_f32(const float* gy, float* gx, int64
     const int rc = check_up2("sae_upsample2x_bilinear_bwd_f32", gy, gx, planes, h, w);
     if (rc != SAE_OK || planes == 0) return rc;
     Up2Params p{planes, (int)h, (int)w, alpha};
-    int64_t blocks = ceil_div64(planes * h * w, kBlock);
+    const int64_t total = planes * h * w;
+    int64_t blocks = ceil_div64(total, kBlock);
     if (blocks > 32768) blocks = 32768;
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, gy, gx, p);
+    if (total + blocks * kBlock < ((int64_t)1 << 31))
+        hipLaunchKernelGGL((upsample2x_bwd_kernel<uint32_t>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, gy, gx,
+                           p, (uint32_t)total);
+    else
+        hipLaunchKernelGGL((upsample2x_bwd_kernel<int64_t>), dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, gy, gx, p,
+                           (int64_t)total);
     return check_launch("sae_upsample2x_bilinear_bwd_f32");
 }

@@ -23,6 +23,10 @@ UPFIRDN_SMALL = [
     ((5, 37, 70, 1), (4, 4), (1, 1), (2, 2), (1, 1, 1, 1)), ((5, 19, 35, 1), (4, 4), (2, 2), (1, 1), (2, 3, 2, 3)),
     ((7, 9, 9, 1), (3, 3), (1, 1), (2, 2), (0, 0, 0, 0)), ((7, 4, 4, 1), (3, 3), (2, 2), (1, 1), (2, 2, 2, 2)),
     ((2, 257, 257, 1), (3, 3), (1, 1), (2, 2), (0, 0, 0, 0)),
+    # 64-column tiles + a remainder of 1 ... 8 columns (blur_tail_kernel): 65, 129 + 2 wide outputs, 3 taps, row groups that
+    # do not fill a unit of 32, more than one unit
+    ((3, 20, 64, 1), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2)), ((2, 17, 130, 1), (4, 4), (1, 1), (1, 1), (2, 2, 2, 2)),
+    ((9, 40, 67, 1), (3, 3), (1, 1), (1, 1), (0, 0, 0, 0)), ((1, 300, 64, 1), (4, 4), (1, 1), (1, 1), (2, 2, 1, 1)),
 ]
 
 # sae_upfirdn2d_epilogue_f32: (outer, channels, ih, iw, taps, up, pad(x0,x1,y0,y1)) -- the backward of the ResBlock's blur
@@ -33,9 +37,11 @@ K1_EPILOGUE = [
     (4, 6, 5, 5, 4, 1, (1, 1, 1, 1)), (2, 4, 33, 33, 4, 1, (2, 2, 2, 2)), (1, 1, 40, 12, 2, 1, (0, 1, 0, 1)),
     (2, 3, 8, 8, 4, 2, (2, 1, 2, 1)), (1, 5, 19, 35, 4, 2, (2, 1, 2, 1)), (3, 4, 4, 4, 3, 2, (2, 2, 2, 2)),
     (2, 2, 32, 32, 4, 2, (2, 1, 2, 1)),
+    (2, 3, 20, 66, 4, 1, (1, 1, 1, 1)), (1, 2, 70, 64, 4, 1, (2, 2, 2, 2)),      # remainder columns (blur_tail_kernel)
 ]
 
-BIAS_ACT_SHAPES = [(2, 8, 16, 16), (3, 5, 7, 7), (4, 16), (2, 4, 33, 31), (2, 3, 32, 32), (5, 6, 20, 20)]
+BIAS_ACT_SHAPES = [(2, 8, 16, 16), (3, 5, 7, 7), (4, 16), (2, 4, 33, 31), (2, 3, 32, 32), (5, 6, 20, 20),
+                   (37, 6, 4, 4), (70, 40)]       # small planes, outer dimension cut into slices (column kernel)
 
 # (n, c, h, w, m, k, stride, pad, weights stored [C,M,k,k])
 CONV_SMALL = [

@@ -151,7 +151,7 @@ def test_argument_errors(emu_lib):
         H.conv(emu_lib, 0, d, np.zeros((1, 4, 8, 8), np.float32), np.zeros((4, 4, 5, 5), np.float32), (1, 4, 8, 8))
 
 
-@pytest.mark.parametrize("shape", [(3, 1, 1), (2, 5, 7), (4, 16, 16), (1, 33, 20)], ids=str)
+@pytest.mark.parametrize("shape", [(3, 1, 1), (2, 5, 7), (4, 16, 16), (1, 33, 20), (2, 3, 130), (1, 5, 64)], ids=str)
 def test_upsample2x(emu_lib, oracle_lib, shape):
     rng = np.random.default_rng(5)
     x = rng.standard_normal(shape).astype(np.float32)
@@ -257,7 +257,7 @@ def _crop_params(rng, k, lo=0.125, hi=0.25):
 
 
 @pytest.mark.parametrize("case", [(2, 3, 32, 32, 4, 16, 0.125, 0.25), (1, 2, 20, 28, 3, 9, 0.3, 1.0),
-                                  (3, 1, 16, 16, 2, 8, 0.9, 1.0)], ids=str)
+                                  (3, 1, 16, 16, 2, 8, 0.9, 1.0), (2, 3, 48, 40, 5, 24, 0.05, 0.2)], ids=str)
 def test_random_crop(emu_lib, oracle_lib, case):
     """Patch sampler: the oracle is pinned to F.grid_sample (what util.apply_random_crop calls,
     util/util.py:338) and to its autograd; the kernels are checked against the oracle."""
@@ -289,7 +289,7 @@ def test_random_crop(emu_lib, oracle_lib, case):
 
 
 @pytest.mark.parametrize("case", [((2, 3, 8, 8), (1, 1, 1, 1)), ((1, 2, 5, 7), (2, 1, 0, 3)), ((2, 1, 2, 2), (1, 1, 1, 1)),
-                                  ((1, 4, 16, 16), (1, 2, 1, 2))], ids=str)
+                                  ((1, 4, 16, 16), (1, 2, 1, 2)), ((1, 3, 5, 300), (2, 1, 1, 1)), ((2, 1, 3, 64), (1, 1, 1, 0))], ids=str)
 def test_reflect_pad(emu_lib, oracle_lib, case):
     """Reflection pad and its adjoint: oracle pinned to F.pad(mode="reflect") + autograd, kernels to the oracle."""
     import torch
