@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 4   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32 */
+#define SAE_ABI_VERSION 5   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_* */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -150,6 +150,19 @@ int sae_noise_bias_act_bwd_f32(const float* gy, const float* y_ref, const float*
                                int64_t channels, int64_t hw, float alpha, float scale, sae_stream_t stream);
 int sae_plane_scale_dot_f32(const float* g, const float* x, const float* s, float* gx, float* gs, int64_t planes,
                             int64_t hw, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Demodulation factor of ModulatedConv2d and its backward (reference: models/networks/stylegan2_layers.py:290-292,
+ *   weight = scale * weight;  demod = rsqrt(weight.pow(2).sum([2, 3, 4]) + 1e-8);  weight = weight * demod
+ * computed from the un-modulated weight, `new_demodulation` :258).  w, geff, gw: [rows][cols] = [out channels][in * k * k].
+ *   sae_weight_demod_f32      d[o] = rsqrt(sum_j (alpha w[o][j])^2 + eps)
+ *   sae_weight_demod_bwd_f32  the weight gradient of a conv that ran on W_eff = alpha d[o] w, from geff = alpha dL/dW_eff
+ *                             (what sae_modconv2d_wgrad_f32 returns):
+ *                             gw[o][j] = d[o] geff[o][j] - (sum_j geff[o][j] w[o][j]) d[o]^3 alpha^2 w[o][j]
+ * ------------------------------------------------------------------------------------------ */
+int sae_weight_demod_f32(const float* w, float* d, int64_t rows, int64_t cols, float alpha, float eps, sae_stream_t stream);
+int sae_weight_demod_bwd_f32(const float* geff, const float* w, const float* d, float* gw, int64_t rows, int64_t cols,
+                             float alpha, sae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Random-crop sampler (patch discriminator input): crop k of image b = k / crops_per_image is

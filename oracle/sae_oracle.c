@@ -39,7 +39,7 @@ typedef struct sae_conv2d_desc {
 
 static __thread char g_err[256];
 
-int oracle_abi_version(void) { return 4; }
+int oracle_abi_version(void) { return 5; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
@@ -567,6 +567,37 @@ int oracle_plane_scale_dot_f32(const float* g, const float* x, const float* s, f
             acc += (double)g[q * hw + p] * x[q * hw + p];
         }
         gs[q] = (float)acc;
+    }
+    return 0;
+}
+
+/* ---- demodulation factor and its backward (include/sae_hip.h; stylegan2_layers.py:290-292): the reference's own sequence --
+ * scale, square, sum, + eps, rsqrt -- with the sum in double; the backward is the closed form of autograd's chain. ---- */
+int oracle_weight_demod_f32(const float* w, float* d, int64_t rows, int64_t cols, float alpha, float eps, void* stream) {
+    (void)stream;
+    if (rows < 0 || cols < 1) return set_err("weight_demod: bad shape");
+#pragma omp parallel for
+    for (int64_t o = 0; o < rows; ++o) {
+        double acc = 0.0;
+        for (int64_t j = 0; j < cols; ++j) {
+            const float u = w[o * cols + j] * alpha;
+            acc += (double)(u * u);
+        }
+        d[o] = 1.0f / sqrtf((float)acc + eps);
+    }
+    return 0;
+}
+
+int oracle_weight_demod_bwd_f32(const float* geff, const float* w, const float* d, float* gw, int64_t rows, int64_t cols,
+                                float alpha, void* stream) {
+    (void)stream;
+    if (rows < 0 || cols < 1) return set_err("weight_demod_bwd: bad shape");
+#pragma omp parallel for
+    for (int64_t o = 0; o < rows; ++o) {
+        double gd = 0.0;
+        for (int64_t j = 0; j < cols; ++j) gd += (double)geff[o * cols + j] * w[o * cols + j];
+        const double dv = d[o], cf = gd * dv * dv * dv * (double)alpha * alpha;
+        for (int64_t j = 0; j < cols; ++j) gw[o * cols + j] = (float)(dv * geff[o * cols + j] - cf * w[o * cols + j]);
     }
     return 0;
 }

@@ -191,6 +191,56 @@ __global__ __launch_bounds__(kBlock) void plane_scale_dot_kernel(const float* __
     if (threadIdx.x == 0) gs[plane] = (float)t;
 }
 
+// Demodulation factor of ModulatedConv2d (stylegan2_layers.py:290-292, from the un-modulated weight):
+//   d[o] = rsqrt(sum_j (alpha w[o][j])^2 + eps),   j over (in channel, ky, kx)
+// one workgroup per output channel; the reference's five ATen launches (mul, pow, sum, add, rsqrt over the [O, I, k, k]
+// weight, 9 MB at 512 x 512 x 3 x 3) in one pass over the weight.
+__global__ __launch_bounds__(kBlock) void weight_demod_kernel(const float* __restrict__ w, float* __restrict__ d, int64_t cols,
+                                                              float alpha, float eps) {
+    __shared__ double red[kBlock / kWave];
+    const float* wr = w + (int64_t)blockIdx.x * cols;
+    double a0 = 0.0, a1 = 0.0;
+    int64_t j = threadIdx.x;
+    for (; j + kBlock < cols; j += 2 * kBlock) {
+        const float u = wr[j] * alpha, v = wr[j + kBlock] * alpha;       // scale first, then square: the reference's order
+        a0 += (double)(u * u);
+        a1 += (double)(v * v);
+    }
+    if (j < cols) {
+        const float u = wr[j] * alpha;
+        a0 += (double)(u * u);
+    }
+    const double t = block_sum_m(a0 + a1, red);
+    if (threadIdx.x == 0) d[blockIdx.x] = 1.0f / sqrtf((float)t + eps);
+}
+
+// Its backward together with the product rule of the effective weight W_eff = alpha d[o] w: with geff = alpha dL/dW_eff
+// (what the weight-gradient kernels return),
+//   dL/dd[o] = sum_j geff[o][j] w[o][j],     dd[o]/dw[o][j] = -d[o]^3 alpha^2 w[o][j]
+//   gw[o][j] = d[o] geff[o][j] - (sum_j geff w) d[o]^3 alpha^2 w[o][j]
+// (autograd spent ~15 launches on this per modulated conv: geff * d, (geff * w).sum, the chain through rsqrt / sum / pow /
+// mul, two gradient accumulations and the select-backward of weight[0]).
+__global__ __launch_bounds__(kBlock) void weight_demod_bwd_kernel(const float* __restrict__ geff, const float* __restrict__ w,
+                                                                  const float* __restrict__ d, float* __restrict__ gw,
+                                                                  int64_t cols, float alpha) {
+    __shared__ double red[kBlock / kWave];
+    __shared__ float coef;
+    const int64_t base = (int64_t)blockIdx.x * cols;
+    double a0 = 0.0, a1 = 0.0;
+    int64_t j = threadIdx.x;
+    for (; j + kBlock < cols; j += 2 * kBlock) {
+        a0 += (double)geff[base + j] * w[base + j];
+        a1 += (double)geff[base + j + kBlock] * w[base + j + kBlock];
+    }
+    if (j < cols) a0 += (double)geff[base + j] * w[base + j];
+    const double t = block_sum_m(a0 + a1, red);
+    const float dv = d[blockIdx.x];
+    if (threadIdx.x == 0) coef = (float)t * (dv * dv * dv) * (alpha * alpha);
+    __syncthreads();
+    const float cf = coef;
+    for (int64_t q = threadIdx.x; q < cols; q += kBlock) gw[base + q] = dv * geff[base + q] - cf * w[base + q];
+}
+
 int bwd_nsplit(int64_t outer, int hw, int channels, int* chunks_per_plane) {
     const int chunk = kBlock * 4 * 2;
     *chunks_per_plane = (int)ceil_div64(hw, chunk);
@@ -282,4 +332,25 @@ extern "C" int sae_plane_scale_dot_f32(const float* g, const float* x, const flo
     hipLaunchKernelGGL(plane_scale_dot_kernel, dim3((unsigned)planes), dim3(kBlock), 0, (hipStream_t)stream, g, x, s,
                        gx, gs, (int)hw);
     return check_launch("sae_plane_scale_dot_f32");
+}
+
+extern "C" int sae_weight_demod_f32(const float* w, float* d, int64_t rows, int64_t cols, float alpha, float eps,
+                                    sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (rows < 0 || cols < 1 || rows >= ((int64_t)1 << 31)) return fail(SAE_EINVAL, "sae_weight_demod_f32: bad shape");
+    if (rows == 0) return SAE_OK;
+    if (!w || !d) return fail(SAE_EINVAL, "sae_weight_demod_f32: null tensor");
+    hipLaunchKernelGGL(weight_demod_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, w, d, cols, alpha, eps);
+    return check_launch("sae_weight_demod_f32");
+}
+
+extern "C" int sae_weight_demod_bwd_f32(const float* geff, const float* w, const float* d, float* gw, int64_t rows,
+                                        int64_t cols, float alpha, sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (rows < 0 || cols < 1 || rows >= ((int64_t)1 << 31)) return fail(SAE_EINVAL, "sae_weight_demod_bwd_f32: bad shape");
+    if (rows == 0) return SAE_OK;
+    if (!geff || !w || !d || !gw) return fail(SAE_EINVAL, "sae_weight_demod_bwd_f32: null tensor");
+    hipLaunchKernelGGL(weight_demod_bwd_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, geff, w, d, gw, cols,
+                       alpha);
+    return check_launch("sae_weight_demod_bwd_f32");
 }

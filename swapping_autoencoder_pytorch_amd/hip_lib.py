@@ -42,7 +42,7 @@ class ConvMod(C.Structure):
     _fields_ = [("x_scale", C.c_void_p), ("y_scale", C.c_void_p), ("wm_scale", C.c_void_p), ("wc_scale", C.c_void_p)]
 
 
-ABI_VERSION = 4      # include/sae_hip.h: SAE_ABI_VERSION
+ABI_VERSION = 5      # include/sae_hip.h: SAE_ABI_VERSION
 
 _SIGNATURES = {
     "abi_version": (C.c_int, []),
@@ -62,6 +62,8 @@ _SIGNATURES = {
     "noise_bias_act_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _f32,
                                          _f32, _stream]),
     "plane_scale_dot_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _stream]),
+    "weight_demod_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, C.c_float, C.c_float, _stream]),
+    "weight_demod_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, C.c_float, _stream]),
     "random_crop_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),
     "random_crop_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),
     "reflect_pad_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _stream]),

@@ -19,8 +19,8 @@ from torch.nn import functional as F
 
 from . import hip_lib, rng
 from .stylegan2_op import (FusedLeakyReLU, ReflectionPad2d, add_scale, conv2d, conv2d_bias_act, conv_transpose2d,
-                           fusable, fused_leaky_relu, linear, modulated_conv2d, noise_bias_act, plane_scale, reflect_pad,
-                           upfirdn2d)
+                           fusable, fused_leaky_relu, l2_normalize, linear, modulated_conv2d, noise_bias_act, plane_scale,
+                           reflect_pad, upfirdn2d)
 
 
 # SAE_MODCONV_FUSED=0 (debug / A-B measurements): ModulatedConv2d takes the two-step path (x * s, then a plain conv)
@@ -223,6 +223,23 @@ class ModulatedConv2d(nn.Module):
         return torch.rsqrt(w.pow(2).sum(dim=(1, 2, 3)) + 1e-8)
 
     def forward(self, input, style):
+        fused = (not self.downsample and input.dtype == torch.float32 and _FUSED_MODCONV and hip_lib.get_conv_math() == "f32"
+                 and (style.dim() == 2 or self._projected_style is not None))
+        if fused:
+            # style normalisation as ONE kernel forward, one backward (csrc/glue.hip l2_normalize):
+            #   s * rsqrt(mean(s^2) + eps) = sqrt(C) * s * rsqrt(sum(s^2) + C eps)
+            # the constant sqrt(C) rides in the conv's output scale (the conv is linear in s); the demodulation factor is
+            # computed and differentiated inside the conv node (weight_demod_*).  ~40 ATen launches per conv and
+            # forward + backward pass become 4.
+            s = self._projected_style if self._projected_style is not None else self.modulation(style.view(input.shape[0], -1))
+            out_scale = 1.0
+            if self.demodulate:
+                c = s.shape[1]
+                s = l2_normalize(s, c * 1e-8)
+                out_scale = math.sqrt(c)
+            out = modulated_conv2d(input, s, self.weight.view(self.weight.shape[1:]), None, padding=self.padding, alpha=self.scale,
+                                   transposed=self.upsample, demod_eps=self.eps if self.demodulate else None, out_scale=out_scale)
+            return self.blur(out) if self.upsample else out
         s = self._input_scale(input, style)
         if (s.dim() == 2 and not self.downsample and input.dtype == torch.float32 and _FUSED_MODCONV
                 and hip_lib.get_conv_math() == "f32"):

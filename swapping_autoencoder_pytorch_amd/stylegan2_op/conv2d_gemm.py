@@ -263,6 +263,27 @@ def _launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_
     return out
 
 
+def _weight_demod(w, alpha, eps):
+    """rsqrt(sum_{i,ky,kx} (alpha w)^2 + eps) per output channel (stylegan2_layers.py:290-292) in one launch"""
+    lib = hip_lib.get()
+    w = w.contiguous()
+    lib.check(w)
+    d = torch.empty(w.shape[0], dtype=torch.float32, device=w.device)
+    lib.call("weight_demod_f32", w.data_ptr(), d.data_ptr(), w.shape[0], w[0].numel(), float(alpha), float(eps), lib.stream(w))
+    return d
+
+
+def _weight_demod_bwd(geff, w, d, alpha, out=None):
+    """The parameter's gradient from the effective-weight gradient of a conv that ran on alpha * d[o] * w."""
+    lib = hip_lib.get()
+    geff, w = geff.contiguous(), w.contiguous()
+    lib.check(geff, w, d)
+    gw = torch.empty_like(w) if out is None else out
+    lib.call("weight_demod_bwd_f32", geff.data_ptr(), w.data_ptr(), d.data_ptr(), gw.data_ptr(), w.shape[0], w[0].numel(),
+             float(alpha), lib.stream(w))
+    return gw
+
+
 class ModulatedConv(Function):
     """ModulatedConv2d's arithmetic (stylegan2_layers.py:280-321) as one kernel per operation:
 
@@ -278,9 +299,16 @@ class ModulatedConv(Function):
     only (the generator is never differentiated twice; the R1 penalties touch D and Dpatch)."""
 
     @staticmethod
-    def forward(ctx, x, s, w, demod, geom, transposed):
+    def forward(ctx, x, s, w, demod, geom, transposed, demod_eps=None, demod_alpha=1.0):
         ctx.set_materialize_grads(False)
         ctx.cfg = (geom, transposed)
+        ctx.own_demod = demod_eps is not None
+        ctx.demod_alpha = demod_alpha
+        if ctx.own_demod:
+            # the demodulation factor d = rsqrt(sum (demod_alpha w)^2 + eps) is part of this node: one kernel here, and one
+            # in the backward that turns the gradient of d * w into the parameter's (csrc/modulate.hip weight_demod_*;
+            # ~20 ATen launches per conv and pass otherwise).  `demod` must be None.
+            demod = _weight_demod(w, demod_alpha, demod_eps)
         ctx.save_for_backward(x, s, w, demod)
         if transposed:      # dgrad of the forward-orientation problem: x is its y side, the result its x side
             return _launch_mod("modconv2d_dgrad_f32", SAE_CONV_DGRAD, geom, x, w, (geom.n, geom.c, geom.h, geom.w),
@@ -295,8 +323,8 @@ class ModulatedConv(Function):
         geom, transposed = ctx.cfg
         if gout is None:
             gw = torch.zeros_like(w) if (ctx.needs_input_grad[2] and _Flags.weight_grads) else None
-            gd = torch.zeros_like(demod) if (demod is not None and ctx.needs_input_grad[3]) else None
-            return None, None, gw, gd, None, None
+            gd = torch.zeros_like(demod) if (demod is not None and not ctx.own_demod and ctx.needs_input_grad[3]) else None
+            return None, None, gw, gd, None, None, None, None
         gout = gout.contiguous()
         gx = gs = gw = gd = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
@@ -316,31 +344,41 @@ class ModulatedConv(Function):
                 geff = _launch_mod("modconv2d_wgrad_f32", SAE_CONV_WGRAD, geom, gout, x, geom.weight_shape(), y_scale=s)
             else:
                 geff = _launch_mod("modconv2d_wgrad_f32", SAE_CONV_WGRAD, geom, x, gout, geom.weight_shape(), x_scale=s)
-            # geff = alpha * d(loss)/d(effective weight), effective weight = w * alpha * demod[o]
+            # geff = d(loss)/d(demod[o] * w) (the kernels' alpha included)
             if demod is None:
                 gw = geff
+            elif ctx.own_demod:
+                from ..grad_allreduce import claim_destination
+                gw = _weight_demod_bwd(geff, w, demod, ctx.demod_alpha, out=claim_destination(w))
             else:
                 gw = geff * demod[:, None, None, None]
                 gd = (geff * w).sum(dim=(1, 2, 3))
-        return gx, gs, gw, gd, None, None
+        return gx, gs, gw, gd, None, None, None, None
 
 
-def modulated_conv2d(input, style_scale, weight, demod=None, padding=0, alpha=1.0, transposed=False):
+def modulated_conv2d(input, style_scale, weight, demod=None, padding=0, alpha=1.0, transposed=False, demod_eps=None,
+                     out_scale=1.0):
     """The modulated conv of ModulatedConv2d in its dense-equivalent form.  input [N, I, H, W], style_scale [N, I],
-    weight [O, I, k, k], demod [O] or None; transposed=True is the stride-2 upsampling form (output (2H+1) x (2W+1))."""
+    weight [O, I, k, k], demod [O] or None; transposed=True is the stride-2 upsampling form (output (2H+1) x (2W+1)).
+    demod_eps (instead of demod): the demodulation factor rsqrt(sum (alpha w)^2 + demod_eps) is computed, and differentiated,
+    inside the node.  out_scale: an extra factor on the output (the conv is linear: a constant pulled out of style_scale)."""
     _check_weight(weight)
     n, c_in, h, w = input.shape
     o, i2, k, _ = weight.shape
     if i2 != c_in or tuple(style_scale.shape) != (n, c_in):
         raise hip_lib.SaeError("modulated_conv2d: input %s, style %s, weight %s do not fit" % (
             tuple(input.shape), tuple(style_scale.shape), tuple(weight.shape)))
+    if demod_eps is not None and demod is not None:
+        raise hip_lib.SaeError("modulated_conv2d: pass demod or demod_eps, not both")
     if transposed:
         oh, ow = (h - 1) * 2 + k, (w - 1) * 2 + k
         geom = _Geom(n, o, oh, ow, c_in, k, 2, 0, True, alpha)
         assert (geom.oh, geom.ow) == (h, w)
     else:
         geom = _Geom(n, c_in, h, w, o, k, 1, padding, False, alpha)
-    return ModulatedConv.apply(input, style_scale, weight, demod, geom, transposed)
+    # the kernels scale by geom.alpha = alpha * out_scale; the demodulation factor is defined on alpha * w
+    geom.alpha = float(alpha * out_scale)
+    return ModulatedConv.apply(input, style_scale, weight, demod, geom, transposed, demod_eps, float(alpha))
 
 
 def _check_weight(weight):

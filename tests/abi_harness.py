@@ -184,6 +184,20 @@ def plane_scale_dot(lib, g, x, s, device=None):
     return bgx.numpy(), bgs.numpy()
 
 
+def weight_demod(lib, w, alpha, eps=1e-8, device=None):
+    rows, cols = w.shape[0], int(np.prod(w.shape[1:]))
+    bw, bd = _Buf(w, device), _out((rows,), device)
+    lib.call("weight_demod_f32", bw.ptr, bd.ptr, rows, cols, alpha, eps, _stream(device))
+    return bd.numpy()
+
+
+def weight_demod_bwd(lib, geff, w, d, alpha, device=None):
+    rows, cols = w.shape[0], int(np.prod(w.shape[1:]))
+    bg, bw, bd, bo = _Buf(geff, device), _Buf(w, device), _Buf(d, device), _out(w.shape, device)
+    lib.call("weight_demod_bwd_f32", bg.ptr, bw.ptr, bd.ptr, bo.ptr, rows, cols, alpha, _stream(device))
+    return bo.numpy()
+
+
 def random_crop(lib, x, params, size, crops, device=None):
     n, c, h, w = x.shape
     import torch

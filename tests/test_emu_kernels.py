@@ -241,6 +241,31 @@ def test_noise_bias_act(emu_lib, oracle_lib, shape):
     assert np.allclose(gs_e, gs_o, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(5, 3, 3, 3), (7, 300, 1, 1), (3, 64, 3, 3), (2, 2, 1, 1)], ids=str)
+def test_weight_demod(emu_lib, oracle_lib, shape):
+    """Demodulation factor and the fused weight gradient: the oracle against the reference's own ATen sequence
+    (stylegan2_layers.py:290-292) and autograd through it; the kernels against the oracle."""
+    import torch
+    rng = np.random.default_rng(17)
+    w = rng.standard_normal(shape).astype(np.float32)
+    geff = rng.standard_normal(shape).astype(np.float32)
+    alpha = 1.0 / np.sqrt(np.prod(shape[1:]))
+    wt = torch.from_numpy(w).double().requires_grad_()
+    weight = alpha * wt                                              # :289
+    demod = torch.rsqrt(weight.pow(2).sum([1, 2, 3]) + 1e-8)         # :290-291 (per-sample copies are identical)
+    # the conv ran on alpha * d * w; geff = alpha * dL/dW_eff  =>  L = sum(geff / alpha * W_eff)
+    loss = (torch.from_numpy(geff).double() / alpha * (weight * demod.view(-1, 1, 1, 1))).sum()
+    gw_ref, = torch.autograd.grad(loss, wt)
+    d_o = H.weight_demod(oracle_lib, w, alpha)
+    assert np.allclose(d_o, demod.detach().numpy(), rtol=3e-7, atol=0)
+    gw_o = H.weight_demod_bwd(oracle_lib, geff, w, d_o, alpha)
+    assert np.allclose(gw_o, gw_ref.numpy(), rtol=1e-5, atol=1e-6 * float(gw_ref.abs().max()))
+    d_e = H.weight_demod(emu_lib, w, alpha)
+    assert np.allclose(d_e, d_o, rtol=3e-7, atol=0)
+    gw_e = H.weight_demod_bwd(emu_lib, geff, w, d_o, alpha)
+    assert np.allclose(gw_e, gw_o, rtol=1e-5, atol=1e-6 * float(np.abs(gw_o).max()))
+
+
 def test_glue_rejects_odd_planes(emu_lib):
     x = np.zeros((1, 2, 3, 3), np.float32)
     with pytest.raises(Exception):

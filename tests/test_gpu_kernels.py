@@ -265,6 +265,20 @@ def test_noise_bias_act(hip_lib, oracle_lib, shape):
     assert np.abs(gs_e - gs_o).max() <= 1e-6 * float(np.abs(gy * x).sum() / (n * c))
 
 
+@pytest.mark.parametrize("shape", [(5, 3, 3, 3), (512, 512, 3, 3), (128, 256, 3, 3), (3, 128, 1, 1)], ids=str)
+def test_weight_demod(hip_lib, oracle_lib, shape):
+    """sae_weight_demod_f32 / _bwd_f32 against the oracle (pinned to the reference's ATen sequence in the CPU suite)."""
+    rng = np.random.default_rng(17)
+    w = rng.standard_normal(shape).astype(np.float32)
+    geff = rng.standard_normal(shape).astype(np.float32)
+    alpha = float(1.0 / np.sqrt(np.prod(shape[1:])))
+    d_o = H.weight_demod(oracle_lib, w, alpha)
+    assert np.allclose(H.weight_demod(hip_lib, w, alpha, device=DEV), d_o, rtol=3e-7, atol=0)
+    gw_o = H.weight_demod_bwd(oracle_lib, geff, w, d_o, alpha)
+    gw_e = H.weight_demod_bwd(hip_lib, geff, w, d_o, alpha, device=DEV)
+    assert np.allclose(gw_e, gw_o, rtol=1e-5, atol=1e-6 * float(np.abs(gw_o).max()))
+
+
 @pytest.mark.parametrize("case", [(2, 3, 32, 32, 4, 16, 0.125, 0.25), (1, 2, 20, 28, 3, 9, 0.3, 1.0),
                                   (4, 3, 256, 256, 8, 128, 0.125, 0.25)], ids=str)
 def test_random_crop(hip_lib, oracle_lib, case):
