@@ -87,6 +87,10 @@ def work_of(name, a):
         return "upsample x2 + residual", "hbm", 4.0 * a[3] * a[4] * a[5] * (1 + 4 + (4 if a[1] else 0))
     if name == "upsample2x_bilinear_bwd_f32":
         return "upsample x2 backward", "hbm", 4.0 * a[2] * a[3] * a[4] * 5
+    if name == "weight_demod_f32":
+        return "demodulation factor (+bwd)", "hbm", 4.0 * a[2] * a[3]
+    if name == "weight_demod_bwd_f32":
+        return "demodulation factor (+bwd)", "hbm", 12.0 * a[4] * a[5]
     if name in ("l2_normalize_f32", "l2_normalize_bwd_f32"):
         n = a[2 if name == "l2_normalize_f32" else 3] * a[3 if name == "l2_normalize_f32" else 4] * a[4 if name == "l2_normalize_f32" else 5]
         return "l2 normalize (+bwd)", "hbm", 4.0 * n * (2 if name == "l2_normalize_f32" else 3)
