@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 5   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_* */
+#define SAE_ABI_VERSION 5   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -271,6 +271,15 @@ typedef struct sae_conv2d_mod {
 } sae_conv2d_mod;
 int sae_modconv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
                           float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+/* StyledConv's plain (stride-1) form in ONE kernel: ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU
+ * (stylegan2_layers.py:398-405, :340-351, fused_act.py:75-86):
+ *   y = lrelu((alpha * conv(x * x_scale, w * wm_scale * wc_scale) + noise_weight[0] * noise[n][oy][ox]) + bias[m], act_slope) * act_scale
+ * noise: [n][oh][ow] (one map per sample) or NULL; noise_weight: one float ON THE DEVICE; bias: [m] or NULL.  mod->x_scale is
+ * required (this entry exists for the modulated kernels only); exact-fp32 arithmetic only (SAE_EINVAL under bf16x6). */
+int sae_modconv2d_fwd_noise_bias_act_f32(const float* x, const float* w, const float* noise, const float* noise_weight,
+                                         const float* bias, float* y, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
+                                         float alpha, float act_slope, float act_scale, float* workspace,
+                                         int64_t workspace_floats, sae_stream_t stream);
 int sae_modconv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
                             float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
 int sae_modconv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,

@@ -795,6 +795,30 @@ int oracle_modconv2d_fwd_f32(const float* x, const float* w, float* y, const sae
     return rc;
 }
 
+int oracle_modconv2d_fwd_noise_bias_act_f32(const float* x, const float* w, const float* noise, const float* noise_weight,
+                                            const float* bias, float* y, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
+                                            float alpha, float act_slope, float act_scale, float* workspace,
+                                            int64_t workspace_floats, sae_stream_t stream) {
+    /* the three modules one after the other: the modulated conv, then NoiseInjection + FusedLeakyReLU */
+    if (!mod || !mod->x_scale) return set_err("oracle_modconv2d_fwd_noise_bias_act_f32: x_scale is required");
+    if (!conv_desc_ok(d) || d->stride != 1) return set_err("oracle_modconv2d_fwd_noise_bias_act_f32: stride 1 only");
+    int rc = oracle_modconv2d_fwd_f32(x, w, y, d, mod, alpha, workspace, workspace_floats, stream);
+    if (rc != 0) return rc;
+    const int64_t hw = d->oh * d->ow;
+    const float wn = noise ? noise_weight[0] : 0.0f;
+#pragma omp parallel for collapse(2)
+    for (int64_t n = 0; n < d->n; ++n)
+        for (int64_t c = 0; c < d->m; ++c) {
+            float* yp = y + (n * d->m + c) * hw;
+            for (int64_t p = 0; p < hw; ++p) {
+                float t = yp[p] + (noise ? wn * noise[n * hw + p] : 0.0f);      /* (image + weight * noise) + bias */
+                t += bias ? bias[c] : 0.0f;
+                yp[p] = (t > 0.0f ? t : t * act_slope) * act_scale;
+            }
+        }
+    return 0;
+}
+
 int oracle_modconv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
                                float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
     if (!gy || !w || !gx || !conv_desc_ok(d)) return set_err("oracle_modconv2d_dgrad_f32: bad argument");

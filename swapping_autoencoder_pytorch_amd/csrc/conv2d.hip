@@ -129,6 +129,11 @@ struct IgemmParams {
     // (out + skip) / sqrt(2) of a ResBlock (stylegan2_layers.py:689) done by the skip path's 1x1 conv on its way out
     const float* residual;
     float res_scale;
+    // fused NoiseInjection in front of the activation (MOD instantiations, forward only, with act != 0):
+    // y = lrelu((acc + noise_w[0] * noise[n][oy][ox]) + bias[m]) * act_scale -- StyledConv's conv -> noise -> FusedLeakyReLU
+    // (stylegan2_layers.py:398-405) without the pass over the conv's output.  noise: [N][OH][OW], noise_w: one float on the device
+    const float* noise;
+    const float* noise_w;
     // style modulation of the INPUT (ModulatedConv2d, stylegan2_layers.py:280-286): when non-null, x[n][c][..] is
     // multiplied by in_scale[n * C + c] on its way into LDS, so the modulated activation never exists in HBM
     const float* in_scale;
@@ -185,6 +190,10 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     __shared__ __attribute__((aligned(16))) float smem[AS + XS];
     float* const As = smem;
     float* const Xs = smem + AS;
+    // the tile's slice of the noise map (IgemmParams::noise): BN floats, shared by all BM rows of the tile, fetched once at the
+    // start and read from LDS in the epilogue -- a global load inside the store loop would make every store wait for its own
+    // round trip, and 8 - 16 quads per thread cannot be prefetched into registers (the fused residual's lesson)
+    __shared__ float zs[MOD ? BN : 1];
 
     SAE_CLOCK_BEGIN
     const int tid = threadIdx.x;
@@ -219,6 +228,19 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     const int tin = bt / p.tiles_y;
     const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
     const int m0 = mt * BM;
+    if constexpr (MOD) {
+        if (p.noise) {      // visible to the epilogue through the barriers of the K loop
+            for (int pp = tid; pp < BN; pp += kBlock) {
+                const int px = pp & (TW - 1);
+                const int py = (pp >> p.tw_log2) & (TH - 1);
+                const int pn = pp >> (p.tw_log2 + p.th_log2);
+                const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
+                const bool ok = n < p.N && oy < p.OH && ox < p.OW;
+                const float v = p.noise[ok ? ((int64_t)n * p.OH + oy) * p.OW + ox : 0];
+                zs[pp] = ok ? v : 0.0f;
+            }
+        }
+    }
 
     const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
     const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
@@ -499,6 +521,10 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     // accumulators go through LDS once, 32 * WM rows at a time, and leave as dwordx4 stores of four consecutive pixels --
     // 16 instead of 64 vector-memory instructions per wave and tile (the eight waves of a CU reach their epilogues
     // together, and a wave64 store occupies the address path as long as a load does).
+    [[maybe_unused]] float noise_wv = 0.0f;
+    if constexpr (MOD) {
+        if (p.noise) noise_wv = p.noise_w[0];
+    }
     constexpr int LDC = BN + 4;
     constexpr bool VEC_OK = AS + XS >= 32 * WM * LDC;         // the staging buffers hold one pass
     if constexpr (VEC_OK) {
@@ -549,6 +575,13 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                         f32x4 c = *reinterpret_cast<const f32x4*>(Cs + row * LDC + 4 * qx);
                         if (p.act) {   // bias + leaky-ReLU of the following FusedLeakyReLU, fused_bias_act_kernel.cu:30,47
                             const float bv = p.bias ? p.bias[m] : 0.0f;
+                            if constexpr (MOD) {
+                                if (p.noise) {   // (image + weight * noise) + bias, the reference's association (:340-351)
+                                    const f32x4 z = *reinterpret_cast<const f32x4*>(zs + 4 * qx);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) c[e] = c[e] + noise_wv * z[e];
+                                }
+                            }
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float t = c[e] + bv;
@@ -606,6 +639,9 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
                     if (m < p.M) {
                         float v = acc[mi][ni][r];
                         if (p.act) {   // bias + leaky-ReLU of the following FusedLeakyReLU, fused_bias_act_kernel.cu:30,47
+                            if constexpr (MOD) {
+                                if (p.noise) v = v + noise_wv * zs[pp];
+                            }
                             v += bv[mi][r];
                             v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
                         }
@@ -3110,7 +3146,9 @@ __global__ __launch_bounds__(kBlock) void conv_splitk_reduce_kernel(const float*
                                                                     const float* __restrict__ bias, int act,
                                                                     float act_slope, float act_scale, int hw,
                                                                     int channels, const float* __restrict__ residual,
-                                                                    float res_scale) {
+                                                                    float res_scale, const float* __restrict__ noise,
+                                                                    const float* __restrict__ noise_w) {
+    const float nwv = noise ? noise_w[0] : 0.0f;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel4; i += (int64_t)gridDim.x * kBlock) {
         f32x4 acc = *reinterpret_cast<const f32x4*>(slab + i * 4);
         for (int s = 1; s < ksplit; ++s) acc += *reinterpret_cast<const f32x4*>(slab + s * slab_stride + i * 4);
@@ -3118,6 +3156,10 @@ __global__ __launch_bounds__(kBlock) void conv_splitk_reduce_kernel(const float*
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = acc[e];
+                if (noise) {        // element (n, m, pix) takes noise[n][pix]
+                    const int64_t f = i * 4 + e, plane = f / hw;
+                    v = v + nwv * noise[(plane / channels) * hw + (f - plane * hw)];
+                }
                 if (bias) v += bias[((i * 4 + e) / hw) % channels];
                 acc[e] = ((v > 0.0f) ? v : v * act_slope) * act_scale;
             }
@@ -3433,7 +3475,11 @@ __global__ __launch_bounds__(kBlock) void conv1x1_thin_kernel(const float* __res
 }
 
 // forward-type gather producing `mout` channels from `cin` channels
-struct Epilogue { const float* bias; int act; float slope, scale; const float* residual = nullptr; float res_scale = 1.0f; };
+struct Epilogue {
+    const float* bias; int act; float slope, scale;
+    const float* residual = nullptr; float res_scale = 1.0f;
+    const float* noise = nullptr; const float* noise_w = nullptr;     // IgemmParams::noise (modulated forward only)
+};
 
 int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_floats, int N, int cin, int H, int W,
                int mout, int OH, int OW, int YH, int YW, int oys, int oxs, int ks, int stride, int pad, int64_t sm,
@@ -3447,7 +3493,9 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     if (ep.residual && (oys != 1 || oxs != 1 || YH != OH || YW != OW || g.bx || (reinterpret_cast<uintptr_t>(ep.residual) & 15) != 0))
         return fail(SAE_EINVAL, "conv2d: the fused residual needs a dense, 16-byte aligned output-shaped tensor and the "
                                 "exact-fp32 kernels");
-    if (thin_knob && !ep.residual && ks == 1 && stride == 1 && pad == 0 && oys == 1 && oxs == 1 && (cin <= 4 || mout <= 4) &&
+    if (ep.noise && (!in_scale || !ep.act || g.bx || oys != 1 || oxs != 1 || YH != OH || YW != OW))
+        return fail(SAE_EINVAL, "conv2d: the fused noise needs the modulated exact-fp32 forward with its activation epilogue");
+    if (thin_knob && !ep.residual && !ep.noise && ks == 1 && stride == 1 && pad == 0 && oys == 1 && oxs == 1 && (cin <= 4 || mout <= 4) &&
         H == OH && W == OW && YH == OH && YW == OW && ((int64_t)H * W) % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && N <= 65535) {
         ThinParams t{};
@@ -3477,6 +3525,7 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     if (g.ksplit == 1) {
         p.bias = ep.bias; p.act = ep.act; p.act_slope = ep.slope; p.act_scale = ep.scale;
         p.residual = ep.residual; p.res_scale = ep.res_scale;
+        p.noise = ep.noise; p.noise_w = ep.noise_w;
     }
     float* out = (g.ksplit > 1) ? ws + g.wp_floats : y;
     static const int vec_knob = tuning_knob("SAE_IGEMM_VEC_STORE", 1);
@@ -3502,7 +3551,7 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
         if (n4 > 0)
             hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s,
                                (const float*)out, y, n4, g.out_floats4, g.ksplit, ep.bias, ep.act, ep.slope, ep.scale,
-                               OH * OW, mout, ep.residual, ep.res_scale);
+                               OH * OW, mout, ep.residual, ep.res_scale, ep.noise, ep.noise_w);
     }
     return SAE_OK;
 }
@@ -3776,7 +3825,7 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, s, (const float*)y, y_final, n4,
                            sp.out_floats4, sp.ksplit, (const float*)nullptr, 0, 0.0f, 1.0f, OH * OW, mout,
-                           (const float*)nullptr, 1.0f);
+                           (const float*)nullptr, 1.0f, (const float*)nullptr, (const float*)nullptr);
     }
     return SAE_OK;
 }
@@ -3863,6 +3912,28 @@ extern "C" int sae_modconv2d_fwd_f32(const float* x, const float* w, float* y, c
                                      sae_stream_t stream) {
     sae::clear_stale_error();
     return conv_fwd_impl("sae_modconv2d_fwd_f32", x, w, y, d, mod ? *mod : kNoMod, alpha, workspace, workspace_floats, stream);
+}
+
+extern "C" int sae_modconv2d_fwd_noise_bias_act_f32(const float* x, const float* w, const float* noise, const float* noise_weight,
+                                                    const float* bias, float* y, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
+                                                    float alpha, float act_slope, float act_scale, float* workspace,
+                                                    int64_t workspace_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
+    const char* who = "sae_modconv2d_fwd_noise_bias_act_f32";
+    if (!desc_ok(d, who)) return SAE_EINVAL;
+    if (d->n == 0) return SAE_OK;
+    if (!x || !w || !y || !mod || !mod->x_scale) return fail(SAE_EINVAL, "%s: null tensor (x, w, y and mod->x_scale are required)", who);
+    if (mod->y_scale) return fail(SAE_EINVAL, "%s: y_scale has no meaning for the forward operation", who);
+    if (noise && !noise_weight) return fail(SAE_EINVAL, "%s: noise needs noise_weight", who);
+    if (d->stride != 1) return fail(SAE_EINVAL, "%s: stride 1 only (StyledConv's plain form)", who);
+    hipStream_t s = (hipStream_t)stream;
+    Epilogue ep{bias, 1, act_slope, act_scale};
+    ep.noise = noise; ep.noise_w = noise ? noise_weight : nullptr;
+    int rc = run_gather(x, w, y, workspace, workspace_floats, (int)d->n, (int)d->c, (int)d->h, (int)d->w, (int)d->m,
+                        (int)d->oh, (int)d->ow, (int)d->oh, (int)d->ow, 1, 1, d->kh, d->stride, d->pad,
+                        d->w_stride_m, d->w_stride_c, 0, alpha, s, ep, mod->x_scale, WScale{mod->wm_scale, mod->wc_scale});
+    if (rc != SAE_OK) return rc;
+    return check_launch(who);
 }
 
 extern "C" int sae_conv2d_fwd_bias_act_f32(const float* x, const float* w, const float* bias, float* y,

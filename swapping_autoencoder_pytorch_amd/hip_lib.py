@@ -76,6 +76,8 @@ _SIGNATURES = {
     "conv2d_dgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "conv2d_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "modconv2d_fwd_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),
+    "modconv2d_fwd_noise_bias_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod),
+                                                   _f32, _f32, _f32, _f32p, _i64, _stream]),
     "modconv2d_dgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),
     "modconv2d_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),
     "gemm_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _stream]),

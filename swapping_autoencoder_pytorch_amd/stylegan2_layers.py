@@ -20,13 +20,15 @@ from torch.nn import functional as F
 from . import hip_lib, rng
 from .stylegan2_op import (FusedLeakyReLU, ReflectionPad2d, add_scale, conv2d, conv2d_bias_act, conv_transpose2d,
                            fusable, fused_leaky_relu, l2_normalize, linear, modulated_conv2d, noise_bias_act, plane_scale,
-                           reflect_pad, upfirdn2d)
+                           reflect_pad, styled_modulated_conv2d, upfirdn2d)
 
 
 # SAE_MODCONV_FUSED=0 (debug / A-B measurements): ModulatedConv2d takes the two-step path (x * s, then a plain conv)
 _FUSED_MODCONV = os.environ.get("SAE_MODCONV_FUSED", "1") != "0"
 # SAE_RESBLOCK_FUSED=0 (debug / A-B measurements): ResBlock runs module by module instead of as one autograd node
 _FUSED_RESBLOCK = os.environ.get("SAE_RESBLOCK_FUSED", "1") != "0"
+# SAE_STYLED_FUSED=0 (A/B): StyledConv runs conv, then noise + bias + activation, instead of the one-kernel form
+_FUSED_STYLED = os.environ.get("SAE_STYLED_FUSED", "1") != "0"
 
 
 def make_kernel(k):
@@ -222,21 +224,29 @@ class ModulatedConv2d(nn.Module):
         w = self.weight[0] * self.scale
         return torch.rsqrt(w.pow(2).sum(dim=(1, 2, 3)) + 1e-8)
 
-    def forward(self, input, style):
+    def _fused_operands(self, input, style):
+        """(style factor [N, C], output scale) for the one-kernel path, or None when it does not apply."""
         fused = (not self.downsample and input.dtype == torch.float32 and _FUSED_MODCONV and hip_lib.get_conv_math() == "f32"
                  and (style.dim() == 2 or self._projected_style is not None))
-        if fused:
-            # style normalisation as ONE kernel forward, one backward (csrc/glue.hip l2_normalize):
-            #   s * rsqrt(mean(s^2) + eps) = sqrt(C) * s * rsqrt(sum(s^2) + C eps)
-            # the constant sqrt(C) rides in the conv's output scale (the conv is linear in s); the demodulation factor is
-            # computed and differentiated inside the conv node (weight_demod_*).  ~40 ATen launches per conv and
-            # forward + backward pass become 4.
-            s = self._projected_style if self._projected_style is not None else self.modulation(style.view(input.shape[0], -1))
-            out_scale = 1.0
-            if self.demodulate:
-                c = s.shape[1]
-                s = l2_normalize(s, c * 1e-8)
-                out_scale = math.sqrt(c)
+        if not fused:
+            return None
+        # style normalisation as ONE kernel forward, one backward (csrc/glue.hip l2_normalize):
+        #   s * rsqrt(mean(s^2) + eps) = sqrt(C) * s * rsqrt(sum(s^2) + C eps)
+        # the constant sqrt(C) rides in the conv's output scale (the conv is linear in s); the demodulation factor is
+        # computed and differentiated inside the conv node (weight_demod_*).  ~40 ATen launches per conv and
+        # forward + backward pass become 4.
+        s = self._projected_style if self._projected_style is not None else self.modulation(style.view(input.shape[0], -1))
+        out_scale = 1.0
+        if self.demodulate:
+            c = s.shape[1]
+            s = l2_normalize(s, c * 1e-8)
+            out_scale = math.sqrt(c)
+        return s, out_scale
+
+    def forward(self, input, style):
+        ops = self._fused_operands(input, style)
+        if ops is not None:
+            s, out_scale = ops
             out = modulated_conv2d(input, s, self.weight.view(self.weight.shape[1:]), None, padding=self.padding, alpha=self.scale,
                                    transposed=self.upsample, demod_eps=self.eps if self.demodulate else None, out_scale=out_scale)
             return self.blur(out) if self.upsample else out
@@ -306,6 +316,22 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None):
+        conv = self.conv
+        if self.use_noise and _FUSED_STYLED and not conv.upsample and not conv.downsample and input.dim() == 4:
+            ops = conv._fused_operands(input, style)
+            if ops is not None:
+                # conv -> noise -> bias + leaky-ReLU as ONE kernel (the noise map rides in the conv's epilogue): the noise is
+                # drawn first, from a memory-less probe of the output's shape -- same stream of draws as the module path
+                n, _, h, w = input.shape
+                oh, ow = h + 2 * conv.padding - conv.kernel_size + 1, w + 2 * conv.padding - conv.kernel_size + 1
+                z = self.noise.resolve(input.new_empty(1).expand(n, conv.out_channel, oh, ow), noise)
+                if tuple(z.shape) == (n, 1, oh, ow) and not z.requires_grad and z.dtype == torch.float32:
+                    s, out_scale = ops
+                    return styled_modulated_conv2d(input, s, conv.weight.view(conv.weight.shape[1:]), z, self.noise.weight,
+                                                   self.activate.bias, padding=conv.padding, alpha=conv.scale,
+                                                   demod_eps=conv.eps if conv.demodulate else None, out_scale=out_scale,
+                                                   negative_slope=self.activate.negative_slope, scale=self.activate.scale)
+                noise = z       # drawn already: the module path below must not draw again
         out = self.conv(input, style)
         if self.use_noise:
             z = self.noise.resolve(out, noise)

@@ -325,6 +325,14 @@ class ModulatedConv(Function):
             gw = torch.zeros_like(w) if (ctx.needs_input_grad[2] and _Flags.weight_grads) else None
             gd = torch.zeros_like(demod) if (demod is not None and not ctx.own_demod and ctx.needs_input_grad[3]) else None
             return None, None, gw, gd, None, None, None, None
+        gx, gs, gw, gd = _modconv_backward(ctx, gout, x, s, w, demod, geom, transposed)
+        return gx, gs, gw, gd, None, None, None, None
+
+
+def _modconv_backward(ctx, gout, x, s, w, demod, geom, transposed):
+    """(grad x, grad s, grad w, grad demod) of a ModulatedConv-type node; ctx: needs_input_grad[0..3] = x, s, w, demod,
+    own_demod, demod_alpha"""
+    if True:
         gout = gout.contiguous()
         gx = gs = gw = gd = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
@@ -353,7 +361,71 @@ class ModulatedConv(Function):
             else:
                 gw = geff * demod[:, None, None, None]
                 gd = (geff * w).sum(dim=(1, 2, 3))
-        return gx, gs, gw, gd, None, None, None, None
+        return gx, gs, gw, gd
+
+
+class StyledModConv(Function):
+    """StyledConv's plain (stride-1) form as ONE forward kernel (sae_modconv2d_fwd_noise_bias_act_f32):
+
+        out = lrelu((conv(x * s, W * alpha * demod) + noise_weight * noise) + bias, slope) * scale
+
+    i.e. ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU (stylegan2_layers.py:398-405) with the noise map read from LDS in the
+    conv's epilogue -- the conv's raw output never exists in HBM.  Backward: the noise + bias + activation backward kernel on the
+    saved OUTPUT (mask, bias / noise-strength gradients), then ModulatedConv's backward.  First-order only, like ModulatedConv."""
+
+    @staticmethod
+    def forward(ctx, x, s, w, noise, noise_weight, bias, geom, demod_eps, demod_alpha, slope, scale):
+        ctx.set_materialize_grads(False)
+        lib = hip_lib.get()
+        ctx.own_demod = True
+        ctx.demod_alpha = demod_alpha
+        demod = _weight_demod(w, demod_alpha, demod_eps) if demod_eps is not None else None
+        x, w, s, noise = x.contiguous(), w.contiguous(), s.contiguous(), noise.contiguous()
+        lib.check(x, w, s, noise, noise_weight, bias, demod)
+        d = geom.desc()
+        mod = hip_lib.ConvMod(s.data_ptr(), None, hip_lib.ptr(demod), None)
+        n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)
+        ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
+        out = torch.empty((geom.n, geom.m, geom.oh, geom.ow), dtype=torch.float32, device=x.device)
+        lib.call("modconv2d_fwd_noise_bias_act_f32", x.data_ptr(), w.data_ptr(), noise.data_ptr(), noise_weight.data_ptr(),
+                 hip_lib.ptr(bias), out.data_ptr(), C.byref(d), C.byref(mod), geom.alpha, float(slope), float(scale),
+                 ws.data_ptr(), n_ws, lib.stream(x))
+        ctx.save_for_backward(x, s, w, demod, out, noise)
+        ctx.cfg = (geom, slope, scale, bias is not None)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x, s, w, demod, out, noise = ctx.saved_tensors
+        geom, slope, scale, has_bias = ctx.cfg
+        need_w = ctx.needs_input_grad[2] and _Flags.weight_grads
+        if gout is None:
+            gnw = torch.zeros(1, dtype=out.dtype, device=out.device) if ctx.needs_input_grad[4] else None
+            gb = torch.zeros(out.shape[1], dtype=out.dtype, device=out.device) if (has_bias and ctx.needs_input_grad[5]) else None
+            return None, None, (torch.zeros_like(w) if need_w else None), None, gnw, gb, None, None, None, None, None
+        from .modulate import NoiseBiasActBackward
+        g_pre, gb, gnw = NoiseBiasActBackward.apply(gout, out, noise, slope, scale)
+        gx, gs, gw, _ = _modconv_backward(ctx, g_pre, x, s, w, demod, geom, False)
+        return gx, gs, gw, None, gnw, (gb if has_bias else None), None, None, None, None, None
+
+
+def styled_modulated_conv2d(input, style_scale, weight, noise, noise_weight, bias, padding=0, alpha=1.0, demod_eps=None,
+                            out_scale=1.0, negative_slope=0.2, scale=2 ** 0.5):
+    """StyledConv's plain form (ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU) as one node; arguments as
+    modulated_conv2d plus noise [N, 1, H, W], noise_weight [1], bias [O] or None."""
+    _check_weight(weight)
+    n, c_in, h, w = input.shape
+    o, i2, k, _ = weight.shape
+    if i2 != c_in or tuple(style_scale.shape) != (n, c_in):
+        raise hip_lib.SaeError("styled_modulated_conv2d: input %s, style %s, weight %s do not fit" % (
+            tuple(input.shape), tuple(style_scale.shape), tuple(weight.shape)))
+    geom = _Geom(n, c_in, h, w, o, k, 1, padding, False, alpha)
+    if tuple(noise.shape) != (n, 1, geom.oh, geom.ow):
+        raise hip_lib.SaeError("noise must be [N, 1, H, W] = %s, got %s" % ((n, 1, geom.oh, geom.ow), tuple(noise.shape)))
+    geom.alpha = float(alpha * out_scale)
+    return StyledModConv.apply(input, style_scale, weight, noise, noise_weight, bias, geom, demod_eps, float(alpha),
+                               negative_slope, scale)
 
 
 def modulated_conv2d(input, style_scale, weight, demod=None, padding=0, alpha=1.0, transposed=False, demod_eps=None,

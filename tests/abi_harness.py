@@ -274,6 +274,20 @@ def modconv(lib, op, d, a, b, out_shape, x_scale=None, y_scale=None, wm_scale=No
     return bo.numpy()
 
 
+def modconv_noise_bias_act(lib, d, x, w, x_scale, wm_scale, noise, noise_weight, bias, alpha=1.0, slope=0.2, scale=2 ** 0.5,
+                           device=None):
+    """sae_modconv2d_fwd_noise_bias_act_f32: StyledConv's plain form in one call"""
+    n = lib.query("conv2d_workspace", C.byref(d), 0)
+    out_shape = (d.n, d.m, d.oh, d.ow)
+    bx, bw, bo, ws = _Buf(x, device), _Buf(w, device), _out(out_shape, device), _out((max(n, 1),), device)
+    keep = [(_Buf(v, device) if v is not None else None) for v in (x_scale, None, wm_scale, None, noise, noise_weight, bias)]
+    mod = ConvMod(*[(k.ptr if k is not None else None) for k in keep[:4]])
+    opt = [(k.ptr if k is not None else None) for k in keep[4:]]
+    lib.call("modconv2d_fwd_noise_bias_act_f32", bx.ptr, bw.ptr, opt[0], opt[1], opt[2], bo.ptr, C.byref(d), C.byref(mod), alpha,
+             slope, scale, ws.ptr, n, _stream(device))
+    return bo.numpy()
+
+
 def l2_normalize(lib, x, eps=1e-8, device=None):
     outer, ch = x.shape[:2]
     inner = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1

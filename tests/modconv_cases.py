@@ -51,6 +51,22 @@ def run_case(lib, oracle, case, device=None, tol=2e-5):
         err = H.rel_err(e, o)
         assert err < tol, (op, sorted(kw), err)
         worst = max(worst, err)
+    if s == 1 and not cm and k == 3:
+        # StyledConv's plain form in one call (sae_modconv2d_fwd_noise_bias_act_f32): against the oracle's three modules one
+        # after the other, and against this library's own two calls (modulated conv, then noise + bias + activation)
+        noise = rng.standard_normal((n, 1, d.oh, d.ow)).astype(np.float32)
+        nw = np.array([0.37], np.float32)
+        bias = rng.standard_normal(m).astype(np.float32)
+        for nz, b_ in ((noise, bias), (None, bias), (noise, None)):
+            e = H.modconv_noise_bias_act(lib, d, x, wt, xs, wm, nz, nw if nz is not None else None, b_, alpha=0.37, device=device)
+            o = H.modconv_noise_bias_act(oracle, d, x, wt, xs, wm, nz, nw if nz is not None else None, b_, alpha=0.37)
+            err = H.rel_err(e, o)
+            assert err < tol, ("fused noise", nz is not None, b_ is not None, err)
+            worst = max(worst, err)
+            if (d.oh * d.ow) % 4 == 0:
+                two = H.noise_bias_act(lib, H.modconv(lib, 0, d, x, wt, gy.shape, alpha=0.37, device=device, x_scale=xs, wm_scale=wm),
+                                       nz, nw, b_, device=device)
+                assert H.rel_err(e, two) < 2e-7, ("fused noise vs two calls", H.rel_err(e, two))
     plain = H.conv(lib, 2, d, x, gy, wt.shape, alpha=0.37, device=device)
     assert np.array_equal(plain, H.modconv(lib, 2, d, x, gy, wt.shape, alpha=0.37, device=device))
     return worst
