@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     float* const As = smem;
     float* const Xs = smem + AS;
     // the tile's slice of the noise map (IgemmParams::noise): BN floats, shared by all BM rows of the tile, fetched once at the
-    // start and read from LDS in the epilogue -- a global load inside the store loop would make every store wait for its own
+    // start (into registers, see below) and read from LDS in the epilogue -- a global load inside the store loop would make every store wait for its own
     // round trip, and 8 - 16 quads per thread cannot be prefetched into registers (the fused residual's lesson)
     __shared__ float zs[MOD ? BN : 1];
 
@@ -228,16 +228,22 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     const int tin = bt / p.tiles_y;
     const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
     const int m0 = mt * BM;
+    // issued here, parked in registers across the K loop (one per thread at BN = 256) and written to LDS just before the
+    // epilogue: written to LDS right away, the wait for this load stood in front of the first chunk's loads of every workgroup
+    constexpr int ZPT = MOD ? (BN + kBlock - 1) / kBlock : 1;
+    [[maybe_unused]] float zreg[ZPT];
     if constexpr (MOD) {
-        if (p.noise) {      // visible to the epilogue through the barriers of the K loop
-            for (int pp = tid; pp < BN; pp += kBlock) {
+        if (p.noise) {
+#pragma unroll
+            for (int k = 0; k < ZPT; ++k) {
+                const int pp = tid + kBlock * k;
                 const int px = pp & (TW - 1);
                 const int py = (pp >> p.tw_log2) & (TH - 1);
                 const int pn = pp >> (p.tw_log2 + p.th_log2);
                 const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
-                const bool ok = n < p.N && oy < p.OH && ox < p.OW;
+                const bool ok = pp < BN && n < p.N && oy < p.OH && ox < p.OW;
                 const float v = p.noise[ok ? ((int64_t)n * p.OH + oy) * p.OW + ox : 0];
-                zs[pp] = ok ? v : 0.0f;
+                zreg[k] = ok ? v : 0.0f;
             }
         }
     }
@@ -523,7 +529,13 @@ __global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restr
     // together, and a wave64 store occupies the address path as long as a load does).
     [[maybe_unused]] float noise_wv = 0.0f;
     if constexpr (MOD) {
-        if (p.noise) noise_wv = p.noise_w[0];
+        if (p.noise) {
+            noise_wv = p.noise_w[0];
+#pragma unroll
+            for (int k = 0; k < ZPT; ++k)
+                if (tid + kBlock * k < BN) zs[tid + kBlock * k] = zreg[k];
+            __syncthreads();
+        }
     }
     constexpr int LDC = BN + 4;
     constexpr bool VEC_OK = AS + XS >= 32 * WM * LDC;         // the staging buffers hold one pass
