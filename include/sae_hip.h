@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 5   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32 */
+#define SAE_ABI_VERSION 5   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -118,6 +118,15 @@ int sae_upfirdn2d_epilogue_f32(const float* x, const float* k, float* y, int64_t
                                int32_t pad_y1, const float* act_ref, float slope, float scale, float* gb,
                                int64_t channels, int32_t accumulate, float* workspace, int64_t workspace_floats,
                                sae_stream_t stream);
+
+/* The blur that ends StyledConv's upsampling conv, followed by NoiseInjection and FusedLeakyReLU (stylegan2_layers.py:313-321,
+ * :398-405, :340-351), in one kernel: up = down = 1, taps <= 4 x 4,
+ *   y = lrelu((upfirdn2d(x, k, pad) + noise_weight[0] * noise[n][oy][ox]) + bias[c], slope) * scale,  plane p = n * channels + c
+ * noise: [major / channels][out_h][out_w] or NULL; noise_weight: one float ON THE DEVICE; bias: [channels] or NULL. */
+int sae_upfirdn2d_noise_bias_act_f32(const float* x, const float* k, float* y, int64_t major, int64_t in_h, int64_t in_w,
+                                     int32_t kh, int32_t kw, int32_t pad_x0, int32_t pad_x1, int32_t pad_y0, int32_t pad_y1,
+                                     const float* noise, const float* noise_weight, const float* bias, int64_t channels,
+                                     float slope, float scale, sae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * bias_act: y[i] = act'(x[i] + b[(i / step_b) % size_b]) * scale       fused_bias_act_kernel.cu:18-49

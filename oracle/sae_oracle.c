@@ -164,6 +164,30 @@ int oracle_upfirdn2d_epilogue_f32(const float* x, const float* k, float* y, int6
     return SAE_OK;
 }
 
+/* the blur, then NoiseInjection + FusedLeakyReLU on its result (include/sae_hip.h) */
+int oracle_upfirdn2d_noise_bias_act_f32(const float* x, const float* k, float* y, int64_t major, int64_t in_h, int64_t in_w,
+                                        int32_t kh, int32_t kw, int32_t pad_x0, int32_t pad_x1, int32_t pad_y0, int32_t pad_y1,
+                                        const float* noise, const float* noise_weight, const float* bias, int64_t channels,
+                                        float slope, float scale, sae_stream_t stream) {
+    if (!x || !k || !y || kh < 1 || kw < 1 || kh > 4 || kw > 4 || channels < 1 || major % channels != 0 || (noise && !noise_weight)) {
+        snprintf(g_err, sizeof g_err, "oracle_upfirdn2d_noise_bias_act_f32: bad argument");
+        return SAE_EINVAL;
+    }
+    const int64_t out_h = in_h + pad_y0 + pad_y1 - kh + 1, out_w = in_w + pad_x0 + pad_x1 - kw + 1;
+    if (out_h < 1 || out_w < 1) return SAE_EINVAL;
+    int rc = oracle_upfirdn2d_f32(x, k, y, major, in_h, in_w, 1, kh, kw, 1, 1, 1, 1, pad_x0, pad_x1, pad_y0, pad_y1, stream);
+    if (rc != SAE_OK) return rc;
+    const int64_t hw = out_h * out_w;
+    const float wn = noise ? noise_weight[0] : 0.0f;
+    for (int64_t p = 0; p < major; ++p)
+        for (int64_t i = 0; i < hw; ++i) {
+            float t = y[p * hw + i] + (noise ? wn * noise[(p / channels) * hw + i] : 0.0f);
+            t += bias ? bias[p % channels] : 0.0f;
+            y[p * hw + i] = (t > 0.0f ? t : t * slope) * scale;
+        }
+    return SAE_OK;
+}
+
 /* fused_bias_act_kernel.cu:18-49; the arithmetic is done in float exactly as the CUDA kernel
  * does for scalar_t = float (one add, one select/multiply, one multiply). */
 int oracle_bias_act_f32(const float* x, const float* b, const float* ref, float* y,

@@ -45,6 +45,12 @@ struct K1Epilogue {
     int accumulate;
     int channels;            // channel of plane p = p % channels
     int64_t q_per_channel;   // outer * (row groups per plane * x tiles)
+    // FORWARD activation on the way out (sae_upfirdn2d_noise_bias_act_f32: the blur that ends StyledConv's upsampling conv, followed by
+    // NoiseInjection + FusedLeakyReLU, stylegan2_layers.py:398-405): y = lrelu((v + fwd_noise_w[0] * noise[n][pixel]) + bias[c], slope) * scale
+    int fwd_act;
+    const float* fwd_noise;    // [outer][out_h * out_w] or null
+    const float* fwd_noise_w;  // one float on the device
+    const float* fwd_bias;     // [channels] or null
 };
 
 // The epilogue's own operands (the old value of y, the activation reference) are fetched together with the strip, long
@@ -57,14 +63,16 @@ struct K1Operands { float old[ACC ? RB : 1], ref[RB]; };
 template <int RB, bool ACC = true>
 __device__ __forceinline__ void k1_prefetch(const K1Epilogue& e, K1Operands<RB, ACC>& q, const float* yp, bool col_ok,
                                             int oy0, int out_h, int out_w, int ox, int64_t plane, int64_t plane_elems) {
-    const float* rp = e.act_ref ? e.act_ref + plane * plane_elems : yp;
+    const float* rp = e.act_ref ? e.act_ref + plane * plane_elems
+                                : (e.fwd_noise ? e.fwd_noise + (plane / e.channels) * plane_elems : yp);
+    const bool want_ref = e.act_ref || e.fwd_noise;
 #pragma unroll
     for (int o = 0; o < RB; ++o) {
         const int oy = oy0 + o;
         const bool ok = col_ok && oy < out_h;
         const int64_t idx = ok ? (int64_t)oy * out_w + ox : 0;       // branch-free (see blur_kernel): element 0 otherwise
         if constexpr (ACC) q.old[o] = e.accumulate ? yp[idx] : 0.0f;
-        q.ref[o] = e.act_ref ? rp[idx] : 1.0f;
+        q.ref[o] = want_ref ? rp[idx] : 1.0f;
     }
 }
 
@@ -74,6 +82,11 @@ __device__ __forceinline__ void k1_epilogue(const K1Epilogue& e, const K1Operand
                                             bool col_ok, int oy0, int out_h, int out_w, int ox, int64_t plane, int strip_q,
                                             int q_per_plane, bool live, int tx) {
     float bsum = 0.0f;
+    float fwd_nw = 0.0f, fwd_b = 0.0f;
+    if (e.fwd_act) {
+        if (e.fwd_noise) fwd_nw = e.fwd_noise_w[0];
+        if (e.fwd_bias) fwd_b = e.fwd_bias[plane % e.channels];
+    }
     if (col_ok) {
 #pragma unroll
         for (int o = 0; o < RB; ++o) {
@@ -86,6 +99,10 @@ __device__ __forceinline__ void k1_epilogue(const K1Epilogue& e, const K1Operand
                 if (e.act_ref) {
                     t = ((q.ref[o] > 0.0f) ? t : t * e.slope) * e.scale;
                     bsum += t;
+                } else if (e.fwd_act) {
+                    if (e.fwd_noise) t = t + fwd_nw * q.ref[o];       // (image + weight * noise) + bias, :340-351
+                    t = t + fwd_b;
+                    t = ((t > 0.0f) ? t : t * e.slope) * e.scale;
                 }
                 yp[(int64_t)oy * out_w + ox] = t;
             }
@@ -697,4 +714,29 @@ extern "C" int sae_upfirdn2d_epilogue_f32(const float* x, const float* k, float*
         hipLaunchKernelGGL(k1_bias_finalize_kernel, dim3((unsigned)channels), dim3(kBlock), 0, s, (const float*)workspace, gb,
                            channels, e.q_per_channel);
     return check_launch("sae_upfirdn2d_epilogue_f32");
+}
+
+extern "C" int sae_upfirdn2d_noise_bias_act_f32(const float* x, const float* k, float* y, int64_t major, int64_t in_h, int64_t in_w,
+                                                int32_t kh, int32_t kw, int32_t pad_x0, int32_t pad_x1, int32_t pad_y0,
+                                                int32_t pad_y1, const float* noise, const float* noise_weight, const float* bias,
+                                                int64_t channels, float slope, float scale, sae_stream_t stream) {
+    sae::clear_stale_error();
+    const char* who = "sae_upfirdn2d_noise_bias_act_f32";
+    if (kh < 1 || kw < 1 || kh > 4 || kw > 4) return fail(SAE_EINVAL, "%s: at most 4 x 4 taps (%dx%d)", who, kh, kw);
+    if (major < 0 || in_h < 1 || in_w < 1 || in_h > (1 << 24) || in_w > (1 << 24) || channels < 1 || major % channels != 0)
+        return fail(SAE_EINVAL, "%s: bad tensor size (major = outer * channels)", who);
+    const int64_t out_h = in_h + pad_y0 + pad_y1 - kh + 1;
+    const int64_t out_w = in_w + pad_x0 + pad_x1 - kw + 1;
+    if (out_h < 1 || out_w < 1) return fail(SAE_EINVAL, "%s: empty output (%lld x %lld)", who, (long long)out_h, (long long)out_w);
+    if (major == 0) return SAE_OK;
+    if (!x || !k || !y || (noise && !noise_weight)) return fail(SAE_EINVAL, "%s: null tensor", who);
+    K1Epilogue e{};
+    e.slope = slope; e.scale = scale; e.channels = (int)channels;
+    e.fwd_act = 1; e.fwd_noise = noise; e.fwd_noise_w = noise_weight; e.fwd_bias = bias;
+    BlurParams p{};
+    p.planes = major;
+    p.in_h = (int)in_h; p.in_w = (int)in_w; p.out_h = (int)out_h; p.out_w = (int)out_w;
+    p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
+    dispatch_blur44<true>(x, k, y, p, (hipStream_t)stream, e);
+    return check_launch(who);
 }

@@ -54,6 +54,8 @@ _SIGNATURES = {
     "upfirdn2d_epilogue_workspace": (_i64, [_i64, _i64, _i64, _i64, _i32]),
     "upfirdn2d_epilogue_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                          _f32p, _f32, _f32, _f32p, _i64, _i32, _f32p, _i64, _stream]),
+    "upfirdn2d_noise_bias_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
+                                               _f32p, _f32p, _f32p, _i64, _f32, _f32, _stream]),
     "bias_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _stream]),
     "bias_act_bwd_workspace": (_i64, [_i64, _i64, _i64]),
     "bias_act_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _f32, _f32, _stream]),

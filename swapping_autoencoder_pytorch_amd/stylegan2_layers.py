@@ -18,7 +18,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import hip_lib, rng
-from .stylegan2_op import (FusedLeakyReLU, ReflectionPad2d, add_scale, conv2d, conv2d_bias_act, conv_transpose2d,
+from .stylegan2_op import (FusedLeakyReLU, ReflectionPad2d, add_scale, blur_noise_bias_act, conv2d, conv2d_bias_act, conv_transpose2d,
                            fusable, fused_leaky_relu, l2_normalize, linear, modulated_conv2d, noise_bias_act, plane_scale,
                            reflect_pad, styled_modulated_conv2d, upfirdn2d)
 
@@ -317,6 +317,7 @@ class StyledConv(nn.Module):
 
     def forward(self, input, style, noise=None):
         conv = self.conv
+        out = None
         if self.use_noise and _FUSED_STYLED and not conv.upsample and not conv.downsample and input.dim() == 4:
             ops = conv._fused_operands(input, style)
             if ops is not None:
@@ -332,7 +333,25 @@ class StyledConv(nn.Module):
                                                    demod_eps=conv.eps if conv.demodulate else None, out_scale=out_scale,
                                                    negative_slope=self.activate.negative_slope, scale=self.activate.scale)
                 noise = z       # drawn already: the module path below must not draw again
-        out = self.conv(input, style)
+        elif (self.use_noise and _FUSED_STYLED and conv.upsample and input.dim() == 4 and not conv.blur.reflection
+              and max(conv.blur.kernel.shape) <= 4):
+            ops = conv._fused_operands(input, style)
+            if ops is not None:
+                # the upsampling form: transposed conv, then blur -> noise -> bias + leaky-ReLU as ONE K1 kernel
+                s, out_scale = ops
+                up = modulated_conv2d(input, s, conv.weight.view(conv.weight.shape[1:]), None, padding=conv.padding,
+                                      alpha=conv.scale, transposed=True, demod_eps=conv.eps if conv.demodulate else None,
+                                      out_scale=out_scale)
+                n, c, h, w = up.shape
+                kh, kw = conv.blur.kernel.shape
+                oh, ow = h + sum(conv.blur.pad) - kh + 1, w + sum(conv.blur.pad) - kw + 1
+                z = self.noise.resolve(up.new_empty(1).expand(n, c, oh, ow), noise)
+                if tuple(z.shape) == (n, 1, oh, ow) and not z.requires_grad and z.dtype == torch.float32:
+                    return blur_noise_bias_act(up, conv.blur.kernel, conv.blur.pad, z, self.noise.weight, self.activate.bias,
+                                               self.activate.negative_slope, self.activate.scale)
+                out, noise = conv.blur(up), z     # an unusual noise map: blur, then the module path's tail with the drawn map
+        if out is None:
+            out = self.conv(input, style)
         if self.use_noise:
             z = self.noise.resolve(out, noise)
             if fusable(out) and z.shape == (out.shape[0], 1) + out.shape[2:] and not z.requires_grad:

@@ -122,3 +122,48 @@ class UpFirDn2dBackward(Function):
 
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     return UpFirDn2d.apply(input, kernel, (up, up), (down, down), (pad[0], pad[1], pad[0], pad[1]))
+
+
+class BlurNoiseBiasAct(Function):
+    """upfirdn2d(x, kernel, pad) -> NoiseInjection -> FusedLeakyReLU as ONE kernel (sae_upfirdn2d_noise_bias_act_f32): the tail of
+    StyledConv's upsampling form (stylegan2_layers.py:313-321, :398-405).  Backward: the noise + bias + activation backward on the
+    saved OUTPUT, then the blur's adjoint.  First-order only (like the modulated conv in front of it)."""
+
+    @staticmethod
+    def forward(ctx, input, kernel, pad, noise, noise_weight, bias, negative_slope, scale):
+        ctx.set_materialize_grads(False)
+        lib = hip_lib.get()
+        input, kernel, noise = input.contiguous(), kernel.contiguous(), noise.contiguous()
+        lib.check(input, kernel, noise, noise_weight, bias)
+        n, c, h, w = input.shape
+        kh, kw = kernel.shape
+        px0, px1, py0, py1 = pad
+        oh, ow = _out_size(h, 1, 1, py0, py1, kh), _out_size(w, 1, 1, px0, px1, kw)
+        if tuple(noise.shape) != (n, 1, oh, ow):
+            raise hip_lib.SaeError("noise must be [N, 1, H, W] = %s, got %s" % ((n, 1, oh, ow), tuple(noise.shape)))
+        out = torch.empty((n, c, oh, ow), dtype=input.dtype, device=input.device)
+        lib.call("upfirdn2d_noise_bias_act_f32", input.data_ptr(), kernel.data_ptr(), out.data_ptr(), n * c, h, w, kh, kw,
+                 px0, px1, py0, py1, noise.data_ptr(), noise_weight.data_ptr(), hip_lib.ptr(bias), c, float(negative_slope),
+                 float(scale), lib.stream(input))
+        ctx.save_for_backward(kernel, out, noise)
+        ctx.cfg = (pad, (h, w), (oh, ow), negative_slope, scale, bias is not None)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_output):
+        kernel, out, noise = ctx.saved_tensors
+        pad, in_hw, out_hw, negative_slope, scale, has_bias = ctx.cfg
+        if grad_output is None:
+            gw = torch.zeros(1, dtype=out.dtype, device=out.device) if ctx.needs_input_grad[4] else None
+            gb = torch.zeros(out.shape[1], dtype=out.dtype, device=out.device) if (has_bias and ctx.needs_input_grad[5]) else None
+            return None, None, None, None, gw, gb, None, None
+        from .modulate import NoiseBiasActBackward
+        g_pre, gb, gw = NoiseBiasActBackward.apply(grad_output, out, noise, negative_slope, scale)
+        gx = UpFirDn2dBackward.apply(g_pre, kernel, (1, 1), (1, 1), pad, in_hw, out_hw) if ctx.needs_input_grad[0] else None
+        return gx, None, None, None, gw, (gb if has_bias else None), None, None
+
+
+def blur_noise_bias_act(input, kernel, pad, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
+    """leaky_relu((upfirdn2d(input, kernel, pad=pad) + noise_weight * noise) + bias) * scale in one kernel; taps <= 4 x 4."""
+    return BlurNoiseBiasAct.apply(input, kernel, (pad[0], pad[1], pad[0], pad[1]), noise, noise_weight, bias, negative_slope, scale)

@@ -68,6 +68,20 @@ def upfirdn2d_epilogue(lib, x, k, up, pad, y_old=None, act_ref=None, channels=1,
     return by.numpy(), (bgb.numpy() if br else None)
 
 
+def upfirdn2d_noise_bias_act(lib, x, k, pad, noise, noise_weight, bias, channels, slope=0.2, scale=2 ** 0.5, device=None):
+    """sae_upfirdn2d_noise_bias_act_f32 on planes x [major, ih, iw]; noise [major / channels, oh, ow] or None"""
+    major, ih, iw = x.shape
+    kh, kw = k.shape
+    oh = ih + pad[2] + pad[3] - kh + 1
+    ow = iw + pad[0] + pad[1] - kw + 1
+    bx, bk, by = _Buf(x, device), _Buf(k, device), _out((major, oh, ow), device)
+    keep = [(_Buf(v, device) if v is not None else None) for v in (noise, noise_weight, bias)]
+    ptrs = [(b.ptr if b is not None else None) for b in keep]
+    lib.call("upfirdn2d_noise_bias_act_f32", bx.ptr, bk.ptr, by.ptr, major, ih, iw, kh, kw, pad[0], pad[1], pad[2], pad[3],
+             ptrs[0], ptrs[1], ptrs[2], channels, slope, scale, _stream(device))
+    return by.numpy()
+
+
 def bias_act(lib, x, b, ref, act=3, grad=0, alpha=0.2, scale=2 ** 0.5, device=None):
     step_b = int(np.prod(x.shape[2:])) if x.ndim > 2 else 1
     bx = _Buf(x, device)

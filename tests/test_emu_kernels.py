@@ -49,6 +49,23 @@ def k1_epilogue_case(lib, oracle_lib, case, device=None):
                 assert np.allclose(gb, gbo, rtol=0, atol=2e-5 * np.abs(want).sum() / ch + 1e-6)
                 assert np.allclose(gb, gbs, rtol=0, atol=2e-5 * np.abs(want).sum() / ch + 1e-6)
             assert np.array_equal(y, want), (acc, act)
+    if up == 1:
+        # the forward activation on the way out (sae_upfirdn2d_noise_bias_act_f32): against the oracle's blur, then NoiseInjection +
+        # FusedLeakyReLU, and against this library's own two calls (bit-identical where the two-call form exists: hw % 4 == 0)
+        noise = rng.standard_normal((outer,) + plain.shape[1:]).astype(np.float32)
+        nw = np.array([0.37], np.float32)
+        bias = rng.standard_normal(ch).astype(np.float32)
+        for nz, b_ in ((noise, bias), (None, bias), (noise, None)):
+            y = H.upfirdn2d_noise_bias_act(lib, x, k, pad, nz, nw if nz is not None else None, b_, ch, device=device)
+            yo = H.upfirdn2d_noise_bias_act(oracle_lib, x, k, pad, nz, nw if nz is not None else None, b_, ch)
+            assert not np.isnan(y).any()
+            assert H.rel_err(y, yo) < TOL, ("forward activation", nz is not None, b_ is not None)
+            hw = plain.shape[1] * plain.shape[2]
+            if hw % 4 == 0:
+                two = H.noise_bias_act(lib, plain.reshape(outer, ch, plain.shape[1], plain.shape[2]),
+                                       None if nz is None else nz.reshape(outer, 1, plain.shape[1], plain.shape[2]), nw, b_,
+                                       device=device)
+                assert H.rel_err(y.reshape(two.shape), two) < 2e-7
 
 
 @pytest.mark.parametrize("case", K1_EPILOGUE, ids=str)
