@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 5   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32 */
+#define SAE_ABI_VERSION 5   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -159,6 +159,14 @@ int sae_noise_bias_act_bwd_f32(const float* gy, const float* y_ref, const float*
                                int64_t channels, int64_t hw, float alpha, float scale, sae_stream_t stream);
 int sae_plane_scale_dot_f32(const float* g, const float* x, const float* s, float* gx, float* gs, int64_t planes,
                             int64_t hw, sae_stream_t stream);
+/* sae_plane_scale_dot_f32 followed by sae_noise_bias_act_bwd_f32 of the StyledConv that PRODUCED x (inside a generator block conv2's
+ * input is conv1's activated output, generator.py:30-53): gs[n][c] = sum_hw g x;  gx = (x > 0 ? g s : alpha g s) * scale;
+ * gbias[c] = sum_{n,hw} gx;  gnoise_weight[0] = sum gx * noise.  g, x, gx: [outer][channels][hw], s, gs: [outer][channels],
+ * noise: [outer][hw] or NULL; gbias / gnoise_weight may be NULL.  Workspace: sae_plane_scale_dot_act_workspace floats. */
+int64_t sae_plane_scale_dot_act_workspace(int64_t outer, int64_t channels);
+int sae_plane_scale_dot_act_f32(const float* g, const float* x, const float* s, const float* noise, float* gx, float* gs,
+                                float* gbias, float* gnoise_weight, float* workspace, int64_t workspace_floats, int64_t outer,
+                                int64_t channels, int64_t hw, float alpha, float scale, sae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Demodulation factor of ModulatedConv2d and its backward (reference: models/networks/stylegan2_layers.py:290-292,

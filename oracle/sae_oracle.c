@@ -595,6 +595,36 @@ int oracle_plane_scale_dot_f32(const float* g, const float* x, const float* s, f
     return 0;
 }
 
+int64_t oracle_plane_scale_dot_act_workspace(int64_t outer, int64_t channels) { (void)outer; (void)channels; return 1; }
+
+/* the two passes one after the other, element by element (include/sae_hip.h) */
+int oracle_plane_scale_dot_act_f32(const float* g, const float* x, const float* s, const float* noise, float* gx, float* gs,
+                                   float* gbias, float* gnoise_weight, float* workspace, int64_t workspace_floats, int64_t outer,
+                                   int64_t channels, int64_t hw, float alpha, float scale, void* stream) {
+    (void)stream; (void)workspace; (void)workspace_floats;
+    if (outer < 0 || channels < 1 || hw < 4 || hw % 4) return set_err("plane_scale_dot_act: bad shape");
+    double gw = 0.0;
+    for (int64_t c = 0; c < channels; ++c) {
+        double gb = 0.0;
+        for (int64_t n = 0; n < outer; ++n) {
+            const int64_t q = n * channels + c;
+            double acc = 0.0;
+            for (int64_t p = 0; p < hw; ++p) {
+                const float t = g[q * hw + p] * s[q];
+                const float o = (x[q * hw + p] > 0.0f ? t : t * alpha) * scale;
+                gx[q * hw + p] = o;
+                acc += (double)g[q * hw + p] * x[q * hw + p];
+                gb += o;
+                if (noise) gw += (double)o * noise[n * hw + p];
+            }
+            gs[q] = (float)acc;
+        }
+        if (gbias) gbias[c] = (float)gb;
+    }
+    if (gnoise_weight && noise) gnoise_weight[0] = (float)gw;
+    return 0;
+}
+
 /* ---- demodulation factor and its backward (include/sae_hip.h; stylegan2_layers.py:290-292): the reference's own sequence --
  * scale, square, sum, + eps, rsqrt -- with the sum in double; the backward is the closed form of autograd's chain. ---- */
 int oracle_weight_demod_f32(const float* w, float* d, int64_t rows, int64_t cols, float alpha, float eps, void* stream) {

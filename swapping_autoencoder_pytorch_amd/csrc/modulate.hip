@@ -241,6 +241,65 @@ __global__ __launch_bounds__(kBlock) void weight_demod_bwd_kernel(const float* _
     for (int64_t q = threadIdx.x; q < cols; q += kBlock) gw[base + q] = dv * geff[base + q] - cf * w[base + q];
 }
 
+// plane_scale_dot followed by the noise + bias + activation backward of the layer that PRODUCED x, in one pass: inside a
+// generator block conv2's input x is conv1's activated output, so the gradient g * s that the style modulation's backward hands
+// to conv1 meets x again as the activation reference --
+//   gs[plane] = sum_hw g x;   gx = (x > 0 ? g s : alpha g s) * scale;   partial_b[c][n] = sum_hw gx;   partial_n[c][n] = sum_hw gx noise
+// (12 B per element instead of 12 + 12: the intermediate g * s is never written).  Same arithmetic per element as the two
+// kernels it replaces (g * s rounded to float first).  One workgroup per plane.
+__global__ __launch_bounds__(kBlock) void plane_scale_dot_act_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                                     const float* __restrict__ s, const float* __restrict__ noise,
+                                                                     float* __restrict__ gx, float* __restrict__ gs,
+                                                                     double* __restrict__ partial_b, double* __restrict__ partial_n,
+                                                                     int hw, int channels, int outer, float alpha, float scale) {
+    __shared__ double red[kBlock / kWave];
+    const int64_t plane = blockIdx.x;
+    const int64_t n = plane / channels;
+    const int c = (int)(plane - n * channels);
+    const float sc = s[plane];
+    const float* gp = g + plane * hw;
+    const float* xp = x + plane * hw;
+    const float* zp = noise ? noise + n * hw : nullptr;
+    float* op = gx + plane * hw;
+    double acc_s = 0.0, acc_b = 0.0, acc_n = 0.0;
+    for (int e0 = 0; e0 < hw; e0 += kBlock * 4 * 2) {
+        f32x4 gv[2], xv[2], zv[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = e0 + (u * kBlock + threadIdx.x) * 4;
+            if (e < hw) {
+                gv[u] = *reinterpret_cast<const f32x4*>(gp + e);
+                xv[u] = *reinterpret_cast<const f32x4*>(xp + e);
+                zv[u] = zp ? *reinterpret_cast<const f32x4*>(zp + e) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = e0 + (u * kBlock + threadIdx.x) * 4;
+            if (e < hw) {
+                f32x4 o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float t = gv[u][q] * sc;
+                    o[q] = ((xv[u][q] > 0.0f) ? t : t * alpha) * scale;
+                }
+                *reinterpret_cast<f32x4*>(op + e) = o;
+                acc_s += (gv[u][0] * xv[u][0] + gv[u][1] * xv[u][1]) + (gv[u][2] * xv[u][2] + gv[u][3] * xv[u][3]);
+                acc_b += (o[0] + o[1]) + (o[2] + o[3]);
+                acc_n += (o[0] * zv[u][0] + o[1] * zv[u][1]) + (o[2] * zv[u][2] + o[3] * zv[u][3]);
+            }
+        }
+    }
+    const double ts = block_sum_m(acc_s, red);
+    const double tb = block_sum_m(acc_b, red);
+    const double tn = block_sum_m(acc_n, red);
+    if (threadIdx.x == 0) {
+        gs[plane] = (float)ts;
+        partial_b[(int64_t)c * outer + n] = tb;
+        partial_n[(int64_t)c * outer + n] = tn;
+    }
+}
+
 int bwd_nsplit(int64_t outer, int hw, int channels, int* chunks_per_plane) {
     const int chunk = kBlock * 4 * 2;
     *chunks_per_plane = (int)ceil_div64(hw, chunk);
@@ -353,4 +412,38 @@ extern "C" int sae_weight_demod_bwd_f32(const float* geff, const float* w, const
     hipLaunchKernelGGL(weight_demod_bwd_kernel, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, geff, w, d, gw, cols,
                        alpha);
     return check_launch("sae_weight_demod_bwd_f32");
+}
+
+extern "C" int64_t sae_plane_scale_dot_act_workspace(int64_t outer, int64_t channels) {
+    if (outer < 1 || channels < 1) return 0;
+    return 4 * outer * channels + 2;       // two double arrays
+}
+
+extern "C" int sae_plane_scale_dot_act_f32(const float* g, const float* x, const float* s, const float* noise, float* gx, float* gs,
+                                           float* gbias, float* gnoise_weight, float* workspace, int64_t workspace_floats,
+                                           int64_t outer, int64_t channels, int64_t hw, float alpha, float scale, sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (!shape_ok(outer, channels, hw) || outer * channels >= ((int64_t)1 << 31))
+        return fail(SAE_EINVAL, "sae_plane_scale_dot_act_f32: need hw %% 4 == 0, got [%lld, %lld, %lld]", (long long)outer,
+                    (long long)channels, (long long)hw);
+    hipStream_t st = (hipStream_t)stream;
+    if (outer == 0) {
+        if (gbias) hipMemsetAsync(gbias, 0, sizeof(float) * (size_t)channels, st);
+        if (gnoise_weight) hipMemsetAsync(gnoise_weight, 0, sizeof(float), st);
+        return check_launch("sae_plane_scale_dot_act_f32(memset)");
+    }
+    if (!g || !x || !s || !gx || !gs) return fail(SAE_EINVAL, "sae_plane_scale_dot_act_f32: null tensor");
+    if (!aligned16(g) || !aligned16(x) || !aligned16(gx) || (noise && !aligned16(noise)))
+        return fail(SAE_EINVAL, "sae_plane_scale_dot_act_f32: tensors must be 16-byte aligned");
+    const int64_t need = 4 * outer * channels + 2;
+    if (!workspace || workspace_floats < need)
+        return fail(SAE_EWORKSPACE, "sae_plane_scale_dot_act_f32: workspace %lld < %lld floats", (long long)workspace_floats,
+                    (long long)need);
+    double* pb = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(workspace) + 7) & ~(uintptr_t)7);
+    double* pn = pb + outer * channels;
+    hipLaunchKernelGGL(plane_scale_dot_act_kernel, dim3((unsigned)(outer * channels)), dim3(kBlock), 0, st, g, x, s, noise, gx, gs,
+                       pb, pn, (int)hw, (int)channels, (int)outer, alpha, scale);
+    hipLaunchKernelGGL(noise_bias_finalize_kernel, dim3((unsigned)ceil_div64(channels, kBlock / kWave) + 1), dim3(kBlock), 0, st,
+                       (const double*)pb, (const double*)pn, gbias, noise ? gnoise_weight : nullptr, (int)channels, (int)outer);
+    return check_launch("sae_plane_scale_dot_act_f32");
 }

@@ -64,6 +64,9 @@ _SIGNATURES = {
     "noise_bias_act_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _f32,
                                          _f32, _stream]),
     "plane_scale_dot_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _stream]),
+    "plane_scale_dot_act_workspace": (_i64, [_i64, _i64]),
+    "plane_scale_dot_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64,
+                                          _f32, _f32, _stream]),
     "weight_demod_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, C.c_float, C.c_float, _stream]),
     "weight_demod_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, C.c_float, _stream]),
     "random_crop_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _stream]),

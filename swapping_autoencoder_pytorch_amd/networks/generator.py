@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from .. import util
 from ..stylegan2_layers import ConvLayer, EqualLinear, ModulatedConv2d, StyledConv, ToRGB
 from ..stylegan2_op import add_scale, linear, plane_affine, upsample2x_add
+from ..stylegan2_op.modulate import ActTicket
 from .base_network import BaseNetwork
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
@@ -37,7 +38,9 @@ class ResolutionPreservingResnetBlock(torch.nn.Module):
         self.skip = ConvLayer(inch, outch, 1, activate=False, bias=False) if inch != outch else torch.nn.Identity()
 
     def forward(self, x, style):
-        res = self.conv2(self.conv1(x, style), style)
+        # conv1's activation has one consumer, conv2: its activation backward rides in conv2's backward (ActTicket)
+        ticket = ActTicket()
+        res = self.conv2(self.conv1(x, style, act_ticket=ticket), style, input_ticket=ticket)
         return add_scale(self.skip(x), res, _INV_SQRT2)
 
 
@@ -52,7 +55,8 @@ class UpsamplingResnetBlock(torch.nn.Module):
         self.skip = ConvLayer(inch, outch, 1, activate=True, bias=True) if inch != outch else torch.nn.Identity()
 
     def forward(self, x, style):
-        res = self.conv2(self.conv1(x, style), style)
+        ticket = ActTicket()      # see ResolutionPreservingResnetBlock
+        res = self.conv2(self.conv1(x, style, act_ticket=ticket), style, input_ticket=ticket)
         # (bilinear_x2(skip) + res) / sqrt(2) in one pass
         return upsample2x_add(self.skip(x), res, _INV_SQRT2)
 

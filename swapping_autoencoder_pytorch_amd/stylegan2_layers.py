@@ -315,7 +315,9 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None):
+    def forward(self, input, style, noise=None, act_ticket=None, input_ticket=None):
+        """act_ticket / input_ticket (stylegan2_op.modulate.ActTicket): set by the generator blocks only -- this layer's output
+        has ONE consumer (the next StyledConv of the block), whose backward then also runs this layer's activation backward."""
         conv = self.conv
         out = None
         if self.use_noise and _FUSED_STYLED and not conv.upsample and not conv.downsample and input.dim() == 4:
@@ -331,7 +333,8 @@ class StyledConv(nn.Module):
                     return styled_modulated_conv2d(input, s, conv.weight.view(conv.weight.shape[1:]), z, self.noise.weight,
                                                    self.activate.bias, padding=conv.padding, alpha=conv.scale,
                                                    demod_eps=conv.eps if conv.demodulate else None, out_scale=out_scale,
-                                                   negative_slope=self.activate.negative_slope, scale=self.activate.scale)
+                                                   negative_slope=self.activate.negative_slope, scale=self.activate.scale,
+                                                   act_ticket=act_ticket, input_ticket=input_ticket)
                 noise = z       # drawn already: the module path below must not draw again
         elif (self.use_noise and _FUSED_STYLED and conv.upsample and input.dim() == 4 and not conv.blur.reflection
               and max(conv.blur.kernel.shape) <= 4):
@@ -348,7 +351,7 @@ class StyledConv(nn.Module):
                 z = self.noise.resolve(up.new_empty(1).expand(n, c, oh, ow), noise)
                 if tuple(z.shape) == (n, 1, oh, ow) and not z.requires_grad and z.dtype == torch.float32:
                     return blur_noise_bias_act(up, conv.blur.kernel, conv.blur.pad, z, self.noise.weight, self.activate.bias,
-                                               self.activate.negative_slope, self.activate.scale)
+                                               self.activate.negative_slope, self.activate.scale, act_ticket=act_ticket)
                 out, noise = conv.blur(up), z     # an unusual noise map: blur, then the module path's tail with the drawn map
         if out is None:
             out = self.conv(input, style)

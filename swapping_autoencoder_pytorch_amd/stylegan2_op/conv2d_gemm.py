@@ -329,7 +329,7 @@ class ModulatedConv(Function):
         return gx, gs, gw, gd, None, None, None, None
 
 
-def _modconv_backward(ctx, gout, x, s, w, demod, geom, transposed):
+def _modconv_backward(ctx, gout, x, s, w, demod, geom, transposed, in_ticket=None):
     """(grad x, grad s, grad w, grad demod) of a ModulatedConv-type node; ctx: needs_input_grad[0..3] = x, s, w, demod,
     own_demod, demod_alpha"""
     if True:
@@ -342,8 +342,10 @@ def _modconv_backward(ctx, gout, x, s, w, demod, geom, transposed):
             else:
                 g = _launch_mod("modconv2d_dgrad_f32", SAE_CONV_DGRAD, geom, gout, w, (geom.n, geom.c, geom.h, geom.w),
                                 wm_scale=demod)
-            from .modulate import fusable, plane_scale_backward
-            if fusable(g):
+            from .modulate import fusable, plane_scale_backward, plane_scale_dot_act
+            if in_ticket is not None and fusable(g) and ctx.needs_input_grad[0]:
+                gx, gs = plane_scale_dot_act(g, x, s, in_ticket)    # ... and the producer's activation backward (ActTicket)
+            elif fusable(g):
                 gx, gs = plane_scale_backward(g, x, s)       # g * s and sum_hw g * x in one pass
             else:
                 gx, gs = g * s[:, :, None, None], (g * x).sum(dim=(2, 3))
@@ -374,9 +376,13 @@ class StyledModConv(Function):
     saved OUTPUT (mask, bias / noise-strength gradients), then ModulatedConv's backward.  First-order only, like ModulatedConv."""
 
     @staticmethod
-    def forward(ctx, x, s, w, noise, noise_weight, bias, geom, demod_eps, demod_alpha, slope, scale):
+    def forward(ctx, x, s, w, noise, noise_weight, bias, geom, demod_eps, demod_alpha, slope, scale, act_ticket=None,
+                input_ticket=None):
         ctx.set_materialize_grads(False)
         lib = hip_lib.get()
+        ctx.act_ticket, ctx.input_ticket = act_ticket, (input_ticket if (input_ticket is not None and input_ticket.armed) else None)
+        if act_ticket is not None:
+            act_ticket.arm(noise, slope, scale)
         ctx.own_demod = True
         ctx.demod_alpha = demod_alpha
         demod = _weight_demod(w, demod_alpha, demod_eps) if demod_eps is not None else None
@@ -403,15 +409,16 @@ class StyledModConv(Function):
         if gout is None:
             gnw = torch.zeros(1, dtype=out.dtype, device=out.device) if ctx.needs_input_grad[4] else None
             gb = torch.zeros(out.shape[1], dtype=out.dtype, device=out.device) if (has_bias and ctx.needs_input_grad[5]) else None
-            return None, None, (torch.zeros_like(w) if need_w else None), None, gnw, gb, None, None, None, None, None
+            return None, None, (torch.zeros_like(w) if need_w else None), None, gnw, gb, None, None, None, None, None, None, None
         from .modulate import NoiseBiasActBackward
-        g_pre, gb, gnw = NoiseBiasActBackward.apply(gout, out, noise, slope, scale)
-        gx, gs, gw, _ = _modconv_backward(ctx, g_pre, x, s, w, demod, geom, False)
-        return gx, gs, gw, None, gnw, (gb if has_bias else None), None, None, None, None, None
+        taken = ctx.act_ticket.take(gout) if ctx.act_ticket is not None else None
+        g_pre, gb, gnw = taken if taken is not None else NoiseBiasActBackward.apply(gout, out, noise, slope, scale)
+        gx, gs, gw, _ = _modconv_backward(ctx, g_pre, x, s, w, demod, geom, False, ctx.input_ticket)
+        return gx, gs, gw, None, gnw, (gb if has_bias else None), None, None, None, None, None, None, None
 
 
 def styled_modulated_conv2d(input, style_scale, weight, noise, noise_weight, bias, padding=0, alpha=1.0, demod_eps=None,
-                            out_scale=1.0, negative_slope=0.2, scale=2 ** 0.5):
+                            out_scale=1.0, negative_slope=0.2, scale=2 ** 0.5, act_ticket=None, input_ticket=None):
     """StyledConv's plain form (ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU) as one node; arguments as
     modulated_conv2d plus noise [N, 1, H, W], noise_weight [1], bias [O] or None."""
     _check_weight(weight)
@@ -425,7 +432,7 @@ def styled_modulated_conv2d(input, style_scale, weight, noise, noise_weight, bia
         raise hip_lib.SaeError("noise must be [N, 1, H, W] = %s, got %s" % ((n, 1, geom.oh, geom.ow), tuple(noise.shape)))
     geom.alpha = float(alpha * out_scale)
     return StyledModConv.apply(input, style_scale, weight, noise, noise_weight, bias, geom, demod_eps, float(alpha),
-                               negative_slope, scale)
+                               negative_slope, scale, act_ticket, input_ticket)
 
 
 def modulated_conv2d(input, style_scale, weight, demod=None, padding=0, alpha=1.0, transposed=False, demod_eps=None,

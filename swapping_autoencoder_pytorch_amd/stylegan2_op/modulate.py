@@ -20,6 +20,55 @@ def fusable(x):
     return x.dim() == 4 and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[2] * x.shape[3] >= 4
 
 
+class ActTicket:
+    """Hand-over between two nodes of ONE generator block (networks/generator.py): conv1's node (the producer: its output is a
+    noise + bias + leaky-ReLU activation) and conv2's node (the ONLY consumer of that output).  The consumer's backward runs
+    `plane_scale_dot` and the producer's activation backward as one kernel (sae_plane_scale_dot_act_f32) and leaves the bias /
+    noise-strength gradients here; the producer's backward recognises the pre-processed gradient by its address and skips its
+    own activation pass.  Only block code that knows the activation has a single consumer may pass a ticket."""
+    __slots__ = ("armed", "noise", "slope", "scale", "gb", "gnw", "grad_ptr", "done")
+
+    def __init__(self):
+        self.armed = self.done = False
+        self.noise = self.gb = self.gnw = None
+        self.slope = self.scale = self.grad_ptr = None
+
+    def arm(self, noise, slope, scale):
+        self.armed, self.noise, self.slope, self.scale = True, noise, float(slope), float(scale)
+
+    def take(self, grad_output):
+        """(g_pre, gb, gnw) when `grad_output` is the consumer's pre-processed gradient, else None."""
+        if not self.done:
+            return None
+        self.done = False
+        if grad_output.data_ptr() != self.grad_ptr:
+            raise hip_lib.SaeError("ActTicket: the activation has a second consumer (its gradient was re-summed); "
+                                   "run with SAE_STYLED_FUSED=0")
+        out = (grad_output, self.gb, self.gnw)
+        self.gb = self.gnw = None
+        return out
+
+
+def plane_scale_dot_act(g, x, s, ticket):
+    """plane_scale_backward(g, x, s) fused with the producer's noise + bias + activation backward: returns (g_pre, gs) and
+    leaves gb / gnw in the ticket."""
+    lib = hip_lib.get()
+    g = g.contiguous()
+    lib.check(g, x, s, ticket.noise)
+    n, c, h, w = x.shape
+    gx = torch.empty_like(g)
+    gs = torch.empty((n, c), dtype=x.dtype, device=x.device)
+    gb = torch.empty(c, dtype=x.dtype, device=x.device)
+    gw = torch.empty(1, dtype=x.dtype, device=x.device)
+    n_ws = lib.query("plane_scale_dot_act_workspace", n, c)
+    ws = torch.empty(max(n_ws, 1), dtype=x.dtype, device=x.device)
+    lib.call("plane_scale_dot_act_f32", g.data_ptr(), x.data_ptr(), s.data_ptr(), hip_lib.ptr(ticket.noise), gx.data_ptr(),
+             gs.data_ptr(), gb.data_ptr(), gw.data_ptr(), ws.data_ptr(), n_ws, n, c, h * w, ticket.slope, ticket.scale,
+             lib.stream(x))
+    ticket.gb, ticket.gnw, ticket.grad_ptr, ticket.done = gb, gw, gx.data_ptr(), True
+    return gx, gs
+
+
 class NoiseBiasActFunction(Function):
     @staticmethod
     def forward(ctx, input, noise, noise_weight, bias, negative_slope, scale):

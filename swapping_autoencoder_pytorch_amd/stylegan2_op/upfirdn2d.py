@@ -130,9 +130,12 @@ class BlurNoiseBiasAct(Function):
     saved OUTPUT, then the blur's adjoint.  First-order only (like the modulated conv in front of it)."""
 
     @staticmethod
-    def forward(ctx, input, kernel, pad, noise, noise_weight, bias, negative_slope, scale):
+    def forward(ctx, input, kernel, pad, noise, noise_weight, bias, negative_slope, scale, act_ticket=None):
         ctx.set_materialize_grads(False)
         lib = hip_lib.get()
+        ctx.act_ticket = act_ticket
+        if act_ticket is not None:
+            act_ticket.arm(noise, negative_slope, scale)
         input, kernel, noise = input.contiguous(), kernel.contiguous(), noise.contiguous()
         lib.check(input, kernel, noise, noise_weight, bias)
         n, c, h, w = input.shape
@@ -157,13 +160,15 @@ class BlurNoiseBiasAct(Function):
         if grad_output is None:
             gw = torch.zeros(1, dtype=out.dtype, device=out.device) if ctx.needs_input_grad[4] else None
             gb = torch.zeros(out.shape[1], dtype=out.dtype, device=out.device) if (has_bias and ctx.needs_input_grad[5]) else None
-            return None, None, None, None, gw, gb, None, None
+            return None, None, None, None, gw, gb, None, None, None
         from .modulate import NoiseBiasActBackward
-        g_pre, gb, gw = NoiseBiasActBackward.apply(grad_output, out, noise, negative_slope, scale)
+        taken = ctx.act_ticket.take(grad_output) if ctx.act_ticket is not None else None
+        g_pre, gb, gw = taken if taken is not None else NoiseBiasActBackward.apply(grad_output, out, noise, negative_slope, scale)
         gx = UpFirDn2dBackward.apply(g_pre, kernel, (1, 1), (1, 1), pad, in_hw, out_hw) if ctx.needs_input_grad[0] else None
-        return gx, None, None, None, gw, (gb if has_bias else None), None, None
+        return gx, None, None, None, gw, (gb if has_bias else None), None, None, None
 
 
-def blur_noise_bias_act(input, kernel, pad, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5):
+def blur_noise_bias_act(input, kernel, pad, noise, noise_weight, bias, negative_slope=0.2, scale=2 ** 0.5, act_ticket=None):
     """leaky_relu((upfirdn2d(input, kernel, pad=pad) + noise_weight * noise) + bias) * scale in one kernel; taps <= 4 x 4."""
-    return BlurNoiseBiasAct.apply(input, kernel, (pad[0], pad[1], pad[0], pad[1]), noise, noise_weight, bias, negative_slope, scale)
+    return BlurNoiseBiasAct.apply(input, kernel, (pad[0], pad[1], pad[0], pad[1]), noise, noise_weight, bias, negative_slope, scale,
+                                  act_ticket)

@@ -198,6 +198,19 @@ def plane_scale_dot(lib, g, x, s, device=None):
     return bgx.numpy(), bgs.numpy()
 
 
+def plane_scale_dot_act(lib, g, x, s, noise, alpha=0.2, scale=2 ** 0.5, device=None):
+    n, c = g.shape[:2]
+    hw = int(np.prod(g.shape[2:]))
+    nws = lib.query("plane_scale_dot_act_workspace", n, c)
+    bg, bx, bs = _Buf(g, device), _Buf(x, device), _Buf(s, device)
+    bn = _Buf(noise, device) if noise is not None else None
+    bgx, bgs, bgb, bgw, bws = (_out(g.shape, device), _out(s.shape, device), _out((c,), device), _out((1,), device),
+                               _out((max(nws, 1),), device))
+    lib.call("plane_scale_dot_act_f32", bg.ptr, bx.ptr, bs.ptr, bn.ptr if bn else None, bgx.ptr, bgs.ptr, bgb.ptr, bgw.ptr, bws.ptr,
+             nws, n, c, hw, alpha, scale, _stream(device))
+    return bgx.numpy(), bgs.numpy(), bgb.numpy(), bgw.numpy()
+
+
 def weight_demod(lib, w, alpha, eps=1e-8, device=None):
     rows, cols = w.shape[0], int(np.prod(w.shape[1:]))
     bw, bd = _Buf(w, device), _out((rows,), device)

@@ -256,6 +256,16 @@ def test_noise_bias_act(emu_lib, oracle_lib, shape):
     g2_o, gs_o = H.plane_scale_dot(oracle_lib, gy, x, s)
     assert np.array_equal(g2_e, g2_o)
     assert np.allclose(gs_e, gs_o, rtol=1e-5, atol=1e-4)
+    # the fused pair (plane_scale_dot, then the producer's noise + bias + activation backward) against the oracle and against
+    # the two kernels it replaces, with and without a noise map
+    for nz in (noise, None):
+        fx, fs, fb, fw = H.plane_scale_dot_act(emu_lib, gy, y, s, nz)
+        ox, os_, ob, ow_ = H.plane_scale_dot_act(oracle_lib, gy, y, s, nz)
+        assert np.array_equal(fx, ox) and np.allclose(fs, os_, rtol=1e-5, atol=1e-4)
+        assert np.allclose(fb, ob, rtol=1e-5, atol=1e-4) and (nz is None or np.allclose(fw, ow_, rtol=1e-5, atol=1e-3))
+        t2, s2 = H.plane_scale_dot(emu_lib, gy, y, s)
+        x2, b2, w2 = H.noise_bias_act_bwd(emu_lib, t2, y, nz)
+        assert np.array_equal(fx, x2) and np.allclose(fs, s2, rtol=1e-6, atol=1e-5) and np.allclose(fb, b2, rtol=1e-5, atol=1e-4)
 
 
 @pytest.mark.parametrize("shape", [(5, 3, 3, 3), (7, 300, 1, 1), (3, 64, 3, 3), (2, 2, 1, 1)], ids=str)

@@ -263,6 +263,13 @@ def test_noise_bias_act(hip_lib, oracle_lib, shape):
     g2_o, gs_o = H.plane_scale_dot(oracle_lib, gy, x, s)
     assert np.array_equal(g2_e, g2_o)
     assert np.abs(gs_e - gs_o).max() <= 1e-6 * float(np.abs(gy * x).sum() / (n * c))
+    for nz in (noise, None):      # the fused pair: plane_scale_dot + the producer's noise / bias / activation backward
+        fx, fs, fb, fw = H.plane_scale_dot_act(hip_lib, gy, y, s, nz, device=DEV)
+        ox, os_, ob, ow_ = H.plane_scale_dot_act(oracle_lib, gy, y, s, nz)
+        assert np.array_equal(fx, ox)
+        assert np.abs(fs - os_).max() <= 1e-6 * float(np.abs(gy * y).sum() / (n * c))
+        assert np.abs(fb - ob).max() <= 1e-6 * float(np.abs(ox).sum() / c)
+        assert nz is None or abs(float(fw[0]) - float(ow_[0])) <= 1e-6 * float(np.abs(ox).sum())
 
 
 @pytest.mark.parametrize("shape", [(5, 3, 3, 3), (512, 512, 3, 3), (128, 256, 3, 3), (3, 128, 1, 1)], ids=str)

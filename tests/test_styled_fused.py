@@ -1,0 +1,93 @@
+"""StyledConv's one-kernel forms and the ActTicket hand-over inside the generator blocks (stylegan2_layers.StyledConv,
+networks/generator.py) against the module-by-module path of the same layers (SAE_STYLED_FUSED=0): outputs, input / style
+gradients and every parameter gradient; the fused entries must really be the ones that ran."""
+import pytest
+import torch
+
+from parity_common import backend
+
+
+def _run_block(block, x, style, fused, lib):
+    from swapping_autoencoder_pytorch_amd import stylegan2_layers as SL
+    prev = SL._FUSED_STYLED
+    SL._FUSED_STYLED = fused
+    calls = []
+    orig = lib.call
+
+    def counting(name, *a):
+        calls.append(name)
+        return orig(name, *a)
+
+    lib.call = counting
+    try:
+        x = x.clone().requires_grad_(True)
+        style = style.clone().requires_grad_(True)
+        torch.manual_seed(3)                   # the noise maps
+        y = block(x, style)
+        torch.manual_seed(4)
+        g = torch.randn_like(y)
+        params = list(block.parameters())
+        grads = torch.autograd.grad(y, [x, style] + params, g)
+        return [y.detach()] + [t.detach() for t in grads], calls
+    finally:
+        lib.call = orig
+        SL._FUSED_STYLED = prev
+
+
+def _compare(lib, device, tol):
+    from swapping_autoencoder_pytorch_amd.networks.generator import ResolutionPreservingResnetBlock, UpsamplingResnetBlock
+    with backend(lib):
+        for make, xshape in ((lambda: ResolutionPreservingResnetBlock(None, 6, 10, 16), (2, 6, 8, 8)),
+                             (lambda: ResolutionPreservingResnetBlock(None, 8, 8, 16), (3, 8, 4, 4)),
+                             (lambda: UpsamplingResnetBlock(6, 10, 16, use_noise=True), (2, 6, 8, 8)),
+                             (lambda: UpsamplingResnetBlock(8, 8, 16, use_noise=True), (1, 8, 16, 16))):
+            torch.manual_seed(11)
+            block = make()
+            with torch.no_grad():
+                for n, p in block.named_parameters():
+                    if p.dim() == 1 or n.endswith("noise.weight"):
+                        p.normal_(0.0, 0.5)        # zero-initialised biases / noise strengths would hide wrong gradients
+            block = block.to(device)
+            x = torch.randn(xshape).to(device)
+            style = torch.randn(xshape[0], 16).to(device)
+            a, calls = _run_block(block, x, style, True, lib)
+            b, calls_b = _run_block(block, x, style, False, lib)
+            # the fused path: one-kernel forward of the plain StyledConv(s), the blur + activation of the upsampling one, the
+            # pair kernel in the backward; the module path: none of them
+            assert "modconv2d_fwd_noise_bias_act_f32" in calls and "plane_scale_dot_act_f32" in calls
+            assert ("upfirdn2d_noise_bias_act_f32" in calls) == isinstance(block, UpsamplingResnetBlock)
+            assert not {"modconv2d_fwd_noise_bias_act_f32", "plane_scale_dot_act_f32", "upfirdn2d_noise_bias_act_f32"} & set(calls_b)
+            assert calls.count("noise_bias_act_bwd_f32") == 1 and calls_b.count("noise_bias_act_bwd_f32") == 2
+            for i, (u, v) in enumerate(zip(a, b)):
+                err = (u - v).abs().max().item() / (v.abs().max().item() + 1e-30)
+                assert err < tol, (type(block).__name__, i, err)
+
+
+def test_fused_styled_blocks_match_the_module_path_oracle(oracle_lib):
+    _compare(oracle_lib, "cpu", 2e-6)
+
+
+def test_fused_styled_blocks_match_the_module_path_emulator(emu_lib):
+    _compare(emu_lib, "cpu", 2e-6)
+
+
+def test_a_second_consumer_of_a_ticketed_activation_is_refused(oracle_lib):
+    """The hand-over is only sound when the activation has one consumer: a re-summed gradient is detected and refused."""
+    from swapping_autoencoder_pytorch_amd.hip_lib import SaeError
+    from swapping_autoencoder_pytorch_amd.stylegan2_layers import StyledConv
+    from swapping_autoencoder_pytorch_amd.stylegan2_op.modulate import ActTicket
+    with backend(oracle_lib):
+        torch.manual_seed(0)
+        c1, c2 = StyledConv(4, 6, 3, 8), StyledConv(6, 6, 3, 8)
+        x, s = torch.randn(1, 4, 8, 8, requires_grad=True), torch.randn(1, 8)
+        t = ActTicket()
+        a1 = c1(x, s, act_ticket=t)
+        y = c2(a1, s, input_ticket=t) + a1.sum()          # a1 used a second time
+        with pytest.raises((SaeError, RuntimeError)):
+            y.sum().backward()
+
+
+@pytest.mark.gpu
+def test_fused_styled_blocks_match_the_module_path_gpu():
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    _compare(hip_lib.get(), "cuda:0", 5e-6)
