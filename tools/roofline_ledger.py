@@ -37,10 +37,11 @@ def _desc(arg):
 def work_of(name, a):
     """(class label, bound, algorithmic work: FLOPs for 'mfma', bytes for 'hbm')"""
     if (name.startswith("conv2d_") and name != "conv2d_workspace") or name.startswith("modconv2d_"):
-        d = _desc(a[4] if name in ("conv2d_fwd_bias_act_f32", "conv2d_fwd_residual_f32") else a[3])
+        d = _desc(a[6] if name == "modconv2d_fwd_noise_bias_act_f32" else
+                  a[4] if name in ("conv2d_fwd_bias_act_f32", "conv2d_fwd_residual_f32") else a[3])
         op = {"conv2d_fwd_f32": "fwd", "conv2d_fwd_bias_act_f32": "fwd+bias+lrelu", "conv2d_fwd_residual_f32": "fwd+residual",
               "conv2d_dgrad_f32": "dgrad",
-              "conv2d_wgrad_f32": "wgrad", "modconv2d_fwd_f32": "fwd (modulated)", "modconv2d_dgrad_f32": "dgrad (modulated)",
+              "conv2d_wgrad_f32": "wgrad", "modconv2d_fwd_f32": "fwd (modulated)", "modconv2d_fwd_noise_bias_act_f32": "fwd (modulated)", "modconv2d_dgrad_f32": "dgrad (modulated)",
               "modconv2d_wgrad_f32": "wgrad (modulated)"}[name]
         width = "narrow(<=64ch)" if max(d.m if op.startswith("fwd") else d.c, 1) <= 64 else "wide"
         if op.startswith("wgrad"):
@@ -65,6 +66,12 @@ def work_of(name, a):
         kind = ("blur" if up == 1 else "zero-insert x2") + (" + accumulate" if acc else "") + (" + act backward" if act else "")
         # algorithmic bytes: the FIR's input and output once, plus one read per fused operand (old y, activation reference)
         return "upfirdn2d %s (fused epilogue)" % kind, "hbm", 4.0 * major * (ih * iw + oh * ow * (1 + int(act) + int(acc)))
+    if name == "upfirdn2d_noise_bias_act_f32":
+        major, ih, iw, kh, kw, px0, px1, py0, py1 = a[3:12]
+        oh, ow = ih + py0 + py1 - kh + 1, iw + px0 + px1 - kw + 1
+        return "upfirdn2d blur + noise + bias + lrelu forward (fused epilogue)", "hbm", 4.0 * major * (ih * iw + oh * ow)
+    if name == "plane_scale_dot_act_f32":
+        return "style modulation backward + activation backward (fused)", "hbm", 4.0 * a[10] * a[12] * (3 * a[11] + 1)
     if name == "upfirdn2d_f32":
         major, ih, iw, minor, kh, kw, ux, uy, dx, dy, px0, px1, py0, py1 = a[3:17]
         oh = (ih * uy + py0 + py1 - kh + dy) // dy
