@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from .. import util
 from ..stylegan2_layers import ConvLayer, EqualLinear, ModulatedConv2d, StyledConv, ToRGB
 from ..stylegan2_op import add_scale, linear, plane_affine, upsample2x_add
-from ..stylegan2_op.modulate import ActTicket
+from ..stylegan2_op.modulate import ActTicket, GradScaleTicket
 from .base_network import BaseNetwork
 
 _INV_SQRT2 = 1.0 / math.sqrt(2)
@@ -56,9 +56,10 @@ class UpsamplingResnetBlock(torch.nn.Module):
 
     def forward(self, x, style):
         ticket = ActTicket()      # see ResolutionPreservingResnetBlock
-        res = self.conv2(self.conv1(x, style, act_ticket=ticket), style, input_ticket=ticket)
+        merge = GradScaleTicket()  # conv2's output has one consumer too, the merge: its 1/sqrt(2) rides in conv2's backward
+        res = self.conv2(self.conv1(x, style, act_ticket=ticket), style, input_ticket=ticket, grad_scale_ticket=merge)
         # (bilinear_x2(skip) + res) / sqrt(2) in one pass
-        return upsample2x_add(self.skip(x), res, _INV_SQRT2)
+        return upsample2x_add(self.skip(x), res, _INV_SQRT2, res_ticket=merge)
 
 
 class GeneratorModulation(torch.nn.Module):

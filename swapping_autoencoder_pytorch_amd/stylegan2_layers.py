@@ -315,7 +315,7 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None, act_ticket=None, input_ticket=None):
+    def forward(self, input, style, noise=None, act_ticket=None, input_ticket=None, grad_scale_ticket=None):
         """act_ticket / input_ticket (stylegan2_op.modulate.ActTicket): set by the generator blocks only -- this layer's output
         has ONE consumer (the next StyledConv of the block), whose backward then also runs this layer's activation backward."""
         conv = self.conv
@@ -334,7 +334,8 @@ class StyledConv(nn.Module):
                                                    self.activate.bias, padding=conv.padding, alpha=conv.scale,
                                                    demod_eps=conv.eps if conv.demodulate else None, out_scale=out_scale,
                                                    negative_slope=self.activate.negative_slope, scale=self.activate.scale,
-                                                   act_ticket=act_ticket, input_ticket=input_ticket)
+                                                   act_ticket=act_ticket, input_ticket=input_ticket,
+                                                   grad_scale_ticket=grad_scale_ticket)
                 noise = z       # drawn already: the module path below must not draw again
         elif (self.use_noise and _FUSED_STYLED and conv.upsample and input.dim() == 4 and not conv.blur.reflection
               and max(conv.blur.kernel.shape) <= 4):

@@ -377,9 +377,12 @@ class StyledModConv(Function):
 
     @staticmethod
     def forward(ctx, x, s, w, noise, noise_weight, bias, geom, demod_eps, demod_alpha, slope, scale, act_ticket=None,
-                input_ticket=None):
+                input_ticket=None, grad_scale_ticket=None):
         ctx.set_materialize_grads(False)
         lib = hip_lib.get()
+        ctx.grad_scale_ticket = grad_scale_ticket
+        if grad_scale_ticket is not None:
+            grad_scale_ticket.armed = True
         ctx.act_ticket, ctx.input_ticket = act_ticket, (input_ticket if (input_ticket is not None and input_ticket.armed) else None)
         if act_ticket is not None:
             act_ticket.arm(noise, slope, scale)
@@ -409,16 +412,21 @@ class StyledModConv(Function):
         if gout is None:
             gnw = torch.zeros(1, dtype=out.dtype, device=out.device) if ctx.needs_input_grad[4] else None
             gb = torch.zeros(out.shape[1], dtype=out.dtype, device=out.device) if (has_bias and ctx.needs_input_grad[5]) else None
-            return None, None, (torch.zeros_like(w) if need_w else None), None, gnw, gb, None, None, None, None, None, None, None
+            return None, None, (torch.zeros_like(w) if need_w else None), None, gnw, gb, None, None, None, None, None, None, None, None
         from .modulate import NoiseBiasActBackward
         taken = ctx.act_ticket.take(gout) if ctx.act_ticket is not None else None
-        g_pre, gb, gnw = taken if taken is not None else NoiseBiasActBackward.apply(gout, out, noise, slope, scale)
+        if taken is None:
+            # a merge that is this activation's only consumer may have left its 1/sqrt(2) for this kernel (GradScaleTicket)
+            fold = ctx.grad_scale_ticket.take(gout) if ctx.grad_scale_ticket is not None else 1.0
+            taken = NoiseBiasActBackward.apply(gout, out, noise, slope, scale * fold)
+        g_pre, gb, gnw = taken
         gx, gs, gw, _ = _modconv_backward(ctx, g_pre, x, s, w, demod, geom, False, ctx.input_ticket)
-        return gx, gs, gw, None, gnw, (gb if has_bias else None), None, None, None, None, None, None, None
+        return gx, gs, gw, None, gnw, (gb if has_bias else None), None, None, None, None, None, None, None, None
 
 
 def styled_modulated_conv2d(input, style_scale, weight, noise, noise_weight, bias, padding=0, alpha=1.0, demod_eps=None,
-                            out_scale=1.0, negative_slope=0.2, scale=2 ** 0.5, act_ticket=None, input_ticket=None):
+                            out_scale=1.0, negative_slope=0.2, scale=2 ** 0.5, act_ticket=None, input_ticket=None,
+                            grad_scale_ticket=None):
     """StyledConv's plain form (ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU) as one node; arguments as
     modulated_conv2d plus noise [N, 1, H, W], noise_weight [1], bias [O] or None."""
     _check_weight(weight)
@@ -432,7 +440,7 @@ def styled_modulated_conv2d(input, style_scale, weight, noise, noise_weight, bia
         raise hip_lib.SaeError("noise must be [N, 1, H, W] = %s, got %s" % ((n, 1, geom.oh, geom.ow), tuple(noise.shape)))
     geom.alpha = float(alpha * out_scale)
     return StyledModConv.apply(input, style_scale, weight, noise, noise_weight, bias, geom, demod_eps, float(alpha),
-                               negative_slope, scale, act_ticket, input_ticket)
+                               negative_slope, scale, act_ticket, input_ticket, grad_scale_ticket)
 
 
 def modulated_conv2d(input, style_scale, weight, demod=None, padding=0, alpha=1.0, transposed=False, demod_eps=None,

@@ -49,6 +49,31 @@ class ActTicket:
         return out
 
 
+class GradScaleTicket:
+    """The other direction inside an upsampling block: the merge `alpha * (up2x(skip) + res)` is the ONLY consumer of conv2's
+    activated output `res`.  Its backward hands the incoming gradient on untouched and leaves `alpha` here; conv2's node folds it
+    into the scale of its activation backward -- the `gy * alpha` pass over the full-resolution tensor disappears."""
+    __slots__ = ("armed", "alpha", "grad_ptr")
+
+    def __init__(self):
+        self.armed, self.alpha, self.grad_ptr = False, None, None
+
+    def offer(self, gy, alpha):
+        self.alpha, self.grad_ptr = float(alpha), gy.data_ptr()
+        return gy
+
+    def take(self, grad_output):
+        """the factor the producer must apply to `grad_output` (1.0 when the merge did not hand over)"""
+        if self.alpha is None:
+            return 1.0
+        alpha, ptr = self.alpha, self.grad_ptr
+        self.alpha = self.grad_ptr = None
+        if grad_output.data_ptr() != ptr:
+            raise hip_lib.SaeError("GradScaleTicket: the activation has a second consumer (its gradient was re-summed); "
+                                   "run with SAE_STYLED_FUSED=0")
+        return alpha
+
+
 def plane_scale_dot_act(g, x, s, ticket):
     """plane_scale_backward(g, x, s) fused with the producer's noise + bias + activation backward: returns (g_pre, gs) and
     leaves gb / gnw in the ticket."""

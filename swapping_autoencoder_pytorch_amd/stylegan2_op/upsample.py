@@ -36,18 +36,24 @@ def _down(gy, alpha):
 
 class Upsample2xAdd(Function):
     @staticmethod
-    def forward(ctx, x, res, alpha):
+    def forward(ctx, x, res, alpha, res_ticket=None):
         ctx.set_materialize_grads(False)   # an undefined gradient skips the kernels instead of running them on zeros
         ctx.alpha = alpha
+        ctx.res_ticket = res_ticket if (res_ticket is not None and res_ticket.armed) else None
         return _up(x, res, alpha)
 
     @staticmethod
     def backward(ctx, gy):
         if gy is None:
-            return None, None, None
+            return None, None, None, None
         gx = Upsample2xAdjoint.apply(gy, ctx.alpha) if ctx.needs_input_grad[0] else None
-        gres = gy * ctx.alpha if ctx.needs_input_grad[1] else None
-        return gx, gres, None
+        gres = None
+        if ctx.needs_input_grad[1]:
+            # the producer of `res` applies alpha inside its own backward kernel when the block handed over a ticket
+            # (stylegan2_op.modulate.GradScaleTicket); otherwise one pass over the full-resolution gradient
+            gres = ctx.res_ticket.offer(gy.contiguous(), ctx.alpha) if (ctx.res_ticket is not None and not torch.is_grad_enabled()) \
+                else gy * ctx.alpha
+        return gx, gres, None, None
 
 
 class Upsample2xAdjoint(Function):
@@ -64,8 +70,8 @@ class Upsample2xAdjoint(Function):
         return (Upsample2xAdd.apply(ggx, None, ctx.alpha) if ctx.needs_input_grad[0] else None), None
 
 
-def upsample2x_add(x, res=None, alpha=1.0):
-    return Upsample2xAdd.apply(x, res, alpha)
+def upsample2x_add(x, res=None, alpha=1.0, res_ticket=None):
+    return Upsample2xAdd.apply(x, res, alpha, res_ticket)
 
 
 class AddScale(Function):

@@ -87,6 +87,30 @@ def test_a_second_consumer_of_a_ticketed_activation_is_refused(oracle_lib):
             y.sum().backward()
 
 
+def test_a_second_consumer_of_a_merged_activation_is_refused(oracle_lib):
+    """GradScaleTicket: the merge hands its 1/sqrt(2) to conv2's backward only if conv2's output goes nowhere else."""
+    from swapping_autoencoder_pytorch_amd.hip_lib import SaeError
+    from swapping_autoencoder_pytorch_amd.stylegan2_layers import StyledConv
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import upsample2x_add
+    from swapping_autoencoder_pytorch_amd.stylegan2_op.modulate import GradScaleTicket
+    with backend(oracle_lib):
+        torch.manual_seed(0)
+        c2 = StyledConv(4, 4, 3, 8)
+        x, s = torch.randn(1, 4, 8, 8, requires_grad=True), torch.randn(1, 8)
+        skip = torch.randn(1, 4, 4, 4, requires_grad=True)
+        t = GradScaleTicket()
+        res = c2(x, s, grad_scale_ticket=t)
+        assert t.armed
+        y = upsample2x_add(skip, res, 0.5, res_ticket=t)
+        gx_ok, = torch.autograd.grad(y.sum(), x, retain_graph=True)
+        t2 = GradScaleTicket()
+        res2 = c2(x, s, grad_scale_ticket=t2)
+        gx_ref, = torch.autograd.grad(upsample2x_add(skip, res2, 0.5).sum(), x)        # no hand-over: the plain multiply
+        assert (gx_ok - gx_ref).abs().max() < 1e-6 * gx_ref.abs().max() + 1e-9
+        with pytest.raises((SaeError, RuntimeError)):
+            (y.sum() + res.sum()).backward()              # res has a second consumer
+
+
 @pytest.mark.gpu
 def test_fused_styled_blocks_match_the_module_path_gpu():
     from swapping_autoencoder_pytorch_amd import hip_lib
