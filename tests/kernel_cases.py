@@ -70,6 +70,10 @@ CONV_SMALL = [
     # narrow layers: wgrad MODE 1 (M, C <= 32) and MODE 2 (C * taps <= 32, RGB stems)
     (3, 20, 12, 12, 24, 3, 1, 1, False), (2, 3, 16, 16, 40, 3, 1, 1, False), (2, 3, 9, 9, 20, 3, 2, 0, False),
     (2, 3, 8, 8, 70, 1, 1, 0, False), (1, 30, 15, 15, 36, 1, 2, 0, False),
+    # thin 1x1 layers on planes of >= 1024 pixels: the streaming weight gradient (conv1x1_thin_wgrad_kernel) -- FromRGB and ToRGB
+    # shapes, a channel tail on the big side, [C, M] weights, two pixel slices
+    (2, 3, 32, 32, 22, 1, 1, 0, False), (2, 21, 32, 32, 3, 1, 1, 0, False), (1, 2, 32, 40, 6, 1, 1, 0, True),
+    (1, 4, 64, 64, 4, 1, 1, 0, False),
     # 128 x 128 tile with quad staging (rows a multiple of 4 wide, tiles 16 or 32 wide): valid padding with a partial
     # second tile column, two images of one 16 x 8 tile each with a channel tail, dgrad (pad 2) of a valid conv
     (1, 12, 20, 36, 70, 3, 1, 0, False), (2, 20, 16, 16, 130, 3, 1, 1, False), (1, 70, 10, 16, 9, 3, 1, 0, False),

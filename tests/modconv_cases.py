@@ -11,6 +11,7 @@ MODCONV_CASES = [
     (3, 10, 4, 4, 70, 3, 1, 1, False),       # channel tails, 128-row tile
     (1, 9, 20, 33, 130, 3, 1, 1, False),     # one image per tile (uniform factor path), M tail
     (2, 40, 8, 8, 3, 1, 1, 0, False),        # ToRGB: 1x1, 3 output channels
+    (2, 22, 32, 32, 3, 1, 1, 0, False),      # ToRGB on a 1024-pixel plane: the streaming weight gradient with factors
     (2, 64, 8, 8, 40, 3, 1, 1, False),       # split-K
     (1, 70, 17, 17, 12, 3, 2, 0, True),      # transposed conv producing 70 channels ([C, M] weights)
     (2, 40, 19, 35, 8, 3, 2, 0, True),       # transposed, strips (2^k + 1 grid), two images
