@@ -3004,17 +3004,23 @@ __global__ __launch_bounds__(kBlock) void conv1x1_thin_wgrad_kernel(const float*
     }
 }
 
-// gw[m * sm + c * sc] = alpha * sum over the (image, slice) partials in fixed order
+// gw[m * sm + c * sc] = alpha * sum over the (image, slice) partials, one wave per output element: lane l sums parts l, l + 64,
+// ..., then the wave's shuffle tree (fixed order; one thread per element walked up to 1 024 partials as a dependent chain)
 __global__ __launch_bounds__(kBlock) void conv1x1_thin_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw,
                                                                            int CB, int CBp, int CS, int parts, int big_is_m,
                                                                            int64_t sm, int64_t sc, float alpha) {
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= CB * CS) return;
-    const int cb = e / CS, k = e - cb * CS;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int e = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const bool live = e < CB * CS;
+    const int cb = live ? e / CS : 0, k = live ? e - cb * CS : 0;
     float v = 0.0f;
-    for (int t = 0; t < parts; ++t) v += partial[((int64_t)t * CBp + cb) * 4 + k];
-    const int m = big_is_m ? cb : k, c = big_is_m ? k : cb;
-    gw[m * sm + c * sc] = alpha * v;
+    for (int t = lane; t < parts; t += kWave) v += partial[((int64_t)t * CBp + cb) * 4 + k];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (live && lane == 0) {
+        const int m = big_is_m ? cb : k, c = big_is_m ? k : cb;
+        gw[m * sm + c * sc] = alpha * v;
+    }
 }
 
 // l_scale / s_scale / spi (slices per image, 0 = none): operand modulation applied per K-slice.  When every slice
@@ -4174,7 +4180,7 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
             SAE_TRACE("wgrad thin 1x1: big %d small %d split %d", t.cb, t.cs, t.split);
             hipLaunchKernelGGL(conv1x1_thin_wgrad_kernel, dim3((unsigned)(t.cbp / 4), (unsigned)d->n, (unsigned)t.split), dim3(kBlock), 0,
                                s, t.big_is_m ? gy : x, t.big_is_m ? x : gy, workspace, q);
-            hipLaunchKernelGGL(conv1x1_thin_wgrad_reduce_kernel, dim3((unsigned)ceil_div(t.cb * t.cs, kBlock)), dim3(kBlock), 0, s,
+            hipLaunchKernelGGL(conv1x1_thin_wgrad_reduce_kernel, dim3((unsigned)ceil_div(t.cb * t.cs, kBlock / kWave)), dim3(kBlock), 0, s,
                                (const float*)workspace, gw, t.cb, t.cbp, t.cs, (int)d->n * t.split, t.big_is_m ? 1 : 0, d->w_stride_m,
                                d->w_stride_c, alpha);
             return check_launch(who);
