@@ -332,38 +332,37 @@ class ModulatedConv(Function):
 def _modconv_backward(ctx, gout, x, s, w, demod, geom, transposed, in_ticket=None):
     """(grad x, grad s, grad w, grad demod) of a ModulatedConv-type node; ctx: needs_input_grad[0..3] = x, s, w, demod,
     own_demod, demod_alpha"""
-    if True:
-        gout = gout.contiguous()
-        gx = gs = gw = gd = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            if transposed:
-                g = _launch_mod("modconv2d_fwd_f32", SAE_CONV_FWD, geom, gout, w, (geom.n, geom.m, geom.oh, geom.ow),
-                                wc_scale=demod)
-            else:
-                g = _launch_mod("modconv2d_dgrad_f32", SAE_CONV_DGRAD, geom, gout, w, (geom.n, geom.c, geom.h, geom.w),
-                                wm_scale=demod)
-            from .modulate import fusable, plane_scale_backward, plane_scale_dot_act
-            if in_ticket is not None and fusable(g) and ctx.needs_input_grad[0]:
-                gx, gs = plane_scale_dot_act(g, x, s, in_ticket)    # ... and the producer's activation backward (ActTicket)
-            elif fusable(g):
-                gx, gs = plane_scale_backward(g, x, s)       # g * s and sum_hw g * x in one pass
-            else:
-                gx, gs = g * s[:, :, None, None], (g * x).sum(dim=(2, 3))
-        if (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and _Flags.weight_grads:
-            if transposed:
-                geff = _launch_mod("modconv2d_wgrad_f32", SAE_CONV_WGRAD, geom, gout, x, geom.weight_shape(), y_scale=s)
-            else:
-                geff = _launch_mod("modconv2d_wgrad_f32", SAE_CONV_WGRAD, geom, x, gout, geom.weight_shape(), x_scale=s)
-            # geff = d(loss)/d(demod[o] * w) (the kernels' alpha included)
-            if demod is None:
-                gw = geff
-            elif ctx.own_demod:
-                from ..grad_allreduce import claim_destination
-                gw = _weight_demod_bwd(geff, w, demod, ctx.demod_alpha, out=claim_destination(w))
-            else:
-                gw = geff * demod[:, None, None, None]
-                gd = (geff * w).sum(dim=(1, 2, 3))
-        return gx, gs, gw, gd
+    gout = gout.contiguous()
+    gx = gs = gw = gd = None
+    if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        if transposed:
+            g = _launch_mod("modconv2d_fwd_f32", SAE_CONV_FWD, geom, gout, w, (geom.n, geom.m, geom.oh, geom.ow),
+                            wc_scale=demod)
+        else:
+            g = _launch_mod("modconv2d_dgrad_f32", SAE_CONV_DGRAD, geom, gout, w, (geom.n, geom.c, geom.h, geom.w),
+                            wm_scale=demod)
+        from .modulate import fusable, plane_scale_backward, plane_scale_dot_act
+        if in_ticket is not None and fusable(g) and ctx.needs_input_grad[0]:
+            gx, gs = plane_scale_dot_act(g, x, s, in_ticket)    # ... and the producer's activation backward (ActTicket)
+        elif fusable(g):
+            gx, gs = plane_scale_backward(g, x, s)       # g * s and sum_hw g * x in one pass
+        else:
+            gx, gs = g * s[:, :, None, None], (g * x).sum(dim=(2, 3))
+    if (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) and _Flags.weight_grads:
+        if transposed:
+            geff = _launch_mod("modconv2d_wgrad_f32", SAE_CONV_WGRAD, geom, gout, x, geom.weight_shape(), y_scale=s)
+        else:
+            geff = _launch_mod("modconv2d_wgrad_f32", SAE_CONV_WGRAD, geom, x, gout, geom.weight_shape(), x_scale=s)
+        # geff = d(loss)/d(demod[o] * w) (the kernels' alpha included)
+        if demod is None:
+            gw = geff
+        elif ctx.own_demod:
+            from ..grad_allreduce import claim_destination
+            gw = _weight_demod_bwd(geff, w, demod, ctx.demod_alpha, out=claim_destination(w))
+        else:
+            gw = geff * demod[:, None, None, None]
+            gd = (geff * w).sum(dim=(1, 2, 3))
+    return gx, gs, gw, gd
 
 
 class StyledModConv(Function):
