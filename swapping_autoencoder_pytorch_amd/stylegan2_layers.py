@@ -286,17 +286,11 @@ class NoiseInjection(nn.Module):
         self.weight = nn.Parameter(torch.zeros(1))
         self.fixed_noise = None
         self.image_size = None
-        self.queued_noise = None      # a map drawn ahead of the pass (SwappingAutoencoderModel.generate_pair), used once
 
     def resolve(self, image, noise=None):
         """The noise map this call uses (:343-350): the fixed one, the one passed in, or a fresh N(0,1) map."""
         if self.image_size is None:
             self.image_size = image.shape
-        if self.queued_noise is not None and noise is None and self.fixed_noise is None:
-            noise, self.queued_noise = self.queued_noise, None
-            if tuple(noise.shape) != (image.shape[0], 1) + tuple(image.shape[2:]):
-                raise hip_lib.SaeError("queued noise %s does not fit the image %s" % (tuple(noise.shape), tuple(image.shape)))
-            return noise
         if self.fixed_noise is not None:
             noise = self.fixed_noise
             if noise.shape[2:] != image.shape[2:]:

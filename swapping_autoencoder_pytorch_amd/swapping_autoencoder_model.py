@@ -8,12 +8,9 @@ import os
 
 import torch
 
-from . import loss, rng, util
+from . import loss, util
 from . import networks
 from .stylegan2_op import input_grads_only
-
-# SAE_BATCH_G=0 (A/B): the reconstruction and the hybrid are generated by two G calls as in the reference instead of one
-_BATCH_G = os.environ.get("SAE_BATCH_G", "1") != "0"
 
 
 class SwappingAutoencoderModel(torch.nn.Module):
@@ -78,32 +75,6 @@ class SwappingAutoencoderModel(torch.nn.Module):
         paired = x.view(x.shape[0] // 2, 2, *x.shape[1:])
         return torch.flip(paired, [1]).view(x.shape)
 
-    def generate_pair(self, sp_a, gl_a, sp_b, gl_b):
-        """G(sp_a, gl_a), G(sp_b, gl_b) -- the reconstruction and the hybrid of a step (:122-123, :193-204) -- as ONE pass over
-        the concatenated codes: G has no cross-sample statistics, so every sample's image is the one the two calls produce;
-        the kernels see 24 instead of 8 + 16 samples (the 8-sample launches ran 3 - 15 % below the 16-sample ones), every
-        weight is re-laid, demodulated and style-projected once, and the weight gradients of the two uses need no second
-        accumulation.  The noise maps are drawn BEFORE the pass in the order the two calls draw them (all layers of the
-        first call, then all layers of the second), so the random stream is the reference's.  Falls back to two calls until
-        every NoiseInjection has seen its map size, with fixed noise maps, or with SAE_BATCH_G=0."""
-        from .stylegan2_layers import NoiseInjection
-        layers = [m for m in self.G.modules() if isinstance(m, NoiseInjection)]
-        if (not _BATCH_G or not layers or any(m.image_size is None or m.fixed_noise is not None for m in layers)
-                or sp_a.shape[1:] != sp_b.shape[1:] or gl_a.dim() != 2):
-            return self.G(sp_a, gl_a), self.G(sp_b, gl_b)
-        na, nb = sp_a.size(0), sp_b.size(0)
-        probe = sp_a.new_empty(1)
-        first = [rng.randn_like_image(probe.expand(na, 1, m.image_size[2], m.image_size[3])) for m in layers]
-        second = [rng.randn_like_image(probe.expand(nb, 1, m.image_size[2], m.image_size[3])) for m in layers]
-        try:
-            for m, za, zb in zip(layers, first, second):
-                m.queued_noise = torch.cat([za, zb], 0)
-            out = self.G(torch.cat([sp_a, sp_b], 0), torch.cat([gl_a, gl_b], 0))
-        finally:
-            for m in layers:
-                m.queued_noise = None
-        return out[:na], out[na:]
-
     def get_random_crops(self, x, crop_window=None):
         """:84-93"""
         return util.apply_random_crop(x, self.opt.patch_size, (self.opt.patch_min_scale, self.opt.patch_max_scale),
@@ -150,8 +121,8 @@ class SwappingAutoencoderModel(torch.nn.Module):
         sp, gl = self.E(real)
         b = real.size(0)
         assert b % 2 == 0, "Batch size must be even on each GPU."
-        # rec: GAN loss on half of the reconstructions; mix: the hybrids
-        rec, mix = self.generate_pair(sp[:b // 2], gl[:b // 2], self.swap(sp), gl)
+        rec = self.G(sp[:b // 2], gl[:b // 2])     # GAN loss on half of the reconstructions
+        mix = self.G(self.swap(sp), gl)
         losses = self.compute_image_discriminator_losses(real, rec, mix)
         if self.opt.lambda_PatchGAN > 0.0:
             losses.update(self.compute_patch_discriminator_losses(real, mix))
@@ -193,15 +164,17 @@ class SwappingAutoencoderModel(torch.nn.Module):
         losses, metrics = {}, {}
         b = real.size(0)
         sp, gl = self.E(real)
+        rec = self.G(sp[:b // 2], gl[:b // 2])
         sp_mix = self.swap(sp)
-        real_all, gl_mix = real, gl
-        if opt.crop_size >= 1024:   # memory saving of the reference: half the mix batch
-            real, gl_mix, sp_mix = real[b // 2:], gl[b // 2:], sp_mix[b // 2:]
-        rec, mix = self.generate_pair(sp[:b // 2], gl[:b // 2], sp_mix, gl_mix)
 
-        metrics["L1_dist"] = self.l1_loss(rec, real_all[:b // 2])
+        metrics["L1_dist"] = self.l1_loss(rec, real[:b // 2])
         if opt.lambda_L1 > 0.0:
             losses["G_L1"] = metrics["L1_dist"] * opt.lambda_L1
+
+        if opt.crop_size >= 1024:   # memory saving of the reference: half the mix batch
+            real, gl, sp_mix = real[b // 2:], gl[b // 2:], sp_mix[b // 2:]
+
+        mix = self.G(sp_mix, gl)
 
         if opt.lambda_GAN > 0.0:
             pred_rec, pred_mix = torch.split(self.D(torch.cat([rec, mix], 0)), [rec.size(0), mix.size(0)])

@@ -115,53 +115,3 @@ def test_a_second_consumer_of_a_merged_activation_is_refused(oracle_lib):
 def test_fused_styled_blocks_match_the_module_path_gpu():
     from swapping_autoencoder_pytorch_amd import hip_lib
     _compare(hip_lib.get(), "cuda:0", 5e-6)
-
-
-def _pair(lib, device, tol):
-    """SwappingAutoencoderModel.generate_pair: one G pass over the concatenated codes against the reference's two calls --
-    same images, same random stream (the noise maps are drawn ahead in the two calls' order), same parameter gradients."""
-    from parity_common import micro_options
-    from swapping_autoencoder_pytorch_amd import swapping_autoencoder_model as M
-    with backend(lib):
-        opt = micro_options(device)
-        torch.manual_seed(0)
-        model = M.SwappingAutoencoderModel(opt)
-        model.initialize()
-        with torch.no_grad():
-            for n, p in model.G.named_parameters():
-                if n.endswith("noise.weight"):
-                    p.normal_(0.0, 0.5)         # zero noise strengths would hide a wrong noise map
-        b = 4
-        g = torch.Generator().manual_seed(5)
-        sp = torch.randn(b, opt.spatial_code_ch, 8, 8, generator=g).to(device)
-        gl = torch.randn(b, opt.global_code_ch, generator=g).to(device)
-        res = {}
-        for batched in (False, True, True):          # the first pass records the noise map sizes (two calls either way)
-            prev = M._BATCH_G
-            M._BATCH_G = batched
-            try:
-                calls = []
-                orig = model.G.forward
-                model.G.forward = lambda *a, **k: (calls.append(a[0].shape[0]), orig(*a, **k))[1]
-                torch.manual_seed(9)
-                rec, mix = model.generate_pair(sp[:b // 2], gl[:b // 2], model.swap(sp), gl)
-                after = torch.rand(1)                # the generator's state after the pair: the same stream was consumed
-                grads = torch.autograd.grad(rec.square().sum() + mix.sum(), list(model.G.parameters()), allow_unused=True)
-                res[(batched, len(calls))] = [rec.detach(), mix.detach(), after] + [t.detach() for t in grads if t is not None]
-            finally:
-                model.G.forward = orig
-                M._BATCH_G = prev
-        assert (False, 2) in res and (True, 1) in res, list(res)      # the batched pass really was one G call
-        for i, (u, v) in enumerate(zip(res[(True, 1)], res[(False, 2)])):
-            err = (u - v).abs().max().item() / (v.abs().max().item() + 1e-30)
-            assert err < tol, (i, err)
-
-
-def test_generate_pair_is_one_pass_with_the_reference_stream_oracle(oracle_lib):
-    _pair(oracle_lib, "cpu", 2e-6)
-
-
-@pytest.mark.gpu
-def test_generate_pair_is_one_pass_with_the_reference_stream_gpu():
-    from swapping_autoencoder_pytorch_amd import hip_lib
-    _pair(hip_lib.get(), "cuda:0", 1e-5)
