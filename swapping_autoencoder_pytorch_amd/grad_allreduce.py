@@ -95,9 +95,19 @@ class GradAllReducer:
         for b in self.buckets:
             b.pending = len(b.params)
             b.work = None
+            lo, hi = b.flat.data_ptr(), b.flat.data_ptr() + b.flat.numel() * b.flat.element_size()
+            for p in b.params:
+                # a gradient kept alive from the previous pass (zero_grad(set_to_none=False), gradient accumulation) may
+                # BE last pass's bucket slot: move it out before the bucket is cleared, or the next producer would write
+                # into `.grad` itself and autograd's `grad += new` would then add the slot to itself (2x)
+                if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                    p.grad = p.grad.clone()
             b.flat.zero_()
             for p, off in zip(b.params, b.offsets):
-                if p.dim() == 4 and p.is_contiguous():       # conv weights: their wgrad kernels can write into the slot
+                # conv weights: their wgrad kernels can write into the slot -- only when autograd will ADOPT the result as
+                # `.grad` (no gradient alive); otherwise it accumulates into the existing one and the hook copies the sum
+                # (ModulatedConv2d keeps its weight as [1, O, I, k, k] and convolves a 4-D view of it: same address)
+                if (p.dim() == 4 or (p.dim() == 5 and p.shape[0] == 1)) and p.is_contiguous() and p.grad is None:
                     _DESTINATIONS[p.data_ptr()] = b.flat[off:off + p.numel()]
 
     def _on_grad(self, p):
@@ -148,7 +158,10 @@ class GradAllReducer:
         """finish() and optimizer.step() in one: as each bucket's all-reduce completes, the multi-tensor Adam kernel
         (fused_adam.FusedAdam) updates that bucket's parameters reading the SUMMED gradients straight from the flat
         bucket and applying 1 / world itself — no scale pass, no scatter back into ``.grad``, and the update of the
-        early buckets overlaps the collectives of the late ones.  ``.grad`` keeps the local (un-reduced) values."""
+        early buckets overlaps the collectives of the late ones.  Afterwards ``.grad`` is NOT the averaged gradient: a
+        gradient that was copied into its slot keeps this rank's local values, one that was produced in place (a conv
+        weight's bucket view) holds the rank-SUMMED, unscaled values.  Code that reads ``.grad`` after the step (norm
+        logging, clipping) must use ``finish()`` + ``optimizer.step()`` instead."""
         if not self.enabled or not self.armed:
             optimizer.step()
             return

@@ -383,12 +383,12 @@ class StyledModConv(Function):
         if grad_scale_ticket is not None:
             grad_scale_ticket.armed = True
         ctx.act_ticket, ctx.input_ticket = act_ticket, (input_ticket if (input_ticket is not None and input_ticket.armed) else None)
-        if act_ticket is not None:
-            act_ticket.arm(noise, slope, scale)
         ctx.own_demod = True
         ctx.demod_alpha = demod_alpha
         demod = _weight_demod(w, demod_alpha, demod_eps) if demod_eps is not None else None
         x, w, s, noise = x.contiguous(), w.contiguous(), s.contiguous(), noise.contiguous()
+        if act_ticket is not None:
+            act_ticket.arm(noise, slope, scale)      # the CONTIGUOUS map: the consumer's backward hands it to a kernel
         lib.check(x, w, s, noise, noise_weight, bias, demod)
         d = geom.desc()
         mod = hip_lib.ConvMod(s.data_ptr(), None, hip_lib.ptr(demod), None)

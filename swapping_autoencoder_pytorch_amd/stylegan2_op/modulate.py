@@ -25,7 +25,9 @@ class ActTicket:
     noise + bias + leaky-ReLU activation) and conv2's node (the ONLY consumer of that output).  The consumer's backward runs
     `plane_scale_dot` and the producer's activation backward as one kernel (sae_plane_scale_dot_act_f32) and leaves the bias /
     noise-strength gradients here; the producer's backward recognises the pre-processed gradient by its address and skips its
-    own activation pass.  Only block code that knows the activation has a single consumer may pass a ticket."""
+    own activation pass.  Only block code that knows the activation has a single consumer may pass a ticket.  Side effect of the
+    address-based hand-over: a tensor hook or `retain_grad()` on the handed-over activation observes the PRE-activation gradient
+    (what the consumer's fused kernel wrote), not d(loss)/d(activation)."""
     __slots__ = ("armed", "noise", "slope", "scale", "gb", "gnw", "grad_ptr", "done")
 
     def __init__(self):

@@ -134,9 +134,9 @@ class BlurNoiseBiasAct(Function):
         ctx.set_materialize_grads(False)
         lib = hip_lib.get()
         ctx.act_ticket = act_ticket
-        if act_ticket is not None:
-            act_ticket.arm(noise, negative_slope, scale)
         input, kernel, noise = input.contiguous(), kernel.contiguous(), noise.contiguous()
+        if act_ticket is not None:
+            act_ticket.arm(noise, negative_slope, scale)      # the CONTIGUOUS map: the consumer's backward hands it to a kernel
         lib.check(input, kernel, noise, noise_weight, bias)
         n, c, h, w = input.shape
         kh, kw = kernel.shape
