@@ -12,6 +12,22 @@ puts the gfx950 kernels underneath the reference's own networks, model, optimize
 loop.  ``util.is_custom_kernel_supported`` (util/util.py:432-436, which raises on ROCm) is never
 reached because the two modules that called it are replaced.
 
+The reflection loaders of the networks and of the model (models/networks/__init__.py:6-14 -> util/util.py:61-71,
+models/__init__.py:28-48) are ``importlib.import_module`` calls too, so the same mechanism reaches one level up.
+``SAE_DROPIN_LEVEL`` (or ``preseed(level=...)``) chooses how far:
+
+    layers    operators + layer library only: the reference's own networks / model files run on them, un-fused at the
+              block level (three separate D passes, per-module generator blocks, ATen ``normalize``)
+    networks  + models.networks.{base_network,encoder,generator,discriminator,patch_discriminator} of this package
+              (ticketed generator blocks, ResBlock nodes, stems evaluated inside the first block)
+    full      (default) + models.swapping_autoencoder_model: this package's model class, made a subclass of the
+              reference's ``models.base_model.BaseModel`` so that ``find_model_using_name`` accepts it (batched D / Dpatch
+              passes, HIP crop sampler, R1 without weight-gradient kernels) -- the configuration ``bench.py`` times.
+
+At every level ``util.normalize`` / ``util.apply_random_crop`` (util/util.py:18-22,323-343) are rebound to the kernels
+(``SAE_DROPIN_UTIL=0`` keeps the reference's ATen versions).  train.py, options/, optimizers/, data/, models/__init__.py
+(create_model, MultiGPUModelWrapper) and models/base_model.py stay the reference's, byte-identical, at every level.
+
 Besides the pre-seeding the runner
   * stands in for the reference's third-party imports that are absent from a bare PyTorch-ROCm image and never
     executed on the training path (``install_missing_dependency_stubs``: torchvision, dominate, visdom, ...),
@@ -136,14 +152,72 @@ def install_missing_dependency_stubs():
     return stubbed
 
 
-def preseed():
-    """Install this package's operator and layer modules under the reference's import names."""
+LEVELS = ("layers", "networks", "full")
+
+
+def preseed(level=None):
+    """Install this package's modules under the reference's import names, up to `level` (module docstring; default: the
+    ``SAE_DROPIN_LEVEL`` environment variable, else "full").  "full" imports the reference's ``models.base_model`` (two
+    imports: os, torch), so the reference root must be on ``sys.path`` by then.  Returns the level installed."""
+    level = level or os.environ.get("SAE_DROPIN_LEVEL", "full")
+    if level not in LEVELS:
+        raise ValueError("SAE_DROPIN_LEVEL must be one of %s, got %r" % (LEVELS, level))
     from . import stylegan2_layers, stylegan2_op
     from .stylegan2_op import fused_act, upfirdn2d
     sys.modules["models.networks.stylegan2_op"] = stylegan2_op
     sys.modules["models.networks.stylegan2_op.upfirdn2d"] = upfirdn2d
     sys.modules["models.networks.stylegan2_op.fused_act"] = fused_act
     sys.modules["models.networks.stylegan2_layers"] = stylegan2_layers
+    if level in ("networks", "full"):
+        # models/networks/__init__.py:3 binds BaseNetwork from .base_network and asserts issubclass against it (:11-12):
+        # the base class comes along so that the check holds for the four network classes of this package
+        from .networks import base_network, discriminator, encoder, generator, patch_discriminator
+        for name, mod in (("base_network", base_network), ("encoder", encoder), ("generator", generator),
+                          ("discriminator", discriminator), ("patch_discriminator", patch_discriminator)):
+            sys.modules["models.networks." + name] = mod
+    if level == "full":
+        _preseed_model()
+    return level
+
+
+def _preseed_model():
+    """``models.swapping_autoencoder_model`` <- this package's model class under the reference's BaseModel.
+    models/__init__.py:28-48 looks the class up by name in that module and requires ``issubclass(cls, BaseModel)``."""
+    import importlib
+    base = importlib.import_module("models.base_model")          # the reference's own file
+    from . import swapping_autoencoder_model as mirror
+
+    class SwappingAutoencoderModel(mirror.SwappingAutoencoderModel, base.BaseModel):
+        __doc__ = mirror.SwappingAutoencoderModel.__doc__
+
+    SwappingAutoencoderModel.__module__ = "models.swapping_autoencoder_model"
+    mod = types.ModuleType("models.swapping_autoencoder_model")
+    mod.__doc__ = "pre-seeded by swapping_autoencoder_pytorch_amd.dropin (level full)"
+    mod.SwappingAutoencoderModel = SwappingAutoencoderModel
+    sys.modules["models.swapping_autoencoder_model"] = mod
+    return mod
+
+
+def patch_util():
+    """Rebind the two hot helpers of the reference's util/util.py -- ``normalize`` (:18-22, called by the encoder and the
+    generator) and ``apply_random_crop`` (:323-343, called by the model) -- to this package's kernels.  Callers write
+    ``util.normalize(...)`` against the package namespace that ``from .util import *`` filled (util/__init__.py:4), so both
+    the package and the module are patched.  Needs the reference root on sys.path and the third-party stubs installed."""
+    if os.environ.get("SAE_DROPIN_UTIL", "1") == "0":
+        return False
+    import importlib
+    import importlib.util
+    from . import util as mine
+    if importlib.util.find_spec("util") is None:       # a tree without the helper package has nothing to rebind
+        return False
+    pkg = importlib.import_module("util")
+    for target in (pkg, sys.modules.get("util.util")):
+        if target is None:
+            continue
+        for name in ("normalize", "apply_random_crop"):
+            if hasattr(target, name):
+                setattr(target, name, getattr(mine, name))
+    return True
 
 
 def inject_synthetic_dataset():
@@ -234,6 +308,30 @@ def wrap_dataloader(create_dataset):
     return create
 
 
+def wrap_reference_r1():
+    """Levels "layers" / "networks" keep the reference's model, whose ``compute_R1_loss`` (swapping_autoencoder_model.py:
+    138-185) asks ``autograd.grad`` for IMAGE gradients only; a custom autograd node cannot see that and would run its
+    weight-gradient kernels (and, for the ResBlock node, rebuild differentiable weight-gradient graphs) for nothing.  The
+    method only builds the penalty -- its ``backward()`` happens later in the optimizer -- so it runs as a whole under
+    ``input_grads_only()``."""
+    mod = sys.modules.get("models.swapping_autoencoder_model")
+    cls = getattr(mod, "SwappingAutoencoderModel", None)
+    if cls is None or getattr(mod, "__file__", None) is None:        # absent, or this package's own (level full)
+        return False
+    if getattr(cls.compute_R1_loss, "_sae_wrapped", False):
+        return True
+    from .stylegan2_op import input_grads_only
+    inner = cls.compute_R1_loss
+
+    def compute_R1_loss(self, *args, **kwargs):
+        with input_grads_only():
+            return inner(self, *args, **kwargs)
+
+    compute_R1_loss._sae_wrapped = True
+    cls.compute_R1_loss = compute_R1_loss
+    return True
+
+
 def attach_gradient_allreduce(optimizer):
     """Give a reference SwappingAutoencoderOptimizer data-parallel semantics across ranks."""
     import torch.distributed as dist
@@ -241,21 +339,41 @@ def attach_gradient_allreduce(optimizer):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return optimizer
     broadcast_parameters(optimizer.model.singlegpu_model)
+    from .fused_adam import FusedAdam
     for params, opt in ((optimizer.Gparams, optimizer.optimizer_G), (optimizer.Dparams, optimizer.optimizer_D)):
         reducer = GradAllReducer(params)
         reducer.arm()
-        opt.register_step_pre_hook(lambda o, a, k, r=reducer: r.finish())
-        opt.register_step_post_hook(lambda o, a, k, r=reducer: r.arm())
+        if isinstance(opt, FusedAdam):
+            # the bench's path: every bucket goes to the multi-tensor Adam as its collective completes, summed gradients
+            # read in place with 1 / world applied by the kernel (GradAllReducer.finish_into)
+            plain = opt.step
+
+            def step(closure=None, _plain=plain, _r=reducer, _o=opt, **kw):
+                if kw or closure is not None or not (_r.enabled and _r.armed):
+                    return _plain(closure, **kw)
+                _o.step = _plain                 # finish_into drives the optimizer's own step, bucket by bucket
+                try:
+                    _r.finish_into(_o)
+                finally:
+                    _o.step = step
+                _r.arm()
+
+            opt.step = step
+        else:
+            opt.register_step_pre_hook(lambda o, a, k, r=reducer: r.finish())
+            opt.register_step_post_hook(lambda o, a, k, r=reducer: r.arm())
     # one writer: every rank holds the same weights, and N ranks racing on the same checkpoint file and on the
     # remove/symlink of latest_checkpoint.pth (models/base_model.py:33-48) can tear it
-    save = optimizer.save
+    from .swapping_autoencoder_model import SwappingAutoencoderModel as _Mirror
+    if not isinstance(optimizer.model.singlegpu_model, _Mirror):      # (this package's model class does exactly this itself)
+        save = optimizer.save
 
-    def save_on_rank0(*args, **kwargs):
-        if dist.get_rank() == 0:
-            save(*args, **kwargs)
-        dist.barrier()
+        def save_on_rank0(*args, **kwargs):
+            if dist.get_rank() == 0:
+                save(*args, **kwargs)
+            dist.barrier()
 
-    optimizer.save = save_on_rank0
+        optimizer.save = save_on_rank0
     return optimizer
 
 
@@ -287,6 +405,7 @@ def main(argv=None):
     hip_lib.get()               # fail loudly before anything else if the HIP library is not built
     install_missing_dependency_stubs()
     preseed()
+    patch_util()
     inject_synthetic_dataset()
     if os.environ.get("SAE_DROPIN_ADAM", "1") != "0":
         # the reference constructs torch.optim.Adam(params, lr=, betas=) (optimizers/swapping_autoencoder_optimizer.py:
@@ -298,6 +417,15 @@ def main(argv=None):
     import data                 # the reference's package
     data.create_dataset = wrap_dataloader(data.create_dataset)
     import optimizers           # the reference's package (imports its models on the pre-seeded layers)
+    import models               # (already imported by optimizers; the reflection loader fills it lazily)
+    _create_model = models.create_model
+
+    def create_model(opt):
+        model = _create_model(opt)   # find_model_using_name has imported models.swapping_autoencoder_model by now
+        wrap_reference_r1()
+        return model
+
+    models.create_model = create_model
     _create = optimizers.create_optimizer
     optimizers.create_optimizer = lambda opt, model: attach_gradient_allreduce(_create(opt, model))
     sys.argv = [script] + argv[2:]

@@ -31,7 +31,9 @@ class SwappingAutoencoderModel(torch.nn.Module):
         return parser
 
     def __init__(self, opt):
-        super().__init__()
+        # (not super().__init__(): under the drop-in runner this class is combined with the reference's BaseModel, whose
+        # constructor takes `opt` and pins 'cuda:0', base_model.py:11-13)
+        torch.nn.Module.__init__(self)
         self.opt = opt
         # the reference hard-codes "cuda:0" (base_model.py:13); with one process per GPU that is
         # this rank's current device

@@ -40,12 +40,15 @@ def train_end_to_end(ckpt_dir):
     runpy.run_path(os.path.join(REF, "train.py"), run_name="__main__")
 
 
-def _ddp_rank(rank, world, port, out_dir):
+def _ddp_rank(rank, world, port, out_dir, adam="torch"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dropin = _prepare()
+    if adam == "fused":       # as dropin.main does: the all-reduce then hands its buckets to the multi-tensor Adam (finish_into)
+        from swapping_autoencoder_pytorch_amd.fused_adam import FusedAdam
+        torch.optim.Adam = FusedAdam
     import models
     import optimizers
     from options import TrainOptions
@@ -55,6 +58,7 @@ def _ddp_rank(rank, world, port, out_dir):
     model = models.create_model(opt)
     fill_params(model.singlegpu_model, seed=10 + rank)            # deliberately different replicas
     optimizer = dropin.attach_gradient_allreduce(optimizers.create_optimizer(opt, model))
+    assert type(optimizer.optimizer_D).__name__ == ("FusedAdam" if adam == "fused" else "Adam")
     state0 = {k: v.clone() for k, v in model.singlegpu_model.state_dict().items()}
     for it in range(4):                                            # D, G, D (+R1), G with DIFFERENT data per rank
         torch.manual_seed(500 + 10 * it + rank)
@@ -64,9 +68,9 @@ def _ddp_rank(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def ddp(out_dir, port):
+def ddp(out_dir, port, adam="torch"):
     import torch.multiprocessing as mp
-    mp.spawn(_ddp_rank, args=(2, int(port), out_dir), nprocs=2, join=True)
+    mp.spawn(_ddp_rank, args=(2, int(port), out_dir, adam), nprocs=2, join=True)
 
 
 
@@ -154,5 +158,52 @@ def aten_cpu_path_pin():
     print("aten-cpu-path-pinned", err, errb, erre)
 
 
+def preseed_level(level):
+    """The reference's driver (options, models.create_model, optimizers.create_optimizer, train_one_step) on top of
+    dropin.preseed(level) + patch_util(), oracle behind the C-ABI: deviations from the golden loss dictionaries."""
+    import json
+    import torch
+    import ref_shims
+    ref_shims.install()
+    from swapping_autoencoder_pytorch_amd import dropin, hip_lib
+    from swapping_autoencoder_pytorch_amd.hip_lib import SaeLibrary
+    hip_lib._LIB = SaeLibrary(os.path.join(ROOT, "oracle", "libsae_oracle.so"), prefix="oracle_", device_only=False)
+    dropin.preseed(level)
+    dropin.patch_util()
+    import models
+    import optimizers
+    import util
+    import parity_common as P
+    from options import TrainOptions
+    from param_recipe import MICRO, fill_params, uniform_images
+    sys.argv = ["train.py", "--name", "level", "--dataset_mode", "imagefolder"]
+    opt = TrainOptions().gather_options()
+    opt.isTrain = True
+    for k, v in MICRO.items():
+        setattr(opt, k, v)
+    model = models.create_model(opt)
+    wrapped = dropin.wrap_reference_r1()
+    net = model.singlegpu_model
+    fill_params(net, seed=3)
+    optimizer = optimizers.create_optimizer(opt, model)
+    _, info = P.golden()
+    worst = 0.0
+    with P.cpu_random_stream("cpu"):
+        for it in range(4):
+            torch.manual_seed(1000 + it)
+            losses = optimizer.train_one_step({"real_A": uniform_images(4, 32, 600 + it)}, it)
+            want = info["micro_steps"]["step%d" % it]
+            assert set(losses) == set(want), (sorted(losses), sorted(want))
+            worst = max(worst, max(abs(float(losses[k]) - v) / max(1.0, abs(v)) for k, v in want.items()))
+    from models.base_model import BaseModel
+    import swapping_autoencoder_pytorch_amd.swapping_autoencoder_model as mirror
+    print("LEVEL-REPORT " + json.dumps({
+        "level": level, "worst_loss_dev": worst, "layer_module": type(net.E.FromRGB).__module__,
+        "encoder_module": type(net.E).__module__, "model_is_ours": isinstance(net, mirror.SwappingAutoencoderModel),
+        "model_is_basemodel": isinstance(net, BaseModel), "normalize_module": util.normalize.__module__,
+        "crop_module": util.apply_random_crop.__module__, "r1_wrapped": bool(wrapped),
+        "optimizer_module": type(optimizer).__module__, "wrapper": type(model).__name__}))
+
+
 if __name__ == "__main__":
-    {"train": train_end_to_end, "ddp": ddp, "aten_pin": aten_cpu_path_pin}[sys.argv[1]](*sys.argv[2:])
+    {"train": train_end_to_end, "ddp": ddp, "aten_pin": aten_cpu_path_pin, "preseed_level": preseed_level}[sys.argv[1]](*sys.argv[2:])

@@ -35,7 +35,7 @@ def test_reference_training_loop_on_our_layers(oracle_lib):
     assert not already, "reference modules imported before pre-seeding: %s" % already[:3]
     ref_shims.install()
     from swapping_autoencoder_pytorch_amd import dropin
-    dropin.preseed()
+    dropin.preseed("layers")            # operators + layer library only: the reference's own networks and model on top
     import models                       # the reference's package
     import optimizers
     import models.networks              # parent package from the reference checkout
@@ -61,3 +61,26 @@ def test_reference_training_loop_on_our_layers(oracle_lib):
     for name in [m for m in sys.modules if m == "models" or m.startswith("models.") or m == "optimizers"
                  or m.startswith("optimizers.")]:
         del sys.modules[name]           # do not leak the reference's packages into other tests
+
+
+@pytest.mark.parametrize("level", ["layers", "networks", "full"])
+def test_reference_driver_at_every_preseed_level(level, oracle_lib):
+    """dropin.preseed(level) + patch_util(): the reference's unmodified optimizer, models/__init__.py (create_model,
+    MultiGPUModelWrapper / DataParallel) and option parser driving (layers) its own networks and model on our layers,
+    (networks) its own model on our networks, (full) our model class under its BaseModel -- four optimiser calls
+    (D, G, D + lazy R1, G) against the golden loss dictionaries of the reference's own run.  One subprocess per level
+    (tests/dropin_ref_worker.py::preseed_level) so that nothing pre-seeded leaks into this process."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "dropin_ref_worker.py"), "preseed_level", level],
+                         capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    rep = json.loads([l for l in out.stdout.splitlines() if l.startswith("LEVEL-REPORT ")][-1][len("LEVEL-REPORT "):])
+    assert rep["level"] == level and rep["worst_loss_dev"] <= 2e-4, rep
+    ours = "swapping_autoencoder_pytorch_amd"
+    assert rep["layer_module"].startswith(ours)
+    assert rep["encoder_module"].startswith(ours) == (level != "layers"), rep
+    assert rep["model_is_ours"] == (level == "full") and rep["model_is_basemodel"], rep
+    assert rep["normalize_module"].startswith(ours) and rep["crop_module"].startswith(ours), rep
+    assert rep["r1_wrapped"] == (level != "full"), rep

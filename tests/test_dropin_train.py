@@ -128,14 +128,17 @@ def test_reference_train_py_runs_end_to_end(tmp_path):
 
 
 @needs_reference
-def test_reference_optimizer_under_two_rank_allreduce(tmp_path):
+@pytest.mark.parametrize("adam", ["torch", "fused"])
+def test_reference_optimizer_under_two_rank_allreduce(tmp_path, adam):
     """attach_gradient_allreduce on the reference's own optimizer, world_size 2 over gloo: replicas that start
-    different and see different data end bit-identical (broadcast + averaged gradients), and one checkpoint."""
+    different and see different data end bit-identical (broadcast + averaged gradients), and one checkpoint.
+    "torch": the reference's torch.optim.Adam behind step hooks (finish -> step -> arm); "fused": FusedAdam substituted as
+    dropin.main does, its step() replaced by GradAllReducer.finish_into (per-bucket updates on the summed gradients)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    out = subprocess.run([sys.executable, WORKER, "ddp", str(tmp_path), str(port)], cwd=ROOT, capture_output=True, text=True,
+    out = subprocess.run([sys.executable, WORKER, "ddp", str(tmp_path), str(port), adam], cwd=ROOT, capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
