@@ -124,8 +124,8 @@ KERNEL_CLASSES = {
     "s1_gather_128": ("conv 3x3 s1 gather on smaller maps: 128 x 128 tile, quad staging", "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"),
     "s2_dgrad": ("conv 3x3 s2 data gradient / transposed conv (plain + modulated)", "conv_igemm_tr2_kernel<2,16,*> / conv_igemm_tr_kernel"),
     "s2_fwd": ("conv 3x3 s2 forward gather (plain + modulated)", "conv_igemm_kernel<3,2,*>"),
-    "s1_wgrad": ("conv 3x3 s1 weight gradient (plain + modulated)", "conv_wgrad_kernel<3,1,*>"),
-    "s2_wgrad": ("conv 3x3 s2 weight gradient (plain + modulated)", "conv_wgrad_kernel<3,2,*>"),
+    "s1_wgrad": ("conv 3x3 s1 weight gradient (plain + modulated)", "conv_wgrad16_kernel<1> (fallback conv_wgrad_kernel<3,1,*>)"),
+    "s2_wgrad": ("conv 3x3 s2 weight gradient (plain + modulated)", "conv_wgrad_kernel<3,2,*> (<= 64 gradient channels: conv_wgrad16_kernel<2>)"),
 }
 
 

@@ -2611,6 +2611,235 @@ __global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------
+// wgrad, second generation ("wg16"): 64 a x 32 b x 9 taps per workgroup on v_mfma_f32_16x16x4_f32, two or three
+// workgroups per CU.
+//
+// conv_wgrad_kernel<3, S, ..., WQ> gives every wave a 32 x 32 x 9-tap tile: 144 accumulator registers + the chunk's
+// prefetch registers = one wave per SIMD, and nothing overlaps its staging phases (profiles/r2_phase_clock_*.txt: 70 % of
+// the wave's time in the MFMA loop; 0.73 of peak in the step).  Here a wave owns 32 a x 16 b x 9 taps as 2 x 9 tiles of the
+// 16 x 16 x 4 instruction (same FLOP rate, 4 accumulator registers per tile): 72 accumulator registers, 36 (stride 2: 60)
+// prefetch registers, so two independent workgroups share a CU and one's MFMAs cover the other's staging, as in the gather.
+//  * operands: lane l supplies A[a = l & 15][k = l >> 4] and B[k][b = l & 15], k = four consecutive pixels of the chunk; the
+//    32 lanes of an LDS access group read 16 channel rows x 2 adjacent pixels.  Row pitches 66 (S) and 162 (L, stride 1) are
+//    = 2 (mod 32): banks 2 r + {0, 1}, conflict-free (the 32 x 32 form read 32 rows per group: r and r + 16 collided,
+//    SQ_LDS_BANK_CONFLICT = 48 % of the LDS cycles, profiles/r3_pmc_f32.txt).  Stride 2 (pitch 342, pixel offsets even)
+//    keeps two-way conflicts on its L reads.
+//  * staging: S as in the WQ path (a wave loads the 64 pixels of four gy channels per dwordx4); the L patch quads of the 32
+//    channels are dealt out over the workgroup (quad j = tid + 256 k: channel j / QN, quad j % QN), 5 (stride 2: 11) per
+//    thread -- 9 (15) vector-memory instructions per thread and chunk.  Stride 2 fetches 4-byte aligned quads and moves a
+//    quad that would cross its row's end to W - 4, as the WQ path does.
+//  * the k of an instruction sums 4 pixels, so the summation ORDER differs from conv_wgrad_kernel (not bit-identical to it;
+//    both are checked against the oracle).  Slab layout and the fixed-order reduction are unchanged: deterministic.
+// Taken for 3 x 3 layers with one image per 64-pixel chunk under the WQ path's conditions (host: conv_wgrad_impl).
+// ------------------------------------------------------------------------------------------
+// (measured and dropped: __launch_bounds__(kBlock, 3) -- 168 registers with 27 spilled dwords, 83 - 102 instead of 130 TFLOP/s;
+// stride 2 with the L operand read as conflict-free 8-byte pairs on a pitch of 388 floats: 109.8 vs 111.4, the two-way
+// conflicts of its dword reads are not what bounds it)
+template <int S>
+__global__ __launch_bounds__(kBlock, 2) void conv_wgrad16_kernel(const float* __restrict__ xl,
+                                                                 const float* __restrict__ gs,
+                                                                 float* __restrict__ slab, const WgradParams p) {
+    constexpr int T = 9, BA = 64, BB = 32, PK = kWgPix;
+    constexpr int SLD = PK + 2;
+    constexpr int LP = (S == 1) ? 162 : 342;
+    constexpr int QCAP = (S == 1) ? 40 : 85;                       // quads per channel of the widened patch (host-checked)
+    constexpr int QPT = (BB * QCAP + kBlock - 1) / kBlock;          // L quad slots per thread and chunk
+    constexpr int NSQ = BA / 16;
+    constexpr int NB = T;                                           // operand registers of the L side per step
+    __shared__ __attribute__((aligned(16))) float Ss[BA * SLD];
+    __shared__ __attribute__((aligned(16))) float Ls[BB * LP + 4 * kBlock];   // + a dump area for the slots beyond the patch
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+    SAE_CLOCK_BEGIN
+    const int tid = threadIdx.x;
+    __builtin_assume(tid < kBlock);
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, k4 = lane >> 4;
+    const int wa = wid >> 1, wb = wid & 1;
+    // XCD-aware order: all (a, b) tiles of a pixel slice behind one L2 (see conv_wgrad_kernel)
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_order && (gridDim.z & 7) == 0) {
+        const int mn = gridDim.x * gridDim.y;
+        const int lin = bx + gridDim.x * (by + gridDim.y * bz);
+        const int j = lin >> 3;
+        const int tile = j % mn;
+        bz = (j / mn) * 8 + (lin & 7);
+        bx = tile % gridDim.x;
+        by = tile / gridDim.x;
+    }
+    const int b0 = bx * BB, a0 = by * BA, slice = bz;
+
+    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
+    const int PH = (TH - 1) * S + 3;
+    const int PW = (TW - 1) * S + 3;
+    const int RS = (S == 1) ? TW + 8 : ((PW + 3) >> 2) << 2;      // patch rows widened to whole quads
+    const int RQ = RS >> 2, QN = PH * RQ;                          // quads per row, per channel (<= QCAP)
+    const int HWl = p.H * p.W, HWs = p.OH * p.OW;
+
+    f32x4 acc[2][T];
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[ta][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // chunk-invariant part of the L quad slots: patch row, first column relative to the tile's origin, byte offset relative
+    // to (image n0, channel b0, row oy0 * S - pad, column ox0 * S), LDS index.  lrc < 0: the slot never holds data.
+    int lrc[QPT], lbyte[QPT], ldst[QPT];
+#pragma unroll
+    for (int k = 0; k < QPT; ++k) {
+        const int j = tid + kBlock * k;
+        const int ch = j / QN;
+        const int q = j - ch * QN;
+        const int r = q / RQ;
+        const int qc = q - r * RQ;
+        const int col = (S == 1) ? 4 * qc - 4 : 4 * qc;
+        const bool slot = ch < BB;
+        lrc[k] = (slot && b0 + ch < p.C) ? (r << 16) | (col + 4) : -1;
+        lbyte[k] = 4 * (ch * HWl + r * p.W + col);
+        ldst[k] = slot ? ch * LP + 4 * q : BB * LP + 4 * tid;
+    }
+    // S quads: lane = (channel sub-index cs = lane / 16, quad q = lane % 16), load i covers channel 16 i + 4 wid + cs
+    const int sq_q = lane & 15, sq_cs = lane >> 4;
+    const int sq_py = (4 * sq_q) >> p.tw_log2, sq_px = (4 * sq_q) & (TW - 1);
+
+    const int ch_begin = slice * p.chunks_per_slice;
+    int ch_end = ch_begin + p.chunks_per_slice;
+    if (ch_end > p.chunks) ch_end = p.chunks;
+
+    f32x4 sq[NSQ], lq[QPT];
+    bool sq_ok = false;
+    unsigned lq_ok = 0;                     // bit k: slot k of the prefetched chunk holds image data
+    [[maybe_unused]] unsigned lq_sh = 0;    // stride 2, two bits per slot: how far the quad was moved left to stay inside its row
+
+    auto load_chunk = [&](int chunk) {
+        int bt = chunk;
+        const int tix = bt % p.tiles_x; bt /= p.tiles_x;
+        const int tiy = bt % p.tiles_y;
+        const int n0 = bt / p.tiles_y;
+        const int ox0 = tix * TW, oy0 = tiy * TH;
+        {
+            const int oy = oy0 + sq_py, ox = ox0 + sq_px;
+            sq_ok = oy < p.OH && ox < p.OW;
+            const char* sbase = reinterpret_cast<const char*>(gs + ((int64_t)n0 * p.M + a0) * HWs);
+            const unsigned pix = sq_ok ? (unsigned)(oy * p.OW + ox) : 0u;
+#pragma unroll
+            for (int i = 0; i < NSQ; ++i) {
+                const int a = 16 * i + 4 * wid + sq_cs;
+                const unsigned off = (a0 + a < p.M) ? 4u * ((unsigned)(a * HWs) + pix) : 0u;
+                sq[i] = *reinterpret_cast<const f32x4*>(sbase + off);
+            }
+        }
+        const char* lbase = reinterpret_cast<const char*>(xl + ((int64_t)n0 * p.C + b0) * HWl);
+        const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S;
+        const int rel = 4 * (iy0 * p.W + ix0);
+        lq_ok = 0;
+        if constexpr (S == 2) lq_sh = 0;
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            const int iy = iy0 + (lrc[k] >> 16), ix = ix0 + (lrc[k] & 0xffff) - 4;
+            const bool ok = lrc[k] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            int off = lbyte[k] + rel;
+            if constexpr (S == 2) {
+                const int sh = (ok && ix + 4 > p.W) ? ix + 4 - p.W : 0;       // keep the quad inside its row
+                off -= 4 * sh;
+                lq_sh |= (unsigned)sh << (2 * k);
+                struct __attribute__((packed, aligned(4))) U4 { f32x4 v; };     // 4-byte aligned quad
+                lq[k] = reinterpret_cast<const U4*>(lbase + (ok ? off : 0))->v;
+            } else {
+                lq[k] = *reinterpret_cast<const f32x4*>(lbase + (ok ? off : 0));
+            }
+            lq_ok |= (ok ? 1u : 0u) << k;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NSQ; ++i) {
+            const int a = 16 * i + 4 * wid + sq_cs;
+            f32x4 v = sq[i];
+            const bool ok = sq_ok && a0 + a < p.M;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
+            float* dst = Ss + a * SLD + 4 * sq_q;
+            *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
+            *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
+        }
+#pragma unroll
+        for (int k = 0; k < QPT; ++k) {
+            f32x4 v = lq[k];
+            if constexpr (S == 2) {
+                const int sh = (lq_sh >> (2 * k)) & 3;     // fetched sh floats to the left of its place: the tail lies beyond the row
+                const f32x4 u = v;
+                if (sh == 1) v = f32x4{u[1], u[2], u[3], 0.0f};
+                if (sh == 2) v = f32x4{u[2], u[3], 0.0f, 0.0f};
+                if (sh == 3) v = f32x4{u[3], 0.0f, 0.0f, 0.0f};
+            }
+            const bool ok = (lq_ok >> k) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
+            float* dst = Ls + ldst[k];
+            *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
+            *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
+        }
+    };
+
+    const float* const srow = Ss + (wa * 32 + l15) * SLD + k4;
+    const float* const lrow = Ls + (wb * 16 + l15) * LP + ((S == 1) ? 4 - p.pad : 0);
+    if (ch_begin < ch_end) load_chunk(ch_begin);
+    SAE_CLOCK_PHASE(0)
+    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
+        __syncthreads();   // previous chunk fully consumed
+        SAE_CLOCK_PHASE(2)
+        store_chunk();
+        SAE_CLOCK_PHASE(3)
+        __syncthreads();
+        SAE_CLOCK_PHASE(4)
+        if (chunk + 1 < ch_end) load_chunk(chunk + 1);   // in flight under the MFMAs below
+        SAE_CLOCK_PHASE(5)
+        // 16 steps of 4 pixels: 2 + 9 operand reads, 18 MFMAs; the operands of step i + 1 are read before the MFMAs of step i
+        auto fetch = [&](int step, float (&a)[2], float (&b)[NB]) {
+            const int pk = 4 * step + k4;
+            const int px = pk & (TW - 1), py = pk >> p.tw_log2;
+            const float* lp = lrow + py * S * RS + px * S;
+            a[0] = srow[4 * step];
+            a[1] = srow[16 * SLD + 4 * step];
+#pragma unroll
+            for (int t = 0; t < T; ++t) b[t] = lp[(t / 3) * RS + (t % 3)];
+        };
+        auto mma = [&](const float (&a)[2], const float (&b)[NB]) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int ta = 0; ta < 2; ++ta)
+                    acc[ta][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[t], acc[ta][t], 0, 0, 0);
+        };
+        float a_even[2], b_even[NB], a_odd[2], b_odd[NB];
+        fetch(0, a_even, b_even);
+        for (int it = 0; it < PK / 4; it += 2) {
+            fetch(it + 1, a_odd, b_odd);
+            mma(a_even, b_even);
+            if (it + 2 < PK / 4) fetch(it + 2, a_even, b_even);
+            mma(a_odd, b_odd);
+        }
+        SAE_CLOCK_PHASE(1)
+    }
+
+    // ---- slab store: D row = 4 * (lane >> 4) + r (a), column = lane & 15 (b)
+    const int bcol = b0 + wb * 16 + l15;
+#pragma unroll
+    for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int arow = a0 + wa * 32 + ta * 16 + 4 * k4 + r;
+                slab[(((int64_t)slice * T + t) * p.Ap + arow) * p.Bp + bcol] = acc[ta][t][r];
+            }
+    SAE_CLOCK_PHASE(6)
+    SAE_CLOCK_END
+}
+
+// ------------------------------------------------------------------------------------------
 // "bx" arithmetic of the 3x3 wgrad (see conv_igemm_bx_kernel for the split).  K = pixels: the 16 k
 // of an MFMA are two OCTETS, an octet = 8 consecutive pixels of one row of the y side, held as one
 // 16-byte cell per (split, channel).  S (gy) cells are staged as they lie; the x-side operand of tap
@@ -3177,14 +3406,16 @@ struct WgPlan {
     WgShape sh; int tw_log2, th_log2; int tiles_x, tiles_y, tiles_n; int chunks, cps, slices; int Ap, Bp; int taps;
     bool bx; int tw8_log2;   // bf16-split arithmetic: tiles of TH rows x (8 << tw8_log2) columns
 };
-WgPlan wg_plan(const sae_conv2d_desc* d) {
+// wg16: the plan of conv_wgrad16_kernel (64 a x 32 b workgroup tiles, two workgroups per CU) for a 3 x 3 layer
+WgPlan wg_plan(const sae_conv2d_desc* d, bool wg16 = false) {
     WgPlan w{};
     w.sh = wg_shape((int)d->m, (int)d->c, d->kh, d->stride);
+    if (wg16) w.sh = {64, 32, 5};
     w.taps = d->kh * d->kw;
     pick_tile(kWgPix, (int)d->oh, (int)d->ow, 32, &w.tw_log2, &w.th_log2);
     int tw = 1 << w.tw_log2, th = 1 << w.th_log2, tn = kWgPix / (tw * th);
     w.bx = false;
-    if (conv_math() == 1 && d->kh == 3 && w.sh.mode == 0 && d->ow % 8 == 0 && d->ow >= 16) {
+    if (!wg16 && conv_math() == 1 && d->kh == 3 && w.sh.mode == 0 && d->ow % 8 == 0 && d->ow >= 16) {
         // octet tiles: 128 (stride 1) / 64 (stride 2) pixels per chunk, rows of 16 or 32 columns
         const int no = (d->stride == 1) ? 16 : 8;
         const int two = (d->ow > 16) ? 4 : 2;
@@ -3213,13 +3444,14 @@ WgPlan wg_plan(const sae_conv2d_desc* d) {
     // MODE 0 runs one workgroup per CU (register prefetch): one full wave of 256 workgroups; the
     // narrow modes co-reside 2-3 per CU
     int slices = ceil_div(w.sh.mode == 0 ? 256 : 512, mn_tiles);
+    if (wg16) slices = round_up(slices, 8);       // (the XCD-aware order needs slices % 8 == 0)
     if (slices > w.chunks) slices = w.chunks;
     if (slices < 1) slices = 1;
     w.cps = ceil_div(w.chunks, slices);
     // keep a K slice inside one image where the images are large (>= 32 chunks of 64 pixels): the factors of a
     // style-modulated operand can then be applied per slice in the reduction and the main kernel stays the plain
     // (quad-staged) one.  Costs more, smaller slabs only for the generator's 512-channel 64 x 64 layers (4 -> 8 / 16 slices).
-    if (w.sh.mode == 0 && !w.bx && tn == 1) {
+    if ((w.sh.mode == 0 || wg16) && !w.bx && tn == 1) {
         const int cpi = w.tiles_x * w.tiles_y;
         // (batches of at most 16 images only: the generator's; for D / Dpatch at 24 ... 384 images 40 slabs of 9 MB cost
         // more, and moving cps to a divisor of the image breaks the one-workgroup-per-CU balance: 26.9 -> 30.6 ms measured)
@@ -3960,6 +4192,22 @@ void launch_wgrad(const float* x, const float* gy, float* slab, const WgradParam
 using namespace sae;
 
 namespace {
+// conv_wgrad16_kernel: the shape half of its eligibility test (the launch adds pointer alignment and "no per-element factors")
+bool wg16_shape_ok(const sae_conv2d_desc* d) {
+    static const int knob = tuning_knob("SAE_WGRAD16", 1);
+    if (!knob || conv_math() != 0 || d->kh != 3 || d->kw != 3 || d->n < 1) return false;
+    if (wg_shape((int)d->m, (int)d->c, d->kh, d->stride).mode != 0) return false;
+    int tw_log2, th_log2;
+    pick_tile(kWgPix, (int)d->oh, (int)d->ow, 32, &tw_log2, &th_log2);
+    if ((kWgPix >> (tw_log2 + th_log2)) != 1 || d->ow % 4 != 0) return false;          // one image per 64-pixel chunk, gy quads
+    if (d->stride == 1) return d->w % 4 == 0 && d->pad <= 4;
+    // stride 2: only where the 128 a x 32 b tile of the first-generation kernel pads the gradient's channels to twice their
+    // number (Dpatch 32 -> 64 @129^2, B = 128: 55 -> 94 TFLOP/s); on wide layers its larger tile amortises the stride-2
+    // patch (5.3 staged floats per output pixel and channel) better: 114 vs 111 TFLOP/s (profiles/r4_ab_wgrad16.txt)
+    static const int s2_knob = tuning_knob("SAE_WGRAD16_S2", 64);
+    return d->stride == 2 && d->pad == 0 && d->w >= 4 && d->m <= s2_knob;
+}
+
 // the streaming weight gradient of thin 1x1 layers (conv1x1_thin_wgrad_kernel): shape test and launch geometry
 struct ThinWgPlan { bool ok; int cb, cs, cbp, split, qps; bool big_is_m; int64_t ws_floats; };
 ThinWgPlan thin_wg_plan(const sae_conv2d_desc* d) {
@@ -3996,7 +4244,12 @@ extern "C" int64_t sae_conv2d_workspace(const sae_conv2d_desc* d, int32_t op) {
             return tr_ws((int)d->n, (int)d->m, (int)d->c, (int)d->h, (int)d->w, d->pad);
         case SAE_CONV_WGRAD: {
             const WgPlan w = wg_plan(d);
-            const int64_t need = (int64_t)w.slices * w.taps * w.Ap * w.Bp;
+            int64_t need = (int64_t)w.slices * w.taps * w.Ap * w.Bp;
+            if (wg16_shape_ok(d)) {                     // (taken only for suitably aligned tensors: room for either plan)
+                const WgPlan w16 = wg_plan(d, true);
+                const int64_t need16 = (int64_t)w16.slices * w16.taps * w16.Ap * w16.Bp;
+                if (need16 > need) need = need16;
+            }
             const ThinWgPlan t = thin_wg_plan(d);       // (taken only for 16-byte aligned tensors: room for either path)
             return (t.ok && t.ws_floats > need) ? t.ws_floats : need;
         }
@@ -4186,7 +4439,16 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
             return check_launch(who);
         }
     }
-    const WgPlan w = wg_plan(d);
+    // second-generation kernel (conv_wgrad16_kernel): 3 x 3, exact fp32, one image per chunk, quad-addressable rows, operand
+    // factors (if any) applied per K slice in the reduction
+    bool use16 = wg16_shape_ok(d) && (reinterpret_cast<uintptr_t>(gy) & 15) == 0 &&
+                 (d->stride == 2 || (reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    if (use16 && (mod.x_scale || mod.y_scale)) {
+        const WgPlan w16 = wg_plan(d, true);
+        const int cpi = w16.tiles_x * w16.tiles_y;
+        use16 = w16.cps <= cpi && cpi % w16.cps == 0;
+    }
+    const WgPlan w = wg_plan(d, use16);
     if ((mod.x_scale || mod.y_scale) && w.bx)
         return fail(SAE_EINVAL, "modulated conv: the activation factors are staged by the exact-fp32 kernels only "
                                 "(SAE_CONV_MATH_F32); under bf16x6 modulate the activation before the call");
@@ -4229,7 +4491,13 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
     const bool wq2 = wq_knob && !w.bx && w.sh.mode == 0 && d->kh == 3 && d->stride == 2 && d->pad == 0 &&
                      (kWgPix >> (w.tw_log2 + w.th_log2)) == 1 && d->ow % 4 == 0 && d->w >= 4 &&
                      (reinterpret_cast<uintptr_t>(gy) & 15) == 0 && !p.l_scale && !p.s_scale;
-    if (d->n > 0 && w.bx) {
+    if (use16) {
+        if (p.l_scale || p.s_scale) return fail(SAE_EINVAL, "%s: internal error: wg16 with per-element factors", who);
+        const dim3 grid((unsigned)(w.Bp / w.sh.bb), (unsigned)(w.Ap / w.sh.ba), (unsigned)w.slices);
+        SAE_TRACE("wgrad wg16 s%d: %d x %d tiles, %d slices of %d chunks", d->stride, w.Ap / w.sh.ba, w.Bp / w.sh.bb, w.slices, w.cps);
+        if (d->stride == 1) hipLaunchKernelGGL((conv_wgrad16_kernel<1>), grid, dim3(kBlock), 0, s, x, gy, workspace, p);
+        else hipLaunchKernelGGL((conv_wgrad16_kernel<2>), grid, dim3(kBlock), 0, s, x, gy, workspace, p);
+    } else if (d->n > 0 && w.bx) {
         WgBxParams q{};
         q.N = p.N; q.C = p.C; q.H = p.H; q.W = p.W; q.M = p.M; q.OH = p.OH; q.OW = p.OW; q.pad = p.pad;
         q.tw8_log2 = w.tw8_log2; q.th_log2 = w.th_log2; q.tiles_x = w.tiles_x; q.tiles_y = w.tiles_y;

@@ -14,7 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(which, **env):
     # (SAE_TR_SPLITK=0: the K split of conv_igemm_tr_kernel changes the summation order by design)
-    e = dict(os.environ, SAE_CONV_MATH="f32", SAE_CONV_THIN="0", SAE_TRACE_DISPATCH="1", SAE_TR_SPLITK="0", **env)
+    # (SAE_WGRAD16=0: conv_wgrad16_kernel sums four pixels per instruction -- another order by design, checked against the
+    # oracle in the kernel tests; this file holds the first-generation weight-gradient kernels, which remain the fallback)
+    e = dict(os.environ, SAE_CONV_MATH="f32", SAE_CONV_THIN="0", SAE_TRACE_DISPATCH="1", SAE_TR_SPLITK="0", SAE_WGRAD16="0", **env)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "quad_worker.py"), which], cwd=ROOT, env=e,
                          capture_output=True, text=True, timeout=1800)
     assert out.returncode == 0, out.stderr[-3000:]

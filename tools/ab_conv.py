@@ -103,7 +103,8 @@ def main():
     if "--clock" in sys.argv:
         return clock_mode()
     names = [a for a in sys.argv[1:] if not a.startswith("-")] or ["product"]
-    only = [a[2:] for a in sys.argv[1:] if a.startswith("--")]
+    only = [a[2:] for a in sys.argv[1:] if a.startswith("--") and not a.startswith("--op=")]
+    want_ops = [a[5:] for a in sys.argv[1:] if a.startswith("--op=")]       # --op=wgrad: only that operation
     libs = [L.SaeLibrary(libpath(n)) for n in names]
     stream = lambda: torch.cuda.current_stream(dev).cuda_stream
     print("%-20s %-6s " % ("shape", "op") + " ".join("%9s" % n for n in names) + "   (TFLOP/s; * = differs from the first)")
@@ -118,6 +119,8 @@ def main():
         gy = torch.randn(n, m, d.oh, d.ow, device=dev)
         flops = 2.0 * n * m * d.oh * d.ow * c * k * k
         for op, oname in [(0, "fwd"), (1, "dgrad"), (2, "wgrad")]:
+            if want_ops and oname not in want_ops:
+                continue
             a, b = [(x, wt), (gy, wt), (x, gy)][op]
             shape = [(n, m, d.oh, d.ow), (n, c, h, w), (m, c, k, k)][op]
             best = [1e9] * len(libs)
