@@ -1375,6 +1375,7 @@ struct TrRegion {
                           // transposed problems have 2^k + 1 wide grids, power-of-two tiles waste 25-90 %)
     int tiles_x, tiles_y, tiles_n;
     int blocks;           // tiles_x * tiles_y * tiles_n
+    int flat;             // tr2: tiles are runs of 128 consecutive positions of the WHOLE grid in row-major order (tiles_x per image)
 };
 struct TrParams {
     int N, C, IH, IW;     // input tensor (the small, "y side" image)
@@ -1638,17 +1639,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_tr_kernel(const float
 //  * the style factors of a modulated launch are fetched once into LDS (tiles never span images then).
 // Tiles are TN x TH x TW positions with TN (TH + 1) (TW + 4) <= kTr2Cap, chosen per region on the host.
 // ------------------------------------------------------------------------------------------
-constexpr int kTr2Cap = 192;        // patch floats per channel
+constexpr int kTr2Cap = 192;        // patch floats per channel (rectangular tiles)
+constexpr int kTr2FlatCap = 288;    // ... of a flat tile: the rows a run of 128 positions touches, full width (65-wide grids: 4 x 72)
 constexpr int kTr2MaxC = 2048;      // style factors held in LDS (modulated launches)
 
-template <int MI, int CK, bool MOD = false>
+// FLAT (small 2^k + 1 grids: 17, 33, 65 wide): a tile is a run of 128 consecutive positions of the whole q grid of one image in
+// row-major order -- no main region + strips (a 33 x 33 grid is 1024 + 65 positions: the strips were separate tiles with one
+// active wave and a scalar epilogue, 15 - 30 % of these launches) and no padded tile rows: 94 % of the lanes carry a position
+// (9 tiles of 128 for 1089).  The patch is the 3 - 9 full-width input rows the run touches; a lane's two x-classes are two
+// adjacent output columns and leave as one 8-byte store.  Same arithmetic per output in the same order: bit-identical.
+template <int MI, int CK, bool MOD = false, bool FLAT = false>
 __global__ __launch_bounds__(kBlock, 2) void conv_igemm_tr2_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ wp,
                                                                 float* __restrict__ y, const TrParams p) {
     static_assert(CK == 8 || CK == 16, "8- or 16-channel chunks");
     constexpr int T = 9;
     constexpr int BM = 32 * MI;
-    constexpr int XCAP = kTr2Cap;
+    constexpr int XCAP = FLAT ? kTr2FlatCap : kTr2Cap;
     constexpr int QCAP = XCAP / 4;
     constexpr int QPT = (CK * QCAP + kBlock - 1) / kBlock;       // quad slots per thread per chunk
     constexpr int A_VEC = T * CK * BM / 4;
@@ -1694,7 +1701,12 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_tr2_kernel(const float* 
     const int tix = bt % g.tiles_x; bt /= g.tiles_x;
     const int tiy = bt % g.tiles_y;
     const int tin = bt / g.tiles_y;
-    const int qx0 = g.qx_base + tix * TW, qy0 = g.qy_base + tiy * TH, n0 = tin * TN;
+    // FLAT: tile tix of image tin starts at position 128 tix = (row qy0, column s0) of the grid; TW = the grid's width, TH the
+    // most rows a run can touch (patch rows beyond the image are zero-filled like any padding)
+    const int qx0 = FLAT ? 0 : g.qx_base + tix * TW;
+    const int qy0 = FLAT ? (128 * tix) / TW : g.qy_base + tiy * TH;
+    const int n0 = tin * TN;
+    [[maybe_unused]] const int s0 = FLAT ? 128 * tix - qy0 * TW : 0;
     const int m0 = mt * BM;
 
     const int PH = TH + 1;                 // patch row r <-> input row qy0 - 1 + r
@@ -1739,9 +1751,9 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_tr2_kernel(const float* 
     }
 
     const int pp = wn * 32 + l31;
-    const int npos = TN * TH * TW;
-    const int pn_l = pp / (TW * TH);
-    const int prem = pp - pn_l * (TW * TH);
+    const int npos = FLAT ? (g.QH * TW - 128 * tix < 128 ? g.QH * TW - 128 * tix : 128) : TN * TH * TW;
+    const int pn_l = FLAT ? 0 : pp / (TW * TH);
+    const int prem = FLAT ? pp + s0 : pp - pn_l * (TW * TH);
     const int py = prem / TW;
     const int px = prem - py * TW;
     const int pixbase = pp < npos ? pn_l * IP + py * RS + px : 0;     // lanes beyond the tile compute on position 0
@@ -1837,6 +1849,38 @@ __global__ __launch_bounds__(kBlock, 2) void conv_igemm_tr2_kernel(const float* 
     // for rows m8 = 2 v + (lane >> 5).
     __syncthreads();                  // every wave is done with As / Xs
     if (!wave_active) return;
+    if constexpr (FLAT) {
+        // a lane's classes (cy, 0) and (cy, 1) are output columns 2 qx - pad and 2 qx - pad + 1 of row 2 qy + cy - pad: one 8-byte
+        // store (rows are 2^k + 1 floats: 4-byte aligned); a wave instruction writes 2 x 256 contiguous bytes
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        struct __attribute__((packed, aligned(4))) U2 { f32x2 v; };
+        const int qy = qy0 + py, qx = px;
+        const int ox = 2 * qx - p.pad;
+        const bool live = pp < npos;
+        const bool c0 = live && ox >= 0 && ox < p.OW, c1 = live && ox + 1 >= 0 && ox + 1 < p.OW;
+        const int64_t plane = (int64_t)p.OH * p.OW;
+#pragma unroll
+        for (int cy = 0; cy < 2; ++cy) {
+            const int oy = 2 * qy + cy - p.pad;
+            if (oy < 0 || oy >= p.OH || !(c0 || c1)) continue;
+            float* yb = y + ((int64_t)n0 * p.M * p.OH + oy) * p.OW + ox;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m < p.M) {
+                        float* yp = yb + (int64_t)m * plane;
+                        if (c0 && c1) reinterpret_cast<U2*>(yp)->v = f32x2{acc[mi][2 * cy][r], acc[mi][2 * cy + 1][r]};
+                        else if (c0) yp[0] = acc[mi][2 * cy][r];
+                        else yp[1] = acc[mi][2 * cy + 1][r];
+                    }
+                }
+        }
+        SAE_CLOCK_PHASE(6)
+        SAE_CLOCK_END
+        return;
+    }
     if (TW & 1) {                     // one-column strips: positions 2k, 2k + 1 are not neighbours; plain stores
         const int n = n0 + pn_l, qy = qy0 + py, qx = qx0 + px;
         if (pp < npos && n < p.N && qy < g.QH && qx < g.QW) {
@@ -3890,6 +3934,12 @@ int64_t gather_ws(int N, int cin, int mout, int OH, int OW, int ks, int stride, 
 #ifndef SAE_TR2_DEFAULT
 #define SAE_TR2_DEFAULT 1
 #endif
+#ifndef SAE_TR2_MINW_DEFAULT
+#define SAE_TR2_MINW_DEFAULT 32
+#endif
+#ifndef SAE_TR2_FLAT_CK
+#define SAE_TR2_FLAT_CK 16      // channel chunk of the flat 64-row tile (its 16-channel form sits at the 256-register ceiling)
+#endif
 struct Tr2Shape { int mi, bm, ck; };
 Tr2Shape tr2_shape(int mout) {
     static const int knob = tuning_knob("SAE_TR2", SAE_TR2_DEFAULT);      // 0: conv_igemm_tr_kernel, 2: 8-channel chunks
@@ -3908,7 +3958,8 @@ bool tr2_eligible(const float* x, int N, int cin, int IH, int IW, int mout, bool
     // in-step by shape (profiles/r3_tr2_by_shape.txt): 32-wide inputs and up gain (n = 16 modulated 128 -> 256 @257: 100.6 ->
     // 114.9 TFLOP/s; 512 -> 512 @65: 84.3 -> 89.7), the 16- and 8-wide ones lose to the free-form tiles of
     // conv_igemm_tr_kernel (their 2^k + 1 grids are mostly strip), except modulated ones (factors from LDS, not per slot)
-    if (knob == 1 && IW < (modulated ? 16 : 32)) return false;
+    static const int minw_knob = tuning_knob("SAE_TR2_MINW", SAE_TR2_MINW_DEFAULT);
+    if (knob == 1 && IW < (modulated ? 16 : minw_knob)) return false;
     if (modulated && cin > kTr2MaxC) return false;
     // 32-bit byte offsets inside a tile's images (at most 128 of them)
     if ((int64_t)(N < 128 ? N : 128) * cin * IH * IW * 4 >= ((int64_t)1 << 31)) return false;
@@ -3948,6 +3999,34 @@ int run_tr2(const float* x, const float* w, float* y, float* ws, int64_t ws_floa
     p.in_scale = in_scale;
     p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
     const int QH = (OH + pad - 1) / 2 + 1, QW = (OW + pad - 1) / 2 + 1;
+    // small odd grids (17 ... 65 wide): flat tiles, runs of 128 positions of the whole grid (see the kernel)
+    static const int flat_knob = tuning_knob("SAE_TR2_FLAT", 1);
+    const int flat_rows = (QW + 126) / QW + 1;                         // rows a run of 128 positions can touch
+    const int flat_rs = ((QW + 3) & ~3) + 4;
+    const bool flat = flat_knob && (QW & 1) && QW >= 17 && QW <= 72 && QH * QW >= 128 && (flat_rows + 1) * flat_rs <= kTr2FlatCap;
+    if (flat) {
+        for (int r = 0; r < 3; ++r) { p.reg[r] = TrRegion{}; p.reg[r].tw = p.reg[r].th = p.reg[r].tn = p.reg[r].tiles_x = p.reg[r].tiles_y = p.reg[r].tiles_n = 1; }
+        TrRegion& g = p.reg[0];
+        g.QH = QH; g.QW = QW; g.tw = QW; g.th = flat_rows; g.tn = 1; g.flat = 1;
+        g.tiles_x = ceil_div(QH * QW, 128); g.tiles_y = 1; g.tiles_n = N;
+        g.blocks = g.tiles_x * N;
+        p.mtiles = Mp / sh.bm;
+        p.main_items = g.blocks * p.mtiles;
+        p.strip_items = 0;
+        SAE_TRACE("tr2 flat mi=%d ck=%d mod=%d tiles=%d rows=%d", sh.mi, sh.ck, in_scale ? 1 : 0, g.blocks, flat_rows);
+        const dim3 fgrid((unsigned)(8 * ceil_div(p.main_items, 8)));
+#define SAE_TR2F(MI_, CK_)                                                                                                   \
+    do {                                                                                                                     \
+        if (in_scale) hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, true, true>), fgrid, dim3(kBlock), 0, s, x, ws, y, p);  \
+        else hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, false, true>), fgrid, dim3(kBlock), 0, s, x, ws, y, p);          \
+    } while (0)
+        if (sh.mi == 2 && sh.ck == 16 && SAE_TR2_FLAT_CK == 16) SAE_TR2F(2, 16);
+        else if (sh.mi == 2) SAE_TR2F(2, 8);
+        else if (sh.ck == 16) SAE_TR2F(1, 16);
+        else SAE_TR2F(1, 8);
+#undef SAE_TR2F
+        return SAE_OK;
+    }
     // main region (sides a multiple of 4) + right / bottom strips, as in run_tr
     auto main_side = [](int q, int align) {
         int t = 32;

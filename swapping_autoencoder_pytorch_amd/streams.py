@@ -1,0 +1,83 @@
+"""Two HIP streams for the independent branches of a training step.
+
+The step has pairs of sub-graphs that do not depend on each other: the reconstruction and the hybrid pass of the generator
+(swapping_autoencoder_model.py:122-124,192-201 of the reference: ``rec = G(sp[:b/2], gl[:b/2])``, ``mix = G(swap(sp), gl)``),
+and the image discriminator next to the patch discriminator (:62-114).  Each of them ends in small maps (16 x 16 ... 4 x 4)
+whose launches cannot fill 256 CUs; enqueued on two streams the hardware runs a branch's small launches in the slots the
+other branch leaves free.  Autograd runs every backward node on the stream its forward ran on and orders the streams where a
+gradient crosses, so the backward pass forks and joins the same way without further code.
+
+Values do not change: every kernel is deterministic and sees the same inputs (tests/test_gpu_determinism.py compares the two
+modes bit for bit); the host enqueues the branches in the order the single-stream code ran them, so the random draws (Philox
+offsets are advanced at enqueue time) are the same too.  ``SAE_TWO_STREAMS=0`` keeps everything on the current stream."""
+import os
+
+import torch
+
+_SIDE = {}
+_MAIN = {}      # the stream the step itself runs on, as seen at the last fork
+
+
+def enabled():
+    return os.environ.get("SAE_TWO_STREAMS", "1") != "0"
+
+
+def side_stream(device):
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+class side_branch:
+    """``with side_branch(x, y) as br: out = f(x, y)`` enqueues ``f`` on the device's side stream once everything already
+    enqueued on the current stream (the producers of ``x``, ``y``) is ordered before it; ``br.join(out)`` makes the current
+    stream wait for the branch, after which ``out`` may be consumed on it.  Tensors that cross are registered with the
+    other stream (``record_stream``) so the caching allocator does not recycle their memory under a pending reader.
+    With CPU tensors, or ``SAE_TWO_STREAMS=0``, the body simply runs in place."""
+
+    def __init__(self, *inputs):
+        self.inputs = [t for t in inputs if torch.is_tensor(t) and t.is_cuda]
+        self.on = bool(self.inputs) and enabled()
+        self._ctx = None
+
+    def __enter__(self):
+        if self.on:
+            dev = self.inputs[0].device
+            self.main = torch.cuda.current_stream(dev)
+            self.side = side_stream(dev)
+            _MAIN[(dev.type, dev.index if dev.index is not None else torch.cuda.current_device())] = self.main
+            self.side.wait_stream(self.main)
+            for t in self.inputs:
+                t.record_stream(self.side)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+            self._ctx = None
+        return False
+
+    def join(self, *outputs):
+        if not self.on:
+            return
+        self.main.wait_stream(self.side)
+        for t in outputs:
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(self.main)
+
+
+def order_after_all(device):
+    """Make the CURRENT stream of `device` wait for everything enqueued so far on the step's other stream(s).  For code that
+    runs inside a backward pass on whichever stream the node at hand belongs to but consumes results of both branches -- the
+    gradient all-reduce launches a bucket's collective from the hook of its LAST gradient, and the other gradients of that
+    bucket may have been produced on the other stream (grad_allreduce.py)."""
+    if not (device.type == "cuda" and _SIDE):
+        return
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    cur = torch.cuda.current_stream(device)
+    for other in (_SIDE.get(key), _MAIN.get(key)):
+        if other is not None and other != cur:
+            cur.wait_stream(other)

@@ -10,6 +10,7 @@ import torch
 
 from . import loss, util
 from . import networks
+from .streams import side_branch
 from .stylegan2_op import input_grads_only
 
 
@@ -123,23 +124,35 @@ class SwappingAutoencoderModel(torch.nn.Module):
         sp, gl = self.E(real)
         b = real.size(0)
         assert b % 2 == 0, "Batch size must be even on each GPU."
-        rec = self.G(sp[:b // 2], gl[:b // 2])     # GAN loss on half of the reconstructions
+        # the two generator passes, then the two discriminators, are independent pairs: the first of each pair is enqueued on
+        # the side stream (streams.py), in the order the reference runs them (the random draws stay in its order)
+        with side_branch(sp, gl) as br:
+            rec = self.G(sp[:b // 2], gl[:b // 2])     # GAN loss on half of the reconstructions
         mix = self.G(self.swap(sp), gl)
+        br.join(rec)
+        if self.opt.lambda_PatchGAN > 0.0:
+            with side_branch(real, mix) as br:
+                patch_losses = self.compute_patch_discriminator_losses(real, mix)
         losses = self.compute_image_discriminator_losses(real, rec, mix)
         if self.opt.lambda_PatchGAN > 0.0:
-            losses.update(self.compute_patch_discriminator_losses(real, mix))
+            br.join(*patch_losses.values())
+            losses.update(patch_losses)
         return losses, {}, sp.detach(), gl.detach()
 
     def compute_R1_loss(self, real):
         """:138-185 — gradient penalties on D (w.r.t. the image) and Dpatch (w.r.t. both crops)."""
         opt = self.opt
         losses = {}
+        br = None
         if opt.lambda_R1 > 0.0:
-            real.requires_grad_()
-            pred_real = self.D(real).sum()
-            with input_grads_only():     # only d(pred)/d(image) is asked for: no weight-gradient kernels
-                grad_real, = torch.autograd.grad(outputs=pred_real, inputs=[real], create_graph=True, retain_graph=True)
-            grad_penalty = grad_real.pow(2).sum(list(range(1, grad_real.ndim))) * (opt.lambda_R1 * 0.5)
+            # (the image penalty on the side stream, the patch penalty on the current one: streams.py; only the patch branch
+            # draws random numbers, so their order is the reference's)
+            with side_branch(real) as br:
+                real.requires_grad_()
+                pred_real = self.D(real).sum()
+                with input_grads_only():     # only d(pred)/d(image) is asked for: no weight-gradient kernels
+                    grad_real, = torch.autograd.grad(outputs=pred_real, inputs=[real], create_graph=True, retain_graph=True)
+                grad_penalty = grad_real.pow(2).sum(list(range(1, grad_real.ndim))) * (opt.lambda_R1 * 0.5)
         else:
             grad_penalty = 0.0
 
@@ -157,6 +170,8 @@ class SwappingAutoencoderModel(torch.nn.Module):
         else:
             grad_crop_penalty = 0.0
 
+        if br is not None:
+            br.join(grad_penalty)
         losses["D_R1"] = grad_penalty + grad_crop_penalty
         return losses
 
@@ -166,17 +181,25 @@ class SwappingAutoencoderModel(torch.nn.Module):
         losses, metrics = {}, {}
         b = real.size(0)
         sp, gl = self.E(real)
-        rec = self.G(sp[:b // 2], gl[:b // 2])
+        with side_branch(sp, gl, real) as br:        # the reconstruction pass next to the hybrid pass (streams.py)
+            rec = self.G(sp[:b // 2], gl[:b // 2])
+            metrics["L1_dist"] = self.l1_loss(rec, real[:b // 2])
+            if opt.lambda_L1 > 0.0:
+                losses["G_L1"] = metrics["L1_dist"] * opt.lambda_L1
         sp_mix = self.swap(sp)
-
-        metrics["L1_dist"] = self.l1_loss(rec, real[:b // 2])
-        if opt.lambda_L1 > 0.0:
-            losses["G_L1"] = metrics["L1_dist"] * opt.lambda_L1
 
         if opt.crop_size >= 1024:   # memory saving of the reference: half the mix batch
             real, gl, sp_mix = real[b // 2:], gl[b // 2:], sp_mix[b // 2:]
 
         mix = self.G(sp_mix, gl)
+        br.join(rec, metrics["L1_dist"], losses.get("G_L1"))
+
+        if opt.lambda_PatchGAN > 0.0:                # the patch discriminator next to the image discriminator
+            with side_branch(real, mix) as br:
+                real_feat = self.Dpatch.extract_features(self.get_random_crops(real),
+                                                         aggregate=opt.patch_use_aggregation).detach()
+                mix_feat = self.Dpatch.extract_features(self.get_random_crops(mix))
+                g_mix = loss.gan_loss(self.Dpatch.discriminate_features(real_feat, mix_feat), True) * opt.lambda_PatchGAN
 
         if opt.lambda_GAN > 0.0:
             pred_rec, pred_mix = torch.split(self.D(torch.cat([rec, mix], 0)), [rec.size(0), mix.size(0)])
@@ -184,10 +207,8 @@ class SwappingAutoencoderModel(torch.nn.Module):
             losses["G_GAN_mix"] = loss.gan_loss(pred_mix, True) * (opt.lambda_GAN * 1.0)
 
         if opt.lambda_PatchGAN > 0.0:
-            real_feat = self.Dpatch.extract_features(self.get_random_crops(real),
-                                                     aggregate=opt.patch_use_aggregation).detach()
-            mix_feat = self.Dpatch.extract_features(self.get_random_crops(mix))
-            losses["G_mix"] = loss.gan_loss(self.Dpatch.discriminate_features(real_feat, mix_feat), True) * opt.lambda_PatchGAN
+            br.join(g_mix)
+            losses["G_mix"] = g_mix
 
         return losses, metrics
 

@@ -32,6 +32,11 @@ SHAPES = [  # n, c, h, w, m, k, s, p, tag
     (128, 32, 129, 129, 64, 3, 2, 0, "Dp s2 32->64@129"),
     (16, 128, 256, 256, 256, 1, 1, 0, "1x1 128->256@256"),
     (16, 512, 64, 64, 256, 1, 1, 0, "1x1 512->256@64"),
+    # the small 2^k + 1 grids of the stride-2 data gradients (q grids 33, 17 wide)
+    (16, 512, 33, 33, 512, 3, 2, 0, "s2 512->512@33"),
+    (40, 512, 65, 65, 512, 3, 2, 0, "s2 512->512@65 n40"),
+    (128, 64, 65, 65, 128, 3, 2, 0, "Dp s2 64->128@65"),
+    (128, 128, 33, 33, 256, 3, 2, 0, "Dp s2 128->256@33"),
 ]
 
 
