@@ -3958,8 +3958,11 @@ bool tr2_eligible(const float* x, int N, int cin, int IH, int IW, int mout, bool
     // in-step by shape (profiles/r3_tr2_by_shape.txt): 32-wide inputs and up gain (n = 16 modulated 128 -> 256 @257: 100.6 ->
     // 114.9 TFLOP/s; 512 -> 512 @65: 84.3 -> 89.7), the 16- and 8-wide ones lose to the free-form tiles of
     // conv_igemm_tr_kernel (their 2^k + 1 grids are mostly strip), except modulated ones (factors from LDS, not per slot)
+    // ... and 16-wide ones (17 x 17 grids) on FLAT tiles when the launch has a full round of workgroups: Dpatch 128 -> 256 @33,
+    // B = 128: 60 -> 75 TFLOP/s; with 16 images (384 workgroups) the K split of conv_igemm_tr_kernel stays ahead, 60 vs 59
     static const int minw_knob = tuning_knob("SAE_TR2_MINW", SAE_TR2_MINW_DEFAULT);
-    if (knob == 1 && IW < (modulated ? 16 : minw_knob)) return false;
+    const bool flat16 = IW == 16 && IH >= 8 && (int64_t)N * ceil_div((IH + 1) * (IW + 1), 128) * ceil_div(mout, 64) >= 512;
+    if (knob == 1 && IW < (modulated ? 16 : minw_knob) && !flat16) return false;
     if (modulated && cin > kTr2MaxC) return false;
     // 32-bit byte offsets inside a tile's images (at most 128 of them)
     if ((int64_t)(N < 128 ? N : 128) * cin * IH * IW * 4 >= ((int64_t)1 << 31)) return false;
@@ -4003,7 +4006,11 @@ int run_tr2(const float* x, const float* w, float* y, float* ws, int64_t ws_floa
     static const int flat_knob = tuning_knob("SAE_TR2_FLAT", 1);
     const int flat_rows = (QW + 126) / QW + 1;                         // rows a run of 128 positions can touch
     const int flat_rs = ((QW + 3) & ~3) + 4;
-    const bool flat = flat_knob && (QW & 1) && QW >= 17 && QW <= 72 && QH * QW >= 128 && (flat_rows + 1) * flat_rs <= kTr2FlatCap;
+    // (33- and 65-wide grids measured SLOWER flat than as main region + strips: 107.5 vs 112.1 TFLOP/s at 256 -> 512 @129, 95.5 vs
+    // 100.1 at 512 -> 512 @65 -- a run of 128 positions of a 65-wide grid stages 4 x 72 floats per channel where a 4 x 32 tile
+    // stages 5 x 36, and its 8-byte stores are twice as many; profiles/r4_ab_tr2_flat.txt.  SAE_TR2_FLAT=2 takes them anyway.)
+    const bool flat = flat_knob && (QW & 1) && QW >= 17 && QW <= (flat_knob == 2 ? 72 : 20) && QH * QW >= 128 &&
+                      (flat_rows + 1) * flat_rs <= kTr2FlatCap;
     if (flat) {
         for (int r = 0; r < 3; ++r) { p.reg[r] = TrRegion{}; p.reg[r].tw = p.reg[r].th = p.reg[r].tn = p.reg[r].tiles_x = p.reg[r].tiles_y = p.reg[r].tiles_n = 1; }
         TrRegion& g = p.reg[0];

@@ -7,6 +7,10 @@ whose launches cannot fill 256 CUs; enqueued on two streams the hardware runs a 
 other branch leaves free.  Autograd runs every backward node on the stream its forward ran on and orders the streams where a
 gradient crosses, so the backward pass forks and joins the same way without further code.
 
+(Measured and dropped: a third stream for the conv WEIGHT gradients of a backward pass, joined by a final callback of the
+autograd engine -- bit-identical values, 281.9 / 280.2 ms per step in place against 281.8 / 282.6 on the extra stream,
+profiles/r4_ab_async_wgrad.txt: with two branches in flight the chip has no idle slots left for them.)
+
 Values do not change: every kernel is deterministic and sees the same inputs (tests/test_gpu_determinism.py compares the two
 modes bit for bit); the host enqueues the branches in the order the single-stream code ran them, so the random draws (Philox
 offsets are advanced at enqueue time) are the same too.  ``SAE_TWO_STREAMS=0`` keeps everything on the current stream."""
@@ -81,3 +85,4 @@ def order_after_all(device):
     for other in (_SIDE.get(key), _MAIN.get(key)):
         if other is not None and other != cur:
             cur.wait_stream(other)
+

@@ -27,7 +27,8 @@ def _run(which, **env):
 
 
 def _compare(which):
-    quad = _run(which, SAE_IGEMM_QUAD="1", SAE_WGRAD_QUAD="1", SAE_IGEMM_VEC_STORE="2", SAE_TR2="3")
+    # (SAE_TR2_FLAT=2: flat tiles on every odd grid up to 65 wide, not only the 17-wide ones the product takes them for)
+    quad = _run(which, SAE_IGEMM_QUAD="1", SAE_WGRAD_QUAD="1", SAE_IGEMM_VEC_STORE="2", SAE_TR2="3", SAE_TR2_FLAT="2")
     plain = _run(which, SAE_IGEMM_QUAD="0", SAE_WGRAD_QUAD="0", SAE_IGEMM_VEC_STORE="0", SAE_TR2="0")
     assert len(quad) == len(plain) and len(quad) > 0
     diff = [(a, b) for a, b in zip(quad, plain) if a != b]
