@@ -74,6 +74,10 @@ def parse():
                     help="with --gpus 1: run the multi-GPU gradient path (buckets, grad-ready hooks, asynchronous RCCL "
                          "all-reduce, per-bucket Adam) on the single rank -- the cost of that machinery, NOT a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-cpu-baseline", action="store_true",
+                    help="cpu_baseline.value from ONE whole iteration of the preset on the host (a discriminator call + a "
+                         "generator call of the reference's driver through oracle/aten_cpu_path.TrainIterationCPU; several "
+                         "minutes at 256 x 256, B = 16) instead of the bounded, FLOP-scaled sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--via-dropin", action="store_true",
                     help="time the SAME iteration through the drop-in runner's pre-seeding (swapping_autoencoder_pytorch_amd.dropin, "
@@ -280,7 +284,30 @@ def cpu_baseline_config1(A, threads_hint):
                       "(%d parameters), ATen CPU, best of %s" % (sum(p.numel() for p in params), sweep)}
 
 
-def cpu_baseline(preset, size, batch):
+def cpu_baseline_full(A, preset, batch, threads):
+    """SURVEY 8d's CPU figure measured, not scaled: one discriminator call + one generator call of the reference's driver
+    (swapping_autoencoder_model.py:116-136,187-231, Adam updates included, no lazy-R1 call) on the ATen CPU path
+    (oracle/aten_cpu_path.TrainIterationCPU, pinned to the reference's golden loss dictionaries in
+    tests/test_network_parity_cpu.py), the preset's networks and batch, `threads` host threads."""
+    import torch
+    from swapping_autoencoder_pytorch_amd.options import make_options
+    opt = make_options(preset, batch_size=batch, num_gpus=0)
+    torch.manual_seed(0)
+    torch.set_num_threads(threads)
+    it = A.TrainIterationCPU(opt)
+    g = torch.Generator().manual_seed(1)
+    t0 = time.time()
+    it.discriminator_call(torch.rand(batch, 3, opt.crop_size, opt.crop_size, generator=g) * 2 - 1)
+    t1 = time.time()
+    it.generator_call(torch.rand(batch, 3, opt.crop_size, opt.crop_size, generator=g) * 2 - 1)
+    t2 = time.time()
+    return {"value": round(batch / (t2 - t0), 5), "unit": "images/s", "cores": threads, "kind": "port", "extrapolated": False,
+            "s_d_call": round(t1 - t0, 2), "s_g_call": round(t2 - t1, 2),
+            "sample": "ONE whole iteration of the %s preset, B = %d: discriminator call + generator call with their Adam updates, "
+                      "no lazy-R1 call, first and only pass (thread-pool and primitive start-up included)" % (preset, batch)}
+
+
+def cpu_baseline(preset, size, batch, full=False):
     """The reference's CPU code path timed on this host (rank 0, N = 1): the image discriminator forward + backward
     (weights trainable, input without gradient = the D(real) pass of a discriminator step) through ATen on all
     host cores — F.conv2d / its two backward kernels (MKLDNN), upfirdn2d_native (F.pad + F.conv2d), F.leaky_relu —
@@ -334,6 +361,10 @@ def cpu_baseline(preset, size, batch):
                      "TFLOP/s, scaled by %.3f TFLOP/image of the full iteration" % (n, size, size, flops / 1e12, dt,
                                                                                   flops / dt / 1e12, per_image / 1e12)}
 
+    if full:
+        sampled = {k: out[k] for k in ("value", "sample", "extrapolated")}
+        out.update(cpu_baseline_full(A, preset, batch, threads))
+        out["sampled"] = sampled
     out["config1"] = cpu_baseline_config1(A, threads)
 
     so = os.path.join(ROOT, "oracle", "libsae_oracle.so")
@@ -672,7 +703,7 @@ def main():
         if world == 1 and args.dropin_steps > 0 and not args.force_allreduce:
             line["via_dropin"] = via_dropin_leg(args, line)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.preset, size, batch)
+            line["cpu_baseline"] = cpu_baseline(args.preset, size, batch, full=args.full_cpu_baseline)
         print(json.dumps(line), flush=True)
     if launched:
         dist.destroy_process_group()

@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 5   /* 2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
+#define SAE_ABI_VERSION 6   /* 6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -234,6 +234,12 @@ typedef struct sae_conv2d_desc {
     int64_t m, oh, ow;      /* y side: channels, height, width */
     int32_t kh, kw, stride, pad;
     int64_t w_stride_m, w_stride_c;
+    /* optional (ABI 6): weights already re-laid for this launch by sae_conv2d_wprep_f32 (NULL / 0 / 0 = none; the launch then
+     * re-lays them into the head of its workspace as before).  Used only when `prepped_layout` is the identity
+     * sae_conv2d_wprep_query reports for THIS call -- prepared weights of another layout are ignored, never misread. */
+    const float* prepped;
+    int64_t prepped_floats;
+    int64_t prepped_layout;
 } sae_conv2d_desc;
 
 #define SAE_CONV_FWD 0
@@ -301,6 +307,24 @@ int sae_modconv2d_dgrad_f32(const float* gy, const float* w, float* gx, const sa
                             float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
 int sae_modconv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d, const sae_conv2d_mod* mod,
                             float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Prepared weights.  Every forward / data-gradient launch first re-lays its weights for its tile shape ([tap][C_pad][M_pad],
+ * `alpha`, the flip of the data gradient and the weight factors of `mod` folded in).  The layout depends on the descriptor's
+ * geometry, not on the batch, and a parameter changes once per optimiser step (optimizers/swapping_autoencoder_optimizer.py:
+ * 77,95,107), while it is used by 2 - 6 launches in between: a caller may keep the re-laid copy and hand it to the calls
+ * through sae_conv2d_desc::prepped / prepped_floats / prepped_layout.
+ *   sae_conv2d_wprep_query   floats (0: the launch has no weight layout, e.g. the streaming 1x1 kernels) and identity of the
+ *                            layout the call (d, mod, op) would build; pure host function.  Two calls with equal identity,
+ *                            equal `alpha`, equal weight and weight-factor VALUES can share one prepared buffer.
+ *   sae_conv2d_wprep_f32     builds it into `out` (out_floats = the query's floats), asynchronously on `stream`.
+ * op = SAE_CONV_FWD (also for the fused forward entry points) or SAE_CONV_DGRAD; `mod` as for the call itself (NULL = none).
+ * The CALLER answers for freshness: a buffer prepared before the weights (or alpha, or the weight factors) changed holds the
+ * old values -- the library cannot see an in-place update through a raw pointer.
+ * ------------------------------------------------------------------------------------------ */
+int sae_conv2d_wprep_query(const sae_conv2d_desc* d, const sae_conv2d_mod* mod, int32_t op, int64_t* floats, int64_t* layout);
+int sae_conv2d_wprep_f32(const float* w, const sae_conv2d_desc* d, const sae_conv2d_mod* mod, int32_t op, float alpha,
+                         float* out, int64_t out_floats, sae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Strided GEMM on the fp32 matrix cores:  C[i*ldc + j] = alpha * sum_k A[i*a_si + k*a_sk] * B[k*b_sk + j*b_sj]

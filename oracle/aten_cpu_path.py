@@ -278,11 +278,11 @@ class GenConvLayerCPU(torch.nn.Module):
 class GenResBlockCPU(torch.nn.Module):
     """ResBlock (stylegan2_layers.py:672-693) with its blur taps / reflection padding options."""
 
-    def __init__(self, cin, cout, blur_kernel=(1, 3, 3, 1), reflection_pad=False):
+    def __init__(self, cin, cout, blur_kernel=(1, 3, 3, 1), reflection_pad=False, downsample=True):
         super().__init__()
         self.conv1 = GenConvLayerCPU(cin, cin, 3, reflection_pad=reflection_pad)
-        self.conv2 = GenConvLayerCPU(cin, cout, 3, downsample=True, blur_kernel=blur_kernel, reflection_pad=reflection_pad)
-        self.skip = GenConvLayerCPU(cin, cout, 1, downsample=True, blur_kernel=blur_kernel, activate=False, bias=False)
+        self.conv2 = GenConvLayerCPU(cin, cout, 3, downsample=downsample, blur_kernel=blur_kernel, reflection_pad=reflection_pad)
+        self.skip = GenConvLayerCPU(cin, cout, 1, downsample=downsample, blur_kernel=blur_kernel, activate=False, bias=False)
 
     def forward(self, x):
         return (self.conv2(self.conv1(x)) + self.skip(x)) / math.sqrt(2)
@@ -399,3 +399,152 @@ class GeneratorCPU(torch.nn.Module):
             x = b(x, gl)
         return self.to_rgb(x, gl)
 
+
+
+# ---- the patch discriminator, the crop sampler, the losses and ONE full training iteration (a discriminator call and a
+# generator call of the driver) on the same ATen path: bench.py --full-cpu-baseline; pinned to the reference's golden
+# loss dictionaries in tests/test_network_parity_cpu.py --------------------------------------------------------------------------
+class _ActLinearCPU(torch.nn.Module):
+    """EqualLinear(activation='fused_lrelu') (stylegan2_layers.py:172-190): linear without bias, then fused_leaky_relu(out, bias)"""
+
+    def __init__(self, cin, cout, activate):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(cout, cin))
+        self.bias = torch.nn.Parameter(torch.zeros(cout))
+        self.scale, self.activate = 1.0 / math.sqrt(cin), activate
+
+    def forward(self, x):
+        if self.activate:
+            return fused_leaky_relu(F.linear(x, self.weight * self.scale), self.bias * 1.0)
+        return F.linear(x, self.weight * self.scale, bias=self.bias * 1.0)
+
+
+class PatchDiscriminatorCPU(torch.nn.Module):
+    """StyleGAN2PatchDiscriminator (models/networks/patch_discriminator.py:97-171)"""
+
+    def __init__(self, opt):
+        super().__init__()
+        cm, max_nc, size = opt.netPatchD_scale_capacity, opt.netPatchD_max_nc, opt.patch_size
+        channels = {4: min(max_nc, int(256 * cm)), 8: min(max_nc, int(128 * cm)), 16: min(max_nc, int(64 * cm)),
+                    32: int(32 * cm), 64: int(16 * cm), 128: int(8 * cm), 256: int(4 * cm)}
+        log_size = int(math.ceil(math.log(size, 2)))
+        blur = (1, 3, 3, 1) if opt.use_antialias else (1,)
+        ch = channels[2 ** log_size]
+        convs = [GenConvLayerCPU(3, ch, 3)]
+        for i in range(log_size, 2, -1):
+            convs.append(GenResBlockCPU(ch, channels[2 ** (i - 1)], blur))
+            ch = channels[2 ** (i - 1)]
+        convs.append(GenResBlockCPU(ch, max_nc * 2, downsample=False))
+        convs.append(GenConvLayerCPU(max_nc * 2, max_nc, 3, pad=0))
+        self.convs = torch.nn.ModuleList(convs)
+        self.pairlinear = torch.nn.ModuleList([_ActLinearCPU(channels[4] * 2 * 2 * 2, 2048, True), _ActLinearCPU(2048, 2048, True),
+                                               _ActLinearCPU(2048, 1024, True), _ActLinearCPU(1024, 1, False)])
+
+    def extract_features(self, patches, aggregate=False):
+        b, t = patches.shape[:2]
+        x = patches.flatten(0, 1)
+        for c in self.convs:
+            x = c(x)
+        x = x.view(b, t, *x.shape[1:])
+        if aggregate:
+            x = x.mean(1, keepdim=True).expand(-1, t, -1, -1, -1)
+        return x.flatten(0, 1)
+
+    def discriminate_features(self, f1, f2):
+        x = torch.cat([f1.flatten(1), f2.flatten(1)], dim=1)
+        for lin in self.pairlinear:
+            x = lin(x)
+        return x
+
+
+def apply_random_crop(x, target_size, scale_range, num_crops=1):
+    """util/util.py:323-343: per crop a random horizontal flip, independent x / y scale, an offset that keeps the window inside
+    the image; bilinear grid_sample with zero padding, align_corners=False.  Random draws in the reference's order."""
+    b = x.size(0) * num_crops
+    flip = torch.round(torch.rand(b, 1, 1, 1)) * 2 - 1.0
+    gx = torch.linspace(-1.0, 1.0, target_size)[None, None, :, None].repeat(b, target_size, 1, 1)
+    grid = torch.cat([gx * flip, gx.transpose(1, 2)], dim=3)
+    x = x.unsqueeze(1).expand(-1, num_crops, -1, -1, -1).flatten(0, 1)
+    scale = torch.rand(b, 1, 1, 2) * (scale_range[1] - scale_range[0]) + scale_range[0]
+    offset = (torch.rand(b, 1, 1, 2) * 2 - 1) * (1 - scale)
+    crop = F.grid_sample(x, grid * scale + offset, align_corners=False)
+    return crop.view(b // num_crops, num_crops, *crop.shape[1:])
+
+
+def gan_loss(pred, real):
+    """models/networks/loss.py:10-16"""
+    return F.softplus(-pred if real else pred).view(pred.size(0), -1).mean(dim=1)
+
+
+class TrainIterationCPU:
+    """The reference's model and driver for one discriminator call and one generator call (swapping_autoencoder_model.py:
+    116-136,187-231; optimizers/swapping_autoencoder_optimizer.py:34-42,67-111 without the lazy-R1 call) on the CPU path."""
+
+    def __init__(self, opt):
+        self.opt = opt
+        self.E, self.G = EncoderCPU(opt), GeneratorCPU(opt)
+        self.D = DiscriminatorCPU(opt.crop_size, 2.0 * opt.netD_scale_capacity)
+        self.Dpatch = PatchDiscriminatorCPU(opt)
+        self.Gparams = list(self.G.parameters()) + list(self.E.parameters())
+        self.Dparams = list(self.D.parameters()) + list(self.Dpatch.parameters())
+        c = opt.R1_once_every / (1 + opt.R1_once_every)
+        self.optimizer_G = torch.optim.Adam(self.Gparams, lr=opt.lr, betas=(opt.beta1, opt.beta2))
+        self.optimizer_D = torch.optim.Adam(self.Dparams, lr=opt.lr * c, betas=(opt.beta1 ** c, opt.beta2 ** c))
+
+    def modules(self):
+        return {"E": self.E, "G": self.G, "D": self.D, "Dpatch": self.Dpatch}
+
+    @staticmethod
+    def swap(x):
+        return torch.flip(x.view(x.shape[0] // 2, 2, *x.shape[1:]), [1]).view(x.shape)
+
+    def crops(self, x):
+        o = self.opt
+        return apply_random_crop(x, o.patch_size, (o.patch_min_scale, o.patch_max_scale), num_crops=o.patch_num_crops)
+
+    def _trainable(self, on, off):
+        for p in on:
+            p.requires_grad_(True)
+        for p in off:
+            p.requires_grad_(False)
+
+    def discriminator_call(self, real):
+        o = self.opt
+        self._trainable(self.Dparams, self.Gparams)
+        self.optimizer_D.zero_grad()
+        sp, gl = self.E(real)
+        b = real.size(0)
+        rec = self.G(sp[:b // 2], gl[:b // 2])
+        mix = self.G(self.swap(sp), gl)
+        losses = {"D_real": gan_loss(self.D(real), True) * o.lambda_GAN,
+                  "D_rec": gan_loss(self.D(rec), False) * (0.5 * o.lambda_GAN),
+                  "D_mix": gan_loss(self.D(mix), False) * (0.5 * o.lambda_GAN)}
+        real_feat = self.Dpatch.extract_features(self.crops(real), aggregate=o.patch_use_aggregation)
+        target_feat = self.Dpatch.extract_features(self.crops(real))
+        mix_feat = self.Dpatch.extract_features(self.crops(mix))
+        losses["PatchD_real"] = gan_loss(self.Dpatch.discriminate_features(real_feat, target_feat), True) * o.lambda_PatchGAN
+        losses["PatchD_mix"] = gan_loss(self.Dpatch.discriminate_features(real_feat, mix_feat), False) * o.lambda_PatchGAN
+        sum(v.mean() for v in losses.values()).backward()
+        self.optimizer_D.step()
+        return {k: float(v.detach().mean()) for k, v in losses.items()}
+
+    def generator_call(self, real):
+        o = self.opt
+        self._trainable(self.Gparams, self.Dparams)
+        self.optimizer_G.zero_grad()
+        b = real.size(0)
+        sp, gl = self.E(real)
+        rec = self.G(sp[:b // 2], gl[:b // 2])
+        sp_mix = self.swap(sp)
+        losses = {"G_L1": F.l1_loss(rec, real[:b // 2]) * o.lambda_L1}
+        if o.crop_size >= 1024:
+            real, gl, sp_mix = real[b // 2:], gl[b // 2:], sp_mix[b // 2:]
+        mix = self.G(sp_mix, gl)
+        losses["G_GAN_rec"] = gan_loss(self.D(rec), True) * (o.lambda_GAN * 0.5)
+        losses["G_GAN_mix"] = gan_loss(self.D(mix), True) * (o.lambda_GAN * 1.0)
+        real_feat = self.Dpatch.extract_features(self.crops(real), aggregate=o.patch_use_aggregation).detach()
+        mix_feat = self.Dpatch.extract_features(self.crops(mix))
+        losses["G_mix"] = gan_loss(self.Dpatch.discriminate_features(real_feat, mix_feat), True) * o.lambda_PatchGAN
+        sum(v.mean() for v in losses.values()).backward()
+        self.optimizer_G.step()
+        return {k: float(v.detach().mean()) for k, v in losses.items()}

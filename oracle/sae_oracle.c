@@ -35,11 +35,14 @@ typedef struct sae_conv2d_desc {
     int64_t m, oh, ow;
     int32_t kh, kw, stride, pad;
     int64_t w_stride_m, w_stride_c;
+    const float* prepped;          /* include/sae_hip.h (ABI 6): prepared weights -- a GPU launch detail; the oracle convolves */
+    int64_t prepped_floats;        /* with the weights themselves and ignores them                                            */
+    int64_t prepped_layout;
 } sae_conv2d_desc;
 
 static __thread char g_err[256];
 
-int oracle_abi_version(void) { return 5; }
+int oracle_abi_version(void) { return 6; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
@@ -895,6 +898,19 @@ int oracle_modconv2d_wgrad_f32(const float* x, const float* gy, float* gw, const
     int rc = (xs && gs) ? oracle_conv2d_wgrad_f32(xs, gs, gw, d, alpha, workspace, workspace_floats, stream) : SAE_EWORKSPACE;
     free(xs); free(gs);
     return rc;
+}
+
+/* include/sae_hip.h "Prepared weights": the oracle has no weight layout (floats = 0 tells the caller not to prepare) */
+int oracle_conv2d_wprep_query(const sae_conv2d_desc* d, const sae_conv2d_mod* mod, int32_t op, int64_t* floats, int64_t* layout) {
+    (void)mod; (void)op;
+    if (!floats || !layout || !conv_desc_ok(d)) return set_err("oracle_conv2d_wprep_query: bad argument");
+    *floats = 0; *layout = 0;
+    return SAE_OK;
+}
+int oracle_conv2d_wprep_f32(const float* w, const sae_conv2d_desc* d, const sae_conv2d_mod* mod, int32_t op, float alpha,
+                            float* out, int64_t out_floats, sae_stream_t stream) {
+    (void)w; (void)d; (void)mod; (void)op; (void)alpha; (void)out; (void)out_floats; (void)stream;
+    return set_err("oracle_conv2d_wprep_f32: the oracle has no weight layout (oracle_conv2d_wprep_query reports 0 floats)");
 }
 
 /* ---- small glue (include/sae_hip.h, csrc/glue.hip).  util.normalize (util/util.py:18-22): v * rsqrt(sum(v^2, dim 1) + 1e-8);

@@ -3768,6 +3768,68 @@ int run_wprep_bx(const float* w, float* wpb, int M, int C, int Mp, int Cp, int B
     return SAE_OK;
 }
 
+// ---- prepared weights (sae_conv2d_desc::prepped, sae_conv2d_wprep_*) -------------------------------------------------------
+// A launch re-lays its weights (run_wprep / run_wprep_bx) into the head of its workspace.  The layout depends on the launch's
+// tile shape, not on the batch, and the weights change once per optimiser step, so a caller may keep the re-laid copy:
+//   sae_conv2d_wprep_f32 writes it into a caller-owned buffer, later calls hand it back through the descriptor.
+// The request of the call at hand lives in a thread-local record set by the entry point (the calls are re-entrant per thread).
+struct PrepRequest {
+    const float* use;        // prepared weights to use instead of re-laying (null: re-lay into the workspace)
+    int64_t use_floats;
+    int64_t use_layout;      // sae_conv2d_wprep_layout() of the launch they were prepared for
+    float* make;             // wprep-only call: write the layout here and launch nothing else
+    int64_t make_floats;
+    int64_t* want_floats;    // query: floats of the layout (0 when the path has none) ...
+    int64_t* want_layout;    // ... and its identity
+};
+thread_local PrepRequest t_prep = {nullptr, 0, 0, nullptr, 0, nullptr, nullptr};
+struct PrepGuard {
+    PrepRequest saved;
+    explicit PrepGuard(const PrepRequest& r) : saved(t_prep) { t_prep = r; }
+    ~PrepGuard() { t_prep = saved; }
+};
+inline PrepRequest prep_from_desc(const sae_conv2d_desc* d) {
+    return PrepRequest{d ? d->prepped : nullptr, d ? d->prepped_floats : 0, d ? d->prepped_layout : 0, nullptr, 0, nullptr, nullptr};
+}
+inline int64_t layout_id(int kind, int Mp, int Cp, int taps, int flip, int64_t sm, int64_t sc, int bm) {
+    uint64_t h = 1469598103934665603ull;
+    const int64_t v[8] = {kind, Mp, Cp, taps, flip, sm, sc, bm};
+    for (int i = 0; i < 8; ++i) { h ^= (uint64_t)v[i]; h *= 1099511628211ull; }
+    return (int64_t)(h & 0x7fffffffffffffffull) | 1;      // never 0 (= "this path has no layout")
+}
+// The weights of a launch: re-laid into `ws` unless the caller prepared them.  *done = true: the request was a query or a
+// wprep-only call and has been served (the caller returns SAE_OK without launching).  kind 0: fp32 layout [tap][Cp][Mp],
+// 1: bf16x6 cells.
+int stage_weights(const float* w, float* ws, int M, int C, int Mp, int Cp, int taps, int64_t sm, int64_t sc, int flip, float alpha,
+                  hipStream_t s, WScale wsc, bool bx, int bm, const float** wp, bool* done) {
+    const int64_t need = bx ? (int64_t)27 * Mp * (Cp / 8) * 4 : (int64_t)taps * Cp * Mp;
+    const int64_t layout = layout_id(bx ? 1 : 0, Mp, Cp, taps, flip, sm, sc, bx ? bm : 0);
+    *done = false;
+    if (t_prep.want_floats) {
+        *t_prep.want_floats = need;
+        if (t_prep.want_layout) *t_prep.want_layout = layout;
+        *done = true;
+        return SAE_OK;
+    }
+    float* dst = ws;
+    if (t_prep.make) {
+        if (t_prep.make_floats != need)
+            return fail(SAE_EINVAL, "sae_conv2d_wprep_f32: buffer of %lld floats, the layout has %lld", (long long)t_prep.make_floats,
+                        (long long)need);
+        dst = t_prep.make;
+        *done = true;
+    } else if (t_prep.use && t_prep.use_layout == layout && t_prep.use_floats == need) {
+        *wp = t_prep.use;
+        return SAE_OK;
+    }
+    // (prepared weights of ANOTHER layout -- the launch took another kernel than the query assumed, e.g. because of the
+    // alignment of this call's tensors -- are ignored: the weights are re-laid into the workspace as without them)
+    if (bx) run_wprep_bx(w, dst, M, C, Mp, Cp, bm, sm, sc, flip, alpha, s, wsc);
+    else run_wprep(w, dst, M, C, Mp, Cp, taps, sm, sc, flip, alpha, s, wsc);
+    *wp = dst;
+    return SAE_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // 1x1 stride-1 pad-0 convolutions with at most four channels on one side (FromRGB 3 -> 128, ToRGB 128 -> 3, their
 // input gradients): planes in, planes out, no matrix cores.  Through the 128-row gather tile FromRGB ran at 2.5 TFLOP/s
@@ -3856,7 +3918,8 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
                int64_t sc, int flip, float alpha, hipStream_t s, Epilogue ep = Epilogue{nullptr, 0, 0.0f, 1.0f},
                const float* in_scale = nullptr, WScale wsc = WScale{nullptr, nullptr}) {
     const GatherPlan g = gather_plan(N, cin, mout, OH, OW, ks, stride, oys != 1 || oxs != 1);
-    if (!ws || ws_floats < g.ws_floats)
+    const bool prep_only = t_prep.make || t_prep.want_floats;
+    if (!prep_only && (!ws || ws_floats < g.ws_floats))
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)g.ws_floats);
     // thin 1x1 layers (at most four channels on one side, e.g. FromRGB / ToRGB): streamed, see conv1x1_thin_kernel
     static const int thin_knob = tuning_knob("SAE_CONV_THIN", 1);
@@ -3868,6 +3931,10 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     if (thin_knob && !ep.residual && !ep.noise && ks == 1 && stride == 1 && pad == 0 && oys == 1 && oxs == 1 && (cin <= 4 || mout <= 4) &&
         H == OH && W == OW && YH == OH && YW == OW && ((int64_t)H * W) % 4 == 0 &&
         ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0 && N <= 65535) {
+        if (prep_only) {      // the streaming kernels read the parameter layout: nothing to prepare
+            if (t_prep.want_floats) { *t_prep.want_floats = 0; if (t_prep.want_layout) *t_prep.want_layout = 0; return SAE_OK; }
+            return fail(SAE_EINVAL, "sae_conv2d_wprep_f32: this launch has no weight layout (sae_conv2d_wprep_floats returns 0)");
+        }
         ThinParams t{};
         t.N = N; t.C = cin; t.M = mout; t.HW = (int64_t)H * W; t.sm = sm; t.sc = sc; t.alpha = alpha;
         t.rs_m = wsc.rs_m; t.rs_c = wsc.rs_c; t.in_scale = in_scale;
@@ -3880,10 +3947,11 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     if (in_scale && g.bx)
         return fail(SAE_EINVAL, "modulated conv: the activation factors are staged by the exact-fp32 kernels only "
                                 "(SAE_CONV_MATH_F32); under bf16x6 modulate the activation before the call");
-    if (g.bx) {
-        run_wprep_bx(w, ws, mout, cin, g.Mp, g.Cp, g.sh.bm, sm, sc, flip, alpha, s, wsc);
-    } else {
-        run_wprep(w, ws, mout, cin, g.Mp, g.Cp, g.taps, sm, sc, flip, alpha, s, wsc);
+    const float* wp = ws;
+    {
+        bool done;
+        const int rc = stage_weights(w, ws, mout, cin, g.Mp, g.Cp, g.taps, sm, sc, flip, alpha, s, wsc, g.bx, g.sh.bm, &wp, &done);
+        if (rc != SAE_OK || done) return rc;
     }
     IgemmParams p{};
     p.N = N; p.C = cin; p.H = H; p.W = W; p.M = mout; p.OH = OH; p.OW = OW; p.YH = YH; p.YW = YW;
@@ -3907,10 +3975,10 @@ int run_gather(const float* x, const float* w, float* y, float* ws, int64_t ws_f
     p.vec_store = vec_knob && oys == 1 && oxs == 1 && OW % 4 == 0 && YW % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
                   (vec_knob != 3 || g.cps >= 48 || ep.act || ep.residual);
     int rc;
-    if (ks == 3 && stride == 1) rc = launch_igemm<3, 1>(x, ws, out, p, g, s);
-    else if (ks == 3) rc = launch_igemm<3, 2>(x, ws, out, p, g, s);
-    else if (stride == 1) rc = launch_igemm<1, 1>(x, ws, out, p, g, s);
-    else rc = launch_igemm<1, 2>(x, ws, out, p, g, s);
+    if (ks == 3 && stride == 1) rc = launch_igemm<3, 1>(x, wp, out, p, g, s);
+    else if (ks == 3) rc = launch_igemm<3, 2>(x, wp, out, p, g, s);
+    else if (stride == 1) rc = launch_igemm<1, 1>(x, wp, out, p, g, s);
+    else rc = launch_igemm<1, 2>(x, wp, out, p, g, s);
     if (rc != SAE_OK) return rc;
     if (g.ksplit > 1) {
         // y is exactly N*mout*OH*OW floats; the slabs are padded to a multiple of 4, y may not be
@@ -3995,9 +4063,14 @@ int run_tr2(const float* x, const float* w, float* y, float* ws, int64_t ws_floa
     const Tr2Shape sh = tr2_shape(mout);
     const int Mp = round_up(mout, sh.bm), Cp = round_up(cin, sh.ck);
     const int64_t need = (int64_t)9 * Cp * Mp;
-    if (!ws || ws_floats < need)
+    if (!(t_prep.make || t_prep.want_floats) && (!ws || ws_floats < need))
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
-    run_wprep(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s, wsc);
+    const float* wp = ws;
+    {
+        bool done;
+        const int rc = stage_weights(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s, wsc, false, sh.bm, &wp, &done);
+        if (rc != SAE_OK || done) return rc;
+    }
     TrParams p{};
     p.in_scale = in_scale;
     p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
@@ -4024,8 +4097,8 @@ int run_tr2(const float* x, const float* w, float* y, float* ws, int64_t ws_floa
         const dim3 fgrid((unsigned)(8 * ceil_div(p.main_items, 8)));
 #define SAE_TR2F(MI_, CK_)                                                                                                   \
     do {                                                                                                                     \
-        if (in_scale) hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, true, true>), fgrid, dim3(kBlock), 0, s, x, ws, y, p);  \
-        else hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, false, true>), fgrid, dim3(kBlock), 0, s, x, ws, y, p);          \
+        if (in_scale) hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, true, true>), fgrid, dim3(kBlock), 0, s, x, wp, y, p);  \
+        else hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, false, true>), fgrid, dim3(kBlock), 0, s, x, wp, y, p);          \
     } while (0)
         if (sh.mi == 2 && sh.ck == 16 && SAE_TR2_FLAT_CK == 16) SAE_TR2F(2, 16);
         else if (sh.mi == 2) SAE_TR2F(2, 8);
@@ -4070,8 +4143,8 @@ int run_tr2(const float* x, const float* w, float* y, float* ws, int64_t ws_floa
     const dim3 grid((unsigned)(8 * (ceil_div(p.main_items, 8) + ceil_div(p.strip_items, 8))));
 #define SAE_TR2(MI_, CK_)                                                                                              \
     do {                                                                                                               \
-        if (in_scale) hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, true>), grid, dim3(kBlock), 0, s, x, ws, y, p);   \
-        else hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, false>), grid, dim3(kBlock), 0, s, x, ws, y, p);           \
+        if (in_scale) hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);   \
+        else hipLaunchKernelGGL((conv_igemm_tr2_kernel<MI_, CK_, false>), grid, dim3(kBlock), 0, s, x, wp, y, p);           \
     } while (0)
     if (sh.mi == 2 && sh.ck == 16) SAE_TR2(2, 16);
     else if (sh.mi == 2) SAE_TR2(2, 8);
@@ -4184,13 +4257,17 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
     const int Mp = round_up(mout, sh.bm), Cp = round_up(cin, sh.ck);
     const bool bx = conv_math() == 1 && sh.cfg == 0;
     const int64_t need = bx ? (int64_t)27 * Mp * (Cp / 8) * 4 : (int64_t)9 * Cp * Mp;
-    if (!ws || ws_floats < need)
+    if (!(t_prep.make || t_prep.want_floats) && (!ws || ws_floats < need))
         return fail(SAE_EWORKSPACE, "conv2d: workspace %lld < %lld floats", (long long)ws_floats, (long long)need);
     if (in_scale && bx)
         return fail(SAE_EINVAL, "modulated conv: the activation factors are staged by the exact-fp32 kernels only "
                                 "(SAE_CONV_MATH_F32); under bf16x6 modulate the activation before the call");
-    if (bx) run_wprep_bx(w, ws, mout, cin, Mp, Cp, sh.bm, sm, sc, 0, alpha, s, wsc);
-    else run_wprep(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s, wsc);
+    const float* wp = ws;
+    {
+        bool done;
+        const int rc = stage_weights(w, ws, mout, cin, Mp, Cp, 9, sm, sc, 0, alpha, s, wsc, bx, sh.bm, &wp, &done);
+        if (rc != SAE_OK || done) return rc;
+    }
     TrParams p{};
     p.in_scale = in_scale;
     p.N = N; p.C = cin; p.IH = IH; p.IW = IW; p.M = mout; p.OH = OH; p.OW = OW; p.Cp = Cp; p.Mp = Mp; p.pad = pad;
@@ -4211,20 +4288,20 @@ int run_tr(const float* x, const float* w, float* y, float* ws, int64_t ws_float
         const dim3 grid((unsigned)total_blocks, (unsigned)(Mp / sh.bm), (unsigned)sp.ksplit);
         if (bx) {
             hipLaunchKernelGGL((conv_igemm_tr_bx_kernel<2, 2, 2>), grid, dim3(kBlock), 0, s, x,
-                               reinterpret_cast<const u32x4*>(ws), y, p);
+                               reinterpret_cast<const u32x4*>(wp), y, p);
             return SAE_OK;
         }
 #define SAE_TR(...)                                                                                             \
     do {                                                                                                        \
-        if (p.in_scale) hipLaunchKernelGGL((conv_igemm_tr_kernel<__VA_ARGS__, true>), grid, dim3(kBlock), 0, s, x, ws, y, p);   \
-        else hipLaunchKernelGGL((conv_igemm_tr_kernel<__VA_ARGS__, false>), grid, dim3(kBlock), 0, s, x, ws, y, p);             \
+        if (p.in_scale) hipLaunchKernelGGL((conv_igemm_tr_kernel<__VA_ARGS__, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);   \
+        else hipLaunchKernelGGL((conv_igemm_tr_kernel<__VA_ARGS__, false>), grid, dim3(kBlock), 0, s, x, wp, y, p);             \
     } while (0)
         switch (sh.cfg) {
             case 3: SAE_TR(2, 1, 4, 16); break;
             case 0: SAE_TR(2, 2, 2, CK); break;
             case 4:
-                if (p.in_scale) hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 4, CK, true>), grid, dim3(512), 0, s, x, ws, y, p);
-                else hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 4, CK, false>), grid, dim3(512), 0, s, x, ws, y, p);
+                if (p.in_scale) hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 4, CK, true>), grid, dim3(512), 0, s, x, wp, y, p);
+                else hipLaunchKernelGGL((conv_igemm_tr_kernel<2, 2, 4, CK, false>), grid, dim3(512), 0, s, x, wp, y, p);
                 break;
             case 1: SAE_TR(2, 1, 4, CK); break;
             default: SAE_TR(1, 1, 4, CK); break;
@@ -4353,6 +4430,7 @@ int conv_fwd_impl(const char* who, const float* x, const float* w, float* y, con
     if (!x || !w || !y) return fail(SAE_EINVAL, "%s: null tensor", who);
     if (mod.y_scale) return fail(SAE_EINVAL, "%s: y_scale has no meaning for the forward operation", who);
     hipStream_t s = (hipStream_t)stream;
+    const PrepGuard prep(t_prep.make || t_prep.want_floats ? t_prep : prep_from_desc(d));
     int rc = run_gather(x, w, y, workspace, workspace_floats, (int)d->n, (int)d->c, (int)d->h, (int)d->w, (int)d->m,
                         (int)d->oh, (int)d->ow, (int)d->oh, (int)d->ow, 1, 1, d->kh, d->stride, d->pad,
                         d->w_stride_m, d->w_stride_c, 0, alpha, s, Epilogue{nullptr, 0, 0.0f, 1.0f}, mod.x_scale,
@@ -4390,6 +4468,7 @@ extern "C" int sae_modconv2d_fwd_noise_bias_act_f32(const float* x, const float*
     hipStream_t s = (hipStream_t)stream;
     Epilogue ep{bias, 1, act_slope, act_scale};
     ep.noise = noise; ep.noise_w = noise ? noise_weight : nullptr;
+    const PrepGuard prep(prep_from_desc(d));
     int rc = run_gather(x, w, y, workspace, workspace_floats, (int)d->n, (int)d->c, (int)d->h, (int)d->w, (int)d->m,
                         (int)d->oh, (int)d->ow, (int)d->oh, (int)d->ow, 1, 1, d->kh, d->stride, d->pad,
                         d->w_stride_m, d->w_stride_c, 0, alpha, s, ep, mod->x_scale, WScale{mod->wm_scale, mod->wc_scale});
@@ -4405,6 +4484,7 @@ extern "C" int sae_conv2d_fwd_bias_act_f32(const float* x, const float* w, const
     if (d->n == 0) return SAE_OK;
     if (!x || !w || !y) return fail(SAE_EINVAL, "sae_conv2d_fwd_bias_act_f32: null tensor");
     hipStream_t s = (hipStream_t)stream;
+    const PrepGuard prep(prep_from_desc(d));
     int rc = run_gather(x, w, y, workspace, workspace_floats, (int)d->n, (int)d->c, (int)d->h, (int)d->w, (int)d->m,
                         (int)d->oh, (int)d->ow, (int)d->oh, (int)d->ow, 1, 1, d->kh, d->stride, d->pad,
                         d->w_stride_m, d->w_stride_c, 0, alpha, s, Epilogue{bias, 1, act_slope, act_scale});
@@ -4424,6 +4504,7 @@ extern "C" int sae_conv2d_fwd_residual_f32(const float* x, const float* w, const
     hipStream_t s = (hipStream_t)stream;
     Epilogue ep{nullptr, 0, 0.0f, 1.0f};
     ep.residual = residual; ep.res_scale = res_scale;
+    const PrepGuard prep(prep_from_desc(d));
     int rc = run_gather(x, w, y, workspace, workspace_floats, (int)d->n, (int)d->c, (int)d->h, (int)d->w, (int)d->m,
                         (int)d->oh, (int)d->ow, (int)d->oh, (int)d->ow, 1, 1, d->kh, d->stride, d->pad,
                         d->w_stride_m, d->w_stride_c, 0, alpha, s, ep);
@@ -4440,6 +4521,7 @@ int conv_dgrad_impl(const char* who, const float* gy, const float* w, float* gx,
     if (!gy || !w || !gx) return fail(SAE_EINVAL, "%s: null tensor", who);
     if (mod.x_scale) return fail(SAE_EINVAL, "%s: x_scale has no meaning for the data gradient", who);
     hipStream_t s = (hipStream_t)stream;
+    const PrepGuard prep(t_prep.make || t_prep.want_floats ? t_prep : prep_from_desc(d));
     // the launch produces the c axis and contracts over the m axis of the descriptor
     const WScale wsc{mod.wc_scale, mod.wm_scale};
     const Epilogue none{nullptr, 0, 0.0f, 1.0f};
@@ -4451,7 +4533,7 @@ int conv_dgrad_impl(const char* who, const float* gy, const float* w, float* gx,
                         d->w_stride_c, d->w_stride_m, 1, alpha, s, none, mod.y_scale, wsc);
     } else if (d->kh == 1) {
         // 1x1 stride 2 (pad 0): gx[2oy][2ox] = W^T gy, every other position is zero
-        hipMemsetAsync(gx, 0, sizeof(float) * (size_t)(d->n * d->c * d->h * d->w), s);
+        if (!(t_prep.make || t_prep.want_floats)) hipMemsetAsync(gx, 0, sizeof(float) * (size_t)(d->n * d->c * d->h * d->w), s);
         rc = run_gather(gy, w, gx, workspace, workspace_floats, (int)d->n, (int)d->m, (int)d->oh, (int)d->ow,
                         (int)d->c, (int)d->oh, (int)d->ow, (int)d->h, (int)d->w, 2, 2, 1, 1, 0, d->w_stride_c,
                         d->w_stride_m, 0, alpha, s, none, mod.y_scale, wsc);
@@ -4628,6 +4710,35 @@ int conv_wgrad_impl(const char* who, const float* x, const float* gy, float* gw,
     return check_launch(who);
 }
 }  // namespace
+
+namespace {
+int wprep_dispatch(const char* who, const float* w, const sae_conv2d_desc* d, const sae_conv2d_mod* mod, int32_t op, float alpha,
+                   const PrepRequest& req, sae_stream_t stream) {
+    if (op != SAE_CONV_FWD && op != SAE_CONV_DGRAD) return fail(SAE_EINVAL, "%s: op must be SAE_CONV_FWD or SAE_CONV_DGRAD", who);
+    const PrepGuard guard(req);
+    // the activations are not touched by a query / wprep-only call; the dispatch only looks at their alignment
+    float* const stand_in = reinterpret_cast<float*>((uintptr_t)4096);
+    const sae_conv2d_mod& m = mod ? *mod : kNoMod;
+    if (op == SAE_CONV_FWD) return conv_fwd_impl(who, stand_in, w ? w : stand_in, stand_in, d, m, alpha, nullptr, 0, stream);
+    return conv_dgrad_impl(who, stand_in, w ? w : stand_in, stand_in, d, m, alpha, nullptr, 0, stream);
+}
+}  // namespace
+
+extern "C" int sae_conv2d_wprep_query(const sae_conv2d_desc* d, const sae_conv2d_mod* mod, int32_t op, int64_t* floats,
+                                      int64_t* layout) {
+    sae::clear_stale_error();
+    if (!floats || !layout) return fail(SAE_EINVAL, "sae_conv2d_wprep_query: null result pointer");
+    *floats = 0; *layout = 0;
+    if (op == SAE_CONV_WGRAD) return SAE_OK;      // the weight gradient reads no weights
+    return wprep_dispatch("sae_conv2d_wprep_query", nullptr, d, mod, op, 1.0f, PrepRequest{nullptr, 0, 0, nullptr, 0, floats, layout}, nullptr);
+}
+
+extern "C" int sae_conv2d_wprep_f32(const float* w, const sae_conv2d_desc* d, const sae_conv2d_mod* mod, int32_t op, float alpha,
+                                    float* out, int64_t out_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (!w || !out || out_floats < 1) return fail(SAE_EINVAL, "sae_conv2d_wprep_f32: null tensor");
+    return wprep_dispatch("sae_conv2d_wprep_f32", w, d, mod, op, alpha, PrepRequest{nullptr, 0, 0, out, out_floats, nullptr, nullptr}, stream);
+}
 
 #ifdef SAE_CLOCK_PROBE
 // profiling variant only: read (and optionally clear) the ten counters of g_clock_probe

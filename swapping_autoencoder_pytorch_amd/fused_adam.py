@@ -46,7 +46,7 @@ class FusedAdam(torch.optim.Optimizer):
                 loss = closure()
         lib = hip_lib.get()
         for group in self.param_groups:
-            ps, gs, ms, vs, ns, steps, keep = [], [], [], [], [], [], []
+            ps, gs, ms, vs, ns, steps, keep, updated = [], [], [], [], [], [], [], []
             for p in group["params"]:
                 if only is not None and p not in only:
                     continue
@@ -65,6 +65,7 @@ class FusedAdam(torch.optim.Optimizer):
                 ps.append(p.data_ptr()); gs.append(g.data_ptr()); ms.append(st["exp_avg"].data_ptr())
                 vs.append(st["exp_avg_sq"].data_ptr()); ns.append(p.numel()); steps.append(int(st["step"].item()) + 1)
                 keep.append((g, st))
+                updated.append(p)
             if not ps:
                 continue
             n = len(ps)
@@ -75,4 +76,8 @@ class FusedAdam(torch.optim.Optimizer):
                      float(beta2), float(group["eps"]), float(grad_scale), lib.stream(group["params"][0]))
             for _, st in keep:           # the step counters advance only once the launch was accepted
                 st["step"] += 1
+            # the kernel wrote the parameters through raw pointers: tell autograd's version counters, which is what every
+            # in-place op of torch.optim does and what stylegan2_op/weight_prep.py (prepared conv weights) goes by
+            for p in updated:
+                torch.autograd.graph.increment_version(p)
         return loss

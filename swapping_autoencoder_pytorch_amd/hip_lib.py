@@ -30,10 +30,11 @@ class ConvDesc(C.Structure):
     _fields_ = [("n", _i64), ("c", _i64), ("h", _i64), ("w", _i64),
                 ("m", _i64), ("oh", _i64), ("ow", _i64),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
-                ("w_stride_m", _i64), ("w_stride_c", _i64)]
+                ("w_stride_m", _i64), ("w_stride_c", _i64),
+                ("prepped", C.c_void_p), ("prepped_floats", _i64), ("prepped_layout", _i64)]
 
     def key(self):
-        return tuple(getattr(self, f) for f, _ in self._fields_)
+        return tuple(getattr(self, f) for f, _ in self._fields_[:13])
 
 
 class ConvMod(C.Structure):
@@ -42,7 +43,7 @@ class ConvMod(C.Structure):
     _fields_ = [("x_scale", C.c_void_p), ("y_scale", C.c_void_p), ("wm_scale", C.c_void_p), ("wc_scale", C.c_void_p)]
 
 
-ABI_VERSION = 5      # include/sae_hip.h: SAE_ABI_VERSION
+ABI_VERSION = 6      # include/sae_hip.h: SAE_ABI_VERSION
 
 _SIGNATURES = {
     "abi_version": (C.c_int, []),
@@ -80,6 +81,8 @@ _SIGNATURES = {
     "conv2d_fwd_residual_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32, _f32p, _i64, _stream]),
     "conv2d_dgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
     "conv2d_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), _f32, _f32p, _i64, _stream]),
+    "conv2d_wprep_query": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvMod), _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    "conv2d_wprep_f32": (C.c_int, [_f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _i32, _f32, _f32p, _i64, _stream]),
     "modconv2d_fwd_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),
     "modconv2d_fwd_noise_bias_act_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod),
                                                    _f32, _f32, _f32, _f32p, _i64, _stream]),

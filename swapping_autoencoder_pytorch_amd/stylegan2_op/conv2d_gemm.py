@@ -20,6 +20,7 @@ from torch.autograd import Function
 
 from .. import hip_lib
 from ..hip_lib import SAE_CONV_DGRAD, SAE_CONV_FWD, SAE_CONV_WGRAD, ConvDesc
+from . import weight_prep
 
 
 class _Flags:
@@ -81,6 +82,7 @@ def _launch(name, op, geom, a, b, out_shape, out=None):
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=a.device)
     if out is None or tuple(out.shape) != tuple(out_shape):
         out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
+    prepared = weight_prep.attach(lib, d, None, op, b, geom.alpha) if op != SAE_CONV_WGRAD else None   # noqa: F841 (kept alive)
     lib.call(name, a.data_ptr(), b.data_ptr(), out.data_ptr(), C.byref(d), geom.alpha, ws.data_ptr(), n_ws,
              lib.stream(a))
     return out
@@ -96,6 +98,7 @@ def _launch_fused(geom, x, w, bias, slope, scale):
     n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
     out = torch.empty((geom.n, geom.m, geom.oh, geom.ow), dtype=torch.float32, device=x.device)
+    prepared = weight_prep.attach(lib, d, None, SAE_CONV_FWD, w, geom.alpha)   # noqa: F841
     lib.call("conv2d_fwd_bias_act_f32", x.data_ptr(), w.data_ptr(), hip_lib.ptr(bias), out.data_ptr(), C.byref(d),
              geom.alpha, float(slope), float(scale), ws.data_ptr(), n_ws, lib.stream(x))
     return out
@@ -115,6 +118,7 @@ def _launch_residual(geom, x, w, residual, res_scale):
     n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
     out = torch.empty_like(residual)
+    prepared = weight_prep.attach(lib, d, None, SAE_CONV_FWD, w, geom.alpha)   # noqa: F841
     lib.call("conv2d_fwd_residual_f32", x.data_ptr(), w.data_ptr(), residual.data_ptr(), out.data_ptr(), C.byref(d), geom.alpha,
              float(res_scale), ws.data_ptr(), n_ws, lib.stream(x))
     return out
@@ -245,9 +249,10 @@ class ConvBiasAct(Function):
 # ------------------------------------------------------------------------------------------------
 # style-modulated convolution
 # ------------------------------------------------------------------------------------------------
-def _launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_scale=None, wc_scale=None):
+def _launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_scale=None, wc_scale=None, factor_tag=None):
     """One sae_modconv2d_* call: the plain operation `op` on a * factor, b (weights or second activation) with the
-    optional [N, C] activation factors and per-channel weight factors staged inside the kernels."""
+    optional [N, C] activation factors and per-channel weight factors staged inside the kernels.  factor_tag: what the weight
+    factors are as a function of the weight parameter alone (weight_prep.attach), None = unknown (no prepared weights)."""
     lib = hip_lib.get()
     a = a.contiguous()
     b = b.contiguous()
@@ -258,6 +263,9 @@ def _launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_
     n_ws = lib.query("conv2d_workspace", C.byref(d), op)
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=a.device)
     out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
+    if op != SAE_CONV_WGRAD:
+        tag = () if (wm_scale is None and wc_scale is None) else factor_tag
+        prepared = weight_prep.attach(lib, d, mod, op, b, geom.alpha, tag)   # noqa: F841
     lib.call(name, a.data_ptr(), b.data_ptr(), out.data_ptr(), C.byref(d), C.byref(mod), geom.alpha, ws.data_ptr(), n_ws,
              lib.stream(a))
     return out
@@ -310,11 +318,13 @@ class ModulatedConv(Function):
             # ~20 ATen launches per conv and pass otherwise).  `demod` must be None.
             demod = _weight_demod(w, demod_alpha, demod_eps)
         ctx.save_for_backward(x, s, w, demod)
+        # the demodulation factor formed inside this node is a function of the weight alone: prepared weights may be shared
+        ctx.factor_tag = tag = ("demod", float(demod_alpha), float(demod_eps)) if ctx.own_demod else None
         if transposed:      # dgrad of the forward-orientation problem: x is its y side, the result its x side
             return _launch_mod("modconv2d_dgrad_f32", SAE_CONV_DGRAD, geom, x, w, (geom.n, geom.c, geom.h, geom.w),
-                               y_scale=s, wc_scale=demod)
+                               y_scale=s, wc_scale=demod, factor_tag=tag)
         return _launch_mod("modconv2d_fwd_f32", SAE_CONV_FWD, geom, x, w, (geom.n, geom.m, geom.oh, geom.ow),
-                           x_scale=s, wm_scale=demod)
+                           x_scale=s, wm_scale=demod, factor_tag=tag)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -335,12 +345,13 @@ def _modconv_backward(ctx, gout, x, s, w, demod, geom, transposed, in_ticket=Non
     gout = gout.contiguous()
     gx = gs = gw = gd = None
     if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        tag = getattr(ctx, "factor_tag", None)
         if transposed:
             g = _launch_mod("modconv2d_fwd_f32", SAE_CONV_FWD, geom, gout, w, (geom.n, geom.m, geom.oh, geom.ow),
-                            wc_scale=demod)
+                            wc_scale=demod, factor_tag=tag)
         else:
             g = _launch_mod("modconv2d_dgrad_f32", SAE_CONV_DGRAD, geom, gout, w, (geom.n, geom.c, geom.h, geom.w),
-                            wm_scale=demod)
+                            wm_scale=demod, factor_tag=tag)
         from .modulate import fusable, plane_scale_backward, plane_scale_dot_act
         if in_ticket is not None and fusable(g) and ctx.needs_input_grad[0]:
             gx, gs = plane_scale_dot_act(g, x, s, in_ticket)    # ... and the producer's activation backward (ActTicket)
@@ -395,6 +406,8 @@ class StyledModConv(Function):
         n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)
         ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
         out = torch.empty((geom.n, geom.m, geom.oh, geom.ow), dtype=torch.float32, device=x.device)
+        ctx.factor_tag = ("demod", float(demod_alpha), float(demod_eps)) if demod_eps is not None else ()
+        prepared = weight_prep.attach(lib, d, mod, SAE_CONV_FWD, w, geom.alpha, ctx.factor_tag)   # noqa: F841
         lib.call("modconv2d_fwd_noise_bias_act_f32", x.data_ptr(), w.data_ptr(), noise.data_ptr(), noise_weight.data_ptr(),
                  hip_lib.ptr(bias), out.data_ptr(), C.byref(d), C.byref(mod), geom.alpha, float(slope), float(scale),
                  ws.data_ptr(), n_ws, lib.stream(x))

@@ -125,6 +125,30 @@ def conv(lib, op, d, a, b, out_shape, alpha=1.0, device=None):
     return bo.numpy()
 
 
+def conv_prepped(lib, op, d, a, b, out_shape, alpha=1.0, device=None, poison_workspace=True, wrong_layout=False):
+    """The same conv through PREPARED weights (include/sae_hip.h: sae_conv2d_wprep_query / sae_conv2d_wprep_f32 and the
+    descriptor's prepped fields).  Returns (result, floats of the layout).  poison_workspace: the workspace is filled with
+    NaN first, so a launch that re-laid the weights there anyway would still be right, but one that READ the workspace
+    instead of the prepared buffer would not.  wrong_layout: hand the buffer over under a foreign layout identity -- the
+    library must ignore it and re-lay."""
+    floats, layout = C.c_int64(0), C.c_int64(0)
+    lib.call("conv2d_wprep_query", C.byref(d), None, op, C.byref(floats), C.byref(layout))
+    n = lib.query("conv2d_workspace", C.byref(d), op)
+    ba, bb, bo = _Buf(a, device), _Buf(b, device), _out(out_shape, device)
+    wsn = np.full((max(n, 1),), np.nan if (poison_workspace and not wrong_layout) else 0.0, np.float32)
+    ws = _Buf(wsn, device)
+    if floats.value == 0:
+        lib.call(OPS[op], ba.ptr, bb.ptr, bo.ptr, C.byref(d), alpha, ws.ptr, n, _stream(device))
+        return bo.numpy(), 0
+    wp = _out((floats.value,), device)
+    lib.call("conv2d_wprep_f32", bb.ptr, C.byref(d), None, op, alpha, wp.ptr, floats.value, _stream(device))
+    d2 = type(d)()
+    C.memmove(C.byref(d2), C.byref(d), C.sizeof(d))
+    d2.prepped, d2.prepped_floats, d2.prepped_layout = wp.ptr, floats.value, layout.value + (2 if wrong_layout else 0)
+    lib.call(OPS[op], ba.ptr, bb.ptr, bo.ptr, C.byref(d2), alpha, ws.ptr, n, _stream(device))
+    return bo.numpy(), floats.value
+
+
 def conv_bias_act(lib, d, x, w, bias, alpha=1.0, slope=0.2, scale=2 ** 0.5, device=None):
     n = lib.query("conv2d_workspace", C.byref(d), 0)
     bx, bw = _Buf(x, device), _Buf(w, device)

@@ -52,3 +52,32 @@ def test_encoder_generator_reconstruction_matches_the_aten_restatement(oracle_li
         g2 = torch.autograd.grad((yr - x).abs().mean(), sp)
         for a, b in zip(g1, g2):
             assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max() + 1e-12)
+
+
+def test_aten_cpu_train_iteration_reproduces_the_reference_golden_steps(oracle_lib):
+    """oracle/aten_cpu_path.TrainIterationCPU (bench.py --full-cpu-baseline: one discriminator call + one generator call of
+    the reference's driver on its CPU path, crops through F.grid_sample, torch.optim.Adam) against the loss dictionaries the
+    REFERENCE produced on the same weights, images and random stream (tests/golden: micro_steps step0 / step1 -- the second
+    one after the first one's Adam update)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import aten_cpu_path as A
+    import parity_common as P
+    from param_recipe import uniform_images
+    with P.backend(oracle_lib):
+        opt, model, net = P.build_micro("cpu")           # the mirror model only lends its (recipe-filled) parameters
+    it = A.TrainIterationCPU(opt)
+    for name, m in it.modules().items():
+        src, dst = list(getattr(net, name).parameters()), list(m.parameters())
+        assert [tuple(a.shape) for a in src] == [tuple(b.shape) for b in dst], name
+        with torch.no_grad():
+            for a, b in zip(src, dst):
+                b.copy_(a)
+    _, info = P.golden()
+    for call, fn in ((0, it.discriminator_call), (1, it.generator_call)):
+        torch.manual_seed(1000 + call)
+        got = fn(uniform_images(4, 32, 600 + call))
+        want = info["micro_steps"]["step%d" % call]
+        for k, v in got.items():
+            assert abs(v - want[k]) <= 2e-6 * max(1.0, abs(want[k])), (call, k, v, want[k])

@@ -27,6 +27,22 @@ def main(path, top=40):
     print("# rocprofv3 --kernel-trace summary of %s" % os.path.basename(dbs[0]))
     print("# kernels: %d dispatches, %.2f ms busy, %.2f ms first-start..last-end" %
           (sum(r[1] for r in rows), total / 1e6, (span[1] - span[0]) / 1e6))
+    # with more than one stream kernels overlap: time with at least one kernel resident (union of the intervals), and the
+    # time during which two or more were
+    ev = []
+    for st, en in cur.execute("select start, end from kernels"):
+        ev.append((st, 1)); ev.append((en, -1))
+    ev.sort()
+    depth, last, any_ns, multi_ns = 0, None, 0, 0
+    for t, d in ev:
+        if last is not None and depth > 0:
+            any_ns += t - last
+            if depth > 1:
+                multi_ns += t - last
+        depth += d
+        last = t
+    print("# at least one kernel resident %.2f ms (%.1f %% of the span), two or more %.2f ms; sum of durations / resident time = %.3f"
+          % (any_ns / 1e6, 100.0 * any_ns / max(span[1] - span[0], 1), multi_ns / 1e6, total / max(any_ns, 1)))
     print("%10s %6s %7s %11s %11s %11s  %s" % ("total_ms", "pct", "calls", "avg_us", "min_us", "max_us", "kernel"))
     for name, cnt, s, avg, mn, mx in rows[:top]:
         print("%10.3f %6.2f %7d %11.1f %11.1f %11.1f  %s" % (s / 1e6, 100.0 * s / total, cnt, avg / 1e3, mn / 1e3, mx / 1e3,
