@@ -79,6 +79,11 @@ def parse():
                          "generator call of the reference's driver through oracle/aten_cpu_path.TrainIterationCPU; several "
                          "minutes at 256 x 256, B = 16) instead of the bounded, FLOP-scaled sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-steps", type=int, default=8,
+                    help="steps of the kernel pass that follows the timed region: the same iterations with the step's branches on "
+                         "ONE stream (SAE_TWO_STREAMS=0) and a HIP-event bracket around every launch of the tracked kernels -> "
+                         "roofline / roofline_by_kernel.  In the timed region two kernels share the chip (streams.py) and a "
+                         "bracket there would measure the sharing, not the kernel")
     ap.add_argument("--via-dropin", action="store_true",
                     help="time the SAME iteration through the drop-in runner's pre-seeding (swapping_autoencoder_pytorch_amd.dropin, "
                          "SAE_DROPIN_LEVEL, default full) under a reference-style tree: option parser, models.create_model -> "
@@ -192,11 +197,11 @@ class DominantKernelTimer:
         cg._launch_fused = launch_fused
         orig_mod = cg._launch_mod
 
-        def launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_scale=None, wc_scale=None):
+        def launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_scale=None, wc_scale=None, **kw):
             # a modulated-conv call whose ACTIVATION carries no factor runs the un-modulated kernel instantiation (weight
             # factors ride in the weight re-layout): the data gradient of the generator's plain modulated convs
             key = timer.classify(cg, op, geom, x_scale is not None or y_scale is not None)
-            return bracket(key, geom, lambda: orig_mod(name, op, geom, a, b, out_shape, x_scale, y_scale, wm_scale, wc_scale))
+            return bracket(key, geom, lambda: orig_mod(name, op, geom, a, b, out_shape, x_scale, y_scale, wm_scale, wc_scale, **kw))
 
         cg._launch_mod = launch_mod
 
@@ -612,17 +617,43 @@ def main():
         torch.cuda.synchronize()
 
     fence()
-    timer.active = True
     t0 = time.perf_counter()
     for i in range(args.steps):
         iteration(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    timer.active = False
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    done = args.warmup + args.steps
+
+    # kernel pass (not `value`): the same iterations with everything on ONE stream and an event bracket around every launch
+    # of the tracked kernels.  The timed region above runs the step's independent branches on two streams: two kernels then
+    # share the CUs and the duration of either says how the chip was shared, not how good the kernel is.
+    kernel_ms_per_step = None
+    if not args.no_kernel_timing and args.kernel_steps > 0:
+        # (the parameters' AccumulateGrad nodes remember the stream of their first use; moving a branch back to the main stream
+        # for this pass makes autograd point that out once per parameter -- it is the intent here)
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        prev = os.environ.get("SAE_TWO_STREAMS")
+        os.environ["SAE_TWO_STREAMS"] = "0"
+        try:
+            iteration(done)
+            fence()
+            timer.active = True
+            t0 = time.perf_counter()
+            for i in range(args.kernel_steps):
+                iteration(done + 1 + i)
+            fence()
+            kernel_ms_per_step = (time.perf_counter() - t0) / args.kernel_steps * 1e3
+            timer.active = False
+        finally:
+            if prev is None:
+                os.environ.pop("SAE_TWO_STREAMS", None)
+            else:
+                os.environ["SAE_TWO_STREAMS"] = prev
+        done += 1 + args.kernel_steps
 
     # the same iterations with the other conv arithmetic (not `value`)
     alt = None
@@ -630,11 +661,11 @@ def main():
         other = "bf16x6" if args.conv_math == "f32" else "f32"
         hip_lib.set_conv_math(other)
         for i in range(2):                       # workspaces change size with the arithmetic: let the allocator settle
-            iteration(args.warmup + args.steps + i)
+            iteration(done + i)
         fence()
         t0 = time.perf_counter()
         for i in range(args.alt_steps):
-            iteration(args.warmup + args.steps + 2 + i)
+            iteration(done + 2 + i)
         fence()
         adt = time.perf_counter() - t0
         hip_lib.set_conv_math(args.conv_math)
@@ -671,8 +702,8 @@ def main():
         every = opt.R1_once_every
         r1_in_window = sum(1 for j in range(args.warmup + 1, args.warmup + args.steps + 1) if j % every == 0)
         line["r1_iterations_in_window"] = r1_in_window
-        d_calls = sorted(call_ms["d"][args.warmup:])
-        g_calls = sorted(call_ms["g"][args.warmup:])
+        d_calls = sorted(call_ms["d"][args.warmup:args.warmup + args.steps])
+        g_calls = sorted(call_ms["g"][args.warmup:args.warmup + args.steps])
         if d_calls and g_calls:
             # median D call (without the lazy R1 extra), median G call, and the R1 surcharge of the slowest D call
             line["ms_d_call_median"] = round(d_calls[len(d_calls) // 2], 2)
@@ -696,10 +727,14 @@ def main():
             else:
                 line["value_note"] = ("no lazy-R1 call fell into the timed window: value EXCLUDES the R1 surcharge of SURVEY 8d's "
                                       "metric (use --steps 16 or more)")
-        roof, by_kernel = timer.summary(args.conv_math, args.steps)
+        roof, by_kernel = timer.summary(args.conv_math, max(args.kernel_steps, 1))
         if roof:
+            roof["note"] = ("launch durations from the kernel pass: %d further iterations with the step on ONE stream "
+                            "(SAE_TWO_STREAMS=0, %.1f ms per step) -- in the timed region the step's branches run on two streams and "
+                            "kernels overlap; " % (args.kernel_steps, kernel_ms_per_step)) + roof["note"]
             line["roofline"] = roof
             line["roofline_by_kernel"] = by_kernel
+            line["ms_per_step_one_stream"] = round(kernel_ms_per_step, 3)
         if world == 1 and args.dropin_steps > 0 and not args.force_allreduce:
             line["via_dropin"] = via_dropin_leg(args, line)
         if world == 1 and not args.no_cpu_baseline:
