@@ -36,6 +36,10 @@ def _desc(arg):
 
 def work_of(name, a):
     """(class label, bound, algorithmic work: FLOPs for 'mfma', bytes for 'hbm')"""
+    if name == "conv2d_wprep_query":
+        return name, "hbm", 0.0
+    if name == "conv2d_wprep_f32":        # prepared weights (stylegan2_op/weight_prep.py): the layout is written once, the parameter read once
+        return "weight re-layout kept across launches (sae_conv2d_wprep_f32)", "hbm", 8.0 * a[6]
     if (name.startswith("conv2d_") and name != "conv2d_workspace") or name.startswith("modconv2d_"):
         d = _desc(a[6] if name == "modconv2d_fwd_noise_bias_act_f32" else
                   a[4] if name in ("conv2d_fwd_bias_act_f32", "conv2d_fwd_residual_f32") else a[3])
@@ -122,7 +126,7 @@ class Ledger:
         orig = lib.call
 
         def call(name, *args):
-            if not self.active or name in ("set_conv_math",):
+            if not self.active or name in ("set_conv_math", "conv2d_wprep_query"):
                 return orig(name, *args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
