@@ -30,6 +30,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before the HIP runtime starts (see swapping_autoencoder_pytorch_amd/__init__.py: streams that share a hardware queue serialise)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
 # HBM-side traffic of the dominant kernel: read from the committed counter summary (tools/run_pmc.sh -> tools/pmc_summary.py

@@ -395,6 +395,7 @@ def _init_distributed():
 
 
 def main(argv=None):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # (package __init__: the step's two streams need queues of their own)
     pin_rank_device()           # first: before anything can initialise the HIP runtime
     argv = list(sys.argv[1:] if argv is None else argv)
     if len(argv) < 2:

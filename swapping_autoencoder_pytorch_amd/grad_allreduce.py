@@ -121,9 +121,9 @@ class GradAllReducer:
             slot.copy_(p.grad.reshape(-1))
         b.pending -= 1
         if b.pending == 0:
-            from .streams import order_after_all
-            order_after_all(b.flat.device)      # the bucket's other gradients may come from the step's second stream
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            from .streams import collective_launch
+            with collective_launch(b.flat):     # ordered after BOTH streams of the step: the other gradients may come from either
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _release_destinations(self):
         for b in self.buckets:
