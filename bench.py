@@ -15,7 +15,7 @@ Also reported on the same JSON line:
   roofline     – dominant kernel (3x3 stride-1 implicit-GEMM conv, conv_igemm_kernel<3,1,2,2,1,4,8,false,true>):
                  algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
                  launch stream inside the timed region, against the fp32 MFMA peak (157.3 TFLOP/s); `traffic` from the
-                 committed counter record profiles/r3_pmc_dominant.json (refused if it names another kernel);
+                 committed counter record profiles/r4_pmc_dominant.json (refused if it names another kernel);
   roofline_by_kernel – the same event-timed fraction for the second-tier MFMA classes (stride-2 data gradient,
                  stride-2 forward, both weight gradients) next to the dominant one;
   cpu_baseline – the reference's CPU path (ATen on all host cores, restated in oracle/aten_cpu_path.py and pinned
@@ -39,7 +39,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, 
 # those 128-byte requests at 64 B, the x2 correction of the guide, confirmed on a 1 GiB copy in the same passes), writes =
 # TCC_EA0_WRREQ_64B x 64 B + the remaining write requests x 32 B, on the kernel's reference launch (128 -> 128 3x3 @256x256
 # B=16).  Counters cannot be read inside a timed run; the figure is scaled to the average launch of the timed region by FLOPs.
-PMC_DOMINANT_FILE = os.path.join(ROOT, "profiles", "r3_pmc_dominant.json")
+PMC_DOMINANT_FILE = os.path.join(ROOT, "profiles", "r4_pmc_dominant.json")
 DOMINANT_KERNEL = "conv_igemm_kernel<3,1,2,2,1,4,8,false,true>"
 
 
