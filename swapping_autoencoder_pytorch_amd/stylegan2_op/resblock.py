@@ -188,7 +188,10 @@ class ResBlockFunction(Function):
             return _input_grad_graph(ctx, gout, nargs, need)
         if torch.is_grad_enabled():
             # create_graph=True with weight gradients in the graph: differentiate the composition of differentiable
-            # operators (one extra forward of the block; no training path takes this branch)
+            # operators (one extra forward of the block).  Neither this package's model nor the drop-in runner reaches this
+            # branch -- both evaluate the R1 penalty under input_grads_only() (swapping_autoencoder_model.compute_R1_loss,
+            # dropin.wrap_reference_r1 for the reference's own model file); it serves callers that differentiate a block
+            # twice without saying that only the input gradient matters
             slots = {0: x, 1: w1, 2: b1, 3: w2, 4: b2, 5: ws, 7: w0, 8: b0}
             wanted = [i for i, t in slots.items() if t is not None and need[i] and (i == 0 or wflag)]
             with torch.enable_grad():
