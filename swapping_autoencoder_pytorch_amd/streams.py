@@ -19,6 +19,7 @@ import os
 import torch
 
 _SIDE = {}
+_SILENCED = [False]
 _MAIN = {}      # the stream the step itself runs on, as seen at the last fork
 
 
@@ -51,6 +52,14 @@ class side_branch:
             self.main = torch.cuda.current_stream(dev)
             self.side = side_stream(dev)
             _MAIN[(dev.type, dev.index if dev.index is not None else torch.cuda.current_device())] = self.main
+            if not _SILENCED[0]:
+                # a module used by both branches of a pair (the generator) has its gradients summed on the stream of its first
+                # use, the other branch's contribution crossing over: autograd points that out once per process as a possible
+                # oversight; here it is the design (the sum needs both anyway)
+                _SILENCED[0] = True
+                quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+                if quiet is not None:
+                    quiet(False)
             self.side.wait_stream(self.main)
             for t in self.inputs:
                 t.record_stream(self.side)
