@@ -3601,6 +3601,27 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
             g.ksplit = ceil_div(nchunks, g.cps);
         }
     }
+    // Mid-size launches of the exact-fp32 3x3 kernels: a few ROUNDS of workgroups on the 512 slots of the chip (two per CU), the
+    // last one mostly empty -- 512 -> 512 @32^2 with 24 images is 768 workgroups = two rounds for 1.5 rounds of work (0.67 of peak
+    // where the same layer with 16 images, exactly one round, reaches 0.83).  Splitting K in two makes it three rounds of half
+    // the length.  Priced in microseconds: a round of one chunk ~ 7.7 us (144 MFMAs x 64 cycles for each of the two waves of a
+    // SIMD), the slabs and their fixed-order reduction ~ (2 k + 1) x output bytes at 4 TB/s + a launch.
+    static const int rounds_knob = tuning_knob("SAE_IGEMM_ROUND_SPLIT", 1);
+    if (rounds_knob && g.ksplit == 1 && !scatter && conv_math() == 0 && ks == 3 && blocks >= 192 && blocks < 4096 && nchunks >= 16 &&
+        ((int64_t)N * mout * OH * OW) % 4 == 0) {
+        const double out_bytes = 4.0 * (double)N * mout * OH * OW;
+        auto cost = [&](int k) {
+            const double rounds = (double)ceil_div(blocks * k, 512);
+            return rounds * ceil_div(nchunks, k) * 7.7 + (k > 1 ? (2 * k + 1) * out_bytes / 4e6 + 5.0 : 0.0);
+        };
+        int best = 1;
+        for (int k = 2; k <= 4; ++k)
+            if (cost(k) < cost(best)) best = k;
+        if (best > 1 && cost(best) < 0.93 * cost(1)) {
+            g.cps = ceil_div(nchunks, best);
+            g.ksplit = ceil_div(nchunks, g.cps);
+        }
+    }
     g.wp_floats = (int64_t)g.taps * g.Cp * g.Mp;
     // bf16x6: the 128-row tile (8-wave or 4-wave kernel) and, on the 4-wave kernel, the 64- and 32-row tiles of the
     // narrow layers (cfg 1: 64 x 256, cfg 4: 32 x 256)

@@ -405,8 +405,17 @@ def main(argv=None):
     from . import hip_lib
     hip_lib.get()               # fail loudly before anything else if the HIP library is not built
     install_missing_dependency_stubs()
-    preseed()
+    level = preseed()
     patch_util()
+    if int(os.environ.get("RANK", "0")) == 0:
+        # say it once: at the higher levels edits to the checkout's own network / model files are NOT what runs
+        print("[sae dropin] pre-seed level %r: %s come from swapping_autoencoder_pytorch_amd (SAE_DROPIN_LEVEL=layers keeps the "
+              "checkout's own networks and model on the MI355X layer library)"
+              % (level, {"layers": "models.networks.stylegan2_op / stylegan2_layers",
+                         "networks": "the operator / layer library and models.networks.{encoder,generator,discriminator,"
+                                     "patch_discriminator}",
+                         "full": "the operator / layer library, the four networks and models.swapping_autoencoder_model"}[level]),
+              file=sys.stderr)
     inject_synthetic_dataset()
     if os.environ.get("SAE_DROPIN_ADAM", "1") != "0":
         # the reference constructs torch.optim.Adam(params, lr=, betas=) (optimizers/swapping_autoencoder_optimizer.py:

@@ -32,6 +32,11 @@ SHAPES = [  # n, c, h, w, m, k, s, p, tag
     (128, 32, 129, 129, 64, 3, 2, 0, "Dp s2 32->64@129"),
     (16, 128, 256, 256, 256, 1, 1, 0, "1x1 128->256@256"),
     (16, 512, 64, 64, 256, 1, 1, 0, "1x1 512->256@64"),
+    # mid-size launches: a few rounds of workgroups (the image discriminator's batches of 24 / 40)
+    (24, 512, 32, 32, 512, 3, 1, 1, "s1 512@32 n24"),
+    (40, 512, 32, 32, 512, 3, 1, 1, "s1 512@32 n40"),
+    (24, 512, 64, 64, 512, 3, 1, 1, "s1 512@64 n24"),
+    (24, 512, 65, 65, 512, 3, 2, 0, "s2 512->512@65 n24"),
     # the small 2^k + 1 grids of the stride-2 data gradients (q grids 33, 17 wide)
     (16, 512, 33, 33, 512, 3, 2, 0, "s2 512->512@33"),
     (40, 512, 65, 65, 512, 3, 2, 0, "s2 512->512@65 n40"),
