@@ -46,13 +46,14 @@ class input_grads_only:
 
 class _Geom:
     """Immutable description of one conv problem (forward orientation) + weight layout."""
-    __slots__ = ("n", "c", "h", "w", "m", "k", "stride", "pad", "oh", "ow", "cm_layout", "alpha")
+    __slots__ = ("n", "c", "h", "w", "m", "k", "stride", "pad", "oh", "ow", "cm_layout", "alpha", "key")
 
     def __init__(self, n, c, h, w, m, k, stride, pad, cm_layout, alpha):
         self.n, self.c, self.h, self.w, self.m, self.k = n, c, h, w, m, k
         self.stride, self.pad, self.cm_layout, self.alpha = stride, pad, cm_layout, float(alpha)
         self.oh = (h + 2 * pad - k) // stride + 1
         self.ow = (w + 2 * pad - k) // stride + 1
+        self.key = (n, c, h, w, m, k, stride, pad, bool(cm_layout))      # what the descriptor is built from (weight_prep's memo)
         if self.oh < 1 or self.ow < 1:
             raise hip_lib.SaeError("conv2d: empty output for input %dx%d k=%d stride=%d pad=%d" % (h, w, k, stride, pad))
 
@@ -82,7 +83,7 @@ def _launch(name, op, geom, a, b, out_shape, out=None):
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=a.device)
     if out is None or tuple(out.shape) != tuple(out_shape):
         out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
-    prepared = weight_prep.attach(lib, d, None, op, b, geom.alpha) if op != SAE_CONV_WGRAD else None   # noqa: F841 (kept alive)
+    prepared = weight_prep.attach(lib, d, None, op, b, geom.alpha, gkey=geom.key) if op != SAE_CONV_WGRAD else None   # noqa: F841 (kept alive)
     lib.call(name, a.data_ptr(), b.data_ptr(), out.data_ptr(), C.byref(d), geom.alpha, ws.data_ptr(), n_ws,
              lib.stream(a))
     return out
@@ -98,7 +99,7 @@ def _launch_fused(geom, x, w, bias, slope, scale):
     n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
     out = torch.empty((geom.n, geom.m, geom.oh, geom.ow), dtype=torch.float32, device=x.device)
-    prepared = weight_prep.attach(lib, d, None, SAE_CONV_FWD, w, geom.alpha)   # noqa: F841
+    prepared = weight_prep.attach(lib, d, None, SAE_CONV_FWD, w, geom.alpha, gkey=geom.key)   # noqa: F841
     lib.call("conv2d_fwd_bias_act_f32", x.data_ptr(), w.data_ptr(), hip_lib.ptr(bias), out.data_ptr(), C.byref(d),
              geom.alpha, float(slope), float(scale), ws.data_ptr(), n_ws, lib.stream(x))
     return out
@@ -118,7 +119,7 @@ def _launch_residual(geom, x, w, residual, res_scale):
     n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
     out = torch.empty_like(residual)
-    prepared = weight_prep.attach(lib, d, None, SAE_CONV_FWD, w, geom.alpha)   # noqa: F841
+    prepared = weight_prep.attach(lib, d, None, SAE_CONV_FWD, w, geom.alpha, gkey=geom.key)   # noqa: F841
     lib.call("conv2d_fwd_residual_f32", x.data_ptr(), w.data_ptr(), residual.data_ptr(), out.data_ptr(), C.byref(d), geom.alpha,
              float(res_scale), ws.data_ptr(), n_ws, lib.stream(x))
     return out
@@ -265,7 +266,7 @@ def _launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_
     out = torch.empty(out_shape, dtype=torch.float32, device=a.device)
     if op != SAE_CONV_WGRAD:
         tag = () if (wm_scale is None and wc_scale is None) else factor_tag
-        prepared = weight_prep.attach(lib, d, mod, op, b, geom.alpha, tag)   # noqa: F841
+        prepared = weight_prep.attach(lib, d, mod, op, b, geom.alpha, tag, gkey=geom.key)   # noqa: F841
     lib.call(name, a.data_ptr(), b.data_ptr(), out.data_ptr(), C.byref(d), C.byref(mod), geom.alpha, ws.data_ptr(), n_ws,
              lib.stream(a))
     return out
@@ -407,7 +408,7 @@ class StyledModConv(Function):
         ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
         out = torch.empty((geom.n, geom.m, geom.oh, geom.ow), dtype=torch.float32, device=x.device)
         ctx.factor_tag = ("demod", float(demod_alpha), float(demod_eps)) if demod_eps is not None else ()
-        prepared = weight_prep.attach(lib, d, mod, SAE_CONV_FWD, w, geom.alpha, ctx.factor_tag)   # noqa: F841
+        prepared = weight_prep.attach(lib, d, mod, SAE_CONV_FWD, w, geom.alpha, ctx.factor_tag, gkey=geom.key)   # noqa: F841
         lib.call("modconv2d_fwd_noise_bias_act_f32", x.data_ptr(), w.data_ptr(), noise.data_ptr(), noise_weight.data_ptr(),
                  hip_lib.ptr(bias), out.data_ptr(), C.byref(d), C.byref(mod), geom.alpha, float(slope), float(scale),
                  ws.data_ptr(), n_ws, lib.stream(x))

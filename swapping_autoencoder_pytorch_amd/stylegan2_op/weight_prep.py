@@ -37,7 +37,7 @@ def invalidate():
     _ENTRIES.clear()
 
 
-def attach(lib, d, mod, op, w, alpha, tag=()):
+def attach(lib, d, mod, op, w, alpha, tag=(), gkey=None):
     """Point descriptor `d` at prepared weights for the launch (d, mod, op) on weight tensor `w`, preparing them if the cached
     copy is missing or older than the parameter.  `tag`: hashable identity of the weight FACTORS in `mod` as a function of the
     parameter (() = none); a launch whose factors are not a function of the parameter alone must not be cached (tag None).
@@ -48,7 +48,10 @@ def attach(lib, d, mod, op, w, alpha, tag=()):
     if not isinstance(base, torch.nn.Parameter):
         return None
     # (the conv arithmetic is a process-wide switch of the library: bf16x6 lays the weights out as split cells)
-    qkey = (id(lib), lib.query("get_conv_math"), d.key(), op, bool(mod is not None and (mod.x_scale or mod.y_scale)))
+    # (gkey: the caller's own hashable form of the descriptor's geometry -- reading 13 fields back out of the ctypes struct costs
+    # more than the rest of this function)
+    qkey = (id(lib), lib.query("get_conv_math"), gkey if gkey is not None else d.key(), op,
+            bool(mod is not None and (mod.x_scale or mod.y_scale)))
     q = _QUERIES.get(qkey)
     if q is None:
         floats, layout = C.c_int64(0), C.c_int64(0)
