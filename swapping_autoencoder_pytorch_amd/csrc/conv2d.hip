@@ -3450,6 +3450,41 @@ struct WgPlan {
     WgShape sh; int tw_log2, th_log2; int tiles_x, tiles_y, tiles_n; int chunks, cps, slices; int Ap, Bp; int taps;
     bool bx; int tw8_log2;   // bf16-split arithmetic: tiles of TH rows x (8 << tw8_log2) columns
 };
+// Number of K slices of a weight-gradient launch.  "Fill the chip once" (256 / tiles, 512 / tiles for the kernel that runs two
+// workgroups per CU) is right when the tile count divides the slots; Dpatch's 384- and 768-channel layers have 24 ... 144 tiles
+// and it is not: 256 -> 384 @8^2, 384 images: 24 tiles x 11 slices = 264 workgroups = one full round of the 256 CUs and a
+// second one for the last eight (0.39 of peak, profiles/r4_roofline_by_shape_church256.txt).  The candidates are priced in
+// microseconds -- rounds of workgroups x chunks per slice x one chunk (4.7 MFLOP on a CU's matrix cores at the 0.8 the kernels
+// reach), plus the slabs written and read back by the fixed-order reduction at 4 TB/s -- and the cheapest one runs, if it
+// is at least 7 % cheaper than the plain rule's.  A last round with at most one workgroup per CU of the two-per-CU kernel is
+// priced at 0.6 (a workgroup that has its CU to itself runs that much faster; 384 -> 384 @8^2: 576 workgroups, model 0.71 ms,
+// measured 0.70).
+int wg_pick_slices(int tiles, int chunks, bool two_per_cu, int64_t slab_floats, int plain) {
+    static const int knob = tuning_knob("SAE_WGRAD_SLICE_MODEL", 1);
+    if (!knob || tiles < 1 || chunks < 2) return plain;
+    const int slots = two_per_cu ? 512 : 256;
+    constexpr double kChunkUs = 9.4;
+    auto cost = [&](int s) {
+        const int cps = ceil_div(chunks, s);
+        const int eff = ceil_div(chunks, cps);            // slices that exist with this length
+        const int64_t wgs = (int64_t)tiles * eff;
+        const int64_t full = wgs / slots, rem = wgs - full * slots;
+        double rounds = (double)full;
+        if (rem > 0) rounds += (two_per_cu && rem <= 256) ? 0.6 : 1.0;
+        double us = rounds * cps * kChunkUs + (2.0 * eff + 1.0) * 4.0 * (double)slab_floats / 4e6;
+        if (two_per_cu && (eff & 7) != 0) us *= 1.02;     // the XCD-aware order of that kernel wants a multiple of eight
+        return us;
+    };
+    int best = plain;
+    double best_us = cost(plain);
+    const int hi = chunks < 96 ? chunks : 96;
+    for (int s = 1; s <= hi; ++s) {
+        const double us = cost(s);
+        if (us < best_us) { best_us = us; best = s; }
+    }
+    return best_us < 0.93 * cost(plain) ? best : plain;
+}
+
 // wg16: the plan of conv_wgrad16_kernel (64 a x 32 b workgroup tiles, two workgroups per CU) for a 3 x 3 layer
 WgPlan wg_plan(const sae_conv2d_desc* d, bool wg16 = false) {
     WgPlan w{};
@@ -3491,6 +3526,8 @@ WgPlan wg_plan(const sae_conv2d_desc* d, bool wg16 = false) {
     if (wg16) slices = round_up(slices, 8);       // (the XCD-aware order needs slices % 8 == 0)
     if (slices > w.chunks) slices = w.chunks;
     if (slices < 1) slices = 1;
+    if ((w.sh.mode == 0 || wg16) && !w.bx && w.taps == 9)     // (the 1x1 layers are HBM-bound: another model)
+        slices = wg_pick_slices(mn_tiles, w.chunks, wg16, (int64_t)w.taps * w.Ap * w.Bp, slices);
     w.cps = ceil_div(w.chunks, slices);
     // keep a K slice inside one image where the images are large (>= 32 chunks of 64 pixels): the factors of a
     // style-modulated operand can then be applied per slice in the reduction and the main kernel stays the plain

@@ -375,3 +375,16 @@ def test_new_ops_accept_empty_batches_and_reject_bad_geometry(emu_lib, oracle_li
             H.reflect_pad(lib, np.zeros((1, 1, 3, 3), np.float32), (3, 0, 0, 0))      # pad >= size
         with pytest.raises(Exception):
             H.random_crop(lib, np.zeros((1, 1, 4, 4), np.float32), np.zeros((1, 5), np.float32), 1, 1)   # size < 2
+
+
+def test_weight_gradient_slices_follow_the_rounds_of_workgroups(emu_lib):
+    """wg_pick_slices (csrc/conv2d.hip): the K slices of a 3x3 weight gradient are priced by rounds of workgroups.  Dpatch's
+    256 -> 384 stride-2 layer has 3 x 8 = 24 tiles of 128 x 32: "fill the 256 CUs once" gives 11 slices = 264 workgroups, one
+    full round and a second one for eight of them; 10 slices (240) is one round.  The workspace query (a pure host function,
+    slices x 9 x Ap x Bp floats) shows the plan."""
+    import ctypes as C
+    for (n, c, h, m, s, p), slices in [((384, 256, 17, 384, 2, 0), 10), ((384, 384, 8, 384, 1, 1), 7),
+                                       ((384, 768, 4, 384, 1, 0), 7), ((16, 128, 64, 128, 1, 1), 64)]:
+        d = H.conv_desc(n, c, h, h, m, 3, s, p, False)
+        slab = 9 * ((m + 63) // 64 * 64) * ((c + 31) // 32 * 32)
+        assert emu_lib.query("conv2d_workspace", C.byref(d), 2) == slices * slab, (n, c, h, m, s)
