@@ -109,6 +109,14 @@ __device__ unsigned long long g_clock_probe[16];
 #define SAE_IGEMM_AHEAD 1
 #endif
 constexpr int kIgemmAhead = SAE_IGEMM_AHEAD;
+// Workgroups per CU the 1x1 instantiations of the gather are compiled for (register budget 512 / this).  Their K loops are 4 - 16
+// chunks long and the layers are close to HBM-bound (fwd + residual 128 -> 256 @128^2 moves 1.7 GB for 43 GFLOP): a third
+// workgroup per CU hides more of each one's load -> store round trip than the dozen spilled registers cost -- same-box A/B
+// (tools/ab_conv.py, profiles/r4_ab_1x1_occupancy.txt): fwd 84 -> 92, 90 -> 93, 102 -> 111, 91 -> 101 TFLOP/s, dgrad 96 -> 104,
+// 102 -> 107, 107 -> 116, 92 -> 101; four (128 registers) spills the accumulators: 58 - 83.
+#ifndef SAE_IGEMM_1X1_WAVES
+#define SAE_IGEMM_1X1_WAVES 3
+#endif
 
 struct IgemmParams {
     int N, C, H, W;       // input tensor; C = contraction channels
@@ -163,7 +171,7 @@ template <int KS, int S, int MI, int NI, int WM, int WN, int CK, bool MOD = fals
 // (measured and dropped: __launch_bounds__(kBlock, 2) for the 64-accumulator tiles -- it brings the modulated stride-2
 // instantiations, 8 registers over budget, back to two waves per SIMD with 11-16 spilled registers; their time did not move
 // (5.16 ms per iteration either way) and the step got 0.7 % slower, the other instantiations' allocation changes with it)
-__global__ __launch_bounds__(kBlock) void conv_igemm_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(kBlock, (KS == 1 ? (MOD ? 2 : SAE_IGEMM_1X1_WAVES) : 1)) void conv_igemm_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ wp,
                                                             float* __restrict__ y, const IgemmParams p) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -3576,6 +3584,9 @@ __global__ __launch_bounds__(kBlock) void conv_splitk_reduce_kernel(const float*
     }
 }
 
+#ifndef SAE_IGEMM_SPLIT_MODEL_DEFAULT
+#define SAE_IGEMM_SPLIT_MODEL_DEFAULT 1
+#endif
 // Launch plan of a forward-type gather: tile shape, K split and workspace layout
 // [ wp : taps*Cp*Mp ][ slabs : ksplit * round4(N*M*OH*OW) ]  (slabs only when ksplit > 1).
 struct GatherPlan {
@@ -3655,6 +3666,31 @@ GatherPlan gather_plan(int N, int cin, int mout, int OH, int OW, int ks, int str
         for (int k = 2; k <= 4; ++k)
             if (cost(k) < cost(best)) best = k;
         if (best > 1 && cost(best) < 0.93 * cost(1)) {
+            g.cps = ceil_div(nchunks, best);
+            g.ksplit = ceil_div(nchunks, g.cps);
+        }
+    }
+    // One price list for both rules above (exact-fp32 3x3, fewer than 4096 workgroups): k = 1 ... 16 slices, a last round with at
+    // most one workgroup per CU priced at 0.6 of a round (a workgroup that has its CU to itself runs that much faster: 512 -> 512
+    // @32^2 with 8 images, 256 workgroups, reaches 0.76 of peak where two per CU share 0.83)
+    // Same box, tools/ab_conv.py (profiles/r4_ab_plan_models.txt): launches of fewer than 192 workgroups gain (512 -> 512 @8^2, 24
+    // images: fwd 69 -> 78, dgrad 78 -> 88 TFLOP/s; @4^2, 40 images: 44 -> 49, 51 -> 59), the 192-workgroup ones (k 2 -> 4) lose 1 - 2 %:
+    // the list replaces the first rule only.  (knob 2: both)
+    static const int model_knob = tuning_knob("SAE_IGEMM_SPLIT_MODEL", SAE_IGEMM_SPLIT_MODEL_DEFAULT);
+    if (model_knob && !scatter && conv_math() == 0 && ks == 3 && blocks < (model_knob == 2 ? 4096 : 192) && nchunks >= 8 &&
+        ((int64_t)N * mout * OH * OW) % 4 == 0) {
+        const double out_bytes = 4.0 * (double)N * mout * OH * OW;
+        auto cost = [&](int k) {
+            const int cps = ceil_div(nchunks, k), eff = ceil_div(nchunks, cps);
+            const int64_t wgs = (int64_t)blocks * eff, full = wgs / 512, rem = wgs - full * 512;
+            const double rounds = (double)full + (rem > 0 ? (rem <= 256 ? 0.6 : 1.0) : 0.0);
+            return rounds * cps * 9.3 + (eff > 1 ? (2 * eff + 1) * out_bytes / 4e6 + 5.0 : 0.0);
+        };
+        int best = g.ksplit;
+        const int kmax = nchunks / 4 < 16 ? nchunks / 4 : 16;
+        for (int k = 1; k <= kmax; ++k)
+            if (cost(k) < cost(best)) best = k;
+        if (best != g.ksplit && cost(best) < 0.93 * cost(g.ksplit)) {
             g.cps = ceil_div(nchunks, best);
             g.ksplit = ceil_div(nchunks, g.cps);
         }

@@ -42,6 +42,19 @@ SHAPES = [  # n, c, h, w, m, k, s, p, tag
     (40, 512, 65, 65, 512, 3, 2, 0, "s2 512->512@65 n40"),
     (128, 64, 65, 65, 128, 3, 2, 0, "Dp s2 64->128@65"),
     (128, 128, 33, 33, 256, 3, 2, 0, "Dp s2 128->256@33"),
+    # Dpatch's 384- / 768-channel tail with the discriminator step's 384 crops: tile counts that do not divide the CUs
+    (384, 256, 17, 17, 384, 3, 2, 0, "Dp3 s2 256->384@17"),
+    (384, 384, 8, 8, 384, 3, 1, 1, "Dp3 s1 384@8"),
+    (384, 384, 9, 9, 384, 3, 2, 0, "Dp3 s2 384@9"),
+    (384, 384, 4, 4, 384, 3, 1, 1, "Dp3 s1 384@4"),
+    (384, 384, 4, 4, 768, 3, 1, 1, "Dp3 s1 384->768@4"),
+    (384, 768, 4, 4, 384, 3, 1, 0, "Dp3 s1 768->384@4"),
+    (40, 128, 128, 128, 256, 1, 1, 0, "1x1 128->256@128 n40"),
+    (40, 256, 64, 64, 512, 1, 1, 0, "1x1 256->512@64 n40"),
+    (40, 512, 32, 32, 512, 1, 1, 0, "1x1 512->512@32 n40"),
+    (24, 512, 16, 16, 512, 3, 1, 1, "s1 512@16 n24"),
+    (24, 512, 8, 8, 512, 3, 1, 1, "s1 512@8 n24"),
+    (40, 512, 4, 4, 512, 3, 1, 1, "s1 512@4 n40"),
 ]
 
 
