@@ -677,6 +677,283 @@ __global__ __launch_bounds__(kBlock, (KS == 1 ? (MOD ? 2 : SAE_IGEMM_1X1_WAVES) 
     SAE_CLOCK_END
 }
 
+#ifdef SAE_TUNING
+// ------------------------------------------------------------------------------------------
+// Wave-specialised form of the quad-staged 3x3 stride-1 gather ("ws"): six waves per workgroup -- four CONSUMER waves with the
+// K loop of conv_igemm_kernel and not one vector-memory instruction in it, two PRODUCER waves that do nothing but move the next
+// chunk global -> LDS by DMA (global_load_lds_dwordx4) into the other of two staging buffers.  One barrier per chunk.
+//
+// Why: in conv_igemm_kernel every wave issues its share of the chunk's loads (9 - 11 dwordx4 per 144 MFMAs) between two
+// barriers; a wave64 vector-memory instruction occupies the CU's one address path for ~28 cycles and the eight waves of a CU
+// issue theirs together, so a wave spends 14 - 17 % of its time in that phase and 4 - 5 % writing LDS
+// (profiles/r2_phase_clock_quad.txt); the probe kernel loses 8 % of the matrix pipe to the loads alone
+// (profiles/r2_mfma_clock_probe.txt: barrier only 0.977, loads + barrier 0.899).  The 8-wave kernel of round 2
+// (conv_igemm_f8_kernel) moved the weights to DMA but left every wave its input loads and ran one workgroup per CU: 3 % slower.
+// Here the MFMA waves wait for nothing but the barrier, and two workgroups per CU (3 waves per SIMD, 168 registers) still
+// cover each other's prologue and epilogue.
+//
+//   * LDS: two buffers of [A: 9 taps x 8 channels x BM][X: 8 channel rows of XCAP + 64], the layouts of conv_igemm_kernel
+//     (QUAD): 2 x 38.9 KB for the 64 x 256 tile, two workgroups per CU = 156 of the 160 KB;
+//   * DMA data lands lane-linear (lane l of an instruction writes 16 bytes at base + 16 l): an A instruction is 64 consecutive
+//     quads of the chunk's [tap][channel][BM] block, an X instruction 64 consecutive quads of one channel's patch.  Padding
+//     quads (outside the image or the batch) are MASKED lanes: the patch areas are zeroed once and those cells never written;
+//     the rows of channels beyond C (last chunk) are zero-filled by the producer with LDS stores;
+//   * ordering: the producer waits for its own vmcnt(0), then the barrier; a consumer that has passed the barrier reads landed
+//     data.  The buffer a producer overwrites during chunk c is the one every consumer finished before the previous barrier;
+//   * MFMA operand order, accumulation order and the LDS-transposed epilogue are those of conv_igemm_kernel: bit-identical
+//     results (tests/test_ws_gather.py).  The producers take part in the epilogue's barriers and nothing else of it.
+// Plain (not style-modulated) launches with the vector epilogue and no K split; everything else stays on conv_igemm_kernel.
+//
+// MEASURED (same box, tools/ab_conv.py, profiles/r4_ab_wave_specialised.txt): 128 -> 128 @256^2 125.2 vs 131.0 TFLOP/s, 256 -> 256
+// @128^2 128.4 vs 134.1, 64 -> 64 @64^2 (128 images) 117.4 vs 124.1: 4 - 5 % SLOWER than conv_igemm_kernel.  (A first version that
+// computed both roles' state up front needed 168 registers; six waves of that size do not fit a CU twice whatever the SIMD
+// placement, one workgroup per CU ran: 116.4.  With the roles as two programs it is 95.)  The loads the MFMA waves no longer issue
+// were not what held the matrix pipe at 0.83: two workgroups per CU already cover each other's staging, and this form adds a
+// barrier that couples six waves per chunk.  A recorded experiment like conv_igemm_f8_kernel: compiled into tuning builds only
+// (-DSAE_TUNING, SAE_WS=1); the product library does not contain it.
+// ------------------------------------------------------------------------------------------
+constexpr int kBlockWs = 384;
+#ifndef SAE_WS_WAVES
+#define SAE_WS_WAVES 3          // waves per SIMD the kernel is compiled for (512 / this registers)
+#endif
+template <int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(kBlockWs, SAE_WS_WAVES) void conv_igemm_ws_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ wp,
+                                                                  float* __restrict__ y, const IgemmParams p) {
+    static_assert(WM * WN == 4, "4 consumer waves per workgroup");
+    constexpr int T = 9, CK = 8, NPROD = 2;
+    constexpr int BM = 32 * MI * WM;
+    constexpr int BN = 32 * NI * WN;
+    constexpr int XCAP = PatchCap<3, 1, BN>::value;
+    constexpr int QCAP = BN / 2;                               // quads per channel accepted by the host
+    constexpr int XK = QCAP / kWave;                           // X DMA instructions per channel
+    constexpr int XROW = XCAP + 64;
+    constexpr int AS = T * CK * BM, XS = CK * XROW, BUF = AS + XS;
+    constexpr int A_INSTR = AS / 4 / kWave;                    // A DMA instructions per chunk
+    constexpr int APW = (A_INSTR + NPROD - 1) / NPROD;         // ... per producer wave
+    static_assert((AS / 4) % kWave == 0 && QCAP % kWave == 0 && XCAP % 4 == 0 && BUF % 4 == 0, "whole wave DMAs");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    __builtin_assume(tid < kBlockWs);
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wid >= 4;
+    const int pw = wid - 4;                                    // producer index (0, 1)
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = (wid & 3) / WN, wn = (wid & 3) % WN;
+
+    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
+    const int TN = BN >> (p.tw_log2 + p.th_log2);
+    int bt = blockIdx.x;
+    int mt = blockIdx.y;
+    if (p.xcd_order) {                                         // see conv_igemm_kernel
+        const int total = gridDim.x * gridDim.y;
+        if ((total & 7) == 0) {
+            const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+            const int wk = (lin & 7) * (total >> 3) + (lin >> 3);
+            mt = wk % gridDim.y;
+            bt = wk / gridDim.y;
+        }
+    }
+    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
+    const int tiy = bt % p.tiles_y;
+    const int tin = bt / p.tiles_y;
+    const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
+    const int m0 = mt * BM;
+
+    const int PH = TH + 2;
+    const int RS = TW + 8;                                     // patch row = input columns [x0 - 4, x0 + TW + 4)
+    const int RQ = RS >> 2;
+    const int IP = PH * RS;
+    const int QI = PH * RQ, QN = TN * QI;                      // quads per image, per channel (<= QCAP, host)
+    const int HW = p.H * p.W;
+
+    // the patch areas of both buffers start as zeros: a padding quad is a masked DMA lane, its cell is never written
+    for (int i = tid; i < 2 * (XS / 4); i += kBlockWs) {
+        const int b = i / (XS / 4), e = i - b * (XS / 4);
+        *reinterpret_cast<f32x4*>(smem + b * BUF + AS + 4 * e) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    }
+
+    __syncthreads();                             // the zeros are in place
+
+    // The two roles are two straight-line programs with the same sequence of barriers (one per chunk, then two per epilogue
+    // pass); nothing computed for one role is live in the other, so the register allocation is the larger of the two, not their sum.
+    if (producer) {
+        // where this lane's cell of each DMA instruction comes from
+        unsigned qoff[XK];           // X: float offset of quad q = lane + 64 k relative to (image n0, the channel's plane)
+        bool qok[XK];
+        unsigned aoff[APW];          // A: float offset of cell e = 64 j + lane (j = pw + NPROD i) relative to (channel c0, column m0) of wp
+#pragma unroll
+        for (int k = 0; k < XK; ++k) {
+            const int q = lane + kWave * k;
+            const int pn = q / QI;
+            const int rem = q - pn * QI;
+            const int r = rem / RQ;
+            const int qc = rem - r * RQ;
+            const int iy = oy0 - p.pad + r, ix = ox0 - 4 + 4 * qc;
+            const bool in = q < QN && n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            qok[k] = in;
+            qoff[k] = in ? (unsigned)(pn * p.C * HW + iy * p.W + ix) : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < APW; ++i) {
+            const int e = (pw + NPROD * i) * kWave + lane;
+            const int row = e / (BM / 4), col4 = e - row * (BM / 4);
+            const int tap = (row / CK) < T ? row / CK : 0, ch = row - (row / CK) * CK;
+            aoff[i] = (unsigned)((tap * p.Cp + ch) * p.Mp + col4 * 4);
+        }
+        const float* xb = x + (int64_t)n0 * p.C * HW;
+        // iteration c0 (from -CK) stages chunk c0 + CK into the buffer the consumers are NOT reading
+        int buf = 0;                             // the buffer of chunk c0
+        for (int c0 = -CK; c0 < p.Cp; c0 += CK) {
+            const int cn = c0 + CK;
+            if (cn < p.Cp) {
+                float* Ab = smem + (c0 < 0 ? 0 : buf ^ 1) * BUF;
+                float* Xb = Ab + AS;
+                const float* wb = wp + (int64_t)cn * p.Mp + m0;
+#pragma unroll
+                for (int i = 0; i < APW; ++i) {
+                    const int j = pw + NPROD * i;
+                    // (source and destination through local pointers of non-dependent type: with `wb + aoff[i]` as the argument --
+                    // an element of an array whose size depends on the template parameters -- the HOST pass of hipcc drops the
+                    // kernel's stub without a diagnostic and the library fails to load with an undefined symbol)
+                    const float* src = wb + aoff[i];
+                    float* dst = Ab + j * kWave * 4;
+                    if (j < A_INSTR)
+                        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                }
+#pragma unroll
+                for (int h = 0; h < CK / NPROD; ++h) {
+                    const int ch = NPROD * h + pw;
+                    float* row = Xb + ch * XROW;
+                    if (cn + ch < p.C) {
+                        const float* xc = xb + (int64_t)(cn + ch) * HW;
+#pragma unroll
+                        for (int k = 0; k < XK; ++k) {
+                            const float* src = xc + qoff[k];
+                            float* dst = row + kWave * 4 * k;
+                            if (qok[k])
+                                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+                        }
+                    } else {        // a channel beyond C (the last chunk's tail): zeros, whatever an earlier chunk left there
+#pragma unroll
+                        for (int k = 0; k < XK; ++k)
+                            *reinterpret_cast<f32x4*>(row + 4 * (lane + kWave * k)) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA has landed (the barrier publishes it)
+            __syncthreads();
+            if (c0 >= 0) buf ^= 1;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {        // the consumers' epilogue passes
+            __syncthreads();
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---- consumer (conv_igemm_kernel, QUAD)
+    int pixbase[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const int pp = (wn * NI + ni) * 32 + l31;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> p.tw_log2) & (TH - 1);
+        const int pn = pp >> (p.tw_log2 + p.th_log2);
+        pixbase[ni] = pn * IP + py * RS + px + 4 - p.pad;
+    }
+    int tapoff[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) tapoff[t] = (t / 3) * RS + (t % 3);
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    __syncthreads();                             // chunk 0 is staged (the producers' iteration c0 = -CK)
+    int buf = 0;
+    for (int c0 = 0; c0 < p.Cp; c0 += CK) {
+        const float* As = smem + buf * BUF;
+        const float* Xs = As + AS;
+        constexpr int KK = CK / 2;
+        constexpr int NSTEP = T * KK;
+        constexpr int AH = kIgemmAhead, RING = AH + 1;
+        float ra[RING][MI], rb[RING][NI];
+        auto fetch = [&](int s, float (&a)[MI], float (&b)[NI]) {
+            const int t = s / KK, ch = 2 * (s % KK) + half;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) a[mi] = As[(t * CK + ch) * BM + (wm * MI + mi) * 32 + l31];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) b[ni] = Xs[ch * XROW + pixbase[ni] + tapoff[t]];
+        };
+#pragma unroll
+        for (int s = 0; s < AH; ++s) fetch(s, ra[s % RING], rb[s % RING]);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            if (s + AH < NSTEP) fetch(s + AH, ra[(s + AH) % RING], rb[(s + AH) % RING]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s % RING][mi], rb[s % RING][ni],
+                                                                       acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue (conv_igemm_kernel's vector epilogue; p.vec_store is a launch condition)
+    constexpr int LDC = BN + 4;
+    static_assert(BUF >= 32 * WM * LDC, "one epilogue pass fits a staging buffer");
+    constexpr int QROW = BN / 4;
+    constexpr int VPT = 32 * WM * QROW / kBlock;
+    float* Cs = smem;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + (wn * NI + ni) * 32 + l31] = acc[mi][ni][r];
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VPT; ++v) {
+            const int qi = tid + kBlock * v;
+            const int row = qi / QROW, qx = qi - row * QROW;
+            const int m = m0 + ((row >> 5) * MI + mi) * 32 + (row & 31);
+            const int pp = 4 * qx;
+            const int px = pp & (TW - 1);
+            const int py = (pp >> p.tw_log2) & (TH - 1);
+            const int pn = pp >> (p.tw_log2 + p.th_log2);
+            const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
+            if (m < p.M && n < p.N && oy < p.OH && ox < p.OW) {
+                f32x4 c = *reinterpret_cast<const f32x4*>(Cs + row * LDC + 4 * qx);
+                if (p.act) {
+                    const float bv = p.bias ? p.bias[m] : 0.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float t = c[e] + bv;
+                        c[e] = ((t > 0.0f) ? t : t * p.act_slope) * p.act_scale;
+                    }
+                }
+                const int64_t yi = (((int64_t)n * p.M + m) * p.YH + oy) * p.YW + ox;
+                *reinterpret_cast<f32x4*>(y + yi) = c;
+            }
+        }
+    }
+}
+
+#endif   // SAE_TUNING
+
 // ------------------------------------------------------------------------------------------
 // "bx" arithmetic (opt-in, sae_set_conv_math(1)): fp32 products on the bf16 matrix cores.
 //
@@ -3813,6 +4090,14 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
             break;
         case 1:
             if constexpr (KS == 3 && S == 1) {
+#ifdef SAE_TUNING      // the product build does not contain the kernel (a recorded experiment, 4 - 5 % slower)
+                static const int ws_knob = tuning_knob("SAE_WS", 0);
+                if (quad3w && ws_knob && !p.in_scale && p.vec_store && g.ksplit == 1 && !p.residual && !p.noise) {
+                    SAE_TRACE("ws 64x256 tiles=%u x %u chunks=%d", grid.x, grid.y, p.Cp / 8);
+                    hipLaunchKernelGGL((conv_igemm_ws_kernel<2, 2, 1, 4>), grid, dim3(kBlockWs), 0, s, x, wp, y, p);
+                    break;
+                }
+#endif
                 if (quad3w) {
                     if (p.in_scale) hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 2, 2, 1, 4, 8, true, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
                     else hipLaunchKernelGGL((conv_igemm_kernel<3, 1, 2, 2, 1, 4, 8, false, true>), grid, dim3(kBlock), 0, s, x, wp, y, p);
