@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 6   /* 6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
+#define SAE_ABI_VERSION 7   /* 7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -392,6 +392,26 @@ int sae_softplus_mean_bwd_f32(const float* gy, const float* x, float* gx, int64_
 int sae_adam_multi_f32(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                        const int64_t* numel, const int64_t* step, int64_t count, double lr, double beta1, double beta2,
                        double eps, double grad_scale, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Winograd F(2x2, 3x3) transforms for the 3x3 stride-1 pad-1 convolutions (F.conv2d at models/networks/stylegan2_layers.py:136,
+ * 315 -- the algorithm class the reference's cuDNN / MIOpen back end picks for these shapes).  csrc/winograd.hip has the
+ * matrices.  The 16 products of the transform domain are 1x1 convolutions: sae_conv2d_fwd_f32 with kh = kw = 1 on
+ * v + xi * planes_in * tiles (input, c channels of tiles_h x tiles_w "pixels") and u + xi * m * c (weights, [m][c]).
+ *   sae_wino_weights_f32   u[16][m][c] = alpha * (G g G^T) of w[m * w_stride_m + c * w_stride_c + tap];  flip != 0: taps
+ *                          reversed -- with the two strides swapped by the caller that is the data gradient's filter
+ *   sae_wino_input_f32     x [planes][h][w] (h, w even; zero padding of 1 implied) -> v [16][planes][h/2][w/2];
+ *                          plane_scale: NULL or one factor per plane (the style modulation of the input)
+ *   sae_wino_output_f32    md [16][planes][h/2][w/2] -> y [planes][h][w]; act != 0: y = lrelu(y + bias[plane % channels],
+ *                          slope) * act_scale (bias may be NULL), the epilogue of sae_conv2d_fwd_bias_act_f32
+ * Exact fp32; results differ from the direct kernels' by rounding only (another association of the same sums).
+ * ------------------------------------------------------------------------------------------ */
+int sae_wino_weights_f32(const float* w, float* u, int64_t m, int64_t c, int64_t w_stride_m, int64_t w_stride_c, int32_t flip,
+                         float alpha, sae_stream_t stream);
+int sae_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w,
+                       sae_stream_t stream);
+int sae_wino_output_f32(const float* md, const float* bias, float* y, int64_t planes, int64_t channels, int64_t h, int64_t w,
+                        int32_t act, float slope, float act_scale, sae_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,7 @@ typedef struct sae_conv2d_desc {
 
 static __thread char g_err[256];
 
-int oracle_abi_version(void) { return 6; }
+int oracle_abi_version(void) { return 7; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
@@ -1002,5 +1002,89 @@ int oracle_softplus_mean_bwd_f32(const float* gy, const float* x, float* gx, int
             const double dz = z > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-z));
             gx[b * inner + i] = (float)((double)gy[b] * (double)sign * dz / (double)inner);
         }
+    return SAE_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Winograd F(2x2, 3x3) transforms (include/sae_hip.h: sae_wino_*; csrc/winograd.hip).  Restated from the definition -- the
+ * three matrix products written out as loops over the published matrices (Lavin & Gray 2016, the ones cuDNN's and MIOpen's
+ * F(2x2,3x3) kernels use) in double, rounded once -- not from the kernels' factored sums.  The reference itself reaches
+ * these through F.conv2d (models/networks/stylegan2_layers.py:136,315).
+ * ------------------------------------------------------------------------------------------ */
+static const double WINO_BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+static const double WINO_G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+static const double WINO_AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+
+int oracle_wino_weights_f32(const float* w, float* u, int64_t m, int64_t c, int64_t w_stride_m, int64_t w_stride_c, int32_t flip,
+                            float alpha, sae_stream_t stream) {
+    (void)stream;
+    if (m < 1 || c < 1 || !w || !u) return set_err("oracle_wino_weights_f32: bad argument");
+    for (int64_t mi = 0; mi < m; ++mi)
+        for (int64_t ci = 0; ci < c; ++ci) {
+            const float* wp = w + mi * w_stride_m + ci * w_stride_c;
+            double g[3][3];
+            for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = (double)(alpha * wp[flip ? 8 - t : t]);
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) {
+                    double acc = 0.0;
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) acc += WINO_G[a][i] * g[i][j] * WINO_G[b][j];
+                    u[(int64_t)(4 * a + b) * m * c + mi * c + ci] = (float)acc;
+                }
+        }
+    return SAE_OK;
+}
+
+int oracle_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w,
+                          sae_stream_t stream) {
+    (void)stream;
+    if (planes < 0 || h < 2 || w < 2 || (h & 1) || (w & 1)) return set_err("oracle_wino_input_f32: the map must have even sides");
+    if (planes == 0) return SAE_OK;
+    if (!x || !v) return set_err("oracle_wino_input_f32: null tensor");
+    const int64_t th = h / 2, tw = w / 2, tiles = th * tw;
+    for (int64_t p = 0; p < planes; ++p)
+        for (int64_t ty = 0; ty < th; ++ty)
+            for (int64_t tx = 0; tx < tw; ++tx) {
+                double d[4][4];
+                for (int r = 0; r < 4; ++r)
+                    for (int q = 0; q < 4; ++q) {
+                        const int64_t iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + q;
+                        const int in = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                        d[r][q] = in ? (double)(plane_scale ? x[(p * h + iy) * w + ix] * plane_scale[p] : x[(p * h + iy) * w + ix]) : 0.0;
+                    }
+                for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) {
+                        double acc = 0.0;
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j) acc += WINO_BT[a][i] * d[i][j] * WINO_BT[b][j];
+                        v[((int64_t)(4 * a + b) * planes + p) * tiles + ty * tw + tx] = (float)acc;
+                    }
+            }
+    return SAE_OK;
+}
+
+int oracle_wino_output_f32(const float* md, const float* bias, float* y, int64_t planes, int64_t channels, int64_t h, int64_t w,
+                           int32_t act, float slope, float act_scale, sae_stream_t stream) {
+    (void)stream;
+    if (planes < 0 || channels < 1 || h < 2 || w < 2 || (h & 1) || (w & 1)) return set_err("oracle_wino_output_f32: bad shape");
+    if (planes == 0) return SAE_OK;
+    if (!md || !y) return set_err("oracle_wino_output_f32: null tensor");
+    const int64_t th = h / 2, tw = w / 2, tiles = th * tw;
+    for (int64_t p = 0; p < planes; ++p)
+        for (int64_t ty = 0; ty < th; ++ty)
+            for (int64_t tx = 0; tx < tw; ++tx)
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) {
+                        double acc = 0.0;
+                        for (int i = 0; i < 4; ++i)
+                            for (int j = 0; j < 4; ++j)
+                                acc += WINO_AT[a][i] * (double)md[((int64_t)(4 * i + j) * planes + p) * tiles + ty * tw + tx] * WINO_AT[b][j];
+                        float o = (float)acc;
+                        if (act) {
+                            o = o + (bias ? bias[p % channels] : 0.0f);
+                            o = ((o > 0.0f) ? o : o * slope) * act_scale;
+                        }
+                        y[(p * h + 2 * ty + a) * w + 2 * tx + b] = o;
+                    }
     return SAE_OK;
 }

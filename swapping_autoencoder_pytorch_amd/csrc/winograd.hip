@@ -1,0 +1,188 @@
+// Winograd F(2x2, 3x3) for the 3x3 stride-1 pad-1 convolutions of the wide layers (the transforms; the 16 products of the
+// transform domain are 1x1 convolutions on the MFMA gather of conv2d.hip).
+//
+// The reference runs these layers through F.conv2d (models/networks/stylegan2_layers.py:136,315), i.e. whatever algorithm
+// cuDNN / MIOpen picks -- for 3x3 fp32 with 256+ channels that is a Winograd variant.  A 2x2 output tile needs 16
+// multiplications per (output channel, input channel) instead of 36:
+//
+//     Y = A^T [ (G g G^T) o (B^T d B) ] A        g: 3x3 filter, d: 4x4 input tile (stride 2 between tiles), Y: 2x2 outputs
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]    G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]    A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// Unfused, three steps, each a plain tensor in HBM:
+//     V[xi][n][c][t]  = (B^T d B)[xi]              sae_wino_input_f32    (x read once, V = 4x its size written)
+//     M[xi][n][m][t]  = sum_c U[xi][m][c] V[xi][n][c][t]      16 launches of the 1x1 gather (K = C, pixels = tiles)
+//     y[n][m][2ty+a][2tx+b] = (A^T M A)[a][b]     sae_wino_output_f32   (+ optional bias + leaky-ReLU, as the fused epilogue)
+// with U[xi][m][c] = alpha (G g G^T)[xi] from sae_wino_weights_f32 (flip = 1: the filter of the data gradient, taps reversed;
+// the caller swaps the roles of the two channel strides).  The matrix work falls by 2.25; the price is moving 4x the
+// activation through HBM twice, so it pays where a layer's FLOP per activation byte are high: 256 channels and up on maps up
+// to 64 wide (estimate from the per-shape ledger: DESIGN.md 4.0f).  Exact-fp32 arithmetic throughout; the result differs from
+// the direct kernels' by rounding (different association), ~1e-6 relative -- inside the per-op tolerance of 1e-4
+// (BASELINE.json) and of the kernel tests (2e-5), but NOT bit-identical to them.
+//
+// Transform kernels: one thread per (plane, tile); consecutive threads = consecutive tiles of a row, so each of the 16
+// transform-domain planes is written / read in coalesced runs and the 2x2 outputs leave as 8-byte stores.
+#include "sae_common.h"
+
+namespace sae {
+namespace {
+
+// U[xi][m][c], xi = 4 a + b:  (G g G^T)[a][b]
+__global__ __launch_bounds__(kBlock) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int M, int C,
+                                                             int64_t sm, int64_t sc, int flip, float alpha) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)M * C) return;
+    const int m = (int)(i / C), c = (int)(i - (int64_t)m * C);
+    const float* wp = w + m * sm + c * sc;
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = alpha * wp[flip ? 8 - t : t];
+    float r[4][3];      // G g
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        r[0][k] = g[0][k];
+        r[1][k] = 0.5f * ((g[0][k] + g[2][k]) + g[1][k]);
+        r[2][k] = 0.5f * ((g[0][k] + g[2][k]) - g[1][k]);
+        r[3][k] = g[2][k];
+    }
+    const int64_t plane = (int64_t)M * C;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float u0 = r[a][0];
+        const float u1 = 0.5f * ((r[a][0] + r[a][2]) + r[a][1]);
+        const float u2 = 0.5f * ((r[a][0] + r[a][2]) - r[a][1]);
+        const float u3 = r[a][2];
+        U[(4 * a + 0) * plane + i] = u0;
+        U[(4 * a + 1) * plane + i] = u1;
+        U[(4 * a + 2) * plane + i] = u2;
+        U[(4 * a + 3) * plane + i] = u3;
+    }
+}
+
+// x: [planes][H][W] (pad 1 implied) -> V: [16][planes][TH][TW], TH = H / 2, TW = W / 2.  scale: per-plane factor or null
+// (the style modulation of a ModulatedConv2d input, stylegan2_layers.py:280-286, applied on the way).
+__global__ __launch_bounds__(kBlock) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                            const float* __restrict__ scale, int64_t planes, int H, int W) {
+    const int TH = H >> 1, TW = W >> 1;
+    const int64_t T = (int64_t)TH * TW;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= planes * T) return;
+    const int64_t pl = i / T;
+    const int t = (int)(i - pl * T);
+    const int ty = t / TW, tx = t - ty * TW;
+    const float* xp = x + pl * H * W;
+    const float s = scale ? scale[pl] : 1.0f;
+    float d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int iy = 2 * ty - 1 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ix = 2 * tx - 1 + q;
+            const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const float v = xp[in ? (int64_t)iy * W + ix : 0];
+            d[r][q] = in ? v * s : 0.0f;
+        }
+    }
+    float e[4][4];      // B^T d
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        e[0][q] = d[0][q] - d[2][q];
+        e[1][q] = d[1][q] + d[2][q];
+        e[2][q] = d[2][q] - d[1][q];
+        e[3][q] = d[1][q] - d[3][q];
+    }
+    const int64_t plane = planes * T;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        V[(4 * a + 0) * plane + i] = e[a][0] - e[a][2];
+        V[(4 * a + 1) * plane + i] = e[a][1] + e[a][2];
+        V[(4 * a + 2) * plane + i] = e[a][2] - e[a][1];
+        V[(4 * a + 3) * plane + i] = e[a][1] - e[a][3];
+    }
+}
+
+// Md: [16][planes][TH][TW] -> y: [planes][H][W]; act != 0: y = lrelu(Y + bias[plane % channels]) * act_scale
+__global__ __launch_bounds__(kBlock) void wino_output_kernel(const float* __restrict__ Md, float* __restrict__ y,
+                                                             const float* __restrict__ bias, int64_t planes, int channels,
+                                                             int H, int W, int act, float slope, float act_scale) {
+    const int TH = H >> 1, TW = W >> 1;
+    const int64_t T = (int64_t)TH * TW;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= planes * T) return;
+    const int64_t pl = i / T;
+    const int t = (int)(i - pl * T);
+    const int ty = t / TW, tx = t - ty * TW;
+    const int64_t plane = planes * T;
+    float m[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) m[a][b] = Md[(4 * a + b) * plane + i];
+    float r[2][4];      // A^T m
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        r[0][b] = (m[0][b] + m[1][b]) + m[2][b];
+        r[1][b] = (m[1][b] - m[2][b]) - m[3][b];
+    }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const float bv = (act && bias) ? bias[pl % channels] : 0.0f;
+    float* yp = y + pl * H * W + (int64_t)(2 * ty) * W + 2 * tx;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        float o0 = (r[a][0] + r[a][1]) + r[a][2];
+        float o1 = (r[a][1] - r[a][2]) - r[a][3];
+        if (act) {
+            o0 += bv; o1 += bv;
+            o0 = ((o0 > 0.0f) ? o0 : o0 * slope) * act_scale;
+            o1 = ((o1 > 0.0f) ? o1 : o1 * slope) * act_scale;
+        }
+        *reinterpret_cast<f32x2*>(yp + (int64_t)a * W) = f32x2{o0, o1};      // 2 tx is even and W is even: 8-byte aligned
+    }
+}
+
+inline unsigned blocks_for(int64_t work) {
+    const int64_t b = ceil_div64(work > 0 ? work : 1, kBlock);
+    return (unsigned)(b > 2147483647 ? 2147483647 : b);
+}
+
+}  // namespace
+}  // namespace sae
+
+using namespace sae;
+
+extern "C" int sae_wino_weights_f32(const float* w, float* u, int64_t m, int64_t c, int64_t w_stride_m, int64_t w_stride_c,
+                                    int32_t flip, float alpha, sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (m < 1 || c < 1 || m * c >= ((int64_t)1 << 31)) return fail(SAE_EINVAL, "sae_wino_weights_f32: bad shape");
+    if (!w || !u) return fail(SAE_EINVAL, "sae_wino_weights_f32: null tensor");
+    hipLaunchKernelGGL(wino_weight_kernel, dim3(blocks_for(m * c)), dim3(kBlock), 0, (hipStream_t)stream, w, u, (int)m, (int)c,
+                       w_stride_m, w_stride_c, flip ? 1 : 0, alpha);
+    return check_launch("sae_wino_weights_f32");
+}
+
+extern "C" int sae_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w,
+                                  sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (planes < 0 || h < 2 || w < 2 || (h & 1) || (w & 1) || h >= 32768 || w >= 32768)
+        return fail(SAE_EINVAL, "sae_wino_input_f32: the map must have even sides (2x2 output tiles), got %lld x %lld",
+                    (long long)h, (long long)w);
+    if (planes == 0) return SAE_OK;
+    if (!x || !v) return fail(SAE_EINVAL, "sae_wino_input_f32: null tensor");
+    hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_for(planes * (h / 2) * (w / 2))), dim3(kBlock), 0, (hipStream_t)stream, x,
+                       v, plane_scale, planes, (int)h, (int)w);
+    return check_launch("sae_wino_input_f32");
+}
+
+extern "C" int sae_wino_output_f32(const float* md, const float* bias, float* y, int64_t planes, int64_t channels, int64_t h,
+                                   int64_t w, int32_t act, float slope, float act_scale, sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (planes < 0 || channels < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || h >= 32768 || w >= 32768 ||
+        channels >= ((int64_t)1 << 31))
+        return fail(SAE_EINVAL, "sae_wino_output_f32: bad shape");
+    if (planes == 0) return SAE_OK;
+    if (!md || !y) return fail(SAE_EINVAL, "sae_wino_output_f32: null tensor");
+    if ((reinterpret_cast<uintptr_t>(y) & 7) != 0) return fail(SAE_EINVAL, "sae_wino_output_f32: y must be 8-byte aligned");
+    hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_for(planes * (h / 2) * (w / 2))), dim3(kBlock), 0, (hipStream_t)stream,
+                       md, y, bias, planes, (int)channels, (int)h, (int)w, act ? 1 : 0, slope, act_scale);
+    return check_launch("sae_wino_output_f32");
+}

@@ -43,7 +43,7 @@ class ConvMod(C.Structure):
     _fields_ = [("x_scale", C.c_void_p), ("y_scale", C.c_void_p), ("wm_scale", C.c_void_p), ("wc_scale", C.c_void_p)]
 
 
-ABI_VERSION = 6      # include/sae_hip.h: SAE_ABI_VERSION
+ABI_VERSION = 7      # include/sae_hip.h: SAE_ABI_VERSION
 
 _SIGNATURES = {
     "abi_version": (C.c_int, []),
@@ -100,6 +100,9 @@ _SIGNATURES = {
                                  C.c_double, C.c_double, C.c_double, C.c_double, _stream]),
     "upsample2x_bilinear_add_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),
     "upsample2x_bilinear_bwd_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),
+    "wino_weights_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _i64, _i64, _i32, _f32, _stream]),
+    "wino_input_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _stream]),
+    "wino_output_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i32, _f32, _f32, _stream]),
 }
 
 EXPORTED_SYMBOLS = tuple("sae_" + name for name in _SIGNATURES)

@@ -20,7 +20,7 @@ from torch.autograd import Function
 
 from .. import hip_lib
 from ..hip_lib import SAE_CONV_DGRAD, SAE_CONV_FWD, SAE_CONV_WGRAD, ConvDesc
-from . import weight_prep
+from . import weight_prep, winograd
 
 
 class _Flags:
@@ -90,6 +90,8 @@ def _launch(name, op, geom, a, b, out_shape, out=None):
 
 
 def _launch_fused(geom, x, w, bias, slope, scale):
+    if winograd.eligible(geom):
+        return winograd.conv(x, w, geom, bias=bias, act=(slope, scale))
     lib = hip_lib.get()
     x = x.contiguous()
     w = w.contiguous()
@@ -126,10 +128,14 @@ def _launch_residual(geom, x, w, residual, res_scale):
 
 
 def _fwd(x, w, g):
+    if winograd.eligible(g):
+        return winograd.conv(x, w, g)
     return _launch("conv2d_fwd_f32", SAE_CONV_FWD, g, x, w, (g.n, g.m, g.oh, g.ow))
 
 
 def _dgrad(gy, w, g):
+    if winograd.eligible(g):
+        return winograd.conv(gy, w, g, transpose=True)
     return _launch("conv2d_dgrad_f32", SAE_CONV_DGRAD, g, gy, w, (g.n, g.c, g.h, g.w))
 
 

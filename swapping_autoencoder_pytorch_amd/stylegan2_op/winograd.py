@@ -1,0 +1,78 @@
+"""Winograd F(2x2, 3x3) route for the wide 3x3 stride-1 pad-1 convolutions (csrc/winograd.hip, include/sae_hip.h: sae_wino_*).
+
+    y = output_transform( 16 x [ conv1x1( input_transform(x)[xi], U[xi] ) ] )        U = weight_transform(w)
+
+The same three C-ABI transforms serve the forward (``F.conv2d`` at models/networks/stylegan2_layers.py:136,315) and the data
+gradient (the reversed filter with the channel roles swapped); the 16 transform-domain products are calls of the existing 1x1
+MFMA gather.  2.25x fewer multiplications for two extra passes over 4x the activation: it pays on layers with many channels on
+small maps.  OFF unless ``SAE_WINOGRAD=1`` -- built and verified against the oracle this round (CPU emulator), not yet measured
+on the GPU; ``SAE_WINOGRAD_MIN_C`` (default 256) is the smallest channel count that takes it.
+Results differ from the direct kernels' by rounding (~1e-6 relative), so the route is never mixed into bit-identity checks."""
+import ctypes as C
+import os
+
+import torch
+
+from .. import hip_lib
+from ..hip_lib import SAE_CONV_FWD, ConvDesc
+
+
+def enabled():
+    return os.environ.get("SAE_WINOGRAD", "0") == "1"
+
+
+def min_channels():
+    return int(os.environ.get("SAE_WINOGRAD_MIN_C", "256"))
+
+
+def eligible(geom):
+    """3x3, stride 1, pad 1, even sides (whole 2x2 output tiles), wide enough, exact-fp32 arithmetic."""
+    if not enabled() or geom.k != 3 or geom.stride != 1 or geom.pad != 1 or (geom.h & 1) or (geom.w & 1):
+        return False
+    if min(geom.c, geom.m) < min_channels():
+        return False
+    return hip_lib.get().query("get_conv_math") == 0
+
+
+def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None):
+    """alpha * conv(x, w) (transpose=False: x is [n, c, h, w]) or alpha * conv^T(gy, w) (transpose=True: x is the output
+    gradient [n, m, h, w]), optionally followed by lrelu(. + bias) * scale (act = (slope, scale)); x_scale: [n, channels of x]
+    factors applied to the input on its way into the transform."""
+    lib = hip_lib.get()
+    x = x.contiguous()
+    w = w.contiguous()
+    bias = bias.contiguous() if bias is not None else None
+    x_scale = x_scale.contiguous() if x_scale is not None else None
+    lib.check(x, w, bias, x_scale)
+    d = geom.desc()
+    if transpose:
+        cin, cout, sm, sc, flip = geom.m, geom.c, d.w_stride_c, d.w_stride_m, 1
+    else:
+        cin, cout, sm, sc, flip = geom.c, geom.m, d.w_stride_m, d.w_stride_c, 0
+    n, h, wd = geom.n, geom.h, geom.w
+    if tuple(x.shape) != (n, cin, h, wd):
+        raise hip_lib.SaeError("winograd conv: input %s, expected (%d, %d, %d, %d)" % (tuple(x.shape), n, cin, h, wd))
+    th, tw = h // 2, wd // 2
+    tiles = th * tw
+    stream = lib.stream(x)
+    dev = x.device
+    u = torch.empty((16, cout, cin), dtype=torch.float32, device=dev)
+    lib.call("wino_weights_f32", w.data_ptr(), u.data_ptr(), cout, cin, sm, sc, flip, geom.alpha, stream)
+    v = torch.empty((16, n * cin, tiles), dtype=torch.float32, device=dev)
+    lib.call("wino_input_f32", x.data_ptr(), hip_lib.ptr(x_scale), v.data_ptr(), n * cin, h, wd, stream)
+    md = torch.empty((16, n * cout, tiles), dtype=torch.float32, device=dev)
+    g = ConvDesc()
+    g.n, g.c, g.h, g.w, g.m, g.oh, g.ow = n, cin, th, tw, cout, th, tw
+    g.kh = g.kw = 1
+    g.stride, g.pad = 1, 0
+    g.w_stride_m, g.w_stride_c = cin, 1
+    n_ws = lib.query("conv2d_workspace", C.byref(g), SAE_CONV_FWD)
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
+    for xi in range(16):
+        lib.call("conv2d_fwd_f32", v.data_ptr() + 4 * xi * n * cin * tiles, u.data_ptr() + 4 * xi * cout * cin,
+                 md.data_ptr() + 4 * xi * n * cout * tiles, C.byref(g), 1.0, ws.data_ptr(), n_ws, stream)
+    y = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
+    slope, scale = act if act is not None else (0.0, 1.0)
+    lib.call("wino_output_f32", md.data_ptr(), hip_lib.ptr(bias), y.data_ptr(), n * cout, cout, h, wd,
+             1 if act is not None else 0, float(slope), float(scale), stream)
+    return y

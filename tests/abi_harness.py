@@ -382,3 +382,53 @@ def softplus_mean_bwd(lib, gy, x, sign, device=None):
     bg, bx, bo = _Buf(gy, device), _Buf(x, device), _out(x.shape, device)
     lib.call("softplus_mean_bwd_f32", bg.ptr, bx.ptr, bo.ptr, batch, inner, sign, _stream(device))
     return bo.numpy()
+
+
+# ---- Winograd F(2x2, 3x3) transforms (sae_wino_*)
+def wino_weights(lib, w, m, c, sm, sc, flip=False, alpha=1.0, device=None):
+    bw, bu = _Buf(w, device), _out((16, m, c), device)
+    lib.call("wino_weights_f32", bw.ptr, bu.ptr, m, c, sm, sc, 1 if flip else 0, alpha, _stream(device))
+    return bu.numpy()
+
+
+def wino_input(lib, x, plane_scale=None, device=None):
+    planes, h, w = x.shape
+    bx, bv = _Buf(x, device), _out((16, planes, h // 2, w // 2), device)
+    bs = _Buf(plane_scale, device) if plane_scale is not None else None
+    lib.call("wino_input_f32", bx.ptr, bs.ptr if bs else None, bv.ptr, planes, h, w, _stream(device))
+    return bv.numpy()
+
+
+def wino_output(lib, md, h, w, channels, bias=None, act=None, device=None):
+    planes = md.shape[1]
+    bm, by = _Buf(md, device), _out((planes, h, w), device)
+    bb = _Buf(bias, device) if bias is not None else None
+    slope, scale = act if act is not None else (0.0, 1.0)
+    lib.call("wino_output_f32", bm.ptr, bb.ptr if bb else None, by.ptr, planes, channels, h, w, 1 if act is not None else 0,
+             slope, scale, _stream(device))
+    return by.numpy()
+
+
+def wino_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None, x_scale=None, cm_layout=False, device=None):
+    """The whole route on numpy data: alpha * conv3x3(x, wt) (pad 1) or, transpose=True, its data gradient for x = gy."""
+    n, cin, h, w = x.shape
+    if cm_layout:
+        c_, m_ = wt.shape[0], wt.shape[1]
+        sm, sc = 9, m_ * 9
+    else:
+        m_, c_ = wt.shape[0], wt.shape[1]
+        sm, sc = c_ * 9, 9
+    if transpose:
+        cout, sm, sc = c_, sc, sm
+        assert cin == m_
+    else:
+        cout = m_
+        assert cin == c_
+    u = wino_weights(lib, wt, cout, cin, sm, sc, flip=transpose, alpha=alpha, device=device)
+    v = wino_input(lib, x.reshape(n * cin, h, w), None if x_scale is None else x_scale.reshape(-1), device=device)
+    th, tw = h // 2, w // 2
+    d = conv_desc(n, cin, th, tw, cout, 1, 1, 0)
+    d.w_stride_m, d.w_stride_c = cin, 1
+    md = np.stack([conv(lib, 0, d, v[xi].reshape(n, cin, th, tw), u[xi].reshape(cout, cin, 1, 1), (n, cout, th, tw), device=device)
+                   for xi in range(16)]).reshape(16, n * cout, th, tw)
+    return wino_output(lib, md, h, w, cout, bias=bias, act=act, device=device).reshape(n, cout, h, w)
