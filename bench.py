@@ -81,6 +81,9 @@ def parse():
                          "generator call of the reference's driver through oracle/aten_cpu_path.TrainIterationCPU; several "
                          "minutes at 256 x 256, B = 16) instead of the bounded, FLOP-scaled sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--winograd", action="store_true",
+                    help="A/B only, never the driver's line: SAE_WINOGRAD=1 -- the wide 3x3 stride-1 layers (>= SAE_WINOGRAD_MIN_C "
+                         "channels) take the Winograd F(2x2,3x3) route (stylegan2_op/winograd.py); `config.winograd` records it")
     ap.add_argument("--kernel-steps", type=int, default=8,
                     help="steps of the kernel pass that follows the timed region: the same iterations with the step's branches on "
                          "ONE stream (SAE_TWO_STREAMS=0) and a HIP-event bracket around every launch of the tracked kernels -> "
@@ -580,6 +583,8 @@ def main():
     from swapping_autoencoder_pytorch_amd.swapping_autoencoder_optimizer import create_optimizer
     hip_lib.get()           # fail loudly here if the HIP library is missing
     hip_lib.set_conv_math(args.conv_math)
+    if args.winograd:
+        os.environ["SAE_WINOGRAD"] = "1"
 
     batch = args.batch or DEFAULT_BATCH[args.preset]
     opt = make_options(args.preset, batch_size=batch, num_gpus=1)
@@ -692,6 +697,9 @@ def main():
                                    "every 16th D iteration" % (args.preset, size, size, batch),
                        "global_batch": world * batch, "parallelism": "dp%d" % world, "conv_math": args.conv_math},
         }
+        if os.environ.get("SAE_WINOGRAD") == "1":
+            line["config"]["winograd"] = ("3x3 stride-1 layers with >= %s channels on the F(2x2,3x3) route: 2.25x fewer multiplications than the "
+                                          "FLOP count of this line's roofline figures assumes" % os.environ.get("SAE_WINOGRAD_MIN_C", "256"))
         if args.force_allreduce:
             line["config"]["force_allreduce"] = ("single-rank rehearsal of the multi-GPU gradient path: %d + %d buckets all-reduced over "
                                                  "RCCL per iteration" % (len(optimizer.reducer_D.buckets), len(optimizer.reducer_G.buckets)))
