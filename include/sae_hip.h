@@ -396,8 +396,8 @@ int sae_adam_multi_f32(float* const* params, const float* const* grads, float* c
 /* ------------------------------------------------------------------------------------------
  * Winograd F(2x2, 3x3) transforms for the 3x3 stride-1 pad-1 convolutions (F.conv2d at models/networks/stylegan2_layers.py:136,
  * 315 -- the algorithm class the reference's cuDNN / MIOpen back end picks for these shapes).  csrc/winograd.hip has the
- * matrices.  The 16 products of the transform domain are 1x1 convolutions: sae_conv2d_fwd_f32 with kh = kw = 1 on
- * v + xi * planes_in * tiles (input, c channels of tiles_h x tiles_w "pixels") and u + xi * m * c (weights, [m][c]).
+ * matrices.  The 16 products of the transform domain are 1x1 convolutions (c channels of tiles_h x tiles_w "pixels" each) on the
+ * MFMA gather: sae_wino_gemm_f32.
  *   sae_wino_weights_f32   u[16][m][c] = alpha * (G g G^T) of w[m * w_stride_m + c * w_stride_c + tap];  flip != 0: taps
  *                          reversed -- with the two strides swapped by the caller that is the data gradient's filter
  *   sae_wino_input_f32     x [planes][h][w] (h, w even; zero padding of 1 implied) -> v [16][planes][h/2][w/2];
@@ -405,7 +405,12 @@ int sae_adam_multi_f32(float* const* params, const float* const* grads, float* c
  *   sae_wino_output_f32    md [16][planes][h/2][w/2] -> y [planes][h][w]; act != 0: y = lrelu(y + bias[plane % channels],
  *                          slope) * act_scale (bias may be NULL), the epilogue of sae_conv2d_fwd_bias_act_f32
  * Exact fp32; results differ from the direct kernels' by rounding only (another association of the same sums).
- * ------------------------------------------------------------------------------------------ */
+ *   sae_wino_gemm_f32      md[xi] = u[xi] v[xi] for the 16 xi: v [16][n][c][tiles_h][tiles_w], u [16][m][c],
+ *                          md [16][n][m][tiles_h][tiles_w]; workspace: sae_wino_gemm_workspace floats
+ */
+int64_t sae_wino_gemm_workspace(int64_t n, int64_t c, int64_t m, int64_t tiles_h, int64_t tiles_w);
+int sae_wino_gemm_f32(const float* v, const float* u, float* md, int64_t n, int64_t c, int64_t m, int64_t tiles_h,
+                      int64_t tiles_w, float* workspace, int64_t workspace_floats, sae_stream_t stream);
 int sae_wino_weights_f32(const float* w, float* u, int64_t m, int64_t c, int64_t w_stride_m, int64_t w_stride_c, int32_t flip,
                          float alpha, sae_stream_t stream);
 int sae_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w,

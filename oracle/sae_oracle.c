@@ -1088,3 +1088,29 @@ int oracle_wino_output_f32(const float* md, const float* bias, float* y, int64_t
                     }
     return SAE_OK;
 }
+
+int64_t oracle_wino_gemm_workspace(int64_t n, int64_t c, int64_t m, int64_t tiles_h, int64_t tiles_w) {
+    (void)n; (void)c; (void)m; (void)tiles_h; (void)tiles_w;
+    return 0;
+}
+
+/* md[xi][n][m][t] = sum_c u[xi][m][c] v[xi][n][c][t], double accumulation */
+int oracle_wino_gemm_f32(const float* v, const float* u, float* md, int64_t n, int64_t c, int64_t m, int64_t tiles_h,
+                         int64_t tiles_w, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    (void)workspace; (void)workspace_floats; (void)stream;
+    if (n < 0 || c < 1 || m < 1 || tiles_h < 1 || tiles_w < 1) return set_err("oracle_wino_gemm_f32: bad shape");
+    if (n == 0) return SAE_OK;
+    if (!v || !u || !md) return set_err("oracle_wino_gemm_f32: null tensor");
+    const int64_t t = tiles_h * tiles_w;
+#pragma omp parallel for collapse(2)
+    for (int64_t xi = 0; xi < 16; ++xi)
+        for (int64_t ni = 0; ni < n; ++ni)
+            for (int64_t mi = 0; mi < m; ++mi)
+                for (int64_t ti = 0; ti < t; ++ti) {
+                    double acc = 0.0;
+                    for (int64_t ci = 0; ci < c; ++ci)
+                        acc += (double)u[(xi * m + mi) * c + ci] * (double)v[((xi * n + ni) * c + ci) * t + ti];
+                    md[((xi * n + ni) * m + mi) * t + ti] = (float)acc;
+                }
+    return SAE_OK;
+}

@@ -4825,6 +4825,42 @@ extern "C" int sae_conv2d_fwd_f32(const float* x, const float* w, float* y, cons
     return conv_fwd_impl("sae_conv2d_fwd_f32", x, w, y, d, kNoMod, alpha, workspace, workspace_floats, stream);
 }
 
+// ---- the sixteen transform-domain products of the Winograd route (csrc/winograd.hip): M[xi] = U[xi] V[xi], each a 1x1
+// convolution of `tiles_h x tiles_w` "pixels" on the gather above.  One entry point so that what runs behind it (today: sixteen
+// launches, each re-laying its [m][c] weight slice) can become one batched launch without touching the callers.
+namespace sae {
+namespace {
+sae_conv2d_desc wino_gemm_desc(int64_t n, int64_t c, int64_t m, int64_t th, int64_t tw) {
+    sae_conv2d_desc d{};
+    d.n = n; d.c = c; d.h = th; d.w = tw; d.m = m; d.oh = th; d.ow = tw;
+    d.kh = d.kw = 1; d.stride = 1; d.pad = 0;
+    d.w_stride_m = c; d.w_stride_c = 1;
+    return d;
+}
+}  // namespace
+}  // namespace sae
+
+extern "C" int64_t sae_wino_gemm_workspace(int64_t n, int64_t c, int64_t m, int64_t tiles_h, int64_t tiles_w) {
+    const sae_conv2d_desc d = wino_gemm_desc(n, c, m, tiles_h, tiles_w);
+    return sae_conv2d_workspace(&d, SAE_CONV_FWD);
+}
+
+extern "C" int sae_wino_gemm_f32(const float* v, const float* u, float* md, int64_t n, int64_t c, int64_t m, int64_t tiles_h,
+                                 int64_t tiles_w, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
+    const sae_conv2d_desc d = wino_gemm_desc(n, c, m, tiles_h, tiles_w);
+    if (!desc_ok(&d, "sae_wino_gemm_f32")) return SAE_EINVAL;
+    if (n == 0) return SAE_OK;
+    if (!v || !u || !md) return fail(SAE_EINVAL, "sae_wino_gemm_f32: null tensor");
+    const int64_t tiles = tiles_h * tiles_w;
+    for (int xi = 0; xi < 16; ++xi) {
+        const int rc = conv_fwd_impl("sae_wino_gemm_f32", v + xi * n * c * tiles, u + xi * m * c, md + xi * n * m * tiles, &d, kNoMod,
+                                     1.0f, workspace, workspace_floats, stream);
+        if (rc != SAE_OK) return rc;
+    }
+    return SAE_OK;
+}
+
 extern "C" int sae_modconv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d,
                                      const sae_conv2d_mod* mod, float alpha, float* workspace, int64_t workspace_floats,
                                      sae_stream_t stream) {

@@ -8,13 +8,11 @@ MFMA gather.  2.25x fewer multiplications for two extra passes over 4x the activ
 small maps.  OFF unless ``SAE_WINOGRAD=1`` -- built and verified against the oracle this round (CPU emulator), not yet measured
 on the GPU; ``SAE_WINOGRAD_MIN_C`` (default 256) is the smallest channel count that takes it.
 Results differ from the direct kernels' by rounding (~1e-6 relative), so the route is never mixed into bit-identity checks."""
-import ctypes as C
 import os
 
 import torch
 
 from .. import hip_lib
-from ..hip_lib import SAE_CONV_FWD, ConvDesc
 
 
 def enabled():
@@ -61,16 +59,9 @@ def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None):
     v = torch.empty((16, n * cin, tiles), dtype=torch.float32, device=dev)
     lib.call("wino_input_f32", x.data_ptr(), hip_lib.ptr(x_scale), v.data_ptr(), n * cin, h, wd, stream)
     md = torch.empty((16, n * cout, tiles), dtype=torch.float32, device=dev)
-    g = ConvDesc()
-    g.n, g.c, g.h, g.w, g.m, g.oh, g.ow = n, cin, th, tw, cout, th, tw
-    g.kh = g.kw = 1
-    g.stride, g.pad = 1, 0
-    g.w_stride_m, g.w_stride_c = cin, 1
-    n_ws = lib.query("conv2d_workspace", C.byref(g), SAE_CONV_FWD)
+    n_ws = lib.query("wino_gemm_workspace", n, cin, cout, th, tw)
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
-    for xi in range(16):
-        lib.call("conv2d_fwd_f32", v.data_ptr() + 4 * xi * n * cin * tiles, u.data_ptr() + 4 * xi * cout * cin,
-                 md.data_ptr() + 4 * xi * n * cout * tiles, C.byref(g), 1.0, ws.data_ptr(), n_ws, stream)
+    lib.call("wino_gemm_f32", v.data_ptr(), u.data_ptr(), md.data_ptr(), n, cin, cout, th, tw, ws.data_ptr(), n_ws, stream)
     y = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
     slope, scale = act if act is not None else (0.0, 1.0)
     lib.call("wino_output_f32", md.data_ptr(), hip_lib.ptr(bias), y.data_ptr(), n * cout, cout, h, wd,

@@ -427,8 +427,8 @@ def wino_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None, x_sca
     u = wino_weights(lib, wt, cout, cin, sm, sc, flip=transpose, alpha=alpha, device=device)
     v = wino_input(lib, x.reshape(n * cin, h, w), None if x_scale is None else x_scale.reshape(-1), device=device)
     th, tw = h // 2, w // 2
-    d = conv_desc(n, cin, th, tw, cout, 1, 1, 0)
-    d.w_stride_m, d.w_stride_c = cin, 1
-    md = np.stack([conv(lib, 0, d, v[xi].reshape(n, cin, th, tw), u[xi].reshape(cout, cin, 1, 1), (n, cout, th, tw), device=device)
-                   for xi in range(16)]).reshape(16, n * cout, th, tw)
+    n_ws = lib.query("wino_gemm_workspace", n, cin, cout, th, tw)
+    bv, bu, bm, ws = _Buf(v, device), _Buf(u, device), _out((16, n * cout, th, tw), device), _out((max(n_ws, 1),), device)
+    lib.call("wino_gemm_f32", bv.ptr, bu.ptr, bm.ptr, n, cin, cout, th, tw, ws.ptr, n_ws, _stream(device))
+    md = bm.numpy()
     return wino_output(lib, md, h, w, cout, bias=bias, act=act, device=device).reshape(n, cout, h, w)
