@@ -149,6 +149,10 @@ struct IgemmParams {
     // compiler from turning it into scalar-cache loads, whose out-of-order return shares the LDS wait counter
     // (lgkmcnt) and would serialise the ds_read pipeline of the MFMA loop
     int zmask;
+    // batched 1x1 launches (the sixteen transform-domain products of the Winograd route, csrc/winograd.hip): batch > 0 makes
+    // blockIdx.z a batch index instead of a K slice -- input, weights and output (slab_stride) advance by these many floats
+    int batch;
+    int64_t batch_x, batch_w;
     int xcd_order;          // 1: XCD-aware tile order (see conv_igemm_kernel)
     int vec_store;          // 1: LDS-transposed dwordx4 epilogue (see conv_igemm_kernel)
 };
@@ -383,7 +387,11 @@ __global__ __launch_bounds__(kBlock, (KS == 1 ? (MOD ? 2 : SAE_IGEMM_1X1_WAVES) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    const float* xb = x + (int64_t)n0 * p.C * HW;
+    // (KS == 1 only: blockIdx.z as the batch index of a batched launch, see IgemmParams::batch)
+    int zb = 0;
+    if constexpr (KS == 1) { if (p.batch) zb = blockIdx.z; }
+    const float* xb = x + (int64_t)n0 * p.C * HW + zb * p.batch_x;
+    const float* const wpz = wp + zb * p.batch_w;
     float xv[QUAD ? 1 : CK][PPT] = {};
     f32x4 xq[QPT];
     f32x4 av[APT];
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(kBlock, (KS == 1 ? (MOD ? 2 : SAE_IGEMM_1X1_WAVES) 
             }
         }
         }
-        const char* wb = reinterpret_cast<const char*>(wp + (int64_t)c0 * p.Mp + m0);
+        const char* wb = reinterpret_cast<const char*>(wpz + (int64_t)c0 * p.Mp + m0);
 #pragma unroll
         for (int i = 0; i < APT; ++i) {
             const int e4 = tid + kBlock * i;
@@ -484,7 +492,7 @@ __global__ __launch_bounds__(kBlock, (KS == 1 ? (MOD ? 2 : SAE_IGEMM_1X1_WAVES) 
         }
     };
 
-    const int c_begin = blockIdx.z * p.chunks_per_split * CK;
+    const int c_begin = ((KS == 1 && p.batch) ? 0 : (int)blockIdx.z) * p.chunks_per_split * CK;
     int c_end = c_begin + p.chunks_per_split * CK;
     if (c_end > p.Cp) c_end = p.Cp;
     load_chunk(c_begin);
@@ -3996,7 +4004,7 @@ int launch_igemm(const float* x, const float* wp, float* y, IgemmParams p, const
     const int ph = (KS == 1) ? th : (th - 1) * S + KS, pw = (KS == 1) ? tw : (tw - 1) * S + KS;
     const int cap = (KS == 1) ? sh.bn : (S == 1 ? (9 * sh.bn) / 4 : (41 * sh.bn) / 8);
     if (tn * ph * pw > cap) return fail(SAE_EINVAL, "conv igemm: patch %d exceeds LDS cap %d", tn * ph * pw, cap);
-    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(p.Mp / sh.bm), (unsigned)g.ksplit);
+    const dim3 grid((unsigned)(p.tiles_x * p.tiles_y * p.tiles_n), (unsigned)(p.Mp / sh.bm), (unsigned)(p.batch ? p.batch : g.ksplit));
     constexpr int CK = (KS == 1) ? 32 : 8;
     constexpr int CK2 = (KS == 1) ? 16 : 8;
     if constexpr (KS == 3 && S == 1) {
@@ -4826,39 +4834,68 @@ extern "C" int sae_conv2d_fwd_f32(const float* x, const float* w, float* y, cons
 }
 
 // ---- the sixteen transform-domain products of the Winograd route (csrc/winograd.hip): M[xi] = U[xi] V[xi], each a 1x1
-// convolution of `tiles_h x tiles_w` "pixels" on the gather above.  One entry point so that what runs behind it (today: sixteen
-// launches, each re-laying its [m][c] weight slice) can become one batched launch without touching the callers.
+// convolution of `tiles_h x tiles_w` "pixels" -- ONE batched launch of the 1x1 gather (blockIdx.z = xi, IgemmParams::batch)
+// behind ONE launch that lays the sixteen [m][c] weight slices out as the gather reads them ([c][Mp], zero padded).
 namespace sae {
 namespace {
-sae_conv2d_desc wino_gemm_desc(int64_t n, int64_t c, int64_t m, int64_t th, int64_t tw) {
-    sae_conv2d_desc d{};
-    d.n = n; d.c = c; d.h = th; d.w = tw; d.m = m; d.oh = th; d.ow = tw;
-    d.kh = d.kw = 1; d.stride = 1; d.pad = 0;
-    d.w_stride_m = c; d.w_stride_c = 1;
-    return d;
+// u: [16][M][C] -> wp: [16][Cp][Mp]
+__global__ __launch_bounds__(kBlock) void wino_wprep_kernel(const float* __restrict__ u, float* __restrict__ wp, int M, int C,
+                                                            int Mp, int Cp) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)Cp * Mp) return;
+    const int c = (int)(i / Mp), m = (int)(i - (int64_t)c * Mp);
+    const int xi = blockIdx.y;
+    wp[(int64_t)xi * Cp * Mp + i] = (m < M && c < C) ? u[((int64_t)xi * M + m) * C + c] : 0.0f;
+}
+GatherPlan wino_gemm_plan(int n, int c, int m, int th, int tw) {
+    GatherPlan g = gather_plan(n, c, m, th, tw, 1, 1, false);
+    g.ksplit = 1;                                       // sixteen times the workgroups of one product: no K split
+    g.cps = g.Cp / g.sh.ck;
+    g.ws_floats = 16 * g.wp_floats;
+    return g;
+}
+bool wino_gemm_shape_ok(int64_t n, int64_t c, int64_t m, int64_t th, int64_t tw, const char* who) {
+    if (n < 0 || c < 1 || m < 1 || th < 1 || tw < 1 || n >= 65536 || c >= 65536 || m >= 65536 || th >= 32768 || tw >= 32768 ||
+        n * c * th * tw >= ((int64_t)1 << 31) || n * m * th * tw >= ((int64_t)1 << 31)) {
+        fail(SAE_EINVAL, "%s: bad shape", who);
+        return false;
+    }
+    return true;
 }
 }  // namespace
 }  // namespace sae
 
 extern "C" int64_t sae_wino_gemm_workspace(int64_t n, int64_t c, int64_t m, int64_t tiles_h, int64_t tiles_w) {
-    const sae_conv2d_desc d = wino_gemm_desc(n, c, m, tiles_h, tiles_w);
-    return sae_conv2d_workspace(&d, SAE_CONV_FWD);
+    if (!wino_gemm_shape_ok(n, c, m, tiles_h, tiles_w, "sae_wino_gemm_workspace") || n == 0) return 0;
+    return wino_gemm_plan((int)n, (int)c, (int)m, (int)tiles_h, (int)tiles_w).ws_floats;
 }
 
 extern "C" int sae_wino_gemm_f32(const float* v, const float* u, float* md, int64_t n, int64_t c, int64_t m, int64_t tiles_h,
                                  int64_t tiles_w, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
     sae::clear_stale_error();
-    const sae_conv2d_desc d = wino_gemm_desc(n, c, m, tiles_h, tiles_w);
-    if (!desc_ok(&d, "sae_wino_gemm_f32")) return SAE_EINVAL;
+    const char* who = "sae_wino_gemm_f32";
+    if (!wino_gemm_shape_ok(n, c, m, tiles_h, tiles_w, who)) return SAE_EINVAL;
     if (n == 0) return SAE_OK;
-    if (!v || !u || !md) return fail(SAE_EINVAL, "sae_wino_gemm_f32: null tensor");
-    const int64_t tiles = tiles_h * tiles_w;
-    for (int xi = 0; xi < 16; ++xi) {
-        const int rc = conv_fwd_impl("sae_wino_gemm_f32", v + xi * n * c * tiles, u + xi * m * c, md + xi * n * m * tiles, &d, kNoMod,
-                                     1.0f, workspace, workspace_floats, stream);
-        if (rc != SAE_OK) return rc;
-    }
-    return SAE_OK;
+    if (!v || !u || !md) return fail(SAE_EINVAL, "%s: null tensor", who);
+    if (conv_math() != 0) return fail(SAE_EINVAL, "%s: exact-fp32 arithmetic only (SAE_CONV_MATH_F32)", who);
+    const int N = (int)n, C = (int)c, M = (int)m, TH = (int)tiles_h, TW = (int)tiles_w;
+    const GatherPlan g = wino_gemm_plan(N, C, M, TH, TW);
+    if (!workspace || workspace_floats < g.ws_floats)
+        return fail(SAE_EWORKSPACE, "%s: workspace %lld < %lld floats", who, (long long)workspace_floats, (long long)g.ws_floats);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(wino_wprep_kernel, dim3((unsigned)ceil_div64((int64_t)g.Cp * g.Mp, kBlock), 16), dim3(kBlock), 0, s, u,
+                       workspace, M, C, g.Mp, g.Cp);
+    IgemmParams p{};
+    p.N = N; p.C = C; p.H = TH; p.W = TW; p.M = M; p.OH = TH; p.OW = TW; p.YH = TH; p.YW = TW;
+    p.oys = 1; p.oxs = 1; p.Cp = g.Cp; p.Mp = g.Mp; p.pad = 0;
+    const int64_t tiles = (int64_t)TH * TW;
+    p.batch = 16; p.batch_x = (int64_t)N * C * tiles; p.batch_w = g.wp_floats; p.slab_stride = (int64_t)N * M * tiles;
+    static const int xcd_knob = tuning_knob("SAE_XCD_ORDER", 1);
+    p.xcd_order = xcd_knob;
+    p.vec_store = TW % 4 == 0 && (reinterpret_cast<uintptr_t>(md) & 15) == 0;
+    const int rc = launch_igemm<1, 1>(v, workspace, md, p, g, s);
+    if (rc != SAE_OK) return rc;
+    return check_launch(who);
 }
 
 extern "C" int sae_modconv2d_fwd_f32(const float* x, const float* w, float* y, const sae_conv2d_desc* d,
