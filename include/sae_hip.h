@@ -398,12 +398,15 @@ int sae_adam_multi_f32(float* const* params, const float* const* grads, float* c
  * 315 -- the algorithm class the reference's cuDNN / MIOpen back end picks for these shapes).  csrc/winograd.hip has the
  * matrices.  The 16 products of the transform domain are 1x1 convolutions (c channels of tiles_h x tiles_w "pixels" each) on the
  * MFMA gather: sae_wino_gemm_f32.
- *   sae_wino_weights_f32   u[16][m][c] = alpha * (G g G^T) of w[m * w_stride_m + c * w_stride_c + tap];  flip != 0: taps
- *                          reversed -- with the two strides swapped by the caller that is the data gradient's filter
+ *   sae_wino_weights_f32   u[16][m][c] = (G g G^T) of g = alpha * w[m * w_stride_m + c * w_stride_c + tap] * row_scale[m] *
+ *                          col_scale[c] (either factor may be NULL: the wm_scale / wc_scale of sae_conv2d_mod);  flip != 0: taps
+ *                          reversed -- with the two strides (and factors) swapped by the caller that is the data gradient's filter
  *   sae_wino_input_f32     x [planes][h][w] (h, w even; zero padding of 1 implied) -> v [16][planes][h/2][w/2];
- *                          plane_scale: NULL or one factor per plane (the style modulation of the input)
- *   sae_wino_output_f32    md [16][planes][h/2][w/2] -> y [planes][h][w]; act != 0: y = lrelu(y + bias[plane % channels],
- *                          slope) * act_scale (bias may be NULL), the epilogue of sae_conv2d_fwd_bias_act_f32
+ *                          plane_scale: NULL or one factor per plane (x_scale / y_scale of sae_conv2d_mod)
+ *   sae_wino_output_f32    md [16][planes][h/2][w/2] -> y [planes][h][w], times plane_scale[plane] if given; act != 0:
+ *                          y = lrelu((y + noise_weight[0] * noise[plane / channels][pixel]) + bias[plane % channels], slope) *
+ *                          act_scale (noise: [planes / channels][h][w] or NULL, noise_weight: one float on the device; bias may
+ *                          be NULL) -- the epilogues of sae_conv2d_fwd_bias_act_f32 / sae_modconv2d_fwd_noise_bias_act_f32
  * Exact fp32; results differ from the direct kernels' by rounding only (another association of the same sums).
  *   sae_wino_gemm_f32      md[xi] = u[xi] v[xi] for the 16 xi: v [16][n][c][tiles_h][tiles_w], u [16][m][c],
  *                          md [16][n][m][tiles_h][tiles_w]; workspace: sae_wino_gemm_workspace floats
@@ -411,12 +414,13 @@ int sae_adam_multi_f32(float* const* params, const float* const* grads, float* c
 int64_t sae_wino_gemm_workspace(int64_t n, int64_t c, int64_t m, int64_t tiles_h, int64_t tiles_w);
 int sae_wino_gemm_f32(const float* v, const float* u, float* md, int64_t n, int64_t c, int64_t m, int64_t tiles_h,
                       int64_t tiles_w, float* workspace, int64_t workspace_floats, sae_stream_t stream);
-int sae_wino_weights_f32(const float* w, float* u, int64_t m, int64_t c, int64_t w_stride_m, int64_t w_stride_c, int32_t flip,
-                         float alpha, sae_stream_t stream);
+int sae_wino_weights_f32(const float* w, const float* row_scale, const float* col_scale, float* u, int64_t m, int64_t c,
+                         int64_t w_stride_m, int64_t w_stride_c, int32_t flip, float alpha, sae_stream_t stream);
 int sae_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w,
                        sae_stream_t stream);
-int sae_wino_output_f32(const float* md, const float* bias, float* y, int64_t planes, int64_t channels, int64_t h, int64_t w,
-                        int32_t act, float slope, float act_scale, sae_stream_t stream);
+int sae_wino_output_f32(const float* md, const float* plane_scale, const float* noise, const float* noise_weight,
+                        const float* bias, float* y, int64_t planes, int64_t channels, int64_t h, int64_t w, int32_t act,
+                        float slope, float act_scale, sae_stream_t stream);
 
 #ifdef __cplusplus
 }

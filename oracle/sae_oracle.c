@@ -1015,15 +1015,17 @@ static const double WINO_BT[4][4] = {{1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0},
 static const double WINO_G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
 static const double WINO_AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
 
-int oracle_wino_weights_f32(const float* w, float* u, int64_t m, int64_t c, int64_t w_stride_m, int64_t w_stride_c, int32_t flip,
-                            float alpha, sae_stream_t stream) {
+int oracle_wino_weights_f32(const float* w, const float* row_scale, const float* col_scale, float* u, int64_t m, int64_t c,
+                            int64_t w_stride_m, int64_t w_stride_c, int32_t flip, float alpha, sae_stream_t stream) {
     (void)stream;
     if (m < 1 || c < 1 || !w || !u) return set_err("oracle_wino_weights_f32: bad argument");
     for (int64_t mi = 0; mi < m; ++mi)
         for (int64_t ci = 0; ci < c; ++ci) {
             const float* wp = w + mi * w_stride_m + ci * w_stride_c;
             double g[3][3];
-            for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = (double)(alpha * wp[flip ? 8 - t : t]);
+            for (int t = 0; t < 9; ++t)
+                g[t / 3][t % 3] = (double)alpha * (double)wp[flip ? 8 - t : t] * (row_scale ? (double)row_scale[mi] : 1.0) *
+                                  (col_scale ? (double)col_scale[ci] : 1.0);
             for (int a = 0; a < 4; ++a)
                 for (int b = 0; b < 4; ++b) {
                     double acc = 0.0;
@@ -1063,12 +1065,14 @@ int oracle_wino_input_f32(const float* x, const float* plane_scale, float* v, in
     return SAE_OK;
 }
 
-int oracle_wino_output_f32(const float* md, const float* bias, float* y, int64_t planes, int64_t channels, int64_t h, int64_t w,
-                           int32_t act, float slope, float act_scale, sae_stream_t stream) {
+int oracle_wino_output_f32(const float* md, const float* plane_scale, const float* noise, const float* noise_weight,
+                           const float* bias, float* y, int64_t planes, int64_t channels, int64_t h, int64_t w, int32_t act,
+                           float slope, float act_scale, sae_stream_t stream) {
     (void)stream;
     if (planes < 0 || channels < 1 || h < 2 || w < 2 || (h & 1) || (w & 1)) return set_err("oracle_wino_output_f32: bad shape");
     if (planes == 0) return SAE_OK;
     if (!md || !y) return set_err("oracle_wino_output_f32: null tensor");
+    if (noise && (!act || !noise_weight || planes % channels != 0)) return set_err("oracle_wino_output_f32: noise without its epilogue");
     const int64_t th = h / 2, tw = w / 2, tiles = th * tw;
     for (int64_t p = 0; p < planes; ++p)
         for (int64_t ty = 0; ty < th; ++ty)
@@ -1079,8 +1083,9 @@ int oracle_wino_output_f32(const float* md, const float* bias, float* y, int64_t
                         for (int i = 0; i < 4; ++i)
                             for (int j = 0; j < 4; ++j)
                                 acc += WINO_AT[a][i] * (double)md[((int64_t)(4 * i + j) * planes + p) * tiles + ty * tw + tx] * WINO_AT[b][j];
-                        float o = (float)acc;
+                        float o = plane_scale ? (float)acc * plane_scale[p] : (float)acc;
                         if (act) {
+                            if (noise) o = o + noise_weight[0] * noise[((p / channels) * h + 2 * ty + a) * w + 2 * tx + b];
                             o = o + (bias ? bias[p % channels] : 0.0f);
                             o = ((o > 0.0f) ? o : o * slope) * act_scale;
                         }

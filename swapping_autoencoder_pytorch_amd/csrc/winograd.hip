@@ -28,14 +28,20 @@ namespace {
 
 // U[xi][m][c], xi = 4 a + b:  (G g G^T)[a][b]
 __global__ __launch_bounds__(kBlock) void wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int M, int C,
-                                                             int64_t sm, int64_t sc, int flip, float alpha) {
+                                                             int64_t sm, int64_t sc, int flip, float alpha,
+                                                             const float* __restrict__ rs_m, const float* __restrict__ rs_c) {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= (int64_t)M * C) return;
     const int m = (int)(i / C), c = (int)(i - (int64_t)m * C);
     const float* wp = w + m * sm + c * sc;
     float g[3][3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = alpha * wp[flip ? 8 - t : t];
+    for (int t = 0; t < 9; ++t) {           // alpha * w, then the row factor, then the column factor (conv_wprep_kernel's order)
+        float v = alpha * wp[flip ? 8 - t : t];
+        if (rs_m) v *= rs_m[m];
+        if (rs_c) v *= rs_c[c];
+        g[t / 3][t % 3] = v;
+    }
     float r[4][3];      // G g
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -101,10 +107,14 @@ __global__ __launch_bounds__(kBlock) void wino_input_kernel(const float* __restr
     }
 }
 
-// Md: [16][planes][TH][TW] -> y: [planes][H][W]; act != 0: y = lrelu(Y + bias[plane % channels]) * act_scale
+// Md: [16][planes][TH][TW] -> y: [planes][H][W], times plane_scale[plane] if given; act != 0:
+// y = lrelu((Y + noise_w[0] * noise[plane / channels][pixel]) + bias[plane % channels]) * act_scale  (noise, bias optional)
 __global__ __launch_bounds__(kBlock) void wino_output_kernel(const float* __restrict__ Md, float* __restrict__ y,
                                                              const float* __restrict__ bias, int64_t planes, int channels,
-                                                             int H, int W, int act, float slope, float act_scale) {
+                                                             int H, int W, int act, float slope, float act_scale,
+                                                             const float* __restrict__ plane_scale,
+                                                             const float* __restrict__ noise,
+                                                             const float* __restrict__ noise_w) {
     const int TH = H >> 1, TW = W >> 1;
     const int64_t T = (int64_t)TH * TW;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -126,12 +136,20 @@ __global__ __launch_bounds__(kBlock) void wino_output_kernel(const float* __rest
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     const float bv = (act && bias) ? bias[pl % channels] : 0.0f;
+    const float ps = plane_scale ? plane_scale[pl] : 1.0f;
+    const float nwv = (act && noise) ? noise_w[0] : 0.0f;
+    const float* zp = noise ? noise + (pl / channels) * H * W + (int64_t)(2 * ty) * W + 2 * tx : nullptr;
     float* yp = y + pl * H * W + (int64_t)(2 * ty) * W + 2 * tx;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         float o0 = (r[a][0] + r[a][1]) + r[a][2];
         float o1 = (r[a][1] - r[a][2]) - r[a][3];
+        if (plane_scale) { o0 *= ps; o1 *= ps; }
         if (act) {
+            if (noise) {      // (image + weight * noise) + bias, the reference's association (stylegan2_layers.py:340-351)
+                o0 = o0 + nwv * zp[(int64_t)a * W];
+                o1 = o1 + nwv * zp[(int64_t)a * W + 1];
+            }
             o0 += bv; o1 += bv;
             o0 = ((o0 > 0.0f) ? o0 : o0 * slope) * act_scale;
             o1 = ((o1 > 0.0f) ? o1 : o1 * slope) * act_scale;
@@ -150,13 +168,14 @@ inline unsigned blocks_for(int64_t work) {
 
 using namespace sae;
 
-extern "C" int sae_wino_weights_f32(const float* w, float* u, int64_t m, int64_t c, int64_t w_stride_m, int64_t w_stride_c,
-                                    int32_t flip, float alpha, sae_stream_t stream) {
+extern "C" int sae_wino_weights_f32(const float* w, const float* row_scale, const float* col_scale, float* u, int64_t m,
+                                    int64_t c, int64_t w_stride_m, int64_t w_stride_c, int32_t flip, float alpha,
+                                    sae_stream_t stream) {
     sae::clear_stale_error();
     if (m < 1 || c < 1 || m * c >= ((int64_t)1 << 31)) return fail(SAE_EINVAL, "sae_wino_weights_f32: bad shape");
     if (!w || !u) return fail(SAE_EINVAL, "sae_wino_weights_f32: null tensor");
     hipLaunchKernelGGL(wino_weight_kernel, dim3(blocks_for(m * c)), dim3(kBlock), 0, (hipStream_t)stream, w, u, (int)m, (int)c,
-                       w_stride_m, w_stride_c, flip ? 1 : 0, alpha);
+                       w_stride_m, w_stride_c, flip ? 1 : 0, alpha, row_scale, col_scale);
     return check_launch("sae_wino_weights_f32");
 }
 
@@ -173,8 +192,9 @@ extern "C" int sae_wino_input_f32(const float* x, const float* plane_scale, floa
     return check_launch("sae_wino_input_f32");
 }
 
-extern "C" int sae_wino_output_f32(const float* md, const float* bias, float* y, int64_t planes, int64_t channels, int64_t h,
-                                   int64_t w, int32_t act, float slope, float act_scale, sae_stream_t stream) {
+extern "C" int sae_wino_output_f32(const float* md, const float* plane_scale, const float* noise, const float* noise_weight,
+                                   const float* bias, float* y, int64_t planes, int64_t channels, int64_t h, int64_t w,
+                                   int32_t act, float slope, float act_scale, sae_stream_t stream) {
     sae::clear_stale_error();
     if (planes < 0 || channels < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || h >= 32768 || w >= 32768 ||
         channels >= ((int64_t)1 << 31))
@@ -182,7 +202,11 @@ extern "C" int sae_wino_output_f32(const float* md, const float* bias, float* y,
     if (planes == 0) return SAE_OK;
     if (!md || !y) return fail(SAE_EINVAL, "sae_wino_output_f32: null tensor");
     if ((reinterpret_cast<uintptr_t>(y) & 7) != 0) return fail(SAE_EINVAL, "sae_wino_output_f32: y must be 8-byte aligned");
+    if (noise && (!act || !noise_weight || planes % channels != 0))
+        return fail(SAE_EINVAL, "sae_wino_output_f32: the noise term belongs to the activation epilogue (act != 0, noise_weight, "
+                                "planes a multiple of channels)");
     hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_for(planes * (h / 2) * (w / 2))), dim3(kBlock), 0, (hipStream_t)stream,
-                       md, y, bias, planes, (int)channels, (int)h, (int)w, act ? 1 : 0, slope, act_scale);
+                       md, y, bias, planes, (int)channels, (int)h, (int)w, act ? 1 : 0, slope, act_scale, plane_scale, noise,
+                       noise_weight);
     return check_launch("sae_wino_output_f32");
 }

@@ -260,6 +260,12 @@ def _launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_
     """One sae_modconv2d_* call: the plain operation `op` on a * factor, b (weights or second activation) with the
     optional [N, C] activation factors and per-channel weight factors staged inside the kernels.  factor_tag: what the weight
     factors are as a function of the weight parameter alone (weight_prep.attach), None = unknown (no prepared weights)."""
+    if op != SAE_CONV_WGRAD and winograd.eligible(geom):
+        # the factors of sae_conv2d_mod in the route's terms: the activation factor of the operation's input; the weight factors by
+        # the axes of the product that is computed (the data gradient's outputs are the c axis)
+        if op == SAE_CONV_FWD:
+            return winograd.conv(a, b, geom, x_scale=x_scale, row_scale=wm_scale, col_scale=wc_scale)
+        return winograd.conv(a, b, geom, transpose=True, x_scale=y_scale, row_scale=wc_scale, col_scale=wm_scale)
     lib = hip_lib.get()
     a = a.contiguous()
     b = b.contiguous()
@@ -408,6 +414,13 @@ class StyledModConv(Function):
         if act_ticket is not None:
             act_ticket.arm(noise, slope, scale)      # the CONTIGUOUS map: the consumer's backward hands it to a kernel
         lib.check(x, w, s, noise, noise_weight, bias, demod)
+        if winograd.eligible(geom):
+            out = winograd.conv(x, w, geom, x_scale=s, row_scale=demod, noise=noise, noise_weight=noise_weight, bias=bias,
+                                act=(slope, scale))
+            ctx.factor_tag = ("demod", float(demod_alpha), float(demod_eps)) if demod_eps is not None else ()
+            ctx.save_for_backward(x, s, w, demod, out, noise)
+            ctx.cfg = (geom, slope, scale, bias is not None)
+            return out
         d = geom.desc()
         mod = hip_lib.ConvMod(s.data_ptr(), None, hip_lib.ptr(demod), None)
         n_ws = lib.query("conv2d_workspace", C.byref(d), SAE_CONV_FWD)

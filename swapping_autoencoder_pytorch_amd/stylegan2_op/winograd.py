@@ -32,16 +32,18 @@ def eligible(geom):
     return hip_lib.get().query("get_conv_math") == 0
 
 
-def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None):
-    """alpha * conv(x, w) (transpose=False: x is [n, c, h, w]) or alpha * conv^T(gy, w) (transpose=True: x is the output
-    gradient [n, m, h, w]), optionally followed by lrelu(. + bias) * scale (act = (slope, scale)); x_scale: [n, channels of x]
-    factors applied to the input on its way into the transform."""
+def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None, row_scale=None, col_scale=None, out_scale=None,
+         noise=None, noise_weight=None):
+    """alpha * conv(x * x_scale, w') (transpose=False: x is [n, c, h, w]) or alpha * conv^T(gy * x_scale, w') (transpose=True: x
+    is the output gradient [n, m, h, w]) with w' = w * row_scale * col_scale along the OUTPUT / CONTRACTION axes of the product
+    that is computed; times out_scale [n, outputs] if given; then, with act = (slope, scale),
+    lrelu((. + noise_weight * noise[n]) + bias) * scale (noise, bias optional)."""
     lib = hip_lib.get()
     x = x.contiguous()
     w = w.contiguous()
-    bias = bias.contiguous() if bias is not None else None
-    x_scale = x_scale.contiguous() if x_scale is not None else None
-    lib.check(x, w, bias, x_scale)
+    opt = [None if t is None else t.contiguous() for t in (bias, x_scale, row_scale, col_scale, out_scale, noise, noise_weight)]
+    bias, x_scale, row_scale, col_scale, out_scale, noise, noise_weight = opt
+    lib.check(x, w, *opt)
     d = geom.desc()
     if transpose:
         cin, cout, sm, sc, flip = geom.m, geom.c, d.w_stride_c, d.w_stride_m, 1
@@ -55,7 +57,8 @@ def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None):
     stream = lib.stream(x)
     dev = x.device
     u = torch.empty((16, cout, cin), dtype=torch.float32, device=dev)
-    lib.call("wino_weights_f32", w.data_ptr(), u.data_ptr(), cout, cin, sm, sc, flip, geom.alpha, stream)
+    lib.call("wino_weights_f32", w.data_ptr(), hip_lib.ptr(row_scale), hip_lib.ptr(col_scale), u.data_ptr(), cout, cin, sm, sc,
+             flip, geom.alpha, stream)
     v = torch.empty((16, n * cin, tiles), dtype=torch.float32, device=dev)
     lib.call("wino_input_f32", x.data_ptr(), hip_lib.ptr(x_scale), v.data_ptr(), n * cin, h, wd, stream)
     md = torch.empty((16, n * cout, tiles), dtype=torch.float32, device=dev)
@@ -64,6 +67,6 @@ def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None):
     lib.call("wino_gemm_f32", v.data_ptr(), u.data_ptr(), md.data_ptr(), n, cin, cout, th, tw, ws.data_ptr(), n_ws, stream)
     y = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
     slope, scale = act if act is not None else (0.0, 1.0)
-    lib.call("wino_output_f32", md.data_ptr(), hip_lib.ptr(bias), y.data_ptr(), n * cout, cout, h, wd,
-             1 if act is not None else 0, float(slope), float(scale), stream)
+    lib.call("wino_output_f32", md.data_ptr(), hip_lib.ptr(out_scale), hip_lib.ptr(noise), hip_lib.ptr(noise_weight),
+             hip_lib.ptr(bias), y.data_ptr(), n * cout, cout, h, wd, 1 if act is not None else 0, float(slope), float(scale), stream)
     return y

@@ -385,9 +385,12 @@ def softplus_mean_bwd(lib, gy, x, sign, device=None):
 
 
 # ---- Winograd F(2x2, 3x3) transforms (sae_wino_*)
-def wino_weights(lib, w, m, c, sm, sc, flip=False, alpha=1.0, device=None):
+def wino_weights(lib, w, m, c, sm, sc, flip=False, alpha=1.0, row_scale=None, col_scale=None, device=None):
     bw, bu = _Buf(w, device), _out((16, m, c), device)
-    lib.call("wino_weights_f32", bw.ptr, bu.ptr, m, c, sm, sc, 1 if flip else 0, alpha, _stream(device))
+    br = _Buf(row_scale, device) if row_scale is not None else None
+    bc = _Buf(col_scale, device) if col_scale is not None else None
+    lib.call("wino_weights_f32", bw.ptr, br.ptr if br else None, bc.ptr if bc else None, bu.ptr, m, c, sm, sc, 1 if flip else 0,
+             alpha, _stream(device))
     return bu.numpy()
 
 
@@ -399,18 +402,21 @@ def wino_input(lib, x, plane_scale=None, device=None):
     return bv.numpy()
 
 
-def wino_output(lib, md, h, w, channels, bias=None, act=None, device=None):
+def wino_output(lib, md, h, w, channels, bias=None, act=None, plane_scale=None, noise=None, noise_weight=None, device=None):
     planes = md.shape[1]
     bm, by = _Buf(md, device), _out((planes, h, w), device)
-    bb = _Buf(bias, device) if bias is not None else None
+    opt = [(_Buf(t, device) if t is not None else None) for t in (plane_scale, noise, noise_weight, bias)]
     slope, scale = act if act is not None else (0.0, 1.0)
-    lib.call("wino_output_f32", bm.ptr, bb.ptr if bb else None, by.ptr, planes, channels, h, w, 1 if act is not None else 0,
-             slope, scale, _stream(device))
+    lib.call("wino_output_f32", bm.ptr, *[(b.ptr if b else None) for b in opt], by.ptr, planes, channels, h, w,
+             1 if act is not None else 0, slope, scale, _stream(device))
     return by.numpy()
 
 
-def wino_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None, x_scale=None, cm_layout=False, device=None):
-    """The whole route on numpy data: alpha * conv3x3(x, wt) (pad 1) or, transpose=True, its data gradient for x = gy."""
+def wino_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None, x_scale=None, cm_layout=False, row_scale=None,
+              col_scale=None, out_scale=None, noise=None, noise_weight=None, device=None):
+    """The whole route on numpy data: alpha * conv3x3(x * x_scale, wt * row_scale[m] * col_scale[c]) (pad 1) or, transpose=True,
+    its data gradient for x = gy (row_scale / col_scale then name the axes of THAT product: rows = its outputs), times
+    out_scale per output plane, then the optional noise + bias + leaky-ReLU epilogue."""
     n, cin, h, w = x.shape
     if cm_layout:
         c_, m_ = wt.shape[0], wt.shape[1]
@@ -424,11 +430,12 @@ def wino_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None, x_sca
     else:
         cout = m_
         assert cin == c_
-    u = wino_weights(lib, wt, cout, cin, sm, sc, flip=transpose, alpha=alpha, device=device)
+    u = wino_weights(lib, wt, cout, cin, sm, sc, flip=transpose, alpha=alpha, row_scale=row_scale, col_scale=col_scale, device=device)
     v = wino_input(lib, x.reshape(n * cin, h, w), None if x_scale is None else x_scale.reshape(-1), device=device)
     th, tw = h // 2, w // 2
     n_ws = lib.query("wino_gemm_workspace", n, cin, cout, th, tw)
     bv, bu, bm, ws = _Buf(v, device), _Buf(u, device), _out((16, n * cout, th, tw), device), _out((max(n_ws, 1),), device)
     lib.call("wino_gemm_f32", bv.ptr, bu.ptr, bm.ptr, n, cin, cout, th, tw, ws.ptr, n_ws, _stream(device))
     md = bm.numpy()
-    return wino_output(lib, md, h, w, cout, bias=bias, act=act, device=device).reshape(n, cout, h, w)
+    return wino_output(lib, md, h, w, cout, bias=bias, act=act, plane_scale=None if out_scale is None else out_scale.reshape(-1),
+                       noise=noise, noise_weight=noise_weight, device=device).reshape(n, cout, h, w)

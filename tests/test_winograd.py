@@ -15,9 +15,12 @@ def _transforms(lib, oracle_lib, dev):
     rng = np.random.default_rng(31)
     w = rng.standard_normal((10, 7, 3, 3)).astype(np.float32)
     for flip, (m, c, sm, sc) in [(False, (10, 7, 63, 9)), (True, (7, 10, 9, 63))]:
-        a = H.wino_weights(lib, w, m, c, sm, sc, flip=flip, alpha=0.37, device=dev)
-        o = H.wino_weights(oracle_lib, w, m, c, sm, sc, flip=flip, alpha=0.37)
-        assert H.rel_err(a, o) < 1e-6, (flip, H.rel_err(a, o))
+        rs = (1 + 0.5 * rng.standard_normal(m)).astype(np.float32)
+        cs = (1 + 0.5 * rng.standard_normal(c)).astype(np.float32)
+        for row, col in [(None, None), (rs, None), (rs, cs)]:
+            a = H.wino_weights(lib, w, m, c, sm, sc, flip=flip, alpha=0.37, row_scale=row, col_scale=col, device=dev)
+            o = H.wino_weights(oracle_lib, w, m, c, sm, sc, flip=flip, alpha=0.37, row_scale=row, col_scale=col)
+            assert H.rel_err(a, o) < 1e-6, (flip, H.rel_err(a, o))
     x = rng.standard_normal((5, 6, 10)).astype(np.float32)
     s = (1 + 0.5 * rng.standard_normal(5)).astype(np.float32)
     for scale in (None, s):
@@ -25,9 +28,14 @@ def _transforms(lib, oracle_lib, dev):
         assert not np.isnan(a).any() and H.rel_err(a, o) < 1e-6, H.rel_err(a, o)
     md = rng.standard_normal((16, 6, 3, 5)).astype(np.float32)
     b = rng.standard_normal(3).astype(np.float32)
-    for bias, act in [(None, None), (b, (0.2, 2 ** 0.5)), (None, (0.2, 1.0))]:
-        a = H.wino_output(lib, md, 6, 10, 3, bias=bias, act=act, device=dev)
-        o = H.wino_output(oracle_lib, md, 6, 10, 3, bias=bias, act=act)
+    ps = (1 + 0.5 * rng.standard_normal(6)).astype(np.float32)
+    z = rng.standard_normal((2, 6, 10)).astype(np.float32)
+    zw = np.array([0.7], np.float32)
+    for bias, act, scale, noise in [(None, None, None, None), (b, (0.2, 2 ** 0.5), None, None), (None, (0.2, 1.0), ps, None),
+                                    (b, (0.2, 2 ** 0.5), None, z), (None, None, ps, None)]:
+        kw = dict(bias=bias, act=act, plane_scale=scale, noise=noise, noise_weight=zw if noise is not None else None)
+        a = H.wino_output(lib, md, 6, 10, 3, device=dev, **kw)
+        o = H.wino_output(oracle_lib, md, 6, 10, 3, **kw)
         assert not np.isnan(a).any() and H.rel_err(a, o) < 1e-6, H.rel_err(a, o)
 
 
@@ -50,9 +58,20 @@ def _route(lib, oracle_lib, dev):
         if not cm:
             act = H.wino_conv(lib, x, wt, alpha=0.11, bias=b, act=(0.2, 2 ** 0.5), device=dev)
             assert H.rel_err(act, H.conv_bias_act(oracle_lib, d, x, wt, b, alpha=0.11)) < TOL
-        mod = H.wino_conv(lib, x, wt, alpha=0.3, x_scale=xs, cm_layout=cm, device=dev)
-        ref = H.conv(oracle_lib, 0, d, x * xs[:, :, None, None], wt, gy.shape, alpha=0.3)
-        assert H.rel_err(mod, ref) < TOL
+        # the style-modulated forms against the oracle's modulated convolutions (include/sae_hip.h: sae_conv2d_mod)
+        ys = (1 + 0.5 * rng.standard_normal((n, m))).astype(np.float32)
+        wm = rng.uniform(0.5, 2, m).astype(np.float32)
+        wc = rng.uniform(0.5, 2, c).astype(np.float32)
+        mod = H.wino_conv(lib, x, wt, alpha=0.3, x_scale=xs, row_scale=wm, col_scale=wc, cm_layout=cm, device=dev)
+        assert H.rel_err(mod, H.modconv(oracle_lib, 0, d, x, wt, gy.shape, x_scale=xs, wm_scale=wm, wc_scale=wc, alpha=0.3)) < TOL
+        mdg = H.wino_conv(lib, gy, wt, alpha=0.3, transpose=True, x_scale=ys, row_scale=wc, col_scale=wm, cm_layout=cm, device=dev)
+        assert H.rel_err(mdg, H.modconv(oracle_lib, 1, d, gy, wt, x.shape, y_scale=ys, wm_scale=wm, wc_scale=wc, alpha=0.3)) < TOL
+        if not cm:          # StyledConv's plain form: modulated forward + noise + bias + leaky-ReLU
+            z = rng.standard_normal((n, h, w)).astype(np.float32)
+            zw = np.array([0.6], np.float32)
+            st = H.wino_conv(lib, x, wt, alpha=0.2, x_scale=xs, row_scale=wm, noise=z, noise_weight=zw, bias=b, act=(0.2, 2 ** 0.5),
+                             device=dev)
+            assert H.rel_err(st, H.modconv_noise_bias_act(oracle_lib, d, x, wt, xs, wm, z, zw, b, alpha=0.2)) < TOL
 
 
 def test_transforms_on_the_emulator(emu_lib, oracle_lib):
@@ -105,6 +124,39 @@ def test_python_route_through_autograd(oracle_lib, monkeypatch):
         assert float((a - o).abs().max() / o.abs().max()) < TOL
 
 
+def test_modulated_nodes_take_the_route(oracle_lib, monkeypatch):
+    """ModulatedConv (forward: x_scale + demodulation; backward: the data gradient with the factors on the transposed axes) and the
+    fused StyledConv forward (noise + bias + activation in the output transform) behind SAE_WINOGRAD=1 against the direct path."""
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as G, winograd
+    monkeypatch.setattr(hip_lib, "_LIB", oracle_lib)
+    torch.manual_seed(5)
+    x = torch.randn(2, 12, 8, 8, requires_grad=True)
+    s = (1 + 0.3 * torch.randn(2, 12)).requires_grad_(True)
+    w = torch.randn(16, 12, 3, 3, requires_grad=True)
+    noise = torch.randn(2, 1, 8, 8)
+    nw = torch.tensor([0.4], requires_grad=True)
+    b = torch.randn(16, requires_grad=True)
+
+    def run():
+        y1 = G.modulated_conv2d(x, s, w, padding=1, alpha=0.1, demod_eps=1e-8)
+        y2 = G.styled_modulated_conv2d(x, s, w, noise, nw, b, padding=1, alpha=0.1, demod_eps=1e-8)
+        grads = torch.autograd.grad((y1 * y1).sum() + (y2 * y2).sum(), (x, s, w, nw, b))
+        return (y1.detach(), y2.detach()) + grads
+
+    monkeypatch.setenv("SAE_WINOGRAD", "0")
+    direct = run()
+    monkeypatch.setenv("SAE_WINOGRAD", "1")
+    monkeypatch.setenv("SAE_WINOGRAD_MIN_C", "8")
+    calls = []
+    orig = winograd.conv
+    monkeypatch.setattr(winograd, "conv", lambda *a, **k: (calls.append(k.get("transpose", False)), orig(*a, **k))[1])
+    routed = run()
+    assert calls.count(False) == 2 and calls.count(True) == 2, calls      # two forwards, two data gradients
+    for a, o in zip(routed, direct):
+        assert float((a - o).abs().max() / o.abs().max()) < TOL
+
+
 @pytest.mark.gpu
 def test_transforms_and_route_on_the_gpu(oracle_lib):
     from swapping_autoencoder_pytorch_amd import hip_lib
@@ -118,3 +170,42 @@ def test_transforms_and_route_on_the_gpu(oracle_lib):
     d = H.conv_desc(4, 512, 32, 32, 512, 3, 1, 1)
     direct = H.conv(lib, 0, d, x, wt, (4, 512, 32, 32), alpha=1.0, device="cuda:0")
     assert H.rel_err(H.wino_conv(lib, x, wt, device="cuda:0"), direct) < TOL
+
+
+def test_train_step_with_the_route(oracle_lib, monkeypatch):
+    """Four optimiser calls of the micro preset (D, G, D + lazy R1 -- the second-order path --, G) with every eligible layer on the
+    route against the same calls on the direct kernels: the losses agree to the rounding of the route."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import parity_common as P
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import winograd
+    from swapping_autoencoder_pytorch_amd.swapping_autoencoder_optimizer import SwappingAutoencoderOptimizer
+    monkeypatch.setattr(hip_lib, "_LIB", oracle_lib)
+
+    def run(route):
+        monkeypatch.setenv("SAE_WINOGRAD", "1" if route else "0")
+        monkeypatch.setenv("SAE_WINOGRAD_MIN_C", "4")
+        calls = []
+        orig = winograd.conv
+        monkeypatch.setattr(winograd, "conv", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        torch.manual_seed(0)
+        opt, model, net = P.build_micro("cpu", batch_size=4)
+        opt.R1_once_every = 2
+        optimizer = SwappingAutoencoderOptimizer(model, fused_adam=True)
+        out = []
+        for i in range(4):
+            torch.manual_seed(100 + i)
+            x = torch.rand(4, 3, 32, 32) * 2 - 1
+            out.append({k: float(v) for k, v in optimizer.train_one_step({"real_A": x}, i).items()})
+        monkeypatch.setattr(winograd, "conv", orig)
+        return out, len(calls)
+
+    direct, n0 = run(False)
+    routed, n1 = run(True)
+    assert n0 == 0 and n1 > 20, (n0, n1)
+    assert any("D_R1" in c for c in routed)
+    for a, b in zip(routed, direct):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-4 * max(1.0, abs(b[k])), (k, a[k], b[k])
