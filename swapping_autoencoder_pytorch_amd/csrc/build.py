@@ -37,7 +37,19 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    verify_loads(OUT)
     return OUT
+
+
+def verify_loads(path):
+    """dlopen the fresh library in a child process (no GPU needed): hipcc's host pass can drop a kernel's launch stub without a
+    diagnostic (seen with an LDS-DMA builtin whose operand came from a template-sized array), which only shows as an
+    undefined symbol when the library is loaded."""
+    code = "import ctypes, sys; ctypes.CDLL(sys.argv[1])"
+    r = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True)
+    if r.returncode != 0:
+        os.replace(path, path + ".broken")
+        raise RuntimeError("%s was built but does not load: %s" % (path, r.stderr.strip().splitlines()[-1] if r.stderr.strip() else "?"))
 
 
 if __name__ == "__main__":

@@ -2,9 +2,11 @@
 the plans of csrc/conv2d.hip (tile shapes restated here), 512 slots (two workgroups per CU), and the share of each launch's measured
 time that a partly filled last round can account for AT MOST (a workgroup alone on its CU runs ~1.7x faster, and in the step another
 stream fills idle CUs).  Input: profiles/r4_roofline_by_shape_church256.txt.   python tools/round_model.py"""
-import re, math
+import math
+import os
+import re
 rows=[]
-for line in open(__import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'profiles', 'r4_roofline_by_shape_church256.txt')):
+for line in open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r4_roofline_by_shape_church256.txt')):
     m=re.match(r'conv 3x3 s(\d) (fwd\S*|dgrad|wgrad)\s*(\(modulated\))?\s+n(\d+)\s+(\d+)->(\d+)\s+(\d+)x(\d+)\s+mfma\s+([\d.]+)\s+([\d.]+) GF\s+([\d.]+)\s+([\d.]+) TF/s\s+([\d.]+)',line)
     if not m: continue
     s,op,mod,n,ci,co,h,w,calls,gf,ms,tf,frac=m.groups()
