@@ -40,6 +40,8 @@ def build(force=False):
         raise RuntimeError("hipcc not found and no prebuilt %s" % OUT)
     subprocess.check_call([cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
                            "-DSAE_TUNING", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + sources() + ["-o", OUT])
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
     from swapping_autoencoder_pytorch_amd.csrc.build import verify_loads
     verify_loads(OUT)
     return OUT
