@@ -407,6 +407,12 @@ int sae_adam_multi_f32(float* const* params, const float* const* grads, float* c
  *                          y = lrelu((y + noise_weight[0] * noise[plane / channels][pixel]) + bias[plane % channels], slope) *
  *                          act_scale (noise: [planes / channels][h][w] or NULL, noise_weight: one float on the device; bias may
  *                          be NULL) -- the epilogues of sae_conv2d_fwd_bias_act_f32 / sae_modconv2d_fwd_noise_bias_act_f32
+ * Weight gradient on the same sixteen points (the transposition of the forward algorithm):
+ *     gw = G^T [ sum over images and tiles of (A e A^T) o (B^T d B) ] G,    e: the 2x2 tile of the output gradient
+ *   sae_wino_gy_f32            gy [planes][h][w] -> e [16][planes][h/2][w/2]  (plane_scale as in sae_wino_input_f32)
+ *   sae_wino_wgrad_gemm_f32    gu[xi][m][c] = sum_{n,t} e[xi][n][m][t] v[xi][n][c][t]  (sixteen 1x1 weight gradients; v from
+ *                              sae_wino_input_f32 on the layer's input; workspace: sae_wino_wgrad_gemm_workspace floats)
+ *   sae_wino_wgrad_output_f32  gw[m * w_stride_m + c * w_stride_c + tap] = alpha * (G^T gu G)[tap]
  * Exact fp32; results differ from the direct kernels' by rounding only (another association of the same sums).
  *   sae_wino_gemm_f32      md[xi] = u[xi] v[xi] for the 16 xi: v [16][n][c][tiles_h][tiles_w], u [16][m][c],
  *                          md [16][n][m][tiles_h][tiles_w]; workspace: sae_wino_gemm_workspace floats
@@ -414,6 +420,12 @@ int sae_adam_multi_f32(float* const* params, const float* const* grads, float* c
 int64_t sae_wino_gemm_workspace(int64_t n, int64_t c, int64_t m, int64_t tiles_h, int64_t tiles_w);
 int sae_wino_gemm_f32(const float* v, const float* u, float* md, int64_t n, int64_t c, int64_t m, int64_t tiles_h,
                       int64_t tiles_w, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+int sae_wino_gy_f32(const float* gy, const float* plane_scale, float* e, int64_t planes, int64_t h, int64_t w, sae_stream_t stream);
+int64_t sae_wino_wgrad_gemm_workspace(int64_t n, int64_t c, int64_t m, int64_t tiles_h, int64_t tiles_w);
+int sae_wino_wgrad_gemm_f32(const float* v, const float* e, float* gu, int64_t n, int64_t c, int64_t m, int64_t tiles_h,
+                            int64_t tiles_w, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+int sae_wino_wgrad_output_f32(const float* gu, float* gw, int64_t m, int64_t c, int64_t w_stride_m, int64_t w_stride_c, float alpha,
+                              sae_stream_t stream);
 int sae_wino_weights_f32(const float* w, const float* row_scale, const float* col_scale, float* u, int64_t m, int64_t c,
                          int64_t w_stride_m, int64_t w_stride_c, int32_t flip, float alpha, sae_stream_t stream);
 int sae_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w,

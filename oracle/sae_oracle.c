@@ -1119,3 +1119,67 @@ int oracle_wino_gemm_f32(const float* v, const float* u, float* md, int64_t n, i
                 }
     return SAE_OK;
 }
+
+/* ---- weight gradient on the sixteen points: restated from the matrices (A = the transpose of WINO_AT, G = WINO_G) */
+int oracle_wino_gy_f32(const float* gy, const float* plane_scale, float* e, int64_t planes, int64_t h, int64_t w, sae_stream_t stream) {
+    (void)stream;
+    if (planes < 0 || h < 2 || w < 2 || (h & 1) || (w & 1)) return set_err("oracle_wino_gy_f32: the map must have even sides");
+    if (planes == 0) return SAE_OK;
+    if (!gy || !e) return set_err("oracle_wino_gy_f32: null tensor");
+    const int64_t th = h / 2, tw = w / 2, tiles = th * tw;
+    for (int64_t p = 0; p < planes; ++p)
+        for (int64_t ty = 0; ty < th; ++ty)
+            for (int64_t tx = 0; tx < tw; ++tx)
+                for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) {
+                        double acc = 0.0;
+                        for (int i = 0; i < 2; ++i)
+                            for (int j = 0; j < 2; ++j) {
+                                const float g = gy[(p * h + 2 * ty + i) * w + 2 * tx + j];
+                                acc += WINO_AT[i][a] * (double)(plane_scale ? g * plane_scale[p] : g) * WINO_AT[j][b];
+                            }
+                        e[((int64_t)(4 * a + b) * planes + p) * tiles + ty * tw + tx] = (float)acc;
+                    }
+    return SAE_OK;
+}
+
+int64_t oracle_wino_wgrad_gemm_workspace(int64_t n, int64_t c, int64_t m, int64_t tiles_h, int64_t tiles_w) {
+    (void)n; (void)c; (void)m; (void)tiles_h; (void)tiles_w;
+    return 0;
+}
+
+int oracle_wino_wgrad_gemm_f32(const float* v, const float* e, float* gu, int64_t n, int64_t c, int64_t m, int64_t tiles_h,
+                               int64_t tiles_w, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    (void)workspace; (void)workspace_floats; (void)stream;
+    if (n < 0 || c < 1 || m < 1 || tiles_h < 1 || tiles_w < 1 || !gu || (n > 0 && (!v || !e)))
+        return set_err("oracle_wino_wgrad_gemm_f32: bad argument");
+    const int64_t t = tiles_h * tiles_w;
+#pragma omp parallel for collapse(2)
+    for (int64_t xi = 0; xi < 16; ++xi)
+        for (int64_t mi = 0; mi < m; ++mi)
+            for (int64_t ci = 0; ci < c; ++ci) {
+                double acc = 0.0;
+                for (int64_t ni = 0; ni < n; ++ni)
+                    for (int64_t ti = 0; ti < t; ++ti)
+                        acc += (double)e[((xi * n + ni) * m + mi) * t + ti] * (double)v[((xi * n + ni) * c + ci) * t + ti];
+                gu[(xi * m + mi) * c + ci] = (float)acc;
+            }
+    return SAE_OK;
+}
+
+int oracle_wino_wgrad_output_f32(const float* gu, float* gw, int64_t m, int64_t c, int64_t w_stride_m, int64_t w_stride_c, float alpha,
+                                 sae_stream_t stream) {
+    (void)stream;
+    if (m < 1 || c < 1 || !gu || !gw) return set_err("oracle_wino_wgrad_output_f32: bad argument");
+    for (int64_t mi = 0; mi < m; ++mi)
+        for (int64_t ci = 0; ci < c; ++ci)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double acc = 0.0;
+                    for (int a = 0; a < 4; ++a)
+                        for (int b = 0; b < 4; ++b)
+                            acc += WINO_G[a][i] * (double)gu[((int64_t)(4 * a + b) * m + mi) * c + ci] * WINO_G[b][j];
+                    gw[mi * w_stride_m + ci * w_stride_c + 3 * i + j] = (float)((double)alpha * acc);
+                }
+    return SAE_OK;
+}

@@ -5024,6 +5024,43 @@ extern "C" int sae_conv2d_wgrad_f32(const float* x, const float* gy, float* gw, 
     return conv_wgrad_impl("sae_conv2d_wgrad_f32", x, gy, gw, d, kNoMod, alpha, workspace, workspace_floats, stream);
 }
 
+// ---- the sixteen products of the Winograd weight gradient: gU[xi][m][c] = sum over images and tiles of E[xi][n][m][t] V[xi][n][c][t],
+// each the weight gradient of a 1x1 convolution (K = n * tiles): sixteen launches of the 1x1 weight-gradient kernel + its reduction.
+namespace sae {
+namespace {
+sae_conv2d_desc wino_wgrad_desc(int64_t n, int64_t c, int64_t m, int64_t th, int64_t tw) {
+    sae_conv2d_desc d{};
+    d.n = n; d.c = c; d.h = th; d.w = tw; d.m = m; d.oh = th; d.ow = tw;
+    d.kh = d.kw = 1; d.stride = 1; d.pad = 0;
+    d.w_stride_m = c; d.w_stride_c = 1;
+    return d;
+}
+}  // namespace
+}  // namespace sae
+
+extern "C" int64_t sae_wino_wgrad_gemm_workspace(int64_t n, int64_t c, int64_t m, int64_t tiles_h, int64_t tiles_w) {
+    if (!wino_gemm_shape_ok(n, c, m, tiles_h, tiles_w, "sae_wino_wgrad_gemm_workspace") || n == 0) return 0;
+    const sae_conv2d_desc d = wino_wgrad_desc(n, c, m, tiles_h, tiles_w);
+    return sae_conv2d_workspace(&d, SAE_CONV_WGRAD);
+}
+
+extern "C" int sae_wino_wgrad_gemm_f32(const float* v, const float* e, float* gu, int64_t n, int64_t c, int64_t m, int64_t tiles_h,
+                                       int64_t tiles_w, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    sae::clear_stale_error();
+    const char* who = "sae_wino_wgrad_gemm_f32";
+    if (!wino_gemm_shape_ok(n, c, m, tiles_h, tiles_w, who)) return SAE_EINVAL;
+    if (!gu) return fail(SAE_EINVAL, "%s: null tensor", who);
+    if (n > 0 && (!v || !e)) return fail(SAE_EINVAL, "%s: null tensor", who);
+    const sae_conv2d_desc d = wino_wgrad_desc(n, c, m, tiles_h, tiles_w);
+    const int64_t tiles = tiles_h * tiles_w;
+    for (int xi = 0; xi < 16; ++xi) {
+        const int rc = conv_wgrad_impl(who, v + xi * n * c * tiles, e + xi * n * m * tiles, gu + xi * m * c, &d, kNoMod, 1.0f,
+                                       workspace, workspace_floats, stream);
+        if (rc != SAE_OK) return rc;
+    }
+    return SAE_OK;
+}
+
 extern "C" int sae_modconv2d_wgrad_f32(const float* x, const float* gy, float* gw, const sae_conv2d_desc* d,
                                        const sae_conv2d_mod* mod, float alpha, float* workspace,
                                        int64_t workspace_floats, sae_stream_t stream) {

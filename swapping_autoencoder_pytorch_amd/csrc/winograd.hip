@@ -158,6 +158,66 @@ __global__ __launch_bounds__(kBlock) void wino_output_kernel(const float* __rest
     }
 }
 
+// ---- weight gradient on the same 16 points:  gw = G^T [ sum_tiles (A e A^T) o (B^T d B) ] G  with e the 2x2 tile of the
+// output gradient (the transposition of the forward algorithm: sum_j e_j y_j read as a form in g).
+// gy: [planes][H][W] -> E: [16][planes][TH][TW]; A = [1 0; 1 1; 1 -1; 0 -1]
+__global__ __launch_bounds__(kBlock) void wino_gy_kernel(const float* __restrict__ gy, float* __restrict__ E,
+                                                         const float* __restrict__ scale, int64_t planes, int H, int W) {
+    const int TH = H >> 1, TW = W >> 1;
+    const int64_t T = (int64_t)TH * TW;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= planes * T) return;
+    const int64_t pl = i / T;
+    const int t = (int)(i - pl * T);
+    const int ty = t / TW, tx = t - ty * TW;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const float* gp = gy + pl * H * W + (int64_t)(2 * ty) * W + 2 * tx;
+    const float s = scale ? scale[pl] : 1.0f;
+    const f32x2 e0 = *reinterpret_cast<const f32x2*>(gp) * s;
+    const f32x2 e1 = *reinterpret_cast<const f32x2*>(gp + W) * s;
+    float r[4][2];      // A e
+    r[0][0] = e0[0];         r[0][1] = e0[1];
+    r[1][0] = e0[0] + e1[0]; r[1][1] = e0[1] + e1[1];
+    r[2][0] = e0[0] - e1[0]; r[2][1] = e0[1] - e1[1];
+    r[3][0] = -e1[0];        r[3][1] = -e1[1];
+    const int64_t plane = planes * T;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        E[(4 * a + 0) * plane + i] = r[a][0];
+        E[(4 * a + 1) * plane + i] = r[a][0] + r[a][1];
+        E[(4 * a + 2) * plane + i] = r[a][0] - r[a][1];
+        E[(4 * a + 3) * plane + i] = -r[a][1];
+    }
+}
+
+// gU: [16][M][C] -> gw[m * sm + c * sc + tap] = alpha * (G^T gU G)[tap];  G^T = [1 .5 .5 0; 0 .5 -.5 0; 0 .5 .5 1]
+__global__ __launch_bounds__(kBlock) void wino_wgrad_output_kernel(const float* __restrict__ gU, float* __restrict__ gw, int M,
+                                                                   int C, int64_t sm, int64_t sc, float alpha) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)M * C) return;
+    const int m = (int)(i / C), c = (int)(i - (int64_t)m * C);
+    const int64_t plane = (int64_t)M * C;
+    float u[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) u[a][b] = gU[(4 * a + b) * plane + i];
+    float r[3][4];      // G^T u
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        r[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+        r[1][b] = 0.5f * (u[1][b] - u[2][b]);
+        r[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+    }
+    float* wp = gw + m * sm + c * sc;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        wp[3 * k + 0] = alpha * (r[k][0] + 0.5f * (r[k][1] + r[k][2]));
+        wp[3 * k + 1] = alpha * (0.5f * (r[k][1] - r[k][2]));
+        wp[3 * k + 2] = alpha * (0.5f * (r[k][1] + r[k][2]) + r[k][3]);
+    }
+}
+
 inline unsigned blocks_for(int64_t work) {
     const int64_t b = ceil_div64(work > 0 ? work : 1, kBlock);
     return (unsigned)(b > 2147483647 ? 2147483647 : b);
@@ -209,4 +269,28 @@ extern "C" int sae_wino_output_f32(const float* md, const float* plane_scale, co
                        md, y, bias, planes, (int)channels, (int)h, (int)w, act ? 1 : 0, slope, act_scale, plane_scale, noise,
                        noise_weight);
     return check_launch("sae_wino_output_f32");
+}
+
+extern "C" int sae_wino_gy_f32(const float* gy, const float* plane_scale, float* e, int64_t planes, int64_t h, int64_t w,
+                               sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (planes < 0 || h < 2 || w < 2 || (h & 1) || (w & 1) || h >= 32768 || w >= 32768)
+        return fail(SAE_EINVAL, "sae_wino_gy_f32: the map must have even sides (2x2 output tiles), got %lld x %lld", (long long)h,
+                    (long long)w);
+    if (planes == 0) return SAE_OK;
+    if (!gy || !e) return fail(SAE_EINVAL, "sae_wino_gy_f32: null tensor");
+    if ((reinterpret_cast<uintptr_t>(gy) & 7) != 0) return fail(SAE_EINVAL, "sae_wino_gy_f32: gy must be 8-byte aligned");
+    hipLaunchKernelGGL(wino_gy_kernel, dim3(blocks_for(planes * (h / 2) * (w / 2))), dim3(kBlock), 0, (hipStream_t)stream, gy, e,
+                       plane_scale, planes, (int)h, (int)w);
+    return check_launch("sae_wino_gy_f32");
+}
+
+extern "C" int sae_wino_wgrad_output_f32(const float* gu, float* gw, int64_t m, int64_t c, int64_t w_stride_m, int64_t w_stride_c,
+                                         float alpha, sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (m < 1 || c < 1 || m * c >= ((int64_t)1 << 31)) return fail(SAE_EINVAL, "sae_wino_wgrad_output_f32: bad shape");
+    if (!gu || !gw) return fail(SAE_EINVAL, "sae_wino_wgrad_output_f32: null tensor");
+    hipLaunchKernelGGL(wino_wgrad_output_kernel, dim3(blocks_for(m * c)), dim3(kBlock), 0, (hipStream_t)stream, gu, gw, (int)m,
+                       (int)c, w_stride_m, w_stride_c, alpha);
+    return check_launch("sae_wino_wgrad_output_f32");
 }

@@ -140,6 +140,8 @@ def _dgrad(gy, w, g):
 
 
 def _wgrad(x, gy, g, out=None):
+    if winograd.eligible(g):
+        return winograd.wgrad(x, gy, g, out=out)
     return _launch("conv2d_wgrad_f32", SAE_CONV_WGRAD, g, x, gy, g.weight_shape(), out=out)
 
 
@@ -260,9 +262,11 @@ def _launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_
     """One sae_modconv2d_* call: the plain operation `op` on a * factor, b (weights or second activation) with the
     optional [N, C] activation factors and per-channel weight factors staged inside the kernels.  factor_tag: what the weight
     factors are as a function of the weight parameter alone (weight_prep.attach), None = unknown (no prepared weights)."""
-    if op != SAE_CONV_WGRAD and winograd.eligible(geom):
+    if winograd.eligible(geom):
         # the factors of sae_conv2d_mod in the route's terms: the activation factor of the operation's input; the weight factors by
         # the axes of the product that is computed (the data gradient's outputs are the c axis)
+        if op == SAE_CONV_WGRAD:      # a = x, b = gy
+            return winograd.wgrad(a, b, geom, x_scale=x_scale, y_scale=y_scale)
         if op == SAE_CONV_FWD:
             return winograd.conv(a, b, geom, x_scale=x_scale, row_scale=wm_scale, col_scale=wc_scale)
         return winograd.conv(a, b, geom, transpose=True, x_scale=y_scale, row_scale=wc_scale, col_scale=wm_scale)

@@ -3,8 +3,8 @@
     y = output_transform( 16 x [ conv1x1( input_transform(x)[xi], U[xi] ) ] )        U = weight_transform(w)
 
 The same three C-ABI transforms serve the forward (``F.conv2d`` at models/networks/stylegan2_layers.py:136,315) and the data
-gradient (the reversed filter with the channel roles swapped); the 16 transform-domain products are calls of the existing 1x1
-MFMA gather.  2.25x fewer multiplications for two extra passes over 4x the activation: it pays on layers with many channels on
+gradient (the reversed filter with the channel roles swapped); the 16 transform-domain products are one batched launch of the 1x1
+MFMA gather.  ``wgrad`` is the weight gradient on the same sixteen points.  2.25x fewer multiplications for two extra passes over 4x the activation: it pays on layers with many channels on
 small maps.  OFF unless ``SAE_WINOGRAD=1`` -- built and verified against the oracle this round (CPU emulator), not yet measured
 on the GPU; ``SAE_WINOGRAD_MIN_C`` (default 256) is the smallest channel count that takes it.
 Results differ from the direct kernels' by rounding (~1e-6 relative), so the route is never mixed into bit-identity checks."""
@@ -70,3 +70,36 @@ def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None, row_sca
     lib.call("wino_output_f32", md.data_ptr(), hip_lib.ptr(out_scale), hip_lib.ptr(noise), hip_lib.ptr(noise_weight),
              hip_lib.ptr(bias), y.data_ptr(), n * cout, cout, h, wd, 1 if act is not None else 0, float(slope), float(scale), stream)
     return y
+
+
+def wgrad(x, gy, geom, out=None, x_scale=None, y_scale=None):
+    """alpha * sum over images and pixels of (gy * y_scale) (x) (x * x_scale) as the layer's weight gradient (geom.weight_shape()),
+    on the sixteen points: gw = G^T [ sum (A e A^T) o (B^T d B) ] G.  out: an existing tensor of that shape to write into (a
+    slot of an armed gradient bucket)."""
+    lib = hip_lib.get()
+    x = x.contiguous()
+    gy = gy.contiguous()
+    x_scale = x_scale.contiguous() if x_scale is not None else None
+    y_scale = y_scale.contiguous() if y_scale is not None else None
+    lib.check(x, gy, x_scale, y_scale, out)
+    n, c, m, h, wd = geom.n, geom.c, geom.m, geom.h, geom.w
+    if tuple(x.shape) != (n, c, h, wd) or tuple(gy.shape) != (n, m, h, wd):
+        raise hip_lib.SaeError("winograd wgrad: x %s, gy %s for a (%d, %d -> %d, %d x %d) layer" % (
+            tuple(x.shape), tuple(gy.shape), n, c, m, h, wd))
+    th, tw = h // 2, wd // 2
+    tiles = th * tw
+    stream = lib.stream(x)
+    dev = x.device
+    v = torch.empty((16, n * c, tiles), dtype=torch.float32, device=dev)
+    lib.call("wino_input_f32", x.data_ptr(), hip_lib.ptr(x_scale), v.data_ptr(), n * c, h, wd, stream)
+    e = torch.empty((16, n * m, tiles), dtype=torch.float32, device=dev)
+    lib.call("wino_gy_f32", gy.data_ptr(), hip_lib.ptr(y_scale), e.data_ptr(), n * m, h, wd, stream)
+    gu = torch.empty((16, m, c), dtype=torch.float32, device=dev)
+    n_ws = lib.query("wino_wgrad_gemm_workspace", n, c, m, th, tw)
+    ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
+    lib.call("wino_wgrad_gemm_f32", v.data_ptr(), e.data_ptr(), gu.data_ptr(), n, c, m, th, tw, ws.data_ptr(), n_ws, stream)
+    d = geom.desc()
+    if out is None or tuple(out.shape) != tuple(geom.weight_shape()) or not out.is_contiguous():
+        out = torch.empty(geom.weight_shape(), dtype=torch.float32, device=dev)
+    lib.call("wino_wgrad_output_f32", gu.data_ptr(), out.data_ptr(), m, c, d.w_stride_m, d.w_stride_c, geom.alpha, stream)
+    return out

@@ -439,3 +439,21 @@ def wino_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None, x_sca
     md = bm.numpy()
     return wino_output(lib, md, h, w, cout, bias=bias, act=act, plane_scale=None if out_scale is None else out_scale.reshape(-1),
                        noise=noise, noise_weight=noise_weight, device=device).reshape(n, cout, h, w)
+
+
+def wino_wgrad(lib, x, gy, alpha=1.0, cm_layout=False, x_scale=None, y_scale=None, device=None):
+    """The weight gradient on the route: alpha * sum (gy * y_scale) (x) (x * x_scale) -> [m, c, 3, 3] ([c, m, 3, 3] if cm_layout)."""
+    n, c, h, w = x.shape
+    m = gy.shape[1]
+    th, tw = h // 2, w // 2
+    v = wino_input(lib, x.reshape(n * c, h, w), None if x_scale is None else x_scale.reshape(-1), device=device)
+    bg, be = _Buf(gy.reshape(n * m, h, w), device), _out((16, n * m, th, tw), device)
+    bs = _Buf(y_scale.reshape(-1), device) if y_scale is not None else None
+    lib.call("wino_gy_f32", bg.ptr, bs.ptr if bs else None, be.ptr, n * m, h, w, _stream(device))
+    n_ws = lib.query("wino_wgrad_gemm_workspace", n, c, m, th, tw)
+    bv, bu, ws = _Buf(v, device), _out((16, m, c), device), _out((max(n_ws, 1),), device)
+    lib.call("wino_wgrad_gemm_f32", bv.ptr, be.ptr, bu.ptr, n, c, m, th, tw, ws.ptr, n_ws, _stream(device))
+    shape, sm, sc = ((c, m, 3, 3), 9, m * 9) if cm_layout else ((m, c, 3, 3), c * 9, 9)
+    bw = _out(shape, device)
+    lib.call("wino_wgrad_output_f32", bu.ptr, bw.ptr, m, c, sm, sc, alpha, _stream(device))
+    return bw.numpy(), be.numpy(), bu.numpy()

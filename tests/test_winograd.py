@@ -66,6 +66,14 @@ def _route(lib, oracle_lib, dev):
         assert H.rel_err(mod, H.modconv(oracle_lib, 0, d, x, wt, gy.shape, x_scale=xs, wm_scale=wm, wc_scale=wc, alpha=0.3)) < TOL
         mdg = H.wino_conv(lib, gy, wt, alpha=0.3, transpose=True, x_scale=ys, row_scale=wc, col_scale=wm, cm_layout=cm, device=dev)
         assert H.rel_err(mdg, H.modconv(oracle_lib, 1, d, gy, wt, x.shape, y_scale=ys, wm_scale=wm, wc_scale=wc, alpha=0.3)) < TOL
+        # the weight gradient on the route (plain and with both activation factors) against the oracle's direct one, and its
+        # two transforms against the oracle's
+        gw, e, gu = H.wino_wgrad(lib, x, gy, alpha=0.37, cm_layout=cm, device=dev)
+        assert H.rel_err(gw, H.conv(oracle_lib, 2, d, x, gy, wt.shape, alpha=0.37)) < TOL
+        _, eo, guo = H.wino_wgrad(oracle_lib, x, gy, alpha=0.37, cm_layout=cm)
+        assert H.rel_err(e, eo) < 1e-6 and H.rel_err(gu, guo) < TOL
+        gwm, _, _ = H.wino_wgrad(lib, x, gy, alpha=0.3, cm_layout=cm, x_scale=xs, y_scale=ys, device=dev)
+        assert H.rel_err(gwm, H.modconv(oracle_lib, 2, d, x, gy, wt.shape, x_scale=xs, y_scale=ys, alpha=0.3)) < TOL
         if not cm:          # StyledConv's plain form: modulated forward + noise + bias + leaky-ReLU
             z = rng.standard_normal((n, h, w)).astype(np.float32)
             zw = np.array([0.6], np.float32)
@@ -94,8 +102,8 @@ def test_bad_geometry_is_refused(emu_lib):
 
 
 def test_python_route_through_autograd(oracle_lib, monkeypatch):
-    """stylegan2_op.winograd behind conv2d_gemm (SAE_WINOGRAD=1): forward, data gradient and the fused activation take the route
-    and agree with the direct kernels; the weight gradient stays the direct kernel."""
+    """stylegan2_op.winograd behind conv2d_gemm (SAE_WINOGRAD=1): forward with the fused activation, data gradient and weight
+    gradient take the route and agree with the direct kernels."""
     from swapping_autoencoder_pytorch_amd import hip_lib
     from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as G, winograd
     monkeypatch.setattr(hip_lib, "_LIB", oracle_lib)
@@ -118,8 +126,12 @@ def test_python_route_through_autograd(oracle_lib, monkeypatch):
     calls = []
     orig = winograd.conv
     monkeypatch.setattr(winograd, "conv", lambda *a, **k: (calls.append(k.get("transpose", False)), orig(*a, **k))[1])
+    wg_calls = []
+    orig_wg = winograd.wgrad
+    monkeypatch.setattr(winograd, "wgrad", lambda *a, **k: (wg_calls.append(1), orig_wg(*a, **k))[1])
     routed = run()
     assert calls == [False, True], calls          # the fused forward, then the data gradient
+    assert wg_calls == [1], wg_calls              # ... and the weight gradient
     for a, o in zip(routed, direct):
         assert float((a - o).abs().max() / o.abs().max()) < TOL
 
