@@ -114,6 +114,21 @@ def work_of(name, a):
     if name in ("random_crop_f32", "random_crop_bwd_f32"):
         images, ch, h, w, crops, size = a[4:10]
         return name[:-4], "hbm", 4.0 * ch * (images * h * w + images * crops * size * size)
+    # Winograd route (SAE_WINOGRAD=1): the products are counted with the FLOPs they EXECUTE (16 per 2x2 tile and channel pair,
+    # 4/9 of the layer's algorithmic count), the transforms with the bytes they move (x or y once, the transform domain 4x)
+    if name in ("wino_gemm_f32", "wino_wgrad_gemm_f32"):
+        n, c, m, th, tw = a[3:8]
+        if BY_SHAPE:
+            return "winograd products %-5s n%-3d %4d->%-4d %3dx%-3d tiles" % ("wgrad" if "wgrad" in name else "", n, c, m, th, tw), "mfma", 32.0 * n * c * m * th * tw
+        return "winograd products (16 x 1x1%s)" % (" weight gradient" if "wgrad" in name else ""), "mfma", 32.0 * n * c * m * th * tw
+    if name in ("wino_input_f32", "wino_gy_f32"):
+        return "winograd input / gradient transform", "hbm", 20.0 * a[3] * a[4] * a[5]
+    if name == "wino_output_f32":
+        return "winograd output transform (+ epilogue)", "hbm", 20.0 * a[6] * a[8] * a[9]
+    if name == "wino_weights_f32":
+        return "winograd weight transform", "hbm", 100.0 * a[4] * a[5]
+    if name == "wino_wgrad_output_f32":
+        return "winograd weight transform", "hbm", 100.0 * a[2] * a[3]
     if name in ("reflect_pad_f32", "reflect_pad_adj_f32"):
         planes, h, w, l, r, t, b = a[2:9]
         return name[:-4], "hbm", 4.0 * planes * (h * w + (h + t + b) * (w + l + r))
@@ -126,7 +141,7 @@ class Ledger:
         orig = lib.call
 
         def call(name, *args):
-            if not self.active or name in ("set_conv_math", "conv2d_wprep_query"):
+            if not self.active or name in ("set_conv_math", "conv2d_wprep_query", "wino_gemm_workspace", "wino_wgrad_gemm_workspace"):
                 return orig(name, *args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
