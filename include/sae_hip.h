@@ -394,14 +394,15 @@ int sae_adam_multi_f32(float* const* params, const float* const* grads, float* c
                        double eps, double grad_scale, sae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * Winograd F(2x2, 3x3) transforms for the 3x3 stride-1 pad-1 convolutions (F.conv2d at models/networks/stylegan2_layers.py:136,
+ * Winograd F(2x2, 3x3) transforms for the 3x3 stride-1 convolutions (pad 1 or 0) (F.conv2d at models/networks/stylegan2_layers.py:136,
  * 315 -- the algorithm class the reference's cuDNN / MIOpen back end picks for these shapes).  csrc/winograd.hip has the
  * matrices.  The 16 products of the transform domain are 1x1 convolutions (c channels of tiles_h x tiles_w "pixels" each) on the
  * MFMA gather: sae_wino_gemm_f32.
  *   sae_wino_weights_f32   u[16][m][c] = (G g G^T) of g = alpha * w[m * w_stride_m + c * w_stride_c + tap] * row_scale[m] *
  *                          col_scale[c] (either factor may be NULL: the wm_scale / wc_scale of sae_conv2d_mod);  flip != 0: taps
  *                          reversed -- with the two strides (and factors) swapped by the caller that is the data gradient's filter
- *   sae_wino_input_f32     x [planes][h][w] (h, w even; zero padding of 1 implied) -> v [16][planes][h/2][w/2];
+ *   sae_wino_input_f32     x [planes][h][w] (h, w even) with zero padding `pad` (1: the layer's "same" form; 0: valid; 2: the
+ *                          data gradient of a valid layer) -> v [16][planes][(h + 2 pad - 2) / 2][(w + 2 pad - 2) / 2];
  *                          plane_scale: NULL or one factor per plane (x_scale / y_scale of sae_conv2d_mod)
  *   sae_wino_output_f32    md [16][planes][h/2][w/2] -> y [planes][h][w], times plane_scale[plane] if given; act != 0:
  *                          y = lrelu((y + noise_weight[0] * noise[plane / channels][pixel]) + bias[plane % channels], slope) *
@@ -428,7 +429,7 @@ int sae_wino_wgrad_output_f32(const float* gu, float* gw, int64_t m, int64_t c, 
                               sae_stream_t stream);
 int sae_wino_weights_f32(const float* w, const float* row_scale, const float* col_scale, float* u, int64_t m, int64_t c,
                          int64_t w_stride_m, int64_t w_stride_c, int32_t flip, float alpha, sae_stream_t stream);
-int sae_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w,
+int sae_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w, int32_t pad,
                        sae_stream_t stream);
 int sae_wino_output_f32(const float* md, const float* plane_scale, const float* noise, const float* noise_weight,
                         const float* bias, float* y, int64_t planes, int64_t channels, int64_t h, int64_t w, int32_t act,

@@ -1037,20 +1037,21 @@ int oracle_wino_weights_f32(const float* w, const float* row_scale, const float*
     return SAE_OK;
 }
 
-int oracle_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w,
+int oracle_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w, int32_t pad,
                           sae_stream_t stream) {
     (void)stream;
-    if (planes < 0 || h < 2 || w < 2 || (h & 1) || (w & 1)) return set_err("oracle_wino_input_f32: the map must have even sides");
+    if (planes < 0 || pad < 0 || pad > 2 || h < 1 || w < 1 || (h & 1) || (w & 1) || h + 2 * pad < 4 || w + 2 * pad < 4)
+        return set_err("oracle_wino_input_f32: the map must have even sides and pad 0, 1 or 2");
     if (planes == 0) return SAE_OK;
     if (!x || !v) return set_err("oracle_wino_input_f32: null tensor");
-    const int64_t th = h / 2, tw = w / 2, tiles = th * tw;
+    const int64_t th = (h + 2 * pad - 2) / 2, tw = (w + 2 * pad - 2) / 2, tiles = th * tw;
     for (int64_t p = 0; p < planes; ++p)
         for (int64_t ty = 0; ty < th; ++ty)
             for (int64_t tx = 0; tx < tw; ++tx) {
                 double d[4][4];
                 for (int r = 0; r < 4; ++r)
                     for (int q = 0; q < 4; ++q) {
-                        const int64_t iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + q;
+                        const int64_t iy = 2 * ty - pad + r, ix = 2 * tx - pad + q;
                         const int in = iy >= 0 && iy < h && ix >= 0 && ix < w;
                         d[r][q] = in ? (double)(plane_scale ? x[(p * h + iy) * w + ix] * plane_scale[p] : x[(p * h + iy) * w + ix]) : 0.0;
                     }

@@ -1,4 +1,4 @@
-// Winograd F(2x2, 3x3) for the 3x3 stride-1 pad-1 convolutions of the wide layers (the transforms; the 16 products of the
+// Winograd F(2x2, 3x3) for the 3x3 stride-1 convolutions (pad 1 or 0) of the wide layers (the transforms; the 16 products of the
 // transform domain are 1x1 convolutions on the MFMA gather of conv2d.hip).
 //
 // The reference runs these layers through F.conv2d (models/networks/stylegan2_layers.py:136,315), i.e. whatever algorithm
@@ -64,11 +64,13 @@ __global__ __launch_bounds__(kBlock) void wino_weight_kernel(const float* __rest
     }
 }
 
-// x: [planes][H][W] (pad 1 implied) -> V: [16][planes][TH][TW], TH = H / 2, TW = W / 2.  scale: per-plane factor or null
+// x: [planes][H][W], zero padding `pad` (0 valid, 1 same, 2 full: the data gradient of a valid convolution) ->
+// V: [16][planes][TH][TW], TH = (H + 2 pad - 2) / 2 tiles of 2x2 outputs.  scale: per-plane factor or null
 // (the style modulation of a ModulatedConv2d input, stylegan2_layers.py:280-286, applied on the way).
 __global__ __launch_bounds__(kBlock) void wino_input_kernel(const float* __restrict__ x, float* __restrict__ V,
-                                                            const float* __restrict__ scale, int64_t planes, int H, int W) {
-    const int TH = H >> 1, TW = W >> 1;
+                                                            const float* __restrict__ scale, int64_t planes, int H, int W,
+                                                            int pad) {
+    const int TH = (H + 2 * pad - 2) >> 1, TW = (W + 2 * pad - 2) >> 1;
     const int64_t T = (int64_t)TH * TW;
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= planes * T) return;
@@ -80,10 +82,10 @@ __global__ __launch_bounds__(kBlock) void wino_input_kernel(const float* __restr
     float d[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int iy = 2 * ty - 1 + r;
+        const int iy = 2 * ty - pad + r;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int ix = 2 * tx - 1 + q;
+            const int ix = 2 * tx - pad + q;
             const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
             const float v = xp[in ? (int64_t)iy * W + ix : 0];
             d[r][q] = in ? v * s : 0.0f;
@@ -240,15 +242,17 @@ extern "C" int sae_wino_weights_f32(const float* w, const float* row_scale, cons
 }
 
 extern "C" int sae_wino_input_f32(const float* x, const float* plane_scale, float* v, int64_t planes, int64_t h, int64_t w,
-                                  sae_stream_t stream) {
+                                  int32_t pad, sae_stream_t stream) {
     sae::clear_stale_error();
-    if (planes < 0 || h < 2 || w < 2 || (h & 1) || (w & 1) || h >= 32768 || w >= 32768)
-        return fail(SAE_EINVAL, "sae_wino_input_f32: the map must have even sides (2x2 output tiles), got %lld x %lld",
-                    (long long)h, (long long)w);
+    if (planes < 0 || pad < 0 || pad > 2 || h < 1 || w < 1 || (h & 1) || (w & 1) || h + 2 * pad < 4 || w + 2 * pad < 4 ||
+        h >= 32768 || w >= 32768)
+        return fail(SAE_EINVAL, "sae_wino_input_f32: the map must have even sides (2x2 output tiles) and pad 0, 1 or 2, got "
+                                "%lld x %lld pad %d", (long long)h, (long long)w, (int)pad);
     if (planes == 0) return SAE_OK;
     if (!x || !v) return fail(SAE_EINVAL, "sae_wino_input_f32: null tensor");
-    hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_for(planes * (h / 2) * (w / 2))), dim3(kBlock), 0, (hipStream_t)stream, x,
-                       v, plane_scale, planes, (int)h, (int)w);
+    const int64_t tiles = ((h + 2 * pad - 2) / 2) * ((w + 2 * pad - 2) / 2);
+    hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_for(planes * tiles)), dim3(kBlock), 0, (hipStream_t)stream, x,
+                       v, plane_scale, planes, (int)h, (int)w, (int)pad);
     return check_launch("sae_wino_input_f32");
 }
 

@@ -107,7 +107,7 @@ _SIGNATURES = {
     "wino_wgrad_gemm_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _f32p, _i64, _stream]),
     "wino_wgrad_output_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _i64, _i64, _f32, _stream]),
     "wino_weights_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i32, _f32, _stream]),
-    "wino_input_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _stream]),
+    "wino_input_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _i32, _stream]),
     "wino_output_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i32, _f32, _f32, _stream]),
 }
 

@@ -1,4 +1,4 @@
-"""Winograd F(2x2, 3x3) route for the wide 3x3 stride-1 pad-1 convolutions (csrc/winograd.hip, include/sae_hip.h: sae_wino_*).
+"""Winograd F(2x2, 3x3) route for the wide 3x3 stride-1 convolutions (pad 1 or 0) (csrc/winograd.hip, include/sae_hip.h: sae_wino_*).
 
     y = output_transform( 16 x [ conv1x1( input_transform(x)[xi], U[xi] ) ] )        U = weight_transform(w)
 
@@ -24,8 +24,8 @@ def min_channels():
 
 
 def eligible(geom):
-    """3x3, stride 1, pad 1, even sides (whole 2x2 output tiles), wide enough, exact-fp32 arithmetic."""
-    if not enabled() or geom.k != 3 or geom.stride != 1 or geom.pad != 1 or (geom.h & 1) or (geom.w & 1):
+    """3x3, stride 1, pad 1 or 0, even sides (whole 2x2 output tiles), wide enough, exact-fp32 arithmetic."""
+    if not enabled() or geom.k != 3 or geom.stride != 1 or geom.pad not in (0, 1) or (geom.h & 1) or (geom.w & 1):
         return False
     if min(geom.c, geom.m) < min_channels():
         return False
@@ -49,9 +49,12 @@ def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None, row_sca
         cin, cout, sm, sc, flip = geom.m, geom.c, d.w_stride_c, d.w_stride_m, 1
     else:
         cin, cout, sm, sc, flip = geom.c, geom.m, d.w_stride_m, d.w_stride_c, 0
-    n, h, wd = geom.n, geom.h, geom.w
-    if tuple(x.shape) != (n, cin, h, wd):
-        raise hip_lib.SaeError("winograd conv: input %s, expected (%d, %d, %d, %d)" % (tuple(x.shape), n, cin, h, wd))
+    # forward: the layer's input with its own padding; data gradient: the output gradient with padding 2 - pad (a valid layer's
+    # gradient is a full correlation)
+    n = geom.n
+    ih, iw, pad, h, wd = (geom.oh, geom.ow, 2 - geom.pad, geom.h, geom.w) if transpose else (geom.h, geom.w, geom.pad, geom.oh, geom.ow)
+    if tuple(x.shape) != (n, cin, ih, iw):
+        raise hip_lib.SaeError("winograd conv: input %s, expected (%d, %d, %d, %d)" % (tuple(x.shape), n, cin, ih, iw))
     th, tw = h // 2, wd // 2
     tiles = th * tw
     stream = lib.stream(x)
@@ -60,7 +63,7 @@ def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None, row_sca
     lib.call("wino_weights_f32", w.data_ptr(), hip_lib.ptr(row_scale), hip_lib.ptr(col_scale), u.data_ptr(), cout, cin, sm, sc,
              flip, geom.alpha, stream)
     v = torch.empty((16, n * cin, tiles), dtype=torch.float32, device=dev)
-    lib.call("wino_input_f32", x.data_ptr(), hip_lib.ptr(x_scale), v.data_ptr(), n * cin, h, wd, stream)
+    lib.call("wino_input_f32", x.data_ptr(), hip_lib.ptr(x_scale), v.data_ptr(), n * cin, ih, iw, pad, stream)
     md = torch.empty((16, n * cout, tiles), dtype=torch.float32, device=dev)
     n_ws = lib.query("wino_gemm_workspace", n, cin, cout, th, tw)
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
@@ -82,16 +85,16 @@ def wgrad(x, gy, geom, out=None, x_scale=None, y_scale=None):
     x_scale = x_scale.contiguous() if x_scale is not None else None
     y_scale = y_scale.contiguous() if y_scale is not None else None
     lib.check(x, gy, x_scale, y_scale, out)
-    n, c, m, h, wd = geom.n, geom.c, geom.m, geom.h, geom.w
-    if tuple(x.shape) != (n, c, h, wd) or tuple(gy.shape) != (n, m, h, wd):
+    n, c, m, h, wd = geom.n, geom.c, geom.m, geom.oh, geom.ow
+    if tuple(x.shape) != (n, c, geom.h, geom.w) or tuple(gy.shape) != (n, m, h, wd):
         raise hip_lib.SaeError("winograd wgrad: x %s, gy %s for a (%d, %d -> %d, %d x %d) layer" % (
-            tuple(x.shape), tuple(gy.shape), n, c, m, h, wd))
+            tuple(x.shape), tuple(gy.shape), n, c, m, geom.h, geom.w))
     th, tw = h // 2, wd // 2
     tiles = th * tw
     stream = lib.stream(x)
     dev = x.device
     v = torch.empty((16, n * c, tiles), dtype=torch.float32, device=dev)
-    lib.call("wino_input_f32", x.data_ptr(), hip_lib.ptr(x_scale), v.data_ptr(), n * c, h, wd, stream)
+    lib.call("wino_input_f32", x.data_ptr(), hip_lib.ptr(x_scale), v.data_ptr(), n * c, geom.h, geom.w, geom.pad, stream)
     e = torch.empty((16, n * m, tiles), dtype=torch.float32, device=dev)
     lib.call("wino_gy_f32", gy.data_ptr(), hip_lib.ptr(y_scale), e.data_ptr(), n * m, h, wd, stream)
     gu = torch.empty((16, m, c), dtype=torch.float32, device=dev)

@@ -394,11 +394,11 @@ def wino_weights(lib, w, m, c, sm, sc, flip=False, alpha=1.0, row_scale=None, co
     return bu.numpy()
 
 
-def wino_input(lib, x, plane_scale=None, device=None):
+def wino_input(lib, x, plane_scale=None, pad=1, device=None):
     planes, h, w = x.shape
-    bx, bv = _Buf(x, device), _out((16, planes, h // 2, w // 2), device)
+    bx, bv = _Buf(x, device), _out((16, planes, (h + 2 * pad - 2) // 2, (w + 2 * pad - 2) // 2), device)
     bs = _Buf(plane_scale, device) if plane_scale is not None else None
-    lib.call("wino_input_f32", bx.ptr, bs.ptr if bs else None, bv.ptr, planes, h, w, _stream(device))
+    lib.call("wino_input_f32", bx.ptr, bs.ptr if bs else None, bv.ptr, planes, h, w, pad, _stream(device))
     return bv.numpy()
 
 
@@ -413,11 +413,13 @@ def wino_output(lib, md, h, w, channels, bias=None, act=None, plane_scale=None, 
 
 
 def wino_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None, x_scale=None, cm_layout=False, row_scale=None,
-              col_scale=None, out_scale=None, noise=None, noise_weight=None, device=None):
+              col_scale=None, out_scale=None, noise=None, noise_weight=None, pad=1, device=None):
     """The whole route on numpy data: alpha * conv3x3(x * x_scale, wt * row_scale[m] * col_scale[c]) (pad 1) or, transpose=True,
     its data gradient for x = gy (row_scale / col_scale then name the axes of THAT product: rows = its outputs), times
     out_scale per output plane, then the optional noise + bias + leaky-ReLU epilogue."""
-    n, cin, h, w = x.shape
+    n, cin, ih, iw = x.shape
+    ipad = 2 - pad if transpose else pad           # `pad` is the LAYER's; its data gradient pads the output gradient by 2 - pad
+    h, w = ih + 2 * ipad - 2, iw + 2 * ipad - 2
     if cm_layout:
         c_, m_ = wt.shape[0], wt.shape[1]
         sm, sc = 9, m_ * 9
@@ -431,7 +433,7 @@ def wino_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None, x_sca
         cout = m_
         assert cin == c_
     u = wino_weights(lib, wt, cout, cin, sm, sc, flip=transpose, alpha=alpha, row_scale=row_scale, col_scale=col_scale, device=device)
-    v = wino_input(lib, x.reshape(n * cin, h, w), None if x_scale is None else x_scale.reshape(-1), device=device)
+    v = wino_input(lib, x.reshape(n * cin, ih, iw), None if x_scale is None else x_scale.reshape(-1), pad=ipad, device=device)
     th, tw = h // 2, w // 2
     n_ws = lib.query("wino_gemm_workspace", n, cin, cout, th, tw)
     bv, bu, bm, ws = _Buf(v, device), _Buf(u, device), _out((16, n * cout, th, tw), device), _out((max(n_ws, 1),), device)
@@ -441,12 +443,12 @@ def wino_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None, x_sca
                        noise=noise, noise_weight=noise_weight, device=device).reshape(n, cout, h, w)
 
 
-def wino_wgrad(lib, x, gy, alpha=1.0, cm_layout=False, x_scale=None, y_scale=None, device=None):
+def wino_wgrad(lib, x, gy, alpha=1.0, cm_layout=False, x_scale=None, y_scale=None, pad=1, device=None):
     """The weight gradient on the route: alpha * sum (gy * y_scale) (x) (x * x_scale) -> [m, c, 3, 3] ([c, m, 3, 3] if cm_layout)."""
-    n, c, h, w = x.shape
-    m = gy.shape[1]
+    n, c, ih, iw = x.shape
+    m, h, w = gy.shape[1], gy.shape[2], gy.shape[3]
     th, tw = h // 2, w // 2
-    v = wino_input(lib, x.reshape(n * c, h, w), None if x_scale is None else x_scale.reshape(-1), device=device)
+    v = wino_input(lib, x.reshape(n * c, ih, iw), None if x_scale is None else x_scale.reshape(-1), pad=pad, device=device)
     bg, be = _Buf(gy.reshape(n * m, h, w), device), _out((16, n * m, th, tw), device)
     bs = _Buf(y_scale.reshape(-1), device) if y_scale is not None else None
     lib.call("wino_gy_f32", bg.ptr, bs.ptr if bs else None, be.ptr, n * m, h, w, _stream(device))

@@ -23,8 +23,8 @@ def _transforms(lib, oracle_lib, dev):
             assert H.rel_err(a, o) < 1e-6, (flip, H.rel_err(a, o))
     x = rng.standard_normal((5, 6, 10)).astype(np.float32)
     s = (1 + 0.5 * rng.standard_normal(5)).astype(np.float32)
-    for scale in (None, s):
-        a, o = H.wino_input(lib, x, scale, device=dev), H.wino_input(oracle_lib, x, scale)
+    for scale, pad in [(None, 1), (s, 1), (s, 0), (None, 2)]:
+        a, o = H.wino_input(lib, x, scale, pad=pad, device=dev), H.wino_input(oracle_lib, x, scale, pad=pad)
         assert not np.isnan(a).any() and H.rel_err(a, o) < 1e-6, H.rel_err(a, o)
     md = rng.standard_normal((16, 6, 3, 5)).astype(np.float32)
     b = rng.standard_normal(3).astype(np.float32)
@@ -39,46 +39,49 @@ def _transforms(lib, oracle_lib, dev):
         assert not np.isnan(a).any() and H.rel_err(a, o) < 1e-6, H.rel_err(a, o)
 
 
-CASES = [(2, 12, 8, 8, 20, False), (1, 40, 6, 10, 33, False), (3, 9, 4, 4, 70, True), (1, 5, 16, 12, 8, False)]
+# n, c, h, w, m, [C, M] weights, pad (1: same; 0: valid -- its data gradient pads by 2; the last one has ONE tile per image, the
+# 4 x 4 -> 2 x 2 layer at the end of the patch discriminator)
+CASES = [(2, 12, 8, 8, 20, False, 1), (1, 40, 6, 10, 33, False, 1), (3, 9, 4, 4, 70, True, 1), (1, 5, 16, 12, 8, False, 1),
+         (2, 12, 10, 10, 20, False, 0), (5, 24, 4, 4, 16, False, 0), (1, 9, 6, 8, 33, True, 0)]
 
 
 def _route(lib, oracle_lib, dev):
     rng = np.random.default_rng(37)
-    for n, c, h, w, m, cm in CASES:
-        d = H.conv_desc(n, c, h, w, m, 3, 1, 1, cm)
+    for n, c, h, w, m, cm, pad in CASES:
+        d = H.conv_desc(n, c, h, w, m, 3, 1, pad, cm)
         x = rng.standard_normal((n, c, h, w)).astype(np.float32)
         wt = rng.standard_normal((c, m, 3, 3) if cm else (m, c, 3, 3)).astype(np.float32)
-        gy = rng.standard_normal((n, m, h, w)).astype(np.float32)
+        gy = rng.standard_normal((n, m, d.oh, d.ow)).astype(np.float32)
         b = rng.standard_normal(m).astype(np.float32)
         xs = (1 + 0.5 * rng.standard_normal((n, c))).astype(np.float32)
-        fwd = H.wino_conv(lib, x, wt, alpha=0.37, cm_layout=cm, device=dev)
+        fwd = H.wino_conv(lib, x, wt, alpha=0.37, cm_layout=cm, pad=pad, device=dev)
         assert H.rel_err(fwd, H.conv(oracle_lib, 0, d, x, wt, gy.shape, alpha=0.37)) < TOL
-        dg = H.wino_conv(lib, gy, wt, alpha=0.37, transpose=True, cm_layout=cm, device=dev)
+        dg = H.wino_conv(lib, gy, wt, alpha=0.37, transpose=True, cm_layout=cm, pad=pad, device=dev)
         assert H.rel_err(dg, H.conv(oracle_lib, 1, d, gy, wt, x.shape, alpha=0.37)) < TOL
         if not cm:
-            act = H.wino_conv(lib, x, wt, alpha=0.11, bias=b, act=(0.2, 2 ** 0.5), device=dev)
+            act = H.wino_conv(lib, x, wt, alpha=0.11, bias=b, act=(0.2, 2 ** 0.5), pad=pad, device=dev)
             assert H.rel_err(act, H.conv_bias_act(oracle_lib, d, x, wt, b, alpha=0.11)) < TOL
         # the style-modulated forms against the oracle's modulated convolutions (include/sae_hip.h: sae_conv2d_mod)
         ys = (1 + 0.5 * rng.standard_normal((n, m))).astype(np.float32)
         wm = rng.uniform(0.5, 2, m).astype(np.float32)
         wc = rng.uniform(0.5, 2, c).astype(np.float32)
-        mod = H.wino_conv(lib, x, wt, alpha=0.3, x_scale=xs, row_scale=wm, col_scale=wc, cm_layout=cm, device=dev)
+        mod = H.wino_conv(lib, x, wt, alpha=0.3, x_scale=xs, row_scale=wm, col_scale=wc, cm_layout=cm, pad=pad, device=dev)
         assert H.rel_err(mod, H.modconv(oracle_lib, 0, d, x, wt, gy.shape, x_scale=xs, wm_scale=wm, wc_scale=wc, alpha=0.3)) < TOL
-        mdg = H.wino_conv(lib, gy, wt, alpha=0.3, transpose=True, x_scale=ys, row_scale=wc, col_scale=wm, cm_layout=cm, device=dev)
+        mdg = H.wino_conv(lib, gy, wt, alpha=0.3, transpose=True, x_scale=ys, row_scale=wc, col_scale=wm, cm_layout=cm, pad=pad, device=dev)
         assert H.rel_err(mdg, H.modconv(oracle_lib, 1, d, gy, wt, x.shape, y_scale=ys, wm_scale=wm, wc_scale=wc, alpha=0.3)) < TOL
         # the weight gradient on the route (plain and with both activation factors) against the oracle's direct one, and its
         # two transforms against the oracle's
-        gw, e, gu = H.wino_wgrad(lib, x, gy, alpha=0.37, cm_layout=cm, device=dev)
+        gw, e, gu = H.wino_wgrad(lib, x, gy, alpha=0.37, cm_layout=cm, pad=pad, device=dev)
         assert H.rel_err(gw, H.conv(oracle_lib, 2, d, x, gy, wt.shape, alpha=0.37)) < TOL
-        _, eo, guo = H.wino_wgrad(oracle_lib, x, gy, alpha=0.37, cm_layout=cm)
+        _, eo, guo = H.wino_wgrad(oracle_lib, x, gy, alpha=0.37, cm_layout=cm, pad=pad)
         assert H.rel_err(e, eo) < 1e-6 and H.rel_err(gu, guo) < TOL
-        gwm, _, _ = H.wino_wgrad(lib, x, gy, alpha=0.3, cm_layout=cm, x_scale=xs, y_scale=ys, device=dev)
+        gwm, _, _ = H.wino_wgrad(lib, x, gy, alpha=0.3, cm_layout=cm, x_scale=xs, y_scale=ys, pad=pad, device=dev)
         assert H.rel_err(gwm, H.modconv(oracle_lib, 2, d, x, gy, wt.shape, x_scale=xs, y_scale=ys, alpha=0.3)) < TOL
         if not cm:          # StyledConv's plain form: modulated forward + noise + bias + leaky-ReLU
-            z = rng.standard_normal((n, h, w)).astype(np.float32)
+            z = rng.standard_normal((n, d.oh, d.ow)).astype(np.float32)
             zw = np.array([0.6], np.float32)
             st = H.wino_conv(lib, x, wt, alpha=0.2, x_scale=xs, row_scale=wm, noise=z, noise_weight=zw, bias=b, act=(0.2, 2 ** 0.5),
-                             device=dev)
+                             pad=pad, device=dev)
             assert H.rel_err(st, H.modconv_noise_bias_act(oracle_lib, d, x, wt, xs, wm, z, zw, b, alpha=0.2)) < TOL
 
 
@@ -101,17 +104,19 @@ def test_bad_geometry_is_refused(emu_lib):
         H.wino_input(emu_lib, x)           # odd height: no whole 2x2 output tiles
 
 
-def test_python_route_through_autograd(oracle_lib, monkeypatch):
+@pytest.mark.parametrize("pad", [1, 0])
+def test_python_route_through_autograd(oracle_lib, monkeypatch, pad):
     """stylegan2_op.winograd behind conv2d_gemm (SAE_WINOGRAD=1): forward with the fused activation, data gradient and weight
     gradient take the route and agree with the direct kernels."""
     from swapping_autoencoder_pytorch_amd import hip_lib
     from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as G, winograd
     monkeypatch.setattr(hip_lib, "_LIB", oracle_lib)
     torch.manual_seed(3)
-    x = torch.randn(2, 12, 8, 8, requires_grad=True)
+    side = 8 if pad else 10
+    x = torch.randn(2, 12, side, side, requires_grad=True)
     w = torch.randn(16, 12, 3, 3, requires_grad=True)
     b = torch.randn(16, requires_grad=True)
-    geom = G._Geom(2, 12, 8, 8, 16, 3, 1, 1, False, 0.25)
+    geom = G._Geom(2, 12, side, side, 16, 3, 1, pad, False, 0.25)
 
     def run():
         y = G.ConvBiasAct.apply(x, w, b, geom, 0.2, 2 ** 0.5)
