@@ -23,6 +23,13 @@
 // transform-domain planes is written / read in coalesced runs and the 2x2 outputs leave as 8-byte stores.
 #include "sae_common.h"
 
+// SAE_TRACE_DISPATCH=1 (tuning builds): one stderr line per launch decision the tests want to see
+#define SAE_WINO_TRACE(what)                                                   \
+    do {                                                                       \
+        static const int trace_knob = tuning_knob("SAE_TRACE_DISPATCH", 0);    \
+        if (trace_knob) fprintf(stderr, "sae-dispatch wino %s\n", what);       \
+    } while (0)
+
 namespace sae {
 namespace {
 
@@ -220,6 +227,171 @@ __global__ __launch_bounds__(kBlock) void wino_wgrad_output_kernel(const float* 
     }
 }
 
+// ---- four tiles per thread (tiles_w a multiple of 4, 16-byte aligned rows): the same arithmetic per tile, 16-byte accesses.
+// A wave64 vector-memory instruction costs the CU's address path ~28 cycles whatever its width: one tile per
+// thread is 32 - 34 such instructions per 64 tiles (320 B of HBM traffic each) and bound by their issue near 3.5 TB/s; four
+// tiles per thread need 8 per 64 tiles.
+
+// pad 1 only (the window of four tiles starts one column left of an aligned quad; pad 0 / 2 windows start on odd pairs)
+__global__ __launch_bounds__(kBlock) void wino_input4_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                             const float* __restrict__ scale, int64_t planes, int H, int W) {
+    const int TH = H >> 1, TW = W >> 1, TQ = TW >> 2;
+    const int64_t T = (int64_t)TH * TW;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= planes * TH * TQ) return;
+    const int64_t pl = i / ((int64_t)TH * TQ);
+    const int rem = (int)(i - pl * TH * TQ);
+    const int ty = rem / TQ, t4 = rem - ty * TQ;
+    const float* xp = x + pl * H * W;
+    const float s = scale ? scale[pl] : 1.0f;
+    float win[4][16];       // rows 2 ty - 1 ... 2 ty + 2, columns 8 t4 - 4 ... 8 t4 + 11
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int iy = 2 * ty - 1 + r;
+        const bool row_in = iy >= 0 && iy < H;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const int c0 = 8 * t4 - 4 + 4 * q4;
+            const bool in = row_in && c0 >= 0 && c0 < W;          // W is a multiple of 4: a quad is inside or outside as a whole
+            const f32x4 v = *reinterpret_cast<const f32x4*>(xp + (in ? (int64_t)iy * W + c0 : 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) win[r][4 * q4 + e] = in ? v[e] * s : 0.0f;
+        }
+    }
+    f32x4 out[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {            // tile 4 t4 + j: window columns 3 + 2 j ... 6 + 2 j
+        float e[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = 3 + 2 * j + q;
+            e[0][q] = win[0][c] - win[2][c];
+            e[1][q] = win[1][c] + win[2][c];
+            e[2][q] = win[2][c] - win[1][c];
+            e[3][q] = win[1][c] - win[3][c];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            out[4 * a + 0][j] = e[a][0] - e[a][2];
+            out[4 * a + 1][j] = e[a][1] + e[a][2];
+            out[4 * a + 2][j] = e[a][2] - e[a][1];
+            out[4 * a + 3][j] = e[a][1] - e[a][3];
+        }
+    }
+    const int64_t plane = planes * T;
+    const int64_t o = pl * T + (int64_t)ty * TW + 4 * t4;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) *reinterpret_cast<f32x4*>(V + xi * plane + o) = out[xi];
+}
+
+__global__ __launch_bounds__(kBlock) void wino_gy4_kernel(const float* __restrict__ gy, float* __restrict__ E,
+                                                          const float* __restrict__ scale, int64_t planes, int H, int W) {
+    const int TH = H >> 1, TW = W >> 1, TQ = TW >> 2;
+    const int64_t T = (int64_t)TH * TW;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= planes * TH * TQ) return;
+    const int64_t pl = i / ((int64_t)TH * TQ);
+    const int rem = (int)(i - pl * TH * TQ);
+    const int ty = rem / TQ, t4 = rem - ty * TQ;
+    const float* gp = gy + pl * H * W + (int64_t)(2 * ty) * W + 8 * t4;
+    const float s = scale ? scale[pl] : 1.0f;
+    float row[2][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int h4 = 0; h4 < 2; ++h4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(gp + (int64_t)r * W + 4 * h4) * s;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) row[r][4 * h4 + e] = v[e];
+        }
+    f32x4 out[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float e00 = row[0][2 * j], e01 = row[0][2 * j + 1], e10 = row[1][2 * j], e11 = row[1][2 * j + 1];
+        float r[4][2];      // A e
+        r[0][0] = e00;       r[0][1] = e01;
+        r[1][0] = e00 + e10; r[1][1] = e01 + e11;
+        r[2][0] = e00 - e10; r[2][1] = e01 - e11;
+        r[3][0] = -e10;      r[3][1] = -e11;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            out[4 * a + 0][j] = r[a][0];
+            out[4 * a + 1][j] = r[a][0] + r[a][1];
+            out[4 * a + 2][j] = r[a][0] - r[a][1];
+            out[4 * a + 3][j] = -r[a][1];
+        }
+    }
+    const int64_t plane = planes * T;
+    const int64_t o = pl * T + (int64_t)ty * TW + 4 * t4;
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) *reinterpret_cast<f32x4*>(E + xi * plane + o) = out[xi];
+}
+
+__global__ __launch_bounds__(kBlock) void wino_output4_kernel(const float* __restrict__ Md, float* __restrict__ y,
+                                                              const float* __restrict__ bias, int64_t planes, int channels,
+                                                              int H, int W, int act, float slope, float act_scale,
+                                                              const float* __restrict__ plane_scale,
+                                                              const float* __restrict__ noise,
+                                                              const float* __restrict__ noise_w) {
+    const int TH = H >> 1, TW = W >> 1, TQ = TW >> 2;
+    const int64_t T = (int64_t)TH * TW;
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= planes * TH * TQ) return;
+    const int64_t pl = i / ((int64_t)TH * TQ);
+    const int rem = (int)(i - pl * TH * TQ);
+    const int ty = rem / TQ, t4 = rem - ty * TQ;
+    const int64_t plane = planes * T;
+    const int64_t o = pl * T + (int64_t)ty * TW + 4 * t4;
+    f32x4 mv[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) mv[xi] = *reinterpret_cast<const f32x4*>(Md + xi * plane + o);
+    const float bv = (act && bias) ? bias[pl % channels] : 0.0f;
+    const float ps = plane_scale ? plane_scale[pl] : 1.0f;
+    const float nwv = (act && noise) ? noise_w[0] : 0.0f;
+    const float* zp = noise ? noise + (pl / channels) * H * W + (int64_t)(2 * ty) * W + 8 * t4 : nullptr;
+    float* yp = y + pl * H * W + (int64_t)(2 * ty) * W + 8 * t4;
+    float res[2][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r[2][4];      // A^T m
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            r[0][b] = (mv[0 + b][j] + mv[4 + b][j]) + mv[8 + b][j];
+            r[1][b] = (mv[4 + b][j] - mv[8 + b][j]) - mv[12 + b][j];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            res[a][2 * j] = (r[a][0] + r[a][1]) + r[a][2];
+            res[a][2 * j + 1] = (r[a][1] - r[a][2]) - r[a][3];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        float z[8];
+        if (act && noise) {
+#pragma unroll
+            for (int h4 = 0; h4 < 2; ++h4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(zp + (int64_t)a * W + 4 * h4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[4 * h4 + e] = v[e];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float v = res[a][k];
+            if (plane_scale) v *= ps;
+            if (act) {
+                if (noise) v = v + nwv * z[k];
+                v += bv;
+                v = ((v > 0.0f) ? v : v * slope) * act_scale;
+            }
+            res[a][k] = v;
+        }
+        *reinterpret_cast<f32x4*>(yp + (int64_t)a * W) = f32x4{res[a][0], res[a][1], res[a][2], res[a][3]};
+        *reinterpret_cast<f32x4*>(yp + (int64_t)a * W + 4) = f32x4{res[a][4], res[a][5], res[a][6], res[a][7]};
+    }
+}
+
 inline unsigned blocks_for(int64_t work) {
     const int64_t b = ceil_div64(work > 0 ? work : 1, kBlock);
     return (unsigned)(b > 2147483647 ? 2147483647 : b);
@@ -251,6 +423,13 @@ extern "C" int sae_wino_input_f32(const float* x, const float* plane_scale, floa
     if (planes == 0) return SAE_OK;
     if (!x || !v) return fail(SAE_EINVAL, "sae_wino_input_f32: null tensor");
     const int64_t tiles = ((h + 2 * pad - 2) / 2) * ((w + 2 * pad - 2) / 2);
+    static const int vec_knob = tuning_knob("SAE_WINO_VEC", 1);
+    if (vec_knob && pad == 1 && w % 8 == 0 && aligned16(x) && aligned16(v)) {         // four tiles per thread, 16-byte accesses
+        SAE_WINO_TRACE("input4");
+        hipLaunchKernelGGL(wino_input4_kernel, dim3(blocks_for(planes * (h / 2) * (w / 8))), dim3(kBlock), 0, (hipStream_t)stream,
+                           x, v, plane_scale, planes, (int)h, (int)w);
+        return check_launch("sae_wino_input_f32");
+    }
     hipLaunchKernelGGL(wino_input_kernel, dim3(blocks_for(planes * tiles)), dim3(kBlock), 0, (hipStream_t)stream, x,
                        v, plane_scale, planes, (int)h, (int)w, (int)pad);
     return check_launch("sae_wino_input_f32");
@@ -269,6 +448,14 @@ extern "C" int sae_wino_output_f32(const float* md, const float* plane_scale, co
     if (noise && (!act || !noise_weight || planes % channels != 0))
         return fail(SAE_EINVAL, "sae_wino_output_f32: the noise term belongs to the activation epilogue (act != 0, noise_weight, "
                                 "planes a multiple of channels)");
+    static const int vec_knob = tuning_knob("SAE_WINO_VEC", 1);
+    if (vec_knob && w % 8 == 0 && aligned16(md) && aligned16(y) && (!noise || aligned16(noise))) {
+        SAE_WINO_TRACE("output4");
+        hipLaunchKernelGGL(wino_output4_kernel, dim3(blocks_for(planes * (h / 2) * (w / 8))), dim3(kBlock), 0, (hipStream_t)stream,
+                           md, y, bias, planes, (int)channels, (int)h, (int)w, act ? 1 : 0, slope, act_scale, plane_scale, noise,
+                           noise_weight);
+        return check_launch("sae_wino_output_f32");
+    }
     hipLaunchKernelGGL(wino_output_kernel, dim3(blocks_for(planes * (h / 2) * (w / 2))), dim3(kBlock), 0, (hipStream_t)stream,
                        md, y, bias, planes, (int)channels, (int)h, (int)w, act ? 1 : 0, slope, act_scale, plane_scale, noise,
                        noise_weight);
@@ -284,6 +471,13 @@ extern "C" int sae_wino_gy_f32(const float* gy, const float* plane_scale, float*
     if (planes == 0) return SAE_OK;
     if (!gy || !e) return fail(SAE_EINVAL, "sae_wino_gy_f32: null tensor");
     if ((reinterpret_cast<uintptr_t>(gy) & 7) != 0) return fail(SAE_EINVAL, "sae_wino_gy_f32: gy must be 8-byte aligned");
+    static const int vec_knob = tuning_knob("SAE_WINO_VEC", 1);
+    if (vec_knob && w % 8 == 0 && aligned16(gy) && aligned16(e)) {
+        SAE_WINO_TRACE("gy4");
+        hipLaunchKernelGGL(wino_gy4_kernel, dim3(blocks_for(planes * (h / 2) * (w / 8))), dim3(kBlock), 0, (hipStream_t)stream, gy, e,
+                           plane_scale, planes, (int)h, (int)w);
+        return check_launch("sae_wino_gy_f32");
+    }
     hipLaunchKernelGGL(wino_gy_kernel, dim3(blocks_for(planes * (h / 2) * (w / 2))), dim3(kBlock), 0, (hipStream_t)stream, gy, e,
                        plane_scale, planes, (int)h, (int)w);
     return check_launch("sae_wino_gy_f32");

@@ -28,6 +28,16 @@ def _transforms(lib, oracle_lib, dev):
         assert not np.isnan(a).any() and H.rel_err(a, o) < 1e-6, H.rel_err(a, o)
     md = rng.standard_normal((16, 6, 3, 5)).astype(np.float32)
     b = rng.standard_normal(3).astype(np.float32)
+    # rows a multiple of 8 wide: four tiles per thread with 16-byte accesses (wino_*4_kernel)
+    x8 = rng.standard_normal((3, 8, 16)).astype(np.float32)
+    s8 = (1 + 0.5 * rng.standard_normal(3)).astype(np.float32)
+    for scale in (None, s8):
+        assert H.rel_err(H.wino_input(lib, x8, scale, device=dev), H.wino_input(oracle_lib, x8, scale)) < 1e-6
+    md8 = rng.standard_normal((16, 4, 4, 8)).astype(np.float32)
+    z8, b8 = rng.standard_normal((2, 8, 16)).astype(np.float32), rng.standard_normal(2).astype(np.float32)
+    for kw in [dict(), dict(bias=b8, act=(0.2, 2 ** 0.5)), dict(plane_scale=(1 + 0.5 * rng.standard_normal(4)).astype(np.float32)),
+               dict(bias=b8, act=(0.2, 2 ** 0.5), noise=z8, noise_weight=np.array([0.7], np.float32))]:
+        assert H.rel_err(H.wino_output(lib, md8, 8, 16, 2, device=dev, **kw), H.wino_output(oracle_lib, md8, 8, 16, 2, **kw)) < 1e-6
     ps = (1 + 0.5 * rng.standard_normal(6)).astype(np.float32)
     z = rng.standard_normal((2, 6, 10)).astype(np.float32)
     zw = np.array([0.7], np.float32)
@@ -42,6 +52,7 @@ def _transforms(lib, oracle_lib, dev):
 # n, c, h, w, m, [C, M] weights, pad (1: same; 0: valid -- its data gradient pads by 2; the last one has ONE tile per image, the
 # 4 x 4 -> 2 x 2 layer at the end of the patch discriminator)
 CASES = [(2, 12, 8, 8, 20, False, 1), (1, 40, 6, 10, 33, False, 1), (3, 9, 4, 4, 70, True, 1), (1, 5, 16, 12, 8, False, 1),
+         (1, 6, 16, 16, 10, False, 1),
          (2, 12, 10, 10, 20, False, 0), (5, 24, 4, 4, 16, False, 0), (1, 9, 6, 8, 33, True, 0)]
 
 
@@ -226,3 +237,25 @@ def test_train_step_with_the_route(oracle_lib, monkeypatch):
         assert a.keys() == b.keys()
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-4 * max(1.0, abs(b[k])), (k, a[k], b[k])
+
+
+def test_wide_rows_take_the_four_tile_kernels():
+    """Rows a multiple of 8 wide go through wino_input4 / wino_gy4 / wino_output4 (16-byte accesses); the dispatch trace of the
+    emulator build shows it (a subprocess: the trace knob is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, abi_harness as H\n"
+            "from swapping_autoencoder_pytorch_amd.hip_lib import SaeLibrary\n"
+            "from emu import build_emu\n"
+            "lib = SaeLibrary(build_emu.build(), prefix='sae_', device_only=False)\n"
+            "x = np.ones((2, 8, 16, 16), np.float32); w = np.ones((8, 8, 3, 3), np.float32)\n"
+            "H.wino_conv(lib, x, w); H.wino_wgrad(lib, x, x)\n"
+            "H.wino_conv(lib, x[:, :, :6, :10].copy(), w)\n" % (root, os.path.join(root, "tests")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SAE_TRACE_DISPATCH="1"), capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stderr.splitlines() if l.startswith("sae-dispatch wino")]
+    assert lines == ["sae-dispatch wino input4", "sae-dispatch wino output4", "sae-dispatch wino input4", "sae-dispatch wino gy4"], lines
