@@ -44,10 +44,75 @@ def upfirdn2d_native(x, kernel, up=1, down=1, pad=(0, 0)):
     return v.reshape(n, c, v.shape[2], v.shape[3])
 
 
+class ActivationMasks:
+    """Leaky-ReLU sign patterns of one run, for the mask-frozen double reference of the whole-network parity tests
+    (tests/test_gpu_network_parity.py).  A pre-activation within rounding of zero takes the other branch in an fp32 run
+    than in the double run, and the gradient of the network is discontinuous across that flip; evaluated with the fp32
+    run's OWN sign pattern the double run is the exact derivative of the piecewise-linear function the fp32 run
+    evaluated, a continuous function of inputs and weights, and a tolerance can be asserted on gradients directly.
+
+      with ActivationMasks.record() as m:    run the restatement (any dtype): m.masks = sign patterns in call order
+      with ActivationMasks.replay(m.masks):  the same restatement uses them, one per activation call, in call order
+      with ActivationMasks.lookup(fn):       fn(pre_activation, activated) -> bool mask (or None = keep own sign):
+                                             for a run whose patterns are recovered from elsewhere (another
+                                             implementation's saved activations)
+    ``flips`` counts, per activation call, the elements whose imposed sign differs from the run's own."""
+    _active = None
+
+    def __init__(self, mode, masks=None, fn=None):
+        self.mode, self.masks, self.fn, self.flips, self._i = mode, ([] if masks is None else masks), fn, [], 0
+
+    @classmethod
+    def record(cls):
+        return cls("record")
+
+    @classmethod
+    def replay(cls, masks):
+        return cls("replay", masks=masks)
+
+    @classmethod
+    def lookup(cls, fn):
+        return cls("lookup", fn=fn)
+
+    def __enter__(self):
+        assert ActivationMasks._active is None
+        ActivationMasks._active = self
+        return self
+
+    def __exit__(self, *exc):
+        ActivationMasks._active = None
+        if self.mode == "replay" and exc[0] is None:
+            assert self._i == len(self.masks), "replayed %d of %d activation masks" % (self._i, len(self.masks))
+        return False
+
+    def mask_for(self, pre, slope, scale):
+        own = pre > 0
+        if self.mode == "record":
+            self.masks.append(own)
+            return None
+        if self.mode == "replay":
+            m = self.masks[self._i]
+            self._i += 1
+        else:
+            m = self.fn(pre.detach(), (torch.where(own, pre, pre * slope) * scale).detach())
+            if m is None:
+                self.flips.append(-1)
+                return None
+        assert m.shape == pre.shape, (m.shape, pre.shape)
+        self.flips.append(int((m != own).sum()))
+        return m
+
+
+def _leaky_relu(x, negative_slope, scale):
+    a = ActivationMasks._active
+    m = a.mask_for(x, negative_slope, scale) if a is not None else None
+    return (F.leaky_relu(x, negative_slope) if m is None else torch.where(m, x, x * negative_slope)) * scale
+
+
 def fused_leaky_relu(x, bias=None, negative_slope=0.2, scale=2 ** 0.5):
     if bias is not None:
         x = x + bias.view(1, -1, *([1] * (x.dim() - 2)))
-    return F.leaky_relu(x, negative_slope) * scale
+    return _leaky_relu(x, negative_slope, scale)
 
 
 class ConvLayerCPU(torch.nn.Module):
@@ -271,7 +336,7 @@ class GenConvLayerCPU(torch.nn.Module):
         if self.activate:
             if self.act_bias is not None:
                 return fused_leaky_relu(x, self.act_bias)
-            return F.leaky_relu(x, 0.2) * math.sqrt(2)          # ScaledLeakyReLU, stylegan2_layers.py:198-207
+            return _leaky_relu(x, 0.2, math.sqrt(2))             # ScaledLeakyReLU, stylegan2_layers.py:198-207
         return x
 
 

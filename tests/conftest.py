@@ -14,6 +14,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Collection order: with ``-x`` one red test hides everything collected after it, so the strongest evidence goes first --
+# kernels against the C oracle, the HIP path against the reference's own golden outputs, the style-modulated conv, fused nodes
+# and the prepared-weight cache -- and the statistical whole-network comparisons go last.  Files not named keep their
+# alphabetical place in between.
+_FIRST = ["test_gpu_kernels", "test_gpu_parity", "test_modconv", "test_adam", "test_weight_prep", "test_resblock_fused",
+          "test_styled_fused", "test_quad_paths", "test_winograd", "test_ws_gather", "test_glue", "test_f8_gather"]
+_LAST = ["test_gpu_fullsize_oracle", "test_gpu_fullsize_properties", "test_gpu_network_parity"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        name = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if name in _FIRST:
+            return (0, _FIRST.index(name))
+        if name in _LAST:
+            return (2, _LAST.index(name))
+        return (1, 0)
+    items.sort(key=key)          # stable: order within a file and among unnamed files is kept
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _hip_library_is_current():
     """Rebuild csrc/libsae_hip.so when a kernel source is newer (hipcc cross-compiles for gfx950

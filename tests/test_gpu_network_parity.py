@@ -67,50 +67,75 @@ def conv_math(request):
 
 
 def _grads_and_errors(ref64, ref32, ours, inputs, run_ref, run_ours, loss_weight):
-    """(errors of ours vs the double run, errors of ATen fp32 vs the double run): dicts name -> relative error"""
+    """Per tensor (output, input gradients, every parameter gradient), (max-norm, L2, fraction) errors of
+      "ours"            this package vs the double run under THIS package's leaky-ReLU sign patterns (mask_frozen.py): asserted
+      "control"         stock ATen / MIOpen fp32 vs the double run under ITS OWN sign patterns: logged
+      "ours_free" / "control_free"   both against the free double run (what rounds 3-4 compared): logged
+    plus the bookkeeping of the frozen references (activation calls matched, flips imposed)."""
+    import aten_cpu_path as A
+    from mask_frozen import SavedActivations, frozen_reference_grads
     r64 = [t.detach().double().requires_grad_(True) for t in inputs]
     r32 = [t.detach().clone().requires_grad_(True) for t in inputs]
     mine = [t.detach().clone().requires_grad_(True) for t in inputs]
-    y64, y32, yo = run_ref(ref64, r64), run_ref(ref32, r32), run_ours(ours, mine)
+    y64 = run_ref(ref64, r64)
+    with A.ActivationMasks.record() as rec:
+        y32 = run_ref(ref32, r32)
+    with SavedActivations() as saved:
+        yo = run_ours(ours, mine)
     g64 = torch.autograd.grad((y64 * loss_weight.double()).sum(), r64 + list(ref64.parameters()))
     g32 = torch.autograd.grad((y32 * loss_weight).sum(), r32 + list(ref32.parameters()))
     go = torch.autograd.grad((yo * loss_weight).sum(), mine + list(ours.parameters()))
+    y64o, g64o, flips_o = frozen_reference_grads(A, ref64, inputs, run_ref, loss_weight, saved=saved)
+    y64c, g64c, flips_c = frozen_reference_grads(A, ref64, inputs, run_ref, loss_weight, masks=rec.masks)
     names = ["grad_input%d" % i for i in range(len(inputs))] + ["grad " + n for n, _ in ours.named_parameters()]
-    err_o, err_a = {"output": _stats(yo, y64)}, {"output": _stats(y32, y64)}
-    pooled = {}
-    for n, a, b, c in zip(names, go, g32, g64):
-        if c.numel() == 1:
-            # one-element gradients (the NoiseInjection strengths: ONE cancelling sum over N * C * H * W terms each) are
-            # compared as a vector per parameter kind: the error of a single such sum is one random draw, and the ratio of
-            # two draws (ours / the control's) exceeds any fixed factor now and then
-            kind = "grad *." + ".".join(n.split(".")[-2:]) + " (pooled one-element gradients)"
-            pooled.setdefault(kind, ([], [], []))
-            for lst, t in zip(pooled[kind], (a, b, c)):
-                lst.append(t.detach().reshape(1).double())
-            continue
-        err_o[n], err_a[n] = _stats(a, c), _stats(b, c)
-    for kind, (la, lb, lc) in pooled.items():
-        a, b, c = torch.cat(la), torch.cat(lb), torch.cat(lc)
-        err_o[kind], err_a[kind] = _stats(a, c), _stats(b, c)
-    return err_o, err_a
+    cols = {"ours": (go, g64o), "control": (g32, g64c), "ours_free": (go, g64), "control_free": (g32, g64)}
+    errs = {"ours": {"output": _stats(yo, y64o)}, "control": {"output": _stats(y32, y64c)},
+            "ours_free": {"output": _stats(yo, y64)}, "control_free": {"output": _stats(y32, y64)}}
+    for col, (got, want) in cols.items():
+        pooled = {}
+        for n, a, c in zip(names, got, want):
+            if c.numel() == 1:
+                # one-element gradients (the NoiseInjection strengths: ONE cancelling sum over N * C * H * W terms each)
+                # are compared as a vector per parameter kind
+                kind = "grad *." + ".".join(n.split(".")[-2:]) + " (pooled one-element gradients)"
+                pooled.setdefault(kind, ([], []))
+                pooled[kind][0].append(a.detach().reshape(1).double())
+                pooled[kind][1].append(c.detach().reshape(1).double())
+                continue
+            errs[col][n] = _stats(a, c)
+        for kind, (la, lc) in pooled.items():
+            errs[col][kind] = _stats(torch.cat(la), torch.cat(lc))
+    book = {"activation calls": len(flips_o), "matched to a saved activation of this package": saved.matched,
+            "unmatched": saved.unmatched, "elements flipped vs the double run (ours)": int(sum(f for f in flips_o if f > 0)),
+            "elements flipped vs the double run (control)": int(sum(flips_c))}
+    return errs, book
 
 
-def _check(case, conv_math, err_o, err_a):
-    """What can be asserted at this depth (measured, profiles/r3_network_parity.jsonl): the network OUTPUT is continuous in
-    its inputs and agrees with the double run to 3e-6.  GRADIENTS do not: leaky-ReLU masks are discontinuous, a
-    pre-activation within an ulp of zero takes the other branch in fp32 than in double, and the sums behind bias / weight
-    gradients cancel heavily, so ANY fp32 implementation of this network is 0.5e-3 ... 1e-3 (L2) and up to 5e-2 (max norm,
-    input gradient) away from the double run -- stock ATen / MIOpen fp32 shows the same figures as this package, tensor by
-    tensor.  The gradient check is therefore relative to that control: no gradient tensor may be further from the double
-    run (L2) than 3x what stock fp32 PyTorch-ROCm is on the same tensor (floor 1e-4, the north-star tolerance)."""
-    ratio = {k: err_o[k][1] / max(err_a[k][1], 1e-30) for k in err_o}
-    worst = max(err_o, key=lambda k: ratio[k] if err_o[k][1] > TOL else 0.0)
-    _log({"case": case, "conv_math": conv_math, "tensors": len(err_o), "output_max_err": err_o["output"][0],
-          "max over tensors (max norm, l2)": [max(v[i] for v in err_o.values()) for i in range(2)],
-          "aten_fp32_control max over tensors (max norm, l2)": [max(v[i] for v in err_a.values()) for i in range(2)],
-          "worst tensor relative to the control": worst, "its l2 error": err_o[worst][1], "control's l2 error": err_a[worst][1]})
-    assert err_o["output"][0] < TOL, err_o["output"]
-    bad = {k: (v[1], err_a[k][1]) for k, v in err_o.items() if not v[1] <= max(3.0 * err_a[k][1], TOL)}
+GRAD_TOL = 1e-4       # relative L2 of every gradient tensor against the double run under this package's own sign patterns
+
+
+def _check(case, conv_math, errs, book):
+    """The network OUTPUT is continuous in its inputs: within 1e-4 (max norm) of the double run.  GRADIENTS are compared with
+    the MASK-FROZEN double run (tests/mask_frozen.py): the double restatement evaluated under the leaky-ReLU sign pattern this
+    package's run actually took, which makes every gradient a continuous function of inputs and weights and the north-star
+    tolerance assertable directly, on any box.  The free double run and the stock ATen / MIOpen fp32 control (rounds 3-4's
+    criterion, whose limit moved with MIOpen's solver choice per box) ride along as logged columns, tensor by tensor
+    (gpurun_out/network_parity_tensors.jsonl)."""
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "network_parity_tensors.jsonl"), "a") as f:
+            for k in errs["ours"]:
+                f.write(json.dumps({"case": case.split(" vs ")[0], "conv_math": conv_math, "tensor": k,
+                                    **{col: errs[col][k][:2] for col in errs}}) + "\n")
+    worst = max((k for k in errs["ours"] if k != "output"), key=lambda k: errs["ours"][k][1])
+    _log({"case": case, "conv_math": conv_math, "tensors": len(errs["ours"]), "output_max_err": errs["ours"]["output"][0],
+          **{"max over gradient tensors (max norm, l2): " + col: [max(v[i] for k, v in e.items() if k != "output") for i in range(2)]
+             for col, e in errs.items()},
+          "worst tensor (l2, frozen)": worst, "its l2 error": errs["ours"][worst][1],
+          "control's l2 error on it (frozen to its own masks)": errs["control"][worst][1], **book})
+    assert errs["ours"]["output"][0] < TOL and errs["ours_free"]["output"][0] < TOL, errs["ours"]["output"]
+    assert book["unmatched"] == [] and book["matched to a saved activation of this package"] == book["activation calls"], book
+    bad = {k: v[:2] for k, v in errs["ours"].items() if k != "output" and not v[1] <= GRAD_TOL}
     assert not bad, bad
 
 
@@ -125,8 +150,8 @@ def test_discriminator_church256_b16_vs_aten_restatement(conv_math):
     torch.manual_seed(1)
     x = (torch.rand(16, 3, 256, 256) * 2 - 1).to(DEV)
     w = torch.linspace(-1.0, 1.0, 16, device=DEV).view(16, 1)          # a loss with both signs
-    err_o, err_a = _grads_and_errors(ref64, ref32, ours, [x], lambda m, i: m(i[0]), lambda m, i: m(i[0]), w)
-    _check("Discriminator 16x3x256x256 vs ATen restatement in double (cuda:0)", conv_math, err_o, err_a)
+    errs, book = _grads_and_errors(ref64, ref32, ours, [x], lambda m, i: m(i[0]), lambda m, i: m(i[0]), w)
+    _check("Discriminator 16x3x256x256 vs ATen restatement in double (cuda:0)", conv_math, errs, book)
 
 
 def test_generator_upsampling_block_128_to_256_vs_aten_restatement(conv_math):
@@ -149,8 +174,8 @@ def test_generator_upsampling_block_128_to_256_vs_aten_restatement(conv_math):
     def run_ref(m, i):
         return m(i[0], i[1], z1.to(i[0].dtype), z2.to(i[0].dtype))
 
-    err_o, err_a = _grads_and_errors(ref64, ref32, ours, [x, style], run_ref, lambda m, i: m(i[0], i[1]), t)
-    _check("UpsamplingResnetBlock 16x256x128x128 -> 16x128x256x256 vs ATen restatement in double (cuda:0)", conv_math, err_o, err_a)
+    errs, book = _grads_and_errors(ref64, ref32, ours, [x, style], run_ref, lambda m, i: m(i[0], i[1]), t)
+    _check("UpsamplingResnetBlock 16x256x128x128 -> 16x128x256x256 vs ATen restatement in double (cuda:0)", conv_math, errs, book)
 
 
 class _Reconstruction(torch.nn.Module):
@@ -200,5 +225,5 @@ def test_encoder_generator_reconstruction_church256_b16_vs_aten_restatement(conv
         ref_noise[0][i].fixed_noise = z
         ref_noise[1][i].fixed_noise = z
     t = torch.randn(b, 3, 256, 256, generator=g).to(DEV)
-    err_o, err_a = _grads_and_errors(ref64, ref32, ours, [x], lambda m, i: m(i[0]), lambda m, i: m(i[0]), t)
-    _check("Encoder -> Generator reconstruction 16x3x256x256 vs ATen restatement in double (cuda:0)", conv_math, err_o, err_a)
+    errs, book = _grads_and_errors(ref64, ref32, ours, [x], lambda m, i: m(i[0]), lambda m, i: m(i[0]), t)
+    _check("Encoder -> Generator reconstruction 16x3x256x256 vs ATen restatement in double (cuda:0)", conv_math, errs, book)

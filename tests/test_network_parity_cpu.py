@@ -81,3 +81,59 @@ def test_aten_cpu_train_iteration_reproduces_the_reference_golden_steps(oracle_l
         want = info["micro_steps"]["step%d" % call]
         for k, v in got.items():
             assert abs(v - want[k]) <= 2e-6 * max(1.0, abs(want[k])), (call, k, v, want[k])
+
+
+def test_mask_frozen_double_reference_recovers_this_packages_sign_patterns(oracle_lib):
+    """tests/mask_frozen.py on the oracle back end: every activation call of the double restatement finds the tensor this
+    package saved for the same activation (so the GPU test's frozen reference has no silent holes), the double run under
+    those sign patterns is within the north-star tolerance of this package's gradients, and a recorded restatement run
+    replays onto itself with zero flips."""
+    import aten_cpu_path as A
+    from mask_frozen import SavedActivations, frozen_reference_grads
+    from swapping_autoencoder_pytorch_amd.networks.encoder import StyleGAN2ResnetEncoder
+    from swapping_autoencoder_pytorch_amd.networks.generator import StyleGAN2ResnetGenerator
+    from swapping_autoencoder_pytorch_amd.options import make_options
+    from swapping_autoencoder_pytorch_amd.stylegan2_layers import NoiseInjection
+    opt = make_options("tiny32", batch_size=2, num_gpus=0, netE_scale_capacity=0.25, netG_scale_capacity=0.125,
+                       global_code_ch=64, spatial_code_ch=8, netE_num_downsampling_sp=2, netE_num_downsampling_gl=2)
+    torch.manual_seed(0)
+    with backend(oracle_lib):
+        enc, gen = StyleGAN2ResnetEncoder(opt), StyleGAN2ResnetGenerator(opt)
+        ref_enc, ref_gen = A.EncoderCPU(opt), A.GeneratorCPU(opt)
+        sp = list(ref_enc.parameters()) + list(ref_gen.parameters())
+        dp = list(enc.parameters()) + list(gen.parameters())
+        with torch.no_grad():
+            for a, b in zip(sp, dp):
+                v = torch.randn(a.shape) * (1.0 if a.dim() > 1 and tuple(a.shape) != (1, 3, 1, 1) else 0.2)
+                a.copy_(v)
+                b.copy_(v)
+        x = torch.rand(2, 3, 32, 32) * 2 - 1
+        with torch.no_grad():
+            gen(*enc(x[:1]))
+        mine = [m for m in gen.modules() if isinstance(m, NoiseInjection)]
+        theirs = [m for m in ref_gen.modules() if isinstance(m, A.StyledConvCPU)]
+        for m, r in zip(mine, theirs):
+            z = torch.randn(2, 1, m.image_size[2], m.image_size[3])
+            m.fixed_noise = z
+            r.fixed_noise = z.double()
+        t = torch.randn(2, 3, 32, 32)
+        xo = x.clone().requires_grad_(True)
+        with SavedActivations() as saved:
+            y = gen(*enc(xo))
+        g_ours = torch.autograd.grad((y * t).sum(), [xo] + dp)
+
+        class Both(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.E, self.G = ref_enc, ref_gen
+        both = Both().double()
+        run = lambda m, i: m.G(*m.E(i[0]))
+        y64, g64, flips = frozen_reference_grads(A, both, [x], run, t, saved=saved)
+        assert saved.unmatched == [] and saved.matched == len(flips) > 10, (saved.unmatched, saved.matched)
+        assert float((y - y64).abs().max() / y64.abs().max()) < 1e-5
+        for a, b in zip(g_ours, g64):
+            assert float((a.double() - b).norm()) <= 1e-4 * float(b.norm() + 1e-30)
+        with A.ActivationMasks.record() as rec:
+            run(both, [x.double()])
+        _, g_again, flips2 = frozen_reference_grads(A, both, [x], run, t, masks=rec.masks)
+        assert sum(flips2) == 0 and len(flips2) == len(flips)
