@@ -55,6 +55,7 @@ def load_pmc_dominant():
     return rec
 
 
+HBM_PEAK_TBS = 8.0                    # same table: HBM3E
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # same table, dense bf16 matrix; the bf16x6 arithmetic spends 6 bf16 products
                                       # (20/3 with the zero-padded ninth tap) per fp32 product
 FLOPS_PER_IMAGE = {"church256": 1.815e12, "bedroom256": 1.815e12, "ffhq512": 3.91e12, "ffhq1024": 6.08e12}
@@ -89,6 +90,10 @@ def parse():
                          "ONE stream (SAE_TWO_STREAMS=0) and a HIP-event bracket around every launch of the tracked kernels -> "
                          "roofline / roofline_by_kernel.  In the timed region two kernels share the chip (streams.py) and a "
                          "bracket there would measure the sharing, not the kernel")
+    ap.add_argument("--other-presets", default="ffhq512,ffhq1024",
+                    help="default run, one GPU, church256 only: BASELINE configs 3 and 5 (the presets' own batch sizes per GPU) measured "
+                         "in their own processes after the main measurement and reported as `other_presets` ('' = skip)")
+    ap.add_argument("--other-steps", type=int, default=16, help="timed steps of each --other-presets leg (16 holds one lazy-R1 call)")
     ap.add_argument("--via-dropin", action="store_true",
                     help="time the SAME iteration through the drop-in runner's pre-seeding (swapping_autoencoder_pytorch_amd.dropin, "
                          "SAE_DROPIN_LEVEL, default full) under a reference-style tree: option parser, models.create_model -> "
@@ -256,6 +261,84 @@ class DominantKernelTimer:
                               "achieved": round(kfl / (kms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                               "frac": round(kfl / (kms * 1e-3) / 1e12 / peak, 4)})
         return roof, by_kernel
+
+
+class HbmKernelTimer:
+    """Event brackets around the K1 / K2 C-ABI calls (sae_upfirdn2d*_f32, sae_bias_act*_f32, sae_noise_bias_act*_f32) of the
+    one-stream kernel pass: ALGORITHMIC bytes (tools/roofline_ledger.work_of: every operand and the result once) per class
+    over the summed launch durations, against the 8 TB/s HBM peak -- BASELINE config 3's "HBM GB/s vs peak"."""
+    PREFIXES = ("upfirdn2d", "bias_act", "noise_bias_act")
+
+    def __init__(self):
+        self.records, self.active = [], False
+
+    def install(self):
+        import torch
+        from swapping_autoencoder_pytorch_amd import hip_lib
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import roofline_ledger
+        lib = hip_lib.get()
+        orig = lib.call
+
+        def call(name, *a):
+            if not self.active or not name.startswith(self.PREFIXES) or "workspace" in name:
+                return orig(name, *a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(name, *a)
+            e1.record()
+            label, _, work = roofline_ledger.work_of(name, a)
+            self.records.append((label, work, e0, e1))
+            return out
+
+        lib.call = call
+
+    def summary(self, steps):
+        rows = {}
+        for label, work, e0, e1 in self.records:
+            r = rows.setdefault(label, [0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += work
+            r[2] += e0.elapsed_time(e1)
+        out = [{"class": k, "launches": n, "ms_per_step": round(ms / steps, 3), "gb_per_step": round(by / steps / 1e9, 3),
+                "achieved": round(by / (ms * 1e-3) / 1e12, 3), "peak": HBM_PEAK_TBS, "unit": "TB/s",
+                "frac": round(by / (ms * 1e-3) / 1e12 / HBM_PEAK_TBS, 4)} for k, (n, by, ms) in rows.items() if ms > 0]
+        out.sort(key=lambda r: -r["ms_per_step"])
+        tot_by, tot_ms = sum(r[1] for r in rows.values()), sum(r[2] for r in rows.values())
+        total = None
+        if tot_ms > 0:
+            total = {"class": "all K1 / K2 launches", "ms_per_step": round(tot_ms / steps, 3), "gb_per_step": round(tot_by / steps / 1e9, 3),
+                     "achieved": round(tot_by / (tot_ms * 1e-3) / 1e12, 3), "peak": HBM_PEAK_TBS, "unit": "TB/s",
+                     "frac": round(tot_by / (tot_ms * 1e-3) / 1e12 / HBM_PEAK_TBS, 4)}
+        return total, out
+
+
+def other_presets_leg(args):
+    """BASELINE configs 3 and 5 on the driver's line: each preset at its own batch size in its own process (a fresh
+    allocator and module table), `other_steps` timed iterations holding one lazy-R1 call + a short one-stream kernel pass."""
+    import subprocess
+    legs = []
+    for preset in [p for p in args.other_presets.split(",") if p]:
+        cmd = [sys.executable, os.path.abspath(__file__), "--preset", preset, "--steps", str(args.other_steps), "--warmup", "3",
+               "--conv-math", args.conv_math, "--alt-steps", "0", "--dropin-steps", "0", "--no-cpu-baseline", "--kernel-steps", "3",
+               "--other-presets", ""]
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:      # noqa: BLE001 -- the main measurement stands on its own
+            legs.append({"preset": preset, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+            continue
+        leg = {"preset": preset, "workload": rec["config"]["workload"]}
+        for k in ("value", "unit", "steps", "warmup", "ms_per_step", "value_r1_every_16", "ms_r1_extra", "r1_iterations_in_window", "ms_d_call_median",
+                  "ms_g_call_median", "model_tflops_per_gpu", "frac_of_mfma_f32_roofline", "hbm_k1_k2", "hbm_by_kernel"):
+            if k in rec:
+                leg[k] = rec[k]
+        if "roofline" in rec:
+            leg["roofline_dominant"] = {k: rec["roofline"][k] for k in ("kernel", "achieved", "peak", "unit", "frac", "launches")}
+        if "roofline_by_kernel" in rec:
+            leg["roofline_by_kernel"] = [{k: r[k] for k in ("class", "ms_per_step", "achieved", "frac")} for r in rec["roofline_by_kernel"]]
+        legs.append(leg)
+    return legs
 
 
 def cpu_baseline_config1(A, threads_hint):
@@ -598,8 +681,10 @@ def main():
     pool = [torch.rand(batch, 3, size, size, device=dev) * 2 - 1 for _ in range(4)]
 
     timer = DominantKernelTimer()
+    hbm_timer = HbmKernelTimer()
     if not args.no_kernel_timing:
         timer.install()
+        hbm_timer.install()
 
     call_ms = {"d": [], "g": []}
 
@@ -642,19 +727,21 @@ def main():
     if not args.no_kernel_timing and args.kernel_steps > 0:
         # (the parameters' AccumulateGrad nodes remember the stream of their first use; moving a branch back to the main stream
         # for this pass makes autograd point that out once per parameter -- it is the intent here)
-        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+        _quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if _quiet is not None:
+            _quiet(False)
         prev = os.environ.get("SAE_TWO_STREAMS")
         os.environ["SAE_TWO_STREAMS"] = "0"
         try:
             iteration(done)
             fence()
-            timer.active = True
+            timer.active = hbm_timer.active = True
             t0 = time.perf_counter()
             for i in range(args.kernel_steps):
                 iteration(done + 1 + i)
             fence()
             kernel_ms_per_step = (time.perf_counter() - t0) / args.kernel_steps * 1e3
-            timer.active = False
+            timer.active = hbm_timer.active = False
         finally:
             if prev is None:
                 os.environ.pop("SAE_TWO_STREAMS", None)
@@ -712,28 +799,31 @@ def main():
         every = opt.R1_once_every
         r1_in_window = sum(1 for j in range(args.warmup + 1, args.warmup + args.steps + 1) if j % every == 0)
         line["r1_iterations_in_window"] = r1_in_window
-        d_calls = sorted(call_ms["d"][args.warmup:args.warmup + args.steps])
+        d_window = call_ms["d"][args.warmup:args.warmup + args.steps]
+        d_calls = sorted(d_window)
         g_calls = sorted(call_ms["g"][args.warmup:args.warmup + args.steps])
         if d_calls and g_calls:
-            # median D call (without the lazy R1 extra), median G call, and the R1 surcharge of the slowest D call
-            line["ms_d_call_median"] = round(d_calls[len(d_calls) // 2], 2)
+            # median D call (without the lazy R1 extra), median G call, and the R1 surcharge: the D calls KNOWN to carry the R1
+            # penalty (the optimizer's 1-based counter is a multiple of `every`) minus the median D call
+            d_med = d_calls[len(d_calls) // 2]
+            line["ms_d_call_median"] = round(d_med, 2)
             line["ms_g_call_median"] = round(g_calls[len(g_calls) // 2], 2)
-            line["ms_r1_extra_max"] = round(d_calls[-1] - d_calls[len(d_calls) // 2], 2)
-            if r1_in_window > 0:
-                # SURVEY 8d defines the metric as B / (t_D + t_G + t_R1 / 16): the K timed steps re-weighted to exactly one
-                # lazy-R1 call per `every` iterations.  That figure is `value`; the plain wall-clock quotient of the K steps
-                # (which holds r1_in_window R1 calls, whatever K is) stays next to it, and `ms_per_step` stays the wall clock.
-                x = line["ms_r1_extra_max"] * 1e-3
+            r1_calls = [d_window[j - args.warmup - 1] for j in range(args.warmup + 1, args.warmup + args.steps + 1) if j % every == 0]
+            line["metric_version"] = 2      # 2: `value` is the plain wall-clock quotient of the K timed steps (rounds 1-3 and 5); round 4's
+                                            # line carried the R1-normalised figure there
+            if r1_calls:
+                # SURVEY 8d defines the metric as B / (t_D + t_G + t_R1 / 16).  `value` is the wall-clock quotient of exactly the K
+                # timed steps (which hold r1_in_window R1 calls, whatever K is); the same steps re-weighted to one lazy-R1 call
+                # per `every` iterations ride along under their own keys.
+                x = (sum(r1_calls) / len(r1_calls) - d_med) * 1e-3
+                line["ms_r1_extra"] = round(x * 1e3, 2)
                 t_norm = (dt - r1_in_window * x) / args.steps + x / every
-                line["value_wallclock"] = line["value"]
-                line["value"] = round(world * batch / t_norm, 3)
+                line["value_r1_every_%d" % every] = round(world * batch / t_norm, 3)
                 line["ms_per_step_r1_every_%d" % every] = round(t_norm * 1e3, 3)
-                line["value_note"] = ("value = B / (t_D + t_G + t_R1 / %d) (SURVEY 8d), from the %d timed steps with their %d lazy-R1 "
-                                      "call(s) re-weighted to one per %d; value_wallclock = B * steps / wall time of exactly "
-                                      "those steps" % (every, args.steps, r1_in_window, every))
-                if per_image:
-                    line["model_tflops_per_gpu"] = round(line["value"] / world * per_image / 1e12, 2)
-                    line["frac_of_mfma_f32_roofline"] = round(line["value"] / world * per_image / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+                line["value_note"] = ("value = N * B * steps / wall time of exactly the %d timed steps, which hold %d lazy-R1 call(s); "
+                                      "value_r1_every_%d = B / (t_D + t_G + t_R1 / %d) (SURVEY 8d): the same steps with the R1 surcharge "
+                                      "(the R1 iterations' D calls minus the median D call) re-weighted to one per %d"
+                                      % (args.steps, r1_in_window, every, every, every))
             else:
                 line["value_note"] = ("no lazy-R1 call fell into the timed window: value EXCLUDES the R1 surcharge of SURVEY 8d's "
                                       "metric (use --steps 16 or more)")
@@ -745,8 +835,14 @@ def main():
             line["roofline"] = roof
             line["roofline_by_kernel"] = by_kernel
             line["ms_per_step_one_stream"] = round(kernel_ms_per_step, 3)
+            hbm_total, hbm_rows = hbm_timer.summary(max(args.kernel_steps, 1))
+            if hbm_total:
+                line["hbm_k1_k2"] = hbm_total
+                line["hbm_by_kernel"] = hbm_rows
         if world == 1 and args.dropin_steps > 0 and not args.force_allreduce:
             line["via_dropin"] = via_dropin_leg(args, line)
+        if world == 1 and args.preset == "church256" and args.other_presets and not launched and not args.winograd:
+            line["other_presets"] = other_presets_leg(args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.preset, size, batch, full=args.full_cpu_baseline)
         print(json.dumps(line), flush=True)

@@ -332,6 +332,25 @@ def wrap_reference_r1():
     return True
 
 
+def _bucketwise_step(opt, reducer):
+    """``opt.step`` for a FusedAdam behind a GradAllReducer.  (A function of its own: the replacement re-installs ITSELF after
+    every call, and a closure defined in attach_gradient_allreduce's loop would look that name up late and install the last
+    group's wrapper on every optimizer -- the first group would then never be stepped again.)"""
+    plain = opt.step
+
+    def step(closure=None, **kw):
+        if kw or closure is not None or not (reducer.enabled and reducer.armed):
+            return plain(closure, **kw)
+        opt.step = plain                 # finish_into drives the optimizer's own step, bucket by bucket
+        try:
+            reducer.finish_into(opt)
+        finally:
+            opt.step = step
+        reducer.arm_lazily()
+
+    return step
+
+
 def attach_gradient_allreduce(optimizer):
     """Give a reference SwappingAutoencoderOptimizer data-parallel semantics across ranks."""
     import torch.distributed as dist
@@ -346,22 +365,22 @@ def attach_gradient_allreduce(optimizer):
         if isinstance(opt, FusedAdam):
             # the bench's path: every bucket goes to the multi-tensor Adam as its collective completes, summed gradients
             # read in place with 1 / world applied by the kernel (GradAllReducer.finish_into)
-            plain = opt.step
-
-            def step(closure=None, _plain=plain, _r=reducer, _o=opt, **kw):
-                if kw or closure is not None or not (_r.enabled and _r.armed):
-                    return _plain(closure, **kw)
-                _o.step = _plain                 # finish_into drives the optimizer's own step, bucket by bucket
-                try:
-                    _r.finish_into(_o)
-                finally:
-                    _o.step = step
-                _r.arm()
-
-            opt.step = step
+            opt.step = _bucketwise_step(opt, reducer)
         else:
             opt.register_step_pre_hook(lambda o, a, k, r=reducer: r.finish())
-            opt.register_step_post_hook(lambda o, a, k, r=reducer: r.arm())
+            opt.register_step_post_hook(lambda o, a, k, r=reducer: r.arm_lazily())
+        # the reference's loop is zero_grad() -> backward() -> step() (optimizers/swapping_autoencoder_optimizer.py:69-77,
+        # 84-107): re-arm once the old gradients are gone, so that the conv weights' slots are handed out again
+        # (GradAllReducer.arm_lazily covers a loop that never calls zero_grad)
+        plain_zero = opt.zero_grad
+
+        def zero_grad(*a, _z=plain_zero, _r=reducer, **kw):
+            out = _z(*a, **kw)
+            if _r.enabled and (_r.armed or _r._arm_pending):
+                _r.arm()
+            return out
+
+        opt.zero_grad = zero_grad
     # one writer: every rank holds the same weights, and N ranks racing on the same checkpoint file and on the
     # remove/symlink of latest_checkpoint.pth (models/base_model.py:33-48) can tear it
     from .swapping_autoencoder_model import SwappingAutoencoderModel as _Mirror

@@ -33,6 +33,7 @@ SLOT_ALIGN = 64          # floats: every parameter's slot starts on a 256-byte b
 
 # data_ptr of a parameter -> its slot in an armed reducer's flat bucket, handed out ONCE per backward pass
 _DESTINATIONS = {}
+CLAIMED = [0]            # slots handed to weight-gradient producers since import (tests read the difference across a pass)
 
 
 def claim_destination(weight):
@@ -44,6 +45,7 @@ def claim_destination(weight):
     slot = _DESTINATIONS.pop(weight.data_ptr(), None)
     if slot is None or slot.numel() != weight.numel():
         return None
+    CLAIMED[0] += 1
     return slot.view(weight.shape)
 
 
@@ -66,6 +68,7 @@ class GradAllReducer:
             dist.get_world_size(process_group) > 1 or forced)
         self.world = dist.get_world_size(process_group) if self.enabled else 1
         self.armed = False
+        self._arm_pending = False
         self.buckets = []
         self._where = {}
         if not self.enabled:
@@ -92,6 +95,7 @@ class GradAllReducer:
         if not self.enabled:
             return
         self.armed = True
+        self._arm_pending = False
         for b in self.buckets:
             b.pending = len(b.params)
             b.work = None
@@ -110,9 +114,20 @@ class GradAllReducer:
                 if (p.dim() == 4 or (p.dim() == 5 and p.shape[0] == 1)) and p.is_contiguous() and p.grad is None:
                     _DESTINATIONS[p.data_ptr()] = b.flat[off:off + p.numel()]
 
+    def arm_lazily(self):
+        """For a host loop this package does not own (dropin.attach_gradient_allreduce): arm at the first gradient of the next
+        pass unless ``arm()`` is called before (the drop-in calls it from the optimizer's ``zero_grad``).  Right after
+        ``optimizer.step()`` every conv-weight ``.grad`` still IS its bucket slot: arming there would clone each of them out
+        and, with a gradient alive, register no destination -- the write-into-bucket path would be lost from the second
+        iteration on.  After ``zero_grad()`` the gradients are gone and the slots can be handed out again."""
+        if self.enabled:
+            self._arm_pending = True
+
     def _on_grad(self, p):
         if not self.armed:
-            return
+            if not self._arm_pending:
+                return
+            self.arm()       # no zero_grad since the last step (gradient accumulation): the late, always-correct form
         bi, pi = self._where[p]
         b = self.buckets[bi]
         off = b.offsets[pi]

@@ -14,6 +14,7 @@ dgrad-only D/Dpatch passes of a G step (SURVEY.md §7 "grad-mode awareness") lau
 do not need.
 """
 import ctypes as C
+import threading
 
 import torch
 from torch.autograd import Function
@@ -25,6 +26,8 @@ from . import weight_prep, winograd
 
 class _Flags:
     weight_grads = True
+    depth = 0                      # nesting / concurrency count of input_grads_only (weight_grads == (depth == 0))
+    lock = threading.Lock()
 
 
 class input_grads_only:
@@ -36,11 +39,17 @@ class input_grads_only:
     (swapping_autoencoder_model.py:143-148,169-174) is exactly that case."""
 
     def __enter__(self):
-        self._prev = _Flags.weight_grads
-        _Flags.weight_grads = False
+        # (a count, not save / restore: backward passes read the flag from autograd's device threads, so it has to be
+        # process-wide, and entries that interleave across threads -- nn.DataParallel replicas of a host program -- must
+        # leave it True once the last one has exited)
+        with _Flags.lock:
+            _Flags.depth += 1
+            _Flags.weight_grads = False
 
     def __exit__(self, *exc):
-        _Flags.weight_grads = self._prev
+        with _Flags.lock:
+            _Flags.depth -= 1
+            _Flags.weight_grads = _Flags.depth == 0
         return False
 
 

@@ -13,7 +13,9 @@ foreign raw pointer: such code must call ``invalidate()`` or run with ``SAE_WPRE
 
 Only ``torch.nn.Parameter`` weights (or views of one) are cached: a temporary tensor in the weight position (the double-backward
 operators of the R1 penalty convolve with gradients) can be freed and its address and version recur with other contents.
-An entry holds a weak reference to its parameter and is ignored once that is gone."""
+An entry holds a weak reference to its parameter and is dropped -- with its device buffer -- when the parameter dies (the
+weak reference's callback).  Memory: one padded copy per (parameter, layout) in use, i.e. the forward and the data-gradient
+layouts of every conv weight: about twice the conv weights on top of the parameters themselves (0.6 GB at the church preset)."""
 import ctypes as C
 import os
 import weakref
@@ -30,6 +32,13 @@ class _Entry:
 
 def enabled():
     return os.environ.get("SAE_WPREP_CACHE", "1") != "0"
+
+
+def _drop(key, ref):
+    """weakref callback: the parameter behind entry `key` died -- free the prepared copy unless the key was re-used since"""
+    e = _ENTRIES.get(key)
+    if e is not None and e.ref is ref:
+        del _ENTRIES[key]
 
 
 def invalidate():
@@ -65,7 +74,7 @@ def attach(lib, d, mod, op, w, alpha, tag=(), gkey=None):
     cur = torch.cuda.current_stream(w.device) if w.is_cuda else None
     if e is None or e.ref() is not base or e.version != base._version or e.buf.numel() != floats:
         e = _Entry()
-        e.ref, e.version = weakref.ref(base), base._version
+        e.ref, e.version = weakref.ref(base, lambda _r, key=key: _drop(key, _r)), base._version
         e.buf = torch.empty(floats, dtype=torch.float32, device=w.device)
         lib.call("conv2d_wprep_f32", w.data_ptr(), C.byref(d), C.byref(mod) if mod is not None else None, op, float(alpha),
                  e.buf.data_ptr(), floats, lib.stream(w))

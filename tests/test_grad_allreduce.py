@@ -144,3 +144,83 @@ def test_single_process_is_a_noop():
     _loss(net, torch.randn(4, 6)).mean().backward()
     red.finish()
     assert net.a[0].weight.grad is not None
+
+
+class _ConvNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        from swapping_autoencoder_pytorch_amd.stylegan2_layers import ConvLayer
+        self.g = torch.nn.Sequential(ConvLayer(3, 8, 3), ConvLayer(8, 8, 3))
+        self.d = torch.nn.Sequential(ConvLayer(8, 8, 3), ConvLayer(8, 1, 1, activate=False))
+
+
+def _dropin_worker(rank, world, port, tmp, fused):
+    """The reference's loop shape (zero_grad -> backward -> step, optimizers/swapping_autoencoder_optimizer.py:69-107) driven through
+    dropin.attach_gradient_allreduce: from the second iteration on the conv weights' gradients must still be produced inside
+    their bucket slots (arming right after step() found every .grad alive and registered no destination)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from swapping_autoencoder_pytorch_amd import dropin, grad_allreduce, hip_lib
+    from swapping_autoencoder_pytorch_amd.fused_adam import FusedAdam
+    from swapping_autoencoder_pytorch_amd.hip_lib import SaeLibrary
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hip_lib._LIB = SaeLibrary(os.path.join(root, "oracle", "libsae_oracle.so"), prefix="oracle_", device_only=False)
+    torch.manual_seed(7 + rank)
+    net = _ConvNet()
+    gp, dp = list(net.g.parameters()), list(net.d.parameters())
+    make = (lambda ps: FusedAdam(ps, lr=0.01, betas=(0.0, 0.99))) if fused else (lambda ps: torch.optim.Adam(ps, lr=0.01, betas=(0.0, 0.99)))
+    host = types.SimpleNamespace(Gparams=gp, Dparams=dp, optimizer_G=make(gp), optimizer_D=make(dp),
+                                 model=types.SimpleNamespace(singlegpu_model=net), save=lambda *a, **k: None)
+    dropin.attach_gradient_allreduce(host)
+    state = {k: v.clone() for k, v in net.state_dict().items()}
+    torch.manual_seed(0)
+    full = torch.randn(4, 3, 8, 8)
+    shard = full[rank * 2:(rank + 1) * 2]
+    claimed = []
+    for it in range(3):
+        for params, frozen, opt in ((dp, gp, host.optimizer_D), (gp, dp, host.optimizer_G)):
+            for p in params:
+                p.requires_grad_(True)
+            for p in frozen:
+                p.requires_grad_(False)
+            before = grad_allreduce.CLAIMED[0]
+            opt.zero_grad()
+            net.d(net.g(shard)).square().mean().backward()
+            opt.step()
+            claimed.append(grad_allreduce.CLAIMED[0] - before)
+    torch.save({"state": state, "after": net.state_dict(), "claimed": claimed}, os.path.join(tmp, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_two_rank_dropin_loop_keeps_writing_conv_gradients_into_the_buckets(tmp_path, fused, oracle_lib):
+    world, port = 2, _free_port()
+    mp.spawn(_dropin_worker, args=(world, port, str(tmp_path), fused), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    # every pass of every iteration hands out the two conv-weight slots of its group: [D, G] x 3 iterations
+    assert r0["claimed"] == [2] * 6 and r1["claimed"] == [2] * 6, (r0["claimed"], r1["claimed"])
+    for k in r0["after"]:
+        assert torch.equal(r0["after"][k], r1["after"][k]), k
+    # the same three iterations in one process on the global batch
+    from parity_common import backend
+    with backend(oracle_lib):
+        net = _ConvNet()
+        net.load_state_dict(r0["state"])
+        gp, dp = list(net.g.parameters()), list(net.d.parameters())
+        og, od = torch.optim.Adam(gp, lr=0.01, betas=(0.0, 0.99)), torch.optim.Adam(dp, lr=0.01, betas=(0.0, 0.99))
+        torch.manual_seed(0)
+        full = torch.randn(4, 3, 8, 8)
+        for it in range(3):
+            for params, frozen, opt in ((dp, gp, od), (gp, dp, og)):
+                for p in params:
+                    p.requires_grad_(True)
+                for p in frozen:
+                    p.requires_grad_(False)
+                opt.zero_grad()
+                net.d(net.g(full)).square().mean().backward()
+                opt.step()
+        for k, v in net.state_dict().items():
+            assert torch.allclose(r0["after"][k], v, rtol=2e-4, atol=2e-5), k

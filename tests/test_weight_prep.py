@@ -93,6 +93,12 @@ def _check_cache(device):
         opt.step()
         assert w._version > v
         assert torch.equal(layer(x).detach(), fresh())
+    # a parameter that dies takes its prepared copies (and their device buffers) with it
+    import gc
+    assert len(weight_prep._ENTRIES) >= 1
+    del layer, w, opt, xg
+    gc.collect()
+    assert len(weight_prep._ENTRIES) == 0
 
 
 def test_prepared_weights_cache_follows_the_version_counter_on_the_emulator(emu_lib):
