@@ -82,9 +82,11 @@ def parse():
                          "generator call of the reference's driver through oracle/aten_cpu_path.TrainIterationCPU; several "
                          "minutes at 256 x 256, B = 16) instead of the bounded, FLOP-scaled sample")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--winograd", action="store_true",
-                    help="A/B only, never the driver's line: SAE_WINOGRAD=1 -- the wide 3x3 stride-1 layers (>= SAE_WINOGRAD_MIN_C "
-                         "channels) take the Winograd F(2x2,3x3) route (stylegan2_op/winograd.py); `config.winograd` records it")
+    ap.add_argument("--no-winograd", action="store_true",
+                    help="A/B only: SAE_WINOGRAD=0 -- every 3x3 stride-1 layer on the direct MFMA kernels (stylegan2_op/winograd.py "
+                         "routes the wide ones through Winograd F(2x2,3x3) by default); `config.winograd` records it")
+    ap.add_argument("--no-winograd-fused", action="store_true",
+                    help="A/B only: SAE_WINOGRAD_FUSED=0 -- the three-kernel form of the route everywhere (no csrc/winograd_fused.hip)")
     ap.add_argument("--kernel-steps", type=int, default=8,
                     help="steps of the kernel pass that follows the timed region: the same iterations with the step's branches on "
                          "ONE stream (SAE_TWO_STREAMS=0) and a HIP-event bracket around every launch of the tracked kernels -> "
@@ -666,8 +668,11 @@ def main():
     from swapping_autoencoder_pytorch_amd.swapping_autoencoder_optimizer import create_optimizer
     hip_lib.get()           # fail loudly here if the HIP library is missing
     hip_lib.set_conv_math(args.conv_math)
-    if args.winograd:
-        os.environ["SAE_WINOGRAD"] = "1"
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import winograd
+    if args.no_winograd:
+        winograd.configure(enabled=False)
+    if args.no_winograd_fused:
+        winograd.configure(fused=False)
 
     batch = args.batch or DEFAULT_BATCH[args.preset]
     opt = make_options(args.preset, batch_size=batch, num_gpus=1)
@@ -784,9 +789,11 @@ def main():
                                    "every 16th D iteration" % (args.preset, size, size, batch),
                        "global_batch": world * batch, "parallelism": "dp%d" % world, "conv_math": args.conv_math},
         }
-        if os.environ.get("SAE_WINOGRAD") == "1":
-            line["config"]["winograd"] = ("3x3 stride-1 layers with >= %s channels on the F(2x2,3x3) route: 2.25x fewer multiplications than the "
-                                          "FLOP count of this line's roofline figures assumes" % os.environ.get("SAE_WINOGRAD_MIN_C", "256"))
+        line["config"]["winograd"] = (
+            "off: every 3x3 stride-1 layer on the direct MFMA kernels" if not winograd.enabled() else
+            "3x3 stride-1 launches selected by stylegan2_op/winograd.route() run as Winograd F(2x2,3x3) (%s): 2.25x fewer "
+            "multiplications than the ALGORITHMIC FLOP count (direct convolution, SURVEY 8d) this line's roofline figures use"
+            % ("one-kernel form where it pays, three-kernel form elsewhere" if winograd._CFG.fused else "three-kernel form"))
         if args.force_allreduce:
             line["config"]["force_allreduce"] = ("single-rank rehearsal of the multi-GPU gradient path: %d + %d buckets all-reduced over "
                                                  "RCCL per iteration" % (len(optimizer.reducer_D.buckets), len(optimizer.reducer_G.buckets)))
@@ -841,7 +848,7 @@ def main():
                 line["hbm_by_kernel"] = hbm_rows
         if world == 1 and args.dropin_steps > 0 and not args.force_allreduce:
             line["via_dropin"] = via_dropin_leg(args, line)
-        if world == 1 and args.preset == "church256" and args.other_presets and not launched and not args.winograd:
+        if world == 1 and args.preset == "church256" and args.other_presets and not launched and not args.no_winograd:
             line["other_presets"] = other_presets_leg(args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.preset, size, batch, full=args.full_cpu_baseline)

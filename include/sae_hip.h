@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 7   /* 7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
+#define SAE_ABI_VERSION 8   /* 8: sae_wino_fused_* (one-kernel Winograd convolution);  7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -434,6 +434,27 @@ int sae_wino_input_f32(const float* x, const float* plane_scale, float* v, int64
 int sae_wino_output_f32(const float* md, const float* plane_scale, const float* noise, const float* noise_weight,
                         const float* bias, float* y, int64_t planes, int64_t channels, int64_t h, int64_t w, int32_t act,
                         float slope, float act_scale, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused Winograd F(2x2, 3x3) convolution (csrc/winograd_fused.hip): the same layers (F.conv2d at models/networks/
+ * stylegan2_layers.py:136,315; their data gradient with flip = 1, the two weight strides swapped and pad -> 2 - pad) with the
+ * input transform, the sixteen products and the output transform + epilogue in ONE kernel: only x, the prepared weights and y
+ * touch HBM.
+ *   sae_wino_fused_weights_floats(m, c)   floats of the prepared weights: ceil(m / 64) * ceil(c / 8) * 8192
+ *   sae_wino_fused_weights_f32   uf[((mb * chunks + chunk) * 16 + xi) * 512 + (half * 64 + ml) * 4 + s] = U[xi][64 mb + ml][8 chunk +
+ *                                4 half + s], U as sae_wino_weights_f32's u (same factors, same flip), zero beyond m / c;
+ *                                chunks = ceil(c / 8).  uf 16-byte aligned.  Prepared once per weight update.
+ *   sae_wino_fused_conv_f32      x [n][c][h][w] (h, w even; zero padding `pad` 0, 1 or 2) times x_scale[n * c + ci] if given ->
+ *                                y [n][m][h + 2 pad - 2][w + 2 pad - 2], times out_scale[n * m + mi] if given; act != 0:
+ *                                y = lrelu((y + noise_weight[0] * noise[n][pixel]) + bias[mi], slope) * act_scale (noise
+ *                                [n][oh][ow] or NULL, bias may be NULL).  No workspace.  y 8-byte aligned.
+ */
+int64_t sae_wino_fused_weights_floats(int64_t m, int64_t c);
+int sae_wino_fused_weights_f32(const float* w, const float* row_scale, const float* col_scale, float* uf, int64_t m, int64_t c,
+                               int64_t w_stride_m, int64_t w_stride_c, int32_t flip, float alpha, sae_stream_t stream);
+int sae_wino_fused_conv_f32(const float* x, const float* x_scale, const float* uf, const float* out_scale, const float* noise,
+                            const float* noise_weight, const float* bias, float* y, int64_t n, int64_t c, int64_t m, int64_t h,
+                            int64_t w, int32_t pad, int32_t act, float slope, float act_scale, sae_stream_t stream);
 
 #ifdef __cplusplus
 }

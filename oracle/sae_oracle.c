@@ -42,7 +42,7 @@ typedef struct sae_conv2d_desc {
 
 static __thread char g_err[256];
 
-int oracle_abi_version(void) { return 7; }
+int oracle_abi_version(void) { return 8; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
@@ -1182,5 +1182,101 @@ int oracle_wino_wgrad_output_f32(const float* gu, float* gw, int64_t m, int64_t 
                             acc += WINO_G[a][i] * (double)gu[((int64_t)(4 * a + b) * m + mi) * c + ci] * WINO_G[b][j];
                     gw[mi * w_stride_m + ci * w_stride_c + 3 * i + j] = (float)((double)alpha * acc);
                 }
+    return SAE_OK;
+}
+
+/* ---- fused Winograd entry points (include/sae_hip.h: sae_wino_fused_*; csrc/winograd_fused.hip).  The prepared weights are the
+ * transform-domain weights U[xi][m][c] = alpha (G g G^T)[xi] in the layout the header documents:
+ *     uf[((mb * chunks + chunk) * 16 + xi) * 512 + (half * 64 + ml) * 4 + s],  m = 64 mb + ml,  c = 8 chunk + 4 half + s,
+ * zero beyond m / c.  The convolution is restated from the published matrices in double: V = B^T d B of each 4x4 patch,
+ * M[xi] = sum_c U[xi][m][c] V[xi][c], Y = A^T M A, then the epilogue of oracle_wino_output_f32. */
+int64_t oracle_wino_fused_weights_floats(int64_t m, int64_t c) {
+    if (m < 1 || c < 1) return 0;
+    return ((m + 63) / 64) * ((c + 7) / 8) * 8192;
+}
+
+int oracle_wino_fused_weights_f32(const float* w, const float* row_scale, const float* col_scale, float* uf, int64_t m, int64_t c,
+                                  int64_t w_stride_m, int64_t w_stride_c, int32_t flip, float alpha, sae_stream_t stream) {
+    (void)stream;
+    if (m < 1 || c < 1 || !w || !uf) return set_err("oracle_wino_fused_weights_f32: bad argument");
+    const int64_t chunks = (c + 7) / 8, mbs = (m + 63) / 64;
+    memset(uf, 0, sizeof(float) * (size_t)(mbs * chunks * 8192));
+    for (int64_t mi = 0; mi < m; ++mi)
+        for (int64_t ci = 0; ci < c; ++ci) {
+            const float* wp = w + mi * w_stride_m + ci * w_stride_c;
+            double g[3][3];
+            for (int t = 0; t < 9; ++t)
+                g[t / 3][t % 3] = (double)alpha * (double)wp[flip ? 8 - t : t] * (row_scale ? (double)row_scale[mi] : 1.0) *
+                                  (col_scale ? (double)col_scale[ci] : 1.0);
+            const int64_t mb = mi / 64, ml = mi % 64, chunk = ci / 8, half = (ci % 8) / 4, s = ci % 4;
+            for (int a = 0; a < 4; ++a)
+                for (int b = 0; b < 4; ++b) {
+                    double acc = 0.0;
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) acc += WINO_G[a][i] * g[i][j] * WINO_G[b][j];
+                    uf[((mb * chunks + chunk) * 16 + (4 * a + b)) * 512 + (half * 64 + ml) * 4 + s] = (float)acc;
+                }
+        }
+    return SAE_OK;
+}
+
+int oracle_wino_fused_conv_f32(const float* x, const float* x_scale, const float* uf, const float* out_scale, const float* noise,
+                               const float* noise_weight, const float* bias, float* y, int64_t n, int64_t c, int64_t m, int64_t h,
+                               int64_t w, int32_t pad, int32_t act, float slope, float act_scale, sae_stream_t stream) {
+    (void)stream;
+    if (n < 0 || c < 1 || m < 1 || pad < 0 || pad > 2 || h < 1 || w < 1 || (h & 1) || (w & 1) || h + 2 * pad < 4 || w + 2 * pad < 4)
+        return set_err("oracle_wino_fused_conv_f32: the map must have even sides and pad 0, 1 or 2");
+    if (n == 0) return SAE_OK;
+    if (!x || !uf || !y) return set_err("oracle_wino_fused_conv_f32: null tensor");
+    if (noise && (!act || !noise_weight)) return set_err("oracle_wino_fused_conv_f32: noise without its epilogue");
+    const int64_t oh = h + 2 * pad - 2, ow = w + 2 * pad - 2, th = oh / 2, tw = ow / 2, chunks = (c + 7) / 8;
+    double* V = (double*)malloc(sizeof(double) * (size_t)(16 * c));
+    if (!V) return set_err("oracle_wino_fused_conv_f32: out of memory");
+    for (int64_t ni = 0; ni < n; ++ni)
+        for (int64_t ty = 0; ty < th; ++ty)
+            for (int64_t tx = 0; tx < tw; ++tx) {
+                for (int64_t ci = 0; ci < c; ++ci) {
+                    double d[4][4];
+                    const float* xp = x + (ni * c + ci) * h * w;
+                    for (int r = 0; r < 4; ++r)
+                        for (int q = 0; q < 4; ++q) {
+                            const int64_t iy = 2 * ty - pad + r, ix = 2 * tx - pad + q;
+                            const int in = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                            d[r][q] = in ? (double)(x_scale ? xp[iy * w + ix] * x_scale[ni * c + ci] : xp[iy * w + ix]) : 0.0;
+                        }
+                    for (int a = 0; a < 4; ++a)
+                        for (int b = 0; b < 4; ++b) {
+                            double acc = 0.0;
+                            for (int i = 0; i < 4; ++i)
+                                for (int j = 0; j < 4; ++j) acc += WINO_BT[a][i] * d[i][j] * WINO_BT[b][j];
+                            V[(4 * a + b) * c + ci] = acc;
+                        }
+                }
+                for (int64_t mi = 0; mi < m; ++mi) {
+                    double M[16];
+                    const int64_t mb = mi / 64, ml = mi % 64;
+                    for (int xi = 0; xi < 16; ++xi) {
+                        double acc = 0.0;
+                        for (int64_t ci = 0; ci < c; ++ci)
+                            acc += (double)uf[((mb * chunks + ci / 8) * 16 + xi) * 512 + (((ci % 8) / 4) * 64 + ml) * 4 + ci % 4] *
+                                   V[xi * c + ci];
+                        M[xi] = acc;
+                    }
+                    for (int a = 0; a < 2; ++a)
+                        for (int b = 0; b < 2; ++b) {
+                            double acc = 0.0;
+                            for (int i = 0; i < 4; ++i)
+                                for (int j = 0; j < 4; ++j) acc += WINO_AT[a][i] * M[4 * i + j] * WINO_AT[b][j];
+                            float o = out_scale ? (float)acc * out_scale[ni * m + mi] : (float)acc;
+                            if (act) {
+                                if (noise) o = o + noise_weight[0] * noise[(ni * oh + 2 * ty + a) * ow + 2 * tx + b];
+                                o = o + (bias ? bias[mi] : 0.0f);
+                                o = ((o > 0.0f) ? o : o * slope) * act_scale;
+                            }
+                            y[((ni * m + mi) * oh + 2 * ty + a) * ow + 2 * tx + b] = o;
+                        }
+                }
+            }
+    free(V);
     return SAE_OK;
 }

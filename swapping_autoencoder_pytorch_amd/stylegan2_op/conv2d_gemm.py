@@ -24,6 +24,9 @@ from ..hip_lib import SAE_CONV_DGRAD, SAE_CONV_FWD, SAE_CONV_WGRAD, ConvDesc
 from . import weight_prep, winograd
 
 
+_WINO_OP = {SAE_CONV_FWD: winograd.FWD, SAE_CONV_DGRAD: winograd.DGRAD, SAE_CONV_WGRAD: winograd.WGRAD}
+
+
 class _Flags:
     weight_grads = True
     depth = 0                      # nesting / concurrency count of input_grads_only (weight_grads == (depth == 0))
@@ -99,7 +102,7 @@ def _launch(name, op, geom, a, b, out_shape, out=None):
 
 
 def _launch_fused(geom, x, w, bias, slope, scale):
-    if winograd.eligible(geom):
+    if winograd.eligible(geom, winograd.FWD):
         return winograd.conv(x, w, geom, bias=bias, act=(slope, scale))
     lib = hip_lib.get()
     x = x.contiguous()
@@ -137,19 +140,19 @@ def _launch_residual(geom, x, w, residual, res_scale):
 
 
 def _fwd(x, w, g):
-    if winograd.eligible(g):
+    if winograd.eligible(g, winograd.FWD):
         return winograd.conv(x, w, g)
     return _launch("conv2d_fwd_f32", SAE_CONV_FWD, g, x, w, (g.n, g.m, g.oh, g.ow))
 
 
 def _dgrad(gy, w, g):
-    if winograd.eligible(g):
+    if winograd.eligible(g, winograd.DGRAD):
         return winograd.conv(gy, w, g, transpose=True)
     return _launch("conv2d_dgrad_f32", SAE_CONV_DGRAD, g, gy, w, (g.n, g.c, g.h, g.w))
 
 
 def _wgrad(x, gy, g, out=None):
-    if winograd.eligible(g):
+    if winograd.eligible(g, winograd.WGRAD):
         return winograd.wgrad(x, gy, g, out=out)
     return _launch("conv2d_wgrad_f32", SAE_CONV_WGRAD, g, x, gy, g.weight_shape(), out=out)
 
@@ -271,14 +274,15 @@ def _launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_
     """One sae_modconv2d_* call: the plain operation `op` on a * factor, b (weights or second activation) with the
     optional [N, C] activation factors and per-channel weight factors staged inside the kernels.  factor_tag: what the weight
     factors are as a function of the weight parameter alone (weight_prep.attach), None = unknown (no prepared weights)."""
-    if winograd.eligible(geom):
+    if winograd.eligible(geom, _WINO_OP[op]):
         # the factors of sae_conv2d_mod in the route's terms: the activation factor of the operation's input; the weight factors by
         # the axes of the product that is computed (the data gradient's outputs are the c axis)
         if op == SAE_CONV_WGRAD:      # a = x, b = gy
             return winograd.wgrad(a, b, geom, x_scale=x_scale, y_scale=y_scale)
         if op == SAE_CONV_FWD:
-            return winograd.conv(a, b, geom, x_scale=x_scale, row_scale=wm_scale, col_scale=wc_scale)
-        return winograd.conv(a, b, geom, transpose=True, x_scale=y_scale, row_scale=wc_scale, col_scale=wm_scale)
+            return winograd.conv(a, b, geom, x_scale=x_scale, row_scale=wm_scale, col_scale=wc_scale, factor_tag=factor_tag)
+        return winograd.conv(a, b, geom, transpose=True, x_scale=y_scale, row_scale=wc_scale, col_scale=wm_scale,
+                             factor_tag=factor_tag)
     lib = hip_lib.get()
     a = a.contiguous()
     b = b.contiguous()
@@ -427,10 +431,10 @@ class StyledModConv(Function):
         if act_ticket is not None:
             act_ticket.arm(noise, slope, scale)      # the CONTIGUOUS map: the consumer's backward hands it to a kernel
         lib.check(x, w, s, noise, noise_weight, bias, demod)
-        if winograd.eligible(geom):
-            out = winograd.conv(x, w, geom, x_scale=s, row_scale=demod, noise=noise, noise_weight=noise_weight, bias=bias,
-                                act=(slope, scale))
+        if winograd.eligible(geom, winograd.FWD):
             ctx.factor_tag = ("demod", float(demod_alpha), float(demod_eps)) if demod_eps is not None else ()
+            out = winograd.conv(x, w, geom, x_scale=s, row_scale=demod, noise=noise, noise_weight=noise_weight, bias=bias,
+                                act=(slope, scale), factor_tag=ctx.factor_tag)
             ctx.save_for_backward(x, s, w, demod, out, noise)
             ctx.cfg = (geom, slope, scale, bias is not None)
             return out

@@ -46,6 +46,31 @@ def invalidate():
     _ENTRIES.clear()
 
 
+def cached(w, key, build):
+    """A tensor derived from parameter `w` alone (the Winograd-domain weights of stylegan2_op/winograd.py), kept until the
+    parameter's version counter moves: build() -> tensor, made on the current stream.  Not a Parameter (or a view of one), or
+    the cache switched off: built per call."""
+    if not enabled():
+        return build()
+    base = w._base if w._base is not None else w
+    if not isinstance(base, torch.nn.Parameter):
+        return build()
+    k = (w.data_ptr(),) + tuple(key)
+    e = _ENTRIES.get(k)
+    cur = torch.cuda.current_stream(w.device) if w.is_cuda else None
+    if e is None or e.ref() is not base or e.version != base._version:
+        e = _Entry()
+        e.ref, e.version = weakref.ref(base, lambda _r, key=k: _drop(key, _r)), base._version
+        e.buf = build()
+        e.stream = cur
+        e.event = cur.record_event() if cur is not None else None
+        _ENTRIES[k] = e
+    elif cur is not None and cur != e.stream:
+        cur.wait_event(e.event)          # built on the step's other stream (streams.py)
+        e.buf.record_stream(cur)
+    return e.buf
+
+
 def attach(lib, d, mod, op, w, alpha, tag=(), gkey=None):
     """Point descriptor `d` at prepared weights for the launch (d, mod, op) on weight tensor `w`, preparing them if the cached
     copy is missing or older than the parameter.  `tag`: hashable identity of the weight FACTORS in `mod` as a function of the

@@ -5,39 +5,142 @@
 The same three C-ABI transforms serve the forward (``F.conv2d`` at models/networks/stylegan2_layers.py:136,315) and the data
 gradient (the reversed filter with the channel roles swapped); the 16 transform-domain products are one batched launch of the 1x1
 MFMA gather.  ``wgrad`` is the weight gradient on the same sixteen points.  2.25x fewer multiplications for two extra passes over 4x the activation: it pays on layers with many channels on
-small maps.  OFF unless ``SAE_WINOGRAD=1`` -- built and verified against the oracle this round (CPU emulator), not yet measured
-on the GPU; ``SAE_WINOGRAD_MIN_C`` (default 256) is the smallest channel count that takes it.
+small maps.  ON by default since round 5 (measured: profiles/r5_winograd_first_session.txt, r5_wino_ab_*.json) for the launches a
+per-shape rule selects (route()); where it pays, the ONE-kernel form of csrc/winograd_fused.hip (transforms in registers, no
+4x activation round trip) replaces the three-kernel form.  ``SAE_WINOGRAD=0`` turns the route off.
 Results differ from the direct kernels' by rounding (~1e-6 relative), so the route is never mixed into bit-identity checks."""
 import os
 
 import torch
 
 from .. import hip_lib
+from . import weight_prep
+
+FWD, DGRAD, WGRAD = "fwd", "dgrad", "wgrad"
+
+
+class _Config:
+    """Read ONCE (import, or configure()): the conv wrappers ask eligible() on every call, which must not cost an environment
+    lookup.  SAE_WINOGRAD=0 turns the route off; SAE_WINOGRAD_MIN_C overrides the smallest channel count (and with it the
+    measured per-shape rule: every 3x3 stride-1 layer of at least that many channels then takes the route -- the tests'
+    setting); SAE_WINOGRAD_FUSED=0 keeps the three-kernel form everywhere."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("SAE_WINOGRAD", "1") != "0"
+        mc = os.environ.get("SAE_WINOGRAD_MIN_C")
+        self.min_c = int(mc) if mc is not None else None
+        self.fused = os.environ.get("SAE_WINOGRAD_FUSED", "1") != "0"
+        self.memo = {}
+
+
+_CFG = _Config()
+
+
+def configure(enabled=None, min_c="keep", fused=None):
+    """Change the route's switches at run time (tests, bench A/B); returns the previous (enabled, min_c, fused)."""
+    prev = (_CFG.enabled, _CFG.min_c, _CFG.fused)
+    if enabled is not None:
+        _CFG.enabled = bool(enabled)
+    if min_c != "keep":
+        _CFG.min_c = min_c
+    if fused is not None:
+        _CFG.fused = bool(fused)
+    _CFG.memo.clear()
+    return prev
+
+
+class override:
+    """with winograd.override(enabled=True, min_c=8): ...  -- configure() for the duration of a block"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        self.prev = configure(**self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        configure(*self.prev)
+        return False
 
 
 def enabled():
-    return os.environ.get("SAE_WINOGRAD", "0") == "1"
+    return _CFG.enabled
 
 
-def min_channels():
-    return int(os.environ.get("SAE_WINOGRAD_MIN_C", "256"))
+def _route_of(geom, op):
+    """None (direct kernels), "fused" (one kernel) or "unfused" (transform / sixteen products / transform) for a 3x3 stride-1
+    layer.  The per-shape rule is read off the same-box A/B of every such launch of the church256 and ffhq512 iterations
+    (tools/wino_ab.py -> profiles/r5_wino_ab_*.json): it keeps 27.5 of the 27.7 ms per iteration that picking the faster route
+    per launch would save."""
+    if geom.k != 3 or geom.stride != 1 or geom.pad not in (0, 1) or (geom.h & 1) or (geom.w & 1):
+        return None
+    cmin = min(geom.c, geom.m)
+    tiles = (geom.oh >> 1) * (geom.ow >> 1)
+    if _CFG.min_c is not None:                        # explicit threshold: everything at least that wide
+        if cmin < _CFG.min_c:
+            return None
+        unfused = True
+    elif op == WGRAD:                                  # two transforms + sixteen K-sliced 1x1 weight gradients
+        unfused = cmin >= 256 and geom.n * tiles * cmin >= (4 << 20)
+    else:                                              # fewer than 16 tiles per image or ~1000 in all: launch-bound
+        unfused = cmin >= 256 and tiles >= 16 and geom.n * tiles >= 1024
+    if op != WGRAD and _CFG.fused:
+        in_w = geom.ow if op == DGRAD else geom.w      # the operand whose 4x4 patches are fetched as 16-byte rows
+        if in_w >= 4 and (unfused or _fused_pays(geom, cmin, tiles)):
+            return "fused"
+    return "unfused" if unfused else None
 
 
-def eligible(geom):
-    """3x3, stride 1, pad 1 or 0, even sides (whole 2x2 output tiles), wide enough, exact-fp32 arithmetic."""
-    if not enabled() or geom.k != 3 or geom.stride != 1 or geom.pad not in (0, 1) or (geom.h & 1) or (geom.w & 1):
-        return False
-    if min(geom.c, geom.m) < min_channels():
-        return False
-    return hip_lib.get().query("get_conv_math") == 0
+def _fused_pays(geom, cmin, tiles):
+    """Layers the three-kernel form loses on but the one-kernel form wins: 128 channels on large maps (no 4x activation round
+    trip through HBM); needs enough 64-tile x 64-channel workgroups to fill the chip."""
+    return cmin >= 128 and geom.n * tiles >= 16384
+
+
+def route(geom, op=FWD):
+    if not _CFG.enabled:
+        return None
+    key = (geom.key, op)
+    r = _CFG.memo.get(key, 0)
+    if r == 0:
+        r = _CFG.memo[key] = _route_of(geom, op)
+    if r is not None and hip_lib.get().query("get_conv_math") != 0:      # exact-fp32 arithmetic only
+        return None
+    return r
+
+
+def eligible(geom, op=FWD):
+    return route(geom, op) is not None
+
+
+def _weights(lib, w, kind, cout, cin, sm, sc, flip, alpha, row_scale, col_scale, tag):
+    """Transform-domain weights of `w`, kept per parameter version (weight_prep.cached) when the factors are a function of the
+    parameter alone (tag: () = no factors, a hashable description, or None = unknown -> rebuilt per call)."""
+    def build():
+        if kind == "fused":
+            u = torch.empty(lib.query("wino_fused_weights_floats", cout, cin), dtype=torch.float32, device=w.device)
+            lib.call("wino_fused_weights_f32", w.data_ptr(), hip_lib.ptr(row_scale), hip_lib.ptr(col_scale), u.data_ptr(), cout, cin,
+                     sm, sc, flip, alpha, lib.stream(w))
+        else:
+            u = torch.empty((16, cout, cin), dtype=torch.float32, device=w.device)
+            lib.call("wino_weights_f32", w.data_ptr(), hip_lib.ptr(row_scale), hip_lib.ptr(col_scale), u.data_ptr(), cout, cin, sm,
+                     sc, flip, alpha, lib.stream(w))
+        return u
+    if row_scale is None and col_scale is None:
+        tag = ()
+    if tag is None:
+        return build()
+    return weight_prep.cached(w, ("wino", kind, flip, float(alpha), tag), build)
 
 
 def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None, row_scale=None, col_scale=None, out_scale=None,
-         noise=None, noise_weight=None):
+         noise=None, noise_weight=None, factor_tag=None, kind=None):
     """alpha * conv(x * x_scale, w') (transpose=False: x is [n, c, h, w]) or alpha * conv^T(gy * x_scale, w') (transpose=True: x
     is the output gradient [n, m, h, w]) with w' = w * row_scale * col_scale along the OUTPUT / CONTRACTION axes of the product
     that is computed; times out_scale [n, outputs] if given; then, with act = (slope, scale),
-    lrelu((. + noise_weight * noise[n]) + bias) * scale (noise, bias optional)."""
+    lrelu((. + noise_weight * noise[n]) + bias) * scale (noise, bias optional).  factor_tag: what row_scale / col_scale are as a
+    function of the weight parameter alone (weight_prep), None = unknown.  kind: "fused" / "unfused" (default: route())."""
     lib = hip_lib.get()
     x = x.contiguous()
     w = w.contiguous()
@@ -55,21 +158,26 @@ def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None, row_sca
     ih, iw, pad, h, wd = (geom.oh, geom.ow, 2 - geom.pad, geom.h, geom.w) if transpose else (geom.h, geom.w, geom.pad, geom.oh, geom.ow)
     if tuple(x.shape) != (n, cin, ih, iw):
         raise hip_lib.SaeError("winograd conv: input %s, expected (%d, %d, %d, %d)" % (tuple(x.shape), n, cin, ih, iw))
-    th, tw = h // 2, wd // 2
-    tiles = th * tw
+    if kind is None:
+        kind = route(geom, DGRAD if transpose else FWD) or "unfused"
     stream = lib.stream(x)
     dev = x.device
-    u = torch.empty((16, cout, cin), dtype=torch.float32, device=dev)
-    lib.call("wino_weights_f32", w.data_ptr(), hip_lib.ptr(row_scale), hip_lib.ptr(col_scale), u.data_ptr(), cout, cin, sm, sc,
-             flip, geom.alpha, stream)
+    u = _weights(lib, w, kind, cout, cin, sm, sc, flip, geom.alpha, row_scale, col_scale, factor_tag)
+    y = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
+    slope, scale = act if act is not None else (0.0, 1.0)
+    if kind == "fused":
+        lib.call("wino_fused_conv_f32", x.data_ptr(), hip_lib.ptr(x_scale), u.data_ptr(), hip_lib.ptr(out_scale), hip_lib.ptr(noise),
+                 hip_lib.ptr(noise_weight), hip_lib.ptr(bias), y.data_ptr(), n, cin, cout, ih, iw, pad, 1 if act is not None else 0,
+                 float(slope), float(scale), stream)
+        return y
+    th, tw = h // 2, wd // 2
+    tiles = th * tw
     v = torch.empty((16, n * cin, tiles), dtype=torch.float32, device=dev)
     lib.call("wino_input_f32", x.data_ptr(), hip_lib.ptr(x_scale), v.data_ptr(), n * cin, ih, iw, pad, stream)
     md = torch.empty((16, n * cout, tiles), dtype=torch.float32, device=dev)
     n_ws = lib.query("wino_gemm_workspace", n, cin, cout, th, tw)
     ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
     lib.call("wino_gemm_f32", v.data_ptr(), u.data_ptr(), md.data_ptr(), n, cin, cout, th, tw, ws.data_ptr(), n_ws, stream)
-    y = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
-    slope, scale = act if act is not None else (0.0, 1.0)
     lib.call("wino_output_f32", md.data_ptr(), hip_lib.ptr(out_scale), hip_lib.ptr(noise), hip_lib.ptr(noise_weight),
              hip_lib.ptr(bias), y.data_ptr(), n * cout, cout, h, wd, 1 if act is not None else 0, float(slope), float(scale), stream)
     return y

@@ -459,3 +459,34 @@ def wino_wgrad(lib, x, gy, alpha=1.0, cm_layout=False, x_scale=None, y_scale=Non
     bw = _out(shape, device)
     lib.call("wino_wgrad_output_f32", bu.ptr, bw.ptr, m, c, sm, sc, alpha, _stream(device))
     return bw.numpy(), be.numpy(), bu.numpy()
+
+
+def wino_fused_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None, x_scale=None, cm_layout=False, row_scale=None,
+                    col_scale=None, out_scale=None, noise=None, noise_weight=None, pad=1, device=None):
+    """wino_conv's contract through the ONE-kernel route (sae_wino_fused_weights_f32 + sae_wino_fused_conv_f32)."""
+    n, cin, ih, iw = x.shape
+    ipad = 2 - pad if transpose else pad
+    h, w = ih + 2 * ipad - 2, iw + 2 * ipad - 2
+    if cm_layout:
+        c_, m_ = wt.shape[0], wt.shape[1]
+        sm, sc = 9, m_ * 9
+    else:
+        m_, c_ = wt.shape[0], wt.shape[1]
+        sm, sc = c_ * 9, 9
+    if transpose:
+        cout, sm, sc = c_, sc, sm
+        assert cin == m_
+    else:
+        cout = m_
+        assert cin == c_
+    floats = lib.query("wino_fused_weights_floats", cout, cin)
+    bw, bu = _Buf(wt, device), _out((floats,), device)
+    opt = [None if t is None else _Buf(np.asarray(t, np.float32).reshape(-1), device)
+           for t in (row_scale, col_scale, x_scale, out_scale, noise, noise_weight, bias)]
+    prs, pcs, pxs, pos, pnz, pnw, pb = [b.ptr if b is not None else None for b in opt]
+    lib.call("wino_fused_weights_f32", bw.ptr, prs, pcs, bu.ptr, cout, cin, sm, sc, 1 if transpose else 0, alpha, _stream(device))
+    bx, by = _Buf(x, device), _out((n, cout, h, w), device)
+    slope, scale = act if act is not None else (0.0, 1.0)
+    lib.call("wino_fused_conv_f32", bx.ptr, pxs, bu.ptr, pos, pnz, pnw, pb, by.ptr, n, cin, cout, ih, iw, ipad,
+             1 if act is not None else 0, float(slope), float(scale), _stream(device))
+    return by.numpy()

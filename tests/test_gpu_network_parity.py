@@ -113,11 +113,10 @@ def _grads_and_errors(ref64, ref32, ours, inputs, run_ref, run_ours, loss_weight
     return errs, book
 
 
-# relative L2 of every gradient tensor against the double run under this package's own sign patterns: the north-star tolerance
-# for the product's arithmetic (measured r5: worst tensor 2.8e-5, typical 1e-6); the opt-in bf16x6 arithmetic (six
-# bf16 products per fp32 product, the three smallest cross terms dropped) carries a few 1e-7 of TRUNCATION per product, which
-# adds up coherently over the 10^6-term sums of the first layers' bias / weight gradients (measured 1.6e-4): held to 3e-4
-GRAD_TOL = {"f32": 1e-4, "bf16x6": 3e-4}
+# relative L2 of every gradient tensor against the double run under this package's own sign patterns: the north-star tolerance,
+# for both arithmetics (measured r5, profiles/r5_network_parity_tensors.jsonl: f32 worst tensor 2.4e-6; the opt-in bf16x6 arithmetic
+# -- six bf16 products per fp32 product, DESIGN.md 4.1 -- 4.8e-5; with the Winograd route on 2.2e-6)
+GRAD_TOL = {"f32": 1e-4, "bf16x6": 1e-4}
 
 
 def _check(case, conv_math, errs, book):

@@ -115,10 +115,11 @@ def test_bad_geometry_is_refused(emu_lib):
         H.wino_input(emu_lib, x)           # odd height: no whole 2x2 output tiles
 
 
+@pytest.mark.parametrize("one_kernel", [False, True])
 @pytest.mark.parametrize("pad", [1, 0])
-def test_python_route_through_autograd(oracle_lib, monkeypatch, pad):
-    """stylegan2_op.winograd behind conv2d_gemm (SAE_WINOGRAD=1): forward with the fused activation, data gradient and weight
-    gradient take the route and agree with the direct kernels."""
+def test_python_route_through_autograd(oracle_lib, monkeypatch, pad, one_kernel):
+    """stylegan2_op.winograd behind conv2d_gemm: forward with the fused activation, data gradient and weight gradient take the
+    route (three-kernel form / the ONE-kernel form for forward and data gradient) and agree with the direct kernels."""
     from swapping_autoencoder_pytorch_amd import hip_lib
     from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as G, winograd
     monkeypatch.setattr(hip_lib, "_LIB", oracle_lib)
@@ -134,25 +135,27 @@ def test_python_route_through_autograd(oracle_lib, monkeypatch, pad):
         gx, gw, gb = torch.autograd.grad((y * y).sum(), (x, w, b))
         return y.detach(), gx, gw, gb
 
-    monkeypatch.setenv("SAE_WINOGRAD", "0")
-    direct = run()
-    monkeypatch.setenv("SAE_WINOGRAD", "1")
-    monkeypatch.setenv("SAE_WINOGRAD_MIN_C", "8")
-    assert winograd.eligible(geom)
+    with winograd.override(enabled=False):
+        assert not winograd.eligible(geom)
+        direct = run()
     calls = []
     orig = winograd.conv
     monkeypatch.setattr(winograd, "conv", lambda *a, **k: (calls.append(k.get("transpose", False)), orig(*a, **k))[1])
     wg_calls = []
     orig_wg = winograd.wgrad
     monkeypatch.setattr(winograd, "wgrad", lambda *a, **k: (wg_calls.append(1), orig_wg(*a, **k))[1])
-    routed = run()
+    with winograd.override(enabled=True, min_c=8, fused=one_kernel):
+        assert winograd.route(geom, winograd.FWD) == ("fused" if one_kernel else "unfused")
+        assert winograd.route(geom, winograd.WGRAD) == "unfused"
+        routed = run()
     assert calls == [False, True], calls          # the fused forward, then the data gradient
     assert wg_calls == [1], wg_calls              # ... and the weight gradient
     for a, o in zip(routed, direct):
         assert float((a - o).abs().max() / o.abs().max()) < TOL
 
 
-def test_modulated_nodes_take_the_route(oracle_lib, monkeypatch):
+@pytest.mark.parametrize("one_kernel", [False, True])
+def test_modulated_nodes_take_the_route(oracle_lib, monkeypatch, one_kernel):
     """ModulatedConv (forward: x_scale + demodulation; backward: the data gradient with the factors on the transposed axes) and the
     fused StyledConv forward (noise + bias + activation in the output transform) behind SAE_WINOGRAD=1 against the direct path."""
     from swapping_autoencoder_pytorch_amd import hip_lib
@@ -172,14 +175,13 @@ def test_modulated_nodes_take_the_route(oracle_lib, monkeypatch):
         grads = torch.autograd.grad((y1 * y1).sum() + (y2 * y2).sum(), (x, s, w, nw, b))
         return (y1.detach(), y2.detach()) + grads
 
-    monkeypatch.setenv("SAE_WINOGRAD", "0")
-    direct = run()
-    monkeypatch.setenv("SAE_WINOGRAD", "1")
-    monkeypatch.setenv("SAE_WINOGRAD_MIN_C", "8")
+    with winograd.override(enabled=False):
+        direct = run()
     calls = []
     orig = winograd.conv
     monkeypatch.setattr(winograd, "conv", lambda *a, **k: (calls.append(k.get("transpose", False)), orig(*a, **k))[1])
-    routed = run()
+    with winograd.override(enabled=True, min_c=8, fused=one_kernel):
+        routed = run()
     assert calls.count(False) == 2 and calls.count(True) == 2, calls      # two forwards, two data gradients
     for a, o in zip(routed, direct):
         assert float((a - o).abs().max() / o.abs().max()) < TOL
@@ -198,6 +200,27 @@ def test_transforms_and_route_on_the_gpu(oracle_lib):
     d = H.conv_desc(4, 512, 32, 32, 512, 3, 1, 1)
     direct = H.conv(lib, 0, d, x, wt, (4, 512, 32, 32), alpha=1.0, device="cuda:0")
     assert H.rel_err(H.wino_conv(lib, x, wt, device="cuda:0"), direct) < TOL
+    assert H.rel_err(H.wino_fused_conv(lib, x, wt, device="cuda:0"), direct) < TOL
+
+
+@pytest.mark.gpu
+def test_fused_route_on_the_gpu(oracle_lib):
+    """The ONE-kernel route against the oracle's direct convolution (all epilogues, modulated forms, both paddings, the data
+    gradient), then two layers of the step's size against the direct MFMA kernels: 128 -> 128 @64^2 (a partial last channel block
+    is not involved, 16 chunks) and 200 -> 72 @32^2 (channel counts that are no multiple of the chunk or the block)."""
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    lib = hip_lib.get()
+    _fused_route(lib, oracle_lib, "cuda:0")
+    rng = np.random.default_rng(43)
+    for n, c, m, side in [(3, 128, 128, 64), (2, 200, 72, 32)]:
+        x = rng.standard_normal((n, c, side, side)).astype(np.float32)
+        wt = (rng.standard_normal((m, c, 3, 3)) / (3 * c ** 0.5)).astype(np.float32)
+        gy = rng.standard_normal((n, m, side, side)).astype(np.float32)
+        d = H.conv_desc(n, c, side, side, m, 3, 1, 1)
+        direct = H.conv(lib, 0, d, x, wt, gy.shape, alpha=1.0, device="cuda:0")
+        assert H.rel_err(H.wino_fused_conv(lib, x, wt, device="cuda:0"), direct) < TOL
+        dgrad = H.conv(lib, 1, d, gy, wt, x.shape, alpha=1.0, device="cuda:0")
+        assert H.rel_err(H.wino_fused_conv(lib, gy, wt, transpose=True, device="cuda:0"), dgrad) < TOL
 
 
 def test_train_step_with_the_route(oracle_lib, monkeypatch):
@@ -212,8 +235,7 @@ def test_train_step_with_the_route(oracle_lib, monkeypatch):
     monkeypatch.setattr(hip_lib, "_LIB", oracle_lib)
 
     def run(route):
-        monkeypatch.setenv("SAE_WINOGRAD", "1" if route else "0")
-        monkeypatch.setenv("SAE_WINOGRAD_MIN_C", "4")
+        prev = winograd.configure(enabled=route, min_c=4)
         calls = []
         orig = winograd.conv
         monkeypatch.setattr(winograd, "conv", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
@@ -227,6 +249,7 @@ def test_train_step_with_the_route(oracle_lib, monkeypatch):
             x = torch.rand(4, 3, 32, 32) * 2 - 1
             out.append({k: float(v) for k, v in optimizer.train_one_step({"real_A": x}, i).items()})
         monkeypatch.setattr(winograd, "conv", orig)
+        winograd.configure(*prev)
         return out, len(calls)
 
     direct, n0 = run(False)
@@ -259,3 +282,58 @@ def test_wide_rows_take_the_four_tile_kernels():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stderr.splitlines() if l.startswith("sae-dispatch wino")]
     assert lines == ["sae-dispatch wino input4", "sae-dispatch wino output4", "sae-dispatch wino input4", "sae-dispatch wino gy4"], lines
+
+
+# ---- the ONE-kernel route (csrc/winograd_fused.hip): n, c, h, w, m, [C, M] weights, pad.  Channel counts around the 8-channel
+# chunk and the 64-channel block, maps that fill a 4 x 16 tile block, spill over it, or leave most of it empty, several images per block
+FUSED_CASES = [(2, 12, 8, 8, 20, False, 1), (1, 40, 6, 10, 70, False, 1), (3, 9, 4, 4, 70, True, 1), (1, 5, 16, 36, 8, False, 1),
+               (2, 16, 10, 10, 20, False, 0), (5, 24, 4, 4, 16, False, 0), (1, 9, 6, 8, 33, True, 0), (1, 8, 40, 12, 64, False, 1)]
+
+
+def _fused_route(lib, oracle_lib, dev):
+    rng = np.random.default_rng(41)
+    for n, c, h, w, m, cm, pad in FUSED_CASES:
+        d = H.conv_desc(n, c, h, w, m, 3, 1, pad, cm)
+        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+        wt = rng.standard_normal((c, m, 3, 3) if cm else (m, c, 3, 3)).astype(np.float32)
+        gy = rng.standard_normal((n, m, d.oh, d.ow)).astype(np.float32)
+        b = rng.standard_normal(m).astype(np.float32)
+        xs = (1 + 0.5 * rng.standard_normal((n, c))).astype(np.float32)
+        ys = (1 + 0.5 * rng.standard_normal((n, m))).astype(np.float32)
+        wm = rng.uniform(0.5, 2, m).astype(np.float32)
+        wc = rng.uniform(0.5, 2, c).astype(np.float32)
+        case = (n, c, h, w, m, cm, pad)
+        fwd = H.wino_fused_conv(lib, x, wt, alpha=0.37, cm_layout=cm, pad=pad, device=dev)
+        assert not np.isnan(fwd).any() and H.rel_err(fwd, H.conv(oracle_lib, 0, d, x, wt, gy.shape, alpha=0.37)) < TOL, case
+        if d.ow < 4 and lib is not oracle_lib:      # the kernel fetches patch rows as 16-byte loads: rows of at least 4 floats, else refused
+            with pytest.raises(Exception):
+                H.wino_fused_conv(lib, gy, wt, alpha=0.37, transpose=True, cm_layout=cm, pad=pad, device=dev)
+            continue
+        dg = H.wino_fused_conv(lib, gy, wt, alpha=0.37, transpose=True, cm_layout=cm, pad=pad, device=dev)
+        assert not np.isnan(dg).any() and H.rel_err(dg, H.conv(oracle_lib, 1, d, gy, wt, x.shape, alpha=0.37)) < TOL, case
+        mod = H.wino_fused_conv(lib, x, wt, alpha=0.3, x_scale=xs, row_scale=wm, col_scale=wc, cm_layout=cm, pad=pad, device=dev)
+        assert H.rel_err(mod, H.modconv(oracle_lib, 0, d, x, wt, gy.shape, x_scale=xs, wm_scale=wm, wc_scale=wc, alpha=0.3)) < TOL, case
+        mdg = H.wino_fused_conv(lib, gy, wt, alpha=0.3, transpose=True, x_scale=ys, row_scale=wc, col_scale=wm, cm_layout=cm, pad=pad,
+                                device=dev)
+        assert H.rel_err(mdg, H.modconv(oracle_lib, 1, d, gy, wt, x.shape, y_scale=ys, wm_scale=wm, wc_scale=wc, alpha=0.3)) < TOL, case
+        if not cm:
+            act = H.wino_fused_conv(lib, x, wt, alpha=0.11, bias=b, act=(0.2, 2 ** 0.5), pad=pad, device=dev)
+            assert H.rel_err(act, H.conv_bias_act(oracle_lib, d, x, wt, b, alpha=0.11)) < TOL, case
+            z = rng.standard_normal((n, d.oh, d.ow)).astype(np.float32)
+            zw = np.array([0.6], np.float32)
+            st = H.wino_fused_conv(lib, x, wt, alpha=0.2, x_scale=xs, row_scale=wm, noise=z, noise_weight=zw, bias=b,
+                                   act=(0.2, 2 ** 0.5), pad=pad, device=dev)
+            assert H.rel_err(st, H.modconv_noise_bias_act(oracle_lib, d, x, wt, xs, wm, z, zw, b, alpha=0.2)) < TOL, case
+        # ... and the entry point against its own restatement in the oracle (same contract, incl. out_scale)
+        os_ = (1 + 0.5 * rng.standard_normal((n, m))).astype(np.float32)
+        a = H.wino_fused_conv(lib, x, wt, alpha=0.5, out_scale=os_, cm_layout=cm, pad=pad, device=dev)
+        o = H.wino_fused_conv(oracle_lib, x, wt, alpha=0.5, out_scale=os_, cm_layout=cm, pad=pad)
+        assert H.rel_err(a, o) < TOL, case
+
+
+def test_fused_route_equals_the_direct_convolution_on_the_emulator(emu_lib, oracle_lib):
+    _fused_route(emu_lib, oracle_lib, None)
+
+
+def test_oracle_fused_route_equals_the_oracle_direct_convolution(oracle_lib):
+    _fused_route(oracle_lib, oracle_lib, None)

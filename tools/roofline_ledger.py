@@ -121,6 +121,15 @@ def work_of(name, a):
         if BY_SHAPE:
             return "winograd products %-5s n%-3d %4d->%-4d %3dx%-3d tiles" % ("wgrad" if "wgrad" in name else "", n, c, m, th, tw), "mfma", 32.0 * n * c * m * th * tw
         return "winograd products (16 x 1x1%s)" % (" weight gradient" if "wgrad" in name else ""), "mfma", 32.0 * n * c * m * th * tw
+    if name == "wino_fused_conv_f32":
+        # the one-kernel route, counted with the FLOPs it EXECUTES: 16 multiply-adds per 2x2 output tile and channel pair
+        n, c, m, h, w, pad = a[8], a[9], a[10], a[11], a[12], a[13]
+        th, tw = (h + 2 * pad - 2) // 2, (w + 2 * pad - 2) // 2
+        if BY_SHAPE:
+            return "winograd fused conv n%-3d %4d->%-4d %3dx%-3d tiles" % (n, c, m, th, tw), "mfma", 32.0 * n * c * m * th * tw
+        return "winograd fused conv (one kernel; executed FLOPs = direct / 2.25)", "mfma", 32.0 * n * c * m * th * tw
+    if name == "wino_fused_weights_f32":
+        return "winograd weight transform", "hbm", 100.0 * a[4] * a[5]
     if name in ("wino_input_f32", "wino_gy_f32"):
         return "winograd input / gradient transform", "hbm", 20.0 * a[3] * a[4] * a[5]
     if name == "wino_output_f32":
@@ -141,7 +150,8 @@ class Ledger:
         orig = lib.call
 
         def call(name, *args):
-            if not self.active or name in ("set_conv_math", "conv2d_wprep_query", "wino_gemm_workspace", "wino_wgrad_gemm_workspace"):
+            if not self.active or name in ("set_conv_math", "conv2d_wprep_query", "wino_gemm_workspace", "wino_wgrad_gemm_workspace",
+                                               "wino_fused_weights_floats"):
                 return orig(name, *args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
