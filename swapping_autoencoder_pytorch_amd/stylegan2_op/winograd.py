@@ -68,34 +68,61 @@ def enabled():
     return _CFG.enabled
 
 
+def _pow2_ceil_log2(v):
+    e = 0
+    while (1 << e) < v:
+        e += 1
+    return e
+
+
+def _fused_workgroups(n, tiles_h, tiles_w, m):
+    """Workgroups sae_wino_fused_conv_f32 launches: 64-tile blocks (BN images x BH x BW tiles, csrc/winograd_fused.hip's
+    decomposition) x 64-channel blocks."""
+    bw = min(_pow2_ceil_log2(tiles_w), 4)
+    bh = min(_pow2_ceil_log2(tiles_h), 6 - bw)
+    bn = 64 >> (bw + bh)
+    blocks = -(-tiles_w // (1 << bw)) * -(-tiles_h // (1 << bh)) * -(-n // bn)
+    return blocks * -(-m // 64)
+
+
 def _route_of(geom, op):
     """None (direct kernels), "fused" (one kernel) or "unfused" (transform / sixteen products / transform) for a 3x3 stride-1
-    layer.  The per-shape rule is read off the same-box A/B of every such launch of the church256 and ffhq512 iterations
-    (tools/wino_ab.py -> profiles/r5_wino_ab_*.json): it keeps 27.5 of the 27.7 ms per iteration that picking the faster route
-    per launch would save."""
+    layer: the cheapest of three estimates in milliseconds, each fitted to the same-box A/B of every such launch of the church256
+    iteration (tools/wino_ab.py -> profiles/r5_wino_ab_church256_fused.json; the three-kernel rule alone keeps 27.5 of the 27.7 ms
+    per iteration that picking the faster of direct / three-kernel per launch would save):
+      direct    FLOPs at 130 TFLOP/s (the gathers' plateau), never under 35 us
+      unfused   eligible from 256 channels, 16 tiles per image and ~1000 tiles in all (weight gradient: n * tiles * channels >=
+                4M): 0.62 / 0.66 / 0.78 of the direct estimate at >= 512 / 384 / 256 channels (measured 0.60 - 0.80)
+      fused     rounds of 256 workgroups (one per CU: 256 accumulators per lane) x (0.162 ms x C / 512 + 6 us) per round --
+                within 5 % of every measured row; forward and data gradient only"""
     if geom.k != 3 or geom.stride != 1 or geom.pad not in (0, 1) or (geom.h & 1) or (geom.w & 1):
         return None
     cmin = min(geom.c, geom.m)
     tiles = (geom.oh >> 1) * (geom.ow >> 1)
-    if _CFG.min_c is not None:                        # explicit threshold: everything at least that wide
+    if _CFG.min_c is not None:                        # explicit threshold (tests): everything at least that wide
         if cmin < _CFG.min_c:
             return None
-        unfused = True
-    elif op == WGRAD:                                  # two transforms + sixteen K-sliced 1x1 weight gradients
-        unfused = cmin >= 256 and geom.n * tiles * cmin >= (4 << 20)
-    else:                                              # fewer than 16 tiles per image or ~1000 in all: launch-bound
-        unfused = cmin >= 256 and tiles >= 16 and geom.n * tiles >= 1024
-    if op != WGRAD and _CFG.fused:
-        in_w = geom.ow if op == DGRAD else geom.w      # the operand whose 4x4 patches are fetched as 16-byte rows
-        if in_w >= 4 and (unfused or _fused_pays(geom, cmin, tiles)):
+        if op != WGRAD and _CFG.fused and (geom.ow if op == DGRAD else geom.w) >= 4:
             return "fused"
-    return "unfused" if unfused else None
-
-
-def _fused_pays(geom, cmin, tiles):
-    """Layers the three-kernel form loses on but the one-kernel form wins: 128 channels on large maps (no 4x activation round
-    trip through HBM); needs enough 64-tile x 64-channel workgroups to fill the chip."""
-    return cmin >= 128 and geom.n * tiles >= 16384
+        return "unfused"
+    if op == WGRAD:                                    # two transforms + sixteen K-sliced 1x1 weight gradients
+        return "unfused" if (cmin >= 256 and geom.n * tiles * cmin >= (4 << 20)) else None
+    direct = max(2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9 / 130e9, 0.035)
+    best, cost = None, direct
+    if cmin >= 256 and tiles >= 16 and geom.n * tiles >= 1024:
+        est = direct * (0.62 if cmin >= 512 else 0.66 if cmin >= 384 else 0.78)
+        if est < cost:
+            best, cost = "unfused", est
+    if _CFG.fused:
+        # the product that is computed: forward c -> m on the oh x ow grid; data gradient m -> c on the h x w grid
+        cin, cout, th, tw, in_w = ((geom.m, geom.c, geom.h >> 1, geom.w >> 1, geom.ow) if op == DGRAD else
+                                   (geom.c, geom.m, geom.oh >> 1, geom.ow >> 1, geom.w))
+        if in_w >= 4:
+            wgs = _fused_workgroups(geom.n, th, tw, cout)
+            est = -(-wgs // 256) * (0.162 * (-(-cin // 8) * 8) / 512.0 + 0.006)
+            if est < cost:
+                best, cost = "fused", est
+    return best
 
 
 def route(geom, op=FWD):
