@@ -59,7 +59,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 8   /* 8: sae_wino_fused_* (one-kernel Winograd convolution);  7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
+#define SAE_ABI_VERSION 9   /* 9: sae_wino_fused_wgrad_*;  8: sae_wino_fused_* (one-kernel Winograd convolution);  7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -455,6 +455,18 @@ int sae_wino_fused_weights_f32(const float* w, const float* row_scale, const flo
 int sae_wino_fused_conv_f32(const float* x, const float* x_scale, const float* uf, const float* out_scale, const float* noise,
                             const float* noise_weight, const float* bias, float* y, int64_t n, int64_t c, int64_t m, int64_t h,
                             int64_t w, int32_t pad, int32_t act, float slope, float act_scale, sae_stream_t stream);
+/*   sae_wino_fused_wgrad_f32     the weight gradient of the same layers (the reference reaches it through autograd's
+ *                                conv2d backward on stylegan2_layers.py:136,315), both transforms in registers:
+ *                                gw[mi * w_stride_m + ci * w_stride_c + tap] = alpha * sum over images and pixels of
+ *                                (gy * y_scale[n * m + mi]) (x) (x * x_scale[n * c + ci]) -- x [n][c][h][w], gy [n][m][h + 2 pad - 2]
+ *                                [w + 2 pad - 2], pad 0 or 1, output rows a multiple of 16 pixels, gy 16-byte aligned; either
+ *                                factor may be NULL.  Pixel slices are summed in slice order (deterministic).
+ *   sae_wino_fused_wgrad_workspace   floats of workspace it needs (0: shape not supported)
+ */
+int64_t sae_wino_fused_wgrad_workspace(int64_t n, int64_t c, int64_t m, int64_t h, int64_t w, int32_t pad);
+int sae_wino_fused_wgrad_f32(const float* x, const float* x_scale, const float* gy, const float* y_scale, float* gw, int64_t n,
+                             int64_t c, int64_t m, int64_t h, int64_t w, int32_t pad, int64_t w_stride_m, int64_t w_stride_c,
+                             float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
 
 #ifdef __cplusplus
 }

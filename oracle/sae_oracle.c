@@ -42,7 +42,7 @@ typedef struct sae_conv2d_desc {
 
 static __thread char g_err[256];
 
-int oracle_abi_version(void) { return 8; }
+int oracle_abi_version(void) { return 9; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
@@ -1278,5 +1278,67 @@ int oracle_wino_fused_conv_f32(const float* x, const float* x_scale, const float
                 }
             }
     free(V);
+    return SAE_OK;
+}
+
+/* sae_wino_fused_wgrad_f32, restated from the published matrices in double: gU[xi][m][c] = sum over images and tiles of
+ * (A e A^T)[xi] (B^T d B)[xi], gw = alpha G^T gU G.  The workspace is not used (same size contract as the product's). */
+int64_t oracle_wino_fused_wgrad_workspace(int64_t n, int64_t c, int64_t m, int64_t h, int64_t w, int32_t pad) {
+    if (n < 1 || c < 1 || m < 1 || h < 2 || w < 2 || pad < 0 || pad > 1) return 0;
+    const int64_t tw = (w + 2 * pad - 2) / 2;
+    if (tw % 8 != 0) return 0;
+    return 1;
+}
+
+int oracle_wino_fused_wgrad_f32(const float* x, const float* x_scale, const float* gy, const float* y_scale, float* gw, int64_t n,
+                                int64_t c, int64_t m, int64_t h, int64_t w, int32_t pad, int64_t w_stride_m, int64_t w_stride_c,
+                                float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream) {
+    (void)stream; (void)workspace; (void)workspace_floats;
+    if (n < 1 || c < 1 || m < 1 || pad < 0 || pad > 1 || (h & 1) || (w & 1) || h + 2 * pad < 4)
+        return set_err("oracle_wino_fused_wgrad_f32: bad shape");
+    const int64_t oh = h + 2 * pad - 2, ow = w + 2 * pad - 2, th = oh / 2, tw = ow / 2;
+    if (tw < 8 || tw % 8 != 0) return set_err("oracle_wino_fused_wgrad_f32: output rows of a multiple of 16 pixels");
+    if (!x || !gy || !gw) return set_err("oracle_wino_fused_wgrad_f32: null tensor");
+    static const double A4[4][2] = {{1, 0}, {1, 1}, {1, -1}, {0, -1}};
+    #pragma omp parallel for collapse(2)
+    for (int64_t mi = 0; mi < m; ++mi)
+        for (int64_t ci = 0; ci < c; ++ci) {
+            double gU[16];
+            for (int xi = 0; xi < 16; ++xi) gU[xi] = 0.0;
+            for (int64_t ni = 0; ni < n; ++ni) {
+                const float* xp = x + (ni * c + ci) * h * w;
+                const float* gp = gy + (ni * m + mi) * oh * ow;
+                const float sx = x_scale ? x_scale[ni * c + ci] : 1.0f, sy = y_scale ? y_scale[ni * m + mi] : 1.0f;
+                for (int64_t ty = 0; ty < th; ++ty)
+                    for (int64_t tx = 0; tx < tw; ++tx) {
+                        double d[4][4], e[2][2];
+                        for (int r = 0; r < 4; ++r)
+                            for (int q = 0; q < 4; ++q) {
+                                const int64_t iy = 2 * ty - pad + r, ix = 2 * tx - pad + q;
+                                const int in = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                                d[r][q] = in ? (double)(x_scale ? xp[iy * w + ix] * sx : xp[iy * w + ix]) : 0.0;
+                            }
+                        for (int a = 0; a < 2; ++a)
+                            for (int b = 0; b < 2; ++b)
+                                e[a][b] = (double)(y_scale ? gp[(2 * ty + a) * ow + 2 * tx + b] * sy : gp[(2 * ty + a) * ow + 2 * tx + b]);
+                        for (int a = 0; a < 4; ++a)
+                            for (int b = 0; b < 4; ++b) {
+                                double E = 0.0, V = 0.0;
+                                for (int i = 0; i < 2; ++i)
+                                    for (int j = 0; j < 2; ++j) E += A4[a][i] * e[i][j] * A4[b][j];
+                                for (int i = 0; i < 4; ++i)
+                                    for (int j = 0; j < 4; ++j) V += WINO_BT[a][i] * d[i][j] * WINO_BT[b][j];
+                                gU[4 * a + b] += E * V;
+                            }
+                    }
+            }
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double acc = 0.0;
+                    for (int a = 0; a < 4; ++a)
+                        for (int b = 0; b < 4; ++b) acc += WINO_G[a][i] * gU[4 * a + b] * WINO_G[b][j];
+                    gw[mi * w_stride_m + ci * w_stride_c + 3 * i + j] = (float)((double)alpha * acc);
+                }
+        }
     return SAE_OK;
 }

@@ -339,6 +339,284 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the same layers in ONE kernel (+ a fixed-order reduction over pixel slices):
+//     gU[xi][m][c] = sum over images and tiles of (A e A^T)[xi] * (B^T d B)[xi]        e: 2x2 tile of gy[m], d: 4x4 patch of x[c]
+//     gw[m][c][3x3] = alpha G^T gU G
+// A workgroup owns 64 gradient channels (m) x 64 input channels (c) for all sixteen points and walks a slice of the pixels in
+// chunks of 8 tiles (8 consecutive tiles of one tile row: tiles_w % 8 == 0); the contraction index of the MFMAs is the tile.
+// Both operands are transformed in registers on the way from HBM to LDS: thread (channel, tile pair) forms A e A^T of two tiles
+// of its gy channel (two 16-byte loads) and B^T d B of two tiles of its x channel (a 4 x 6 window: eight loads), 32 8-byte LDS
+// writes; the MFMA side reads both operands as one 16-byte read per point.  G^T gU G is lane-local at the end (a lane holds the
+// sixteen points of its (m, c) pairs); slices are summed by wino_fused_wgrad_reduce_kernel in slice order (deterministic).
+struct WinoWgradParams {
+    int N, C, H, W;            // x  [N][C][H][W]
+    int M, OH, OW;             // gy [N][M][OH][OW]
+    int pad;
+    int TH, TW;                // tiles per image; TW % 8 == 0
+    int cpr;                   // chunks per tile row = TW / 8
+    int chunks, chunks_per_slice;
+    int Mp, Cp;                // slab dims (M, C padded to 64)
+    const float* x_scale;      // [N * C] or null
+    const float* y_scale;      // [N * M] or null
+};
+
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+
+template <bool MOD>
+__global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                     float* __restrict__ slab, const WinoWgradParams p) {
+    __shared__ float Es[2][kWfStage];      // [xi][half][m][s]: tile 4 half + s of the chunk
+    __shared__ float Vs[2][kWfStage];      // [xi][half][c][s]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wid >> 1, wt = wid & 1;
+    const int cb = blockIdx.x, mb = blockIdx.y, slice = blockIdx.z;
+
+    // ---- staging role: channel `ch` of both 64-channel blocks, tiles 4 hf + 2 q1 and + 1 of a chunk (hf wave-uniform)
+    const int q1 = lane & 1;
+    const int ch = (wid & 1) * 32 + (lane >> 1);
+    const int hf = wid >> 1;
+    const int kk0 = 4 * hf + 2 * q1;
+    const bool m_ok = mb * kWfM + ch < p.M, c_ok = cb * kWfM + ch < p.C;
+    const int m_ch = m_ok ? mb * kWfM + ch : p.M - 1;
+    const int c_ch = c_ok ? cb * kWfM + ch : p.C - 1;
+    const int64_t HW = (int64_t)p.H * p.W, OHW = (int64_t)p.OH * p.OW;
+    const float* px = (MOD && p.x_scale) ? p.x_scale : x;          // (a valid address either way: the loop body stays branch-free)
+    const float* py = (MOD && p.y_scale) ? p.y_scale : gy;
+
+    const int ch_begin = slice * p.chunks_per_slice;
+    int ch_end = ch_begin + p.chunks_per_slice;
+    if (ch_end > p.chunks) ch_end = p.chunks;
+    // position of the chunk being LOADED: image n, tile row ty, chunk txb of the row
+    int ld_txb = ch_begin % p.cpr;
+    int ld_ty = (ch_begin / p.cpr) % p.TH;
+    int ld_n = ch_begin / (p.cpr * p.TH);
+
+    f32x4 greg[2];             // gy rows 2 ty, 2 ty + 1: two tiles x two columns
+    f32x4 xr4[4];              // window rows: columns 0 .. 3
+    f32x2 xr2[4];              //              columns 4, 5
+    int rowmask = 0, shift = 0;
+    float sx = 1.0f, sy = 1.0f;
+    f32x2 ev[16], vv[16];      // A e A^T and B^T d B of the two tiles, as written to LDS
+    float d6[4][6];            // the 4 x 6 patch of the two tiles
+
+    auto load_gy = [&]() {
+        const int tx = ld_txb * 8 + kk0;
+        const float* gp = gy + ((int64_t)ld_n * p.M + m_ch) * OHW + (int64_t)(2 * ld_ty) * p.OW + 2 * tx;
+        greg[0] = *reinterpret_cast<const f32x4*>(gp);
+        greg[1] = *reinterpret_cast<const f32x4*>(gp + p.OW);
+        if (MOD) {
+            sx = px[(int64_t)ld_n * p.C + c_ch];
+            sy = py[(int64_t)ld_n * p.M + m_ch];
+            sx = p.x_scale ? sx : 1.0f;
+            sy = p.y_scale ? sy : 1.0f;
+        }
+    };
+    auto load_x = [&](int r0) {            // window rows r0, r0 + 1
+        const int tx = ld_txb * 8 + kk0;
+        const int ix0 = 2 * tx - p.pad;
+        int cx = ix0 < 0 ? 0 : ix0;
+        if (cx > p.W - 6) cx = p.W - 6;
+        if (r0 == 0) { shift = ix0 - cx; rowmask = 0; }
+        const float* xp = x + ((int64_t)ld_n * p.C + c_ch) * HW + cx;
+#pragma unroll
+        for (int r = r0; r < r0 + 2; ++r) {
+            const int iy = 2 * ld_ty - p.pad + r;
+            const bool ok = iy >= 0 && iy < p.H;
+            rowmask |= ok ? (1 << r) : 0;
+            const float* rp = xp + (int64_t)(ok ? iy : 0) * p.W;
+            xr4[r] = *reinterpret_cast<const f32x4u*>(rp);
+            xr2[r] = *reinterpret_cast<const f32x2u*>(rp + 4);
+        }
+    };
+    auto advance = [&]() {
+        ++ld_txb;
+        if (ld_txb == p.cpr) {
+            ld_txb = 0;
+            ++ld_ty;
+            if (ld_ty == p.TH) { ld_ty = 0; ++ld_n; }
+        }
+    };
+    auto transform_e = [&]() {             // A e A^T of both tiles
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float e00 = greg[0][2 * t], e01 = greg[0][2 * t + 1], e10 = greg[1][2 * t], e11 = greg[1][2 * t + 1];
+            if (MOD) { e00 *= sy; e01 *= sy; e10 *= sy; e11 *= sy; }
+            if (!m_ok) { e00 = 0.0f; e01 = 0.0f; e10 = 0.0f; e11 = 0.0f; }
+            float r[4][2];
+            r[0][0] = e00;       r[0][1] = e01;
+            r[1][0] = e00 + e10; r[1][1] = e01 + e11;
+            r[2][0] = e00 - e10; r[2][1] = e01 - e11;
+            r[3][0] = -e10;      r[3][1] = -e11;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                ev[4 * a + 0][t] = r[a][0];
+                ev[4 * a + 1][t] = r[a][0] + r[a][1];
+                ev[4 * a + 2][t] = r[a][0] - r[a][1];
+                ev[4 * a + 3][t] = -r[a][1];
+            }
+        }
+    };
+    auto window = [&](int r) {             // row r of the 4 x 6 patch out of the loaded window (shift -1 .. 1)
+        const bool ok = c_ok && ((rowmask >> r) & 1);
+        float l[6] = {xr4[r][0], xr4[r][1], xr4[r][2], xr4[r][3], xr2[r][0], xr2[r][1]};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const float lo = q > 0 ? l[q - 1] : 0.0f, hi = q < 5 ? l[q + 1] : 0.0f;
+            float v = shift == 0 ? l[q] : shift > 0 ? hi : lo;
+            v = ok ? v : 0.0f;
+            d6[r][q] = MOD ? v * sx : v;
+        }
+    };
+    auto transform_v = [&](int t) {        // B^T d B of tile t (columns 2 t .. 2 t + 3 of the patch)
+        float e[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            e[0][q] = d6[0][2 * t + q] - d6[2][2 * t + q];
+            e[1][q] = d6[1][2 * t + q] + d6[2][2 * t + q];
+            e[2][q] = d6[2][2 * t + q] - d6[1][2 * t + q];
+            e[3][q] = d6[1][2 * t + q] - d6[3][2 * t + q];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            vv[4 * a + 0][t] = e[a][0] - e[a][2];
+            vv[4 * a + 1][t] = e[a][1] + e[a][2];
+            vv[4 * a + 2][t] = e[a][2] - e[a][1];
+            vv[4 * a + 3][t] = e[a][1] - e[a][3];
+        }
+    };
+    auto write_e = [&](int buf, int lo) {
+        f32x2* d = reinterpret_cast<f32x2*>(Es[buf]) + ((hf * 64 + ch) * 2 + q1);
+#pragma unroll
+        for (int xi = lo; xi < lo + 8; ++xi) d[xi * 256] = ev[xi];
+    };
+    auto write_v = [&](int buf, int lo) {
+        f32x2* d = reinterpret_cast<f32x2*>(Vs[buf]) + ((hf * 64 + ch) * 2 + q1);
+#pragma unroll
+        for (int xi = lo; xi < lo + 8; ++xi) d[xi * 256] = vv[xi];
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.0f;
+
+    auto pass = [&](auto stage_tag, int cur) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        const f32x4* ea = reinterpret_cast<const f32x4*>(Es[cur]) + (half * 64 + wm * 32 + l31);
+        const f32x4* vb = reinterpret_cast<const f32x4*>(Vs[cur]) + (half * 64 + wt * 32 + l31);
+        f32x4 a = ea[0], b = vb[0];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            f32x4 an = a, bn = b;
+            if (xi < 15) {
+                an = ea[(xi + 1) * 128];
+                bn = vb[(xi + 1) * 128];
+            }
+            if (STAGE) {
+                if (xi == 0) load_gy();
+                if (xi == 1) load_x(0);
+                if (xi == 2) { load_x(2); advance(); }
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], acc[xi], 0, 0, 0);
+            if (STAGE) {
+                if (xi == 5) transform_e();
+                if (xi >= 6 && xi <= 9) window(xi - 6);
+                if (xi == 10) transform_v(0);
+                if (xi == 11) transform_v(1);
+                if (xi == 12) write_e(cur ^ 1, 0);
+                if (xi == 13) write_e(cur ^ 1, 8);
+                if (xi == 14) write_v(cur ^ 1, 0);
+                if (xi == 15) write_v(cur ^ 1, 8);
+            }
+            a = an;
+            b = bn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    if (ch_begin < ch_end) {
+        load_gy();
+        load_x(0);
+        load_x(2);
+        advance();
+        transform_e();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) window(r);
+        transform_v(0);
+        transform_v(1);
+        write_e(0, 0);
+        write_e(0, 8);
+        write_v(0, 0);
+        write_v(0, 8);
+        __syncthreads();
+        int cur = 0;
+        for (int chunk = ch_begin; chunk + 1 < ch_end; ++chunk) {
+            pass(std::true_type{}, cur);
+            __syncthreads();
+            cur ^= 1;
+        }
+        pass(std::false_type{}, cur);
+    }
+
+    // ---- G^T gU G, lane-local: acc[4 a + b][r] of (m = wm * 32 + row(r, half), c = wt * 32 + l31) -> slab[slice][m][tap][c]
+    const int c = cb * kWfM + wt * 32 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb * kWfM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float t[3][4];      // G^T u
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            t[0][bq] = acc[bq][r] + 0.5f * (acc[4 + bq][r] + acc[8 + bq][r]);
+            t[1][bq] = 0.5f * (acc[4 + bq][r] - acc[8 + bq][r]);
+            t[2][bq] = 0.5f * (acc[4 + bq][r] + acc[8 + bq][r]) + acc[12 + bq][r];
+        }
+        float* sp = slab + (((int64_t)slice * p.Mp + m) * 9) * p.Cp + c;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            sp[(int64_t)(3 * k + 0) * p.Cp] = t[k][0] + 0.5f * (t[k][1] + t[k][2]);
+            sp[(int64_t)(3 * k + 1) * p.Cp] = 0.5f * (t[k][1] - t[k][2]);
+            sp[(int64_t)(3 * k + 2) * p.Cp] = 0.5f * (t[k][1] + t[k][2]) + t[k][3];
+        }
+    }
+}
+
+// gw[m * sm + c * sc + tap] = alpha * sum over slices (in slice order) of slab[slice][m][tap][c]
+__global__ __launch_bounds__(kBlock) void wino_fused_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ gw,
+                                                                         int M, int C, int Mp, int Cp, int slices, int64_t sm,
+                                                                         int64_t sc, float alpha) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int64_t)M * 9 * C) return;
+    const int c = (int)(i % C);
+    const int tap = (int)((i / C) % 9);
+    const int m = (int)(i / ((int64_t)C * 9));
+    const float* sp = slab + ((int64_t)m * 9 + tap) * Cp + c;
+    const int64_t stride = (int64_t)Mp * 9 * Cp;
+    float acc = 0.0f;
+    for (int s = 0; s < slices; ++s) acc += sp[s * stride];
+    gw[m * sm + c * sc + tap] = alpha * acc;
+}
+
+// pixel slices of the fused weight gradient: workgroups = 64 x 64 channel blocks x slices in whole rounds of 256 where the
+// pixel count allows (a slice needs at least 8 chunks to pay for its epilogue)
+inline int wgrad_slices(int64_t mbs, int64_t cbs, int64_t chunks) {
+    const int64_t blocks = mbs * cbs;
+    int64_t unit = 256;
+    for (int64_t g = blocks; (g & 1) == 0 && unit > 1; g >>= 1) unit >>= 1;      // 256 / gcd(256, blocks)
+    int64_t slices = (1536 + blocks - 1) / blocks;
+    slices = (slices + unit - 1) / unit * unit;
+    if (slices > 256) slices = 256;
+    const int64_t cap = chunks / 8 > 0 ? chunks / 8 : 1;
+    if (slices > cap) slices = cap;
+    return (int)slices;
+}
+
 inline int64_t fused_weight_floats(int64_t m, int64_t c) {
     return ceil_div64(m, kWfM) * ceil_div64(c, kWfCK) * kWfStage;
 }
@@ -418,4 +696,54 @@ extern "C" int sae_wino_fused_conv_f32(const float* x, const float* x_scale, con
     }
 #undef SAE_WF_LAUNCH
     return check_launch("sae_wino_fused_conv_f32");
+}
+
+extern "C" int64_t sae_wino_fused_wgrad_workspace(int64_t n, int64_t c, int64_t m, int64_t h, int64_t w, int32_t pad) {
+    if (n < 1 || c < 1 || m < 1 || h < 2 || w < 2 || pad < 0 || pad > 1) return 0;
+    const int64_t th = (h + 2 * pad - 2) / 2, tw = (w + 2 * pad - 2) / 2;
+    if (tw % 8 != 0) return 0;
+    const int64_t mbs = ceil_div64(m, kWfM), cbs = ceil_div64(c, kWfM);
+    return (int64_t)wgrad_slices(mbs, cbs, n * th * (tw / 8)) * mbs * kWfM * 9 * cbs * kWfM;
+}
+
+extern "C" int sae_wino_fused_wgrad_f32(const float* x, const float* x_scale, const float* gy, const float* y_scale, float* gw,
+                                        int64_t n, int64_t c, int64_t m, int64_t h, int64_t w, int32_t pad, int64_t w_stride_m,
+                                        int64_t w_stride_c, float alpha, float* workspace, int64_t workspace_floats,
+                                        sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (n < 1 || c < 1 || m < 1 || pad < 0 || pad > 1 || (h & 1) || (w & 1) || h + 2 * pad < 4 || h >= 32768 || w >= 32768 ||
+        c >= (1 << 24) || m >= (1 << 24) || n >= (1 << 24))
+        return fail(SAE_EINVAL, "sae_wino_fused_wgrad_f32: bad shape");
+    const int64_t oh = h + 2 * pad - 2, ow = w + 2 * pad - 2, th = oh / 2, tw = ow / 2;
+    if (tw < 8 || tw % 8 != 0)
+        return fail(SAE_EINVAL, "sae_wino_fused_wgrad_f32: output rows of a multiple of 16 pixels (chunks of 8 tiles), got %lld",
+                    (long long)ow);
+    if (!x || !gy || !gw || !workspace) return fail(SAE_EINVAL, "sae_wino_fused_wgrad_f32: null tensor");
+    if (!aligned16(gy)) return fail(SAE_EINVAL, "sae_wino_fused_wgrad_f32: gy must be 16-byte aligned");
+    const int64_t need = sae_wino_fused_wgrad_workspace(n, c, m, h, w, pad);
+    if (workspace_floats < need)
+        return fail(SAE_EINVAL, "sae_wino_fused_wgrad_f32: workspace of %lld floats, %lld needed", (long long)workspace_floats,
+                    (long long)need);
+    WinoWgradParams p;
+    p.N = (int)n; p.C = (int)c; p.H = (int)h; p.W = (int)w; p.M = (int)m; p.OH = (int)oh; p.OW = (int)ow; p.pad = pad;
+    p.TH = (int)th; p.TW = (int)tw; p.cpr = (int)(tw / 8);
+    const int64_t chunks = n * th * p.cpr;
+    if (chunks >= ((int64_t)1 << 31)) return fail(SAE_EINVAL, "sae_wino_fused_wgrad_f32: too many tiles");
+    p.chunks = (int)chunks;
+    const int64_t mbs = ceil_div64(m, kWfM), cbs = ceil_div64(c, kWfM);
+    const int slices = wgrad_slices(mbs, cbs, chunks);
+    p.chunks_per_slice = (int)ceil_div64(chunks, slices);
+    p.Mp = (int)(mbs * kWfM); p.Cp = (int)(cbs * kWfM);
+    p.x_scale = x_scale; p.y_scale = y_scale;
+    const dim3 grid((unsigned)cbs, (unsigned)mbs, (unsigned)slices);
+    const hipStream_t st = (hipStream_t)stream;
+    if (x_scale || y_scale)
+        hipLaunchKernelGGL(wino_fused_wgrad_kernel<true>, grid, dim3(kBlock), 0, st, x, gy, workspace, p);
+    else
+        hipLaunchKernelGGL(wino_fused_wgrad_kernel<false>, grid, dim3(kBlock), 0, st, x, gy, workspace, p);
+    int rc = check_launch("sae_wino_fused_wgrad_f32");
+    if (rc != SAE_OK) return rc;
+    hipLaunchKernelGGL(wino_fused_wgrad_reduce_kernel, dim3((unsigned)ceil_div64(m * 9 * c, kBlock)), dim3(kBlock), 0, st, workspace,
+                       gw, (int)m, (int)c, p.Mp, p.Cp, slices, w_stride_m, w_stride_c, alpha);
+    return check_launch("sae_wino_fused_wgrad_f32 (reduce)");
 }

@@ -104,8 +104,15 @@ def _route_of(geom, op):
             return None
         if op != WGRAD and _CFG.fused and (geom.ow if op == DGRAD else geom.w) >= 4:
             return "fused"
+        if op == WGRAD and _CFG.fused and geom.ow % 16 == 0:
+            return "fused"
         return "unfused"
-    if op == WGRAD:                                    # two transforms + sixteen K-sliced 1x1 weight gradients
+    if op == WGRAD:
+        # three-kernel form (two transforms + sixteen K-sliced 1x1 weight gradients): from 256 channels on enough pixels;
+        # one-kernel form (sae_wino_fused_wgrad_f32): output rows a multiple of 16 pixels, enough 8-tile chunks for whole
+        # rounds of 64 x 64-channel workgroups with slices of >= 8 chunks
+        if _CFG.fused and geom.ow % 16 == 0 and cmin >= 64 and geom.n * tiles >= 4096:
+            return "fused"
         return "unfused" if (cmin >= 256 and geom.n * tiles * cmin >= (4 << 20)) else None
     direct = max(2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9 / 130e9, 0.035)
     best, cost = None, direct
@@ -117,7 +124,9 @@ def _route_of(geom, op):
         # the product that is computed: forward c -> m on the oh x ow grid; data gradient m -> c on the h x w grid
         cin, cout, th, tw, in_w = ((geom.m, geom.c, geom.h >> 1, geom.w >> 1, geom.ow) if op == DGRAD else
                                    (geom.c, geom.m, geom.oh >> 1, geom.ow >> 1, geom.w))
-        if in_w >= 4:
+        # (from 64 channels and ~2000 tiles: below that both routes are launch-bound, the estimates mean nothing, and the
+        # small presets -- incl. the golden micro steps of the parity tests -- stay on the direct kernels)
+        if in_w >= 4 and cmin >= 64 and geom.n * th * tw >= 2048:
             wgs = _fused_workgroups(geom.n, th, tw, cout)
             est = -(-wgs // 256) * (0.162 * (-(-cin // 8) * 8) / 512.0 + 0.006)
             if est < cost:
@@ -210,10 +219,10 @@ def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None, row_sca
     return y
 
 
-def wgrad(x, gy, geom, out=None, x_scale=None, y_scale=None):
+def wgrad(x, gy, geom, out=None, x_scale=None, y_scale=None, kind=None):
     """alpha * sum over images and pixels of (gy * y_scale) (x) (x * x_scale) as the layer's weight gradient (geom.weight_shape()),
     on the sixteen points: gw = G^T [ sum (A e A^T) o (B^T d B) ] G.  out: an existing tensor of that shape to write into (a
-    slot of an armed gradient bucket)."""
+    slot of an armed gradient bucket).  kind: "fused" (one kernel + the slice reduction) / "unfused" (default: route())."""
     lib = hip_lib.get()
     x = x.contiguous()
     gy = gy.contiguous()
@@ -224,6 +233,19 @@ def wgrad(x, gy, geom, out=None, x_scale=None, y_scale=None):
     if tuple(x.shape) != (n, c, geom.h, geom.w) or tuple(gy.shape) != (n, m, h, wd):
         raise hip_lib.SaeError("winograd wgrad: x %s, gy %s for a (%d, %d -> %d, %d x %d) layer" % (
             tuple(x.shape), tuple(gy.shape), n, c, m, geom.h, geom.w))
+    if kind is None:
+        kind = route(geom, WGRAD) or "unfused"
+    if kind == "fused" and (gy.data_ptr() & 15):          # the kernel fetches gy tile pairs as aligned 16-byte loads
+        kind = "unfused"
+    if kind == "fused":
+        d = geom.desc()
+        if out is None or tuple(out.shape) != tuple(geom.weight_shape()) or not out.is_contiguous():
+            out = torch.empty(geom.weight_shape(), dtype=torch.float32, device=x.device)
+        n_ws = lib.query("wino_fused_wgrad_workspace", n, c, m, geom.h, geom.w, geom.pad)
+        ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
+        lib.call("wino_fused_wgrad_f32", x.data_ptr(), hip_lib.ptr(x_scale), gy.data_ptr(), hip_lib.ptr(y_scale), out.data_ptr(), n, c,
+                 m, geom.h, geom.w, geom.pad, d.w_stride_m, d.w_stride_c, geom.alpha, ws.data_ptr(), n_ws, lib.stream(x))
+        return out
     th, tw = h // 2, wd // 2
     tiles = th * tw
     stream = lib.stream(x)

@@ -490,3 +490,17 @@ def wino_fused_conv(lib, x, wt, alpha=1.0, transpose=False, bias=None, act=None,
     lib.call("wino_fused_conv_f32", bx.ptr, pxs, bu.ptr, pos, pnz, pnw, pb, by.ptr, n, cin, cout, ih, iw, ipad,
              1 if act is not None else 0, float(slope), float(scale), _stream(device))
     return by.numpy()
+
+
+def wino_fused_wgrad(lib, x, gy, alpha=1.0, cm_layout=False, x_scale=None, y_scale=None, pad=1, device=None):
+    """wino_wgrad's contract through sae_wino_fused_wgrad_f32 (one kernel + the slice reduction)."""
+    n, c, ih, iw = x.shape
+    m = gy.shape[1]
+    shape, sm, sc = ((c, m, 3, 3), 9, m * 9) if cm_layout else ((m, c, 3, 3), c * 9, 9)
+    n_ws = lib.query("wino_fused_wgrad_workspace", n, c, m, ih, iw, pad)
+    bx, bg, bw, ws = _Buf(x, device), _Buf(gy, device), _out(shape, device), _out((max(n_ws, 1),), device)
+    bxs = _Buf(x_scale.reshape(-1), device) if x_scale is not None else None
+    bys = _Buf(y_scale.reshape(-1), device) if y_scale is not None else None
+    lib.call("wino_fused_wgrad_f32", bx.ptr, bxs.ptr if bxs else None, bg.ptr, bys.ptr if bys else None, bw.ptr, n, c, m, ih, iw, pad,
+             sm, sc, alpha, ws.ptr, n_ws, _stream(device))
+    return bw.numpy()

@@ -337,3 +337,82 @@ def test_fused_route_equals_the_direct_convolution_on_the_emulator(emu_lib, orac
 
 def test_oracle_fused_route_equals_the_oracle_direct_convolution(oracle_lib):
     _fused_route(oracle_lib, oracle_lib, None)
+
+
+# n, c, h, w, m, [C, M] weights, pad: output rows a multiple of 16 pixels (chunks of 8 tiles); channel counts around the 64 block;
+# pixel counts that give one slice, several slices, and a ragged last slice
+FUSED_WGRAD_CASES = [(1, 12, 16, 16, 20, False, 1), (3, 70, 8, 16, 33, False, 1), (2, 9, 18, 18, 70, True, 0),
+                     (5, 64, 32, 32, 64, False, 1), (2, 5, 4, 34, 130, False, 0)]
+
+
+def _fused_wgrad(lib, oracle_lib, dev):
+    rng = np.random.default_rng(47)
+    for n, c, h, w, m, cm, pad in FUSED_WGRAD_CASES:
+        d = H.conv_desc(n, c, h, w, m, 3, 1, pad, cm)
+        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+        gy = rng.standard_normal((n, m, d.oh, d.ow)).astype(np.float32)
+        xs = (1 + 0.5 * rng.standard_normal((n, c))).astype(np.float32)
+        ys = (1 + 0.5 * rng.standard_normal((n, m))).astype(np.float32)
+        shape = (c, m, 3, 3) if cm else (m, c, 3, 3)
+        case = (n, c, h, w, m, cm, pad)
+        gw = H.wino_fused_wgrad(lib, x, gy, alpha=0.37, cm_layout=cm, pad=pad, device=dev)
+        assert not np.isnan(gw).any() and H.rel_err(gw, H.conv(oracle_lib, 2, d, x, gy, shape, alpha=0.37)) < TOL, case
+        gwm = H.wino_fused_wgrad(lib, x, gy, alpha=0.3, cm_layout=cm, x_scale=xs, y_scale=ys, pad=pad, device=dev)
+        assert H.rel_err(gwm, H.modconv(oracle_lib, 2, d, x, gy, shape, x_scale=xs, y_scale=ys, alpha=0.3)) < TOL, case
+        gwx = H.wino_fused_wgrad(lib, x, gy, alpha=0.3, cm_layout=cm, x_scale=xs, pad=pad, device=dev)
+        assert H.rel_err(gwx, H.modconv(oracle_lib, 2, d, x, gy, shape, x_scale=xs, alpha=0.3)) < TOL, case
+    with pytest.raises(Exception):          # rows of 12 pixels: no whole chunks of 8 tiles
+        H.wino_fused_wgrad(lib, np.zeros((1, 4, 12, 12), np.float32), np.zeros((1, 4, 12, 12), np.float32), device=dev)
+
+
+def test_fused_weight_gradient_on_the_emulator(emu_lib, oracle_lib):
+    _fused_wgrad(emu_lib, oracle_lib, None)
+
+
+def test_oracle_fused_weight_gradient_equals_the_oracle_direct_one(oracle_lib):
+    _fused_wgrad(oracle_lib, oracle_lib, None)
+
+
+@pytest.mark.gpu
+def test_fused_weight_gradient_on_the_gpu(oracle_lib):
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    lib = hip_lib.get()
+    _fused_wgrad(lib, oracle_lib, "cuda:0")
+    rng = np.random.default_rng(53)
+    for n, c, m, side in [(3, 128, 128, 64), (2, 200, 72, 32)]:          # against the direct MFMA weight gradient
+        x = rng.standard_normal((n, c, side, side)).astype(np.float32)
+        gy = rng.standard_normal((n, m, side, side)).astype(np.float32)
+        d = H.conv_desc(n, c, side, side, m, 3, 1, 1)
+        direct = H.conv(lib, 2, d, x, gy, (m, c, 3, 3), alpha=0.01, device="cuda:0")
+        assert H.rel_err(H.wino_fused_wgrad(lib, x, gy, alpha=0.01, device="cuda:0"), direct) < TOL
+
+
+def test_python_route_one_kernel_weight_gradient(oracle_lib, monkeypatch):
+    """A map 16 pixels wide: forward, data gradient AND weight gradient on the one-kernel forms (winograd.route), plain and
+    style-modulated, against the direct kernels -- incl. writing into a given gradient buffer."""
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as G, winograd
+    monkeypatch.setattr(hip_lib, "_LIB", oracle_lib)
+    torch.manual_seed(9)
+    x = torch.randn(2, 12, 16, 16, requires_grad=True)
+    w = torch.randn(16, 12, 3, 3, requires_grad=True)
+    b = torch.randn(16, requires_grad=True)
+    s = (1 + 0.3 * torch.randn(2, 12)).requires_grad_(True)
+    geom = G._Geom(2, 12, 16, 16, 16, 3, 1, 1, False, 0.25)
+
+    def run():
+        y = G.ConvBiasAct.apply(x, w, b, geom, 0.2, 2 ** 0.5)
+        y2 = G.modulated_conv2d(x, s, w, padding=1, alpha=0.1, demod_eps=1e-8)
+        return (y.detach(), y2.detach()) + torch.autograd.grad((y * y).sum() + (y2 * y2).sum(), (x, w, b, s))
+
+    with winograd.override(enabled=False):
+        direct = run()
+    with winograd.override(enabled=True, min_c=8, fused=True):
+        assert [winograd.route(geom, op) for op in (winograd.FWD, winograd.DGRAD, winograd.WGRAD)] == ["fused"] * 3
+        routed = run()
+        out = torch.full((16, 12, 3, 3), float("nan"))
+        gy = torch.randn(2, 16, 16, 16)
+        got = winograd.wgrad(x.detach(), gy, geom, out=out)
+        assert got.data_ptr() == out.data_ptr() and not torch.isnan(out).any()
+    for a, o in zip(routed, direct):
+        assert float((a - o).abs().max() / o.abs().max()) < TOL

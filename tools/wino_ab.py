@@ -87,8 +87,8 @@ def main():
             fused = (lambda: winograd.conv(gy, wt, g, transpose=True, kind="fused")) if g.ow >= 4 else None
         else:
             direct = lambda: cg._launch("conv2d_wgrad_f32", cg.SAE_CONV_WGRAD, g, x, gy, g.weight_shape())
-            wino = lambda: winograd.wgrad(x, gy, g)
-            fused = None
+            wino = lambda: winograd.wgrad(x, gy, g, kind="unfused")
+            fused = (lambda: winograd.wgrad(x, gy, g, kind="fused")) if g.ow % 16 == 0 else None
         td, tw = timed(direct), timed(wino)
         tf = timed(fused) if fused is not None else None
         gf = 2.0 * n * m * g.oh * g.ow * c * 9 / 1e9
