@@ -39,8 +39,11 @@ MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, 
 # those 128-byte requests at 64 B, the x2 correction of the guide, confirmed on a 1 GiB copy in the same passes), writes =
 # TCC_EA0_WRREQ_64B x 64 B + the remaining write requests x 32 B, on the kernel's reference launch (128 -> 128 3x3 @256x256
 # B=16).  Counters cannot be read inside a timed run; the figure is scaled to the average launch of the timed region by FLOPs.
-PMC_DOMINANT_FILE = os.path.join(ROOT, "profiles", "r4_pmc_dominant.json")
-DOMINANT_KERNEL = "conv_igemm_kernel<3,1,2,2,1,4,8,false,true>"
+PMC_DOMINANT_FILE = os.path.join(ROOT, "profiles", "r5_pmc_dominant.json")
+# Round 5: the wide 3x3 stride-1 layers (forward and data gradient) run as ONE-kernel Winograd F(2x2,3x3) convolutions
+# (csrc/winograd_fused.hip); that kernel is now the largest single consumer of the step.  (Rounds 2-4: the direct gather
+# conv_igemm_kernel<3,1,2,2,1,4,8,false,true>, still reported as a class of its own.)
+DOMINANT_KERNEL = "wino_fused_kernel"
 
 
 def load_pmc_dominant():
@@ -49,7 +52,7 @@ def load_pmc_dominant():
     with open(PMC_DOMINANT_FILE) as f:
         rec = json.load(f)
     name = rec["kernel"].replace(" ", "")
-    if name != DOMINANT_KERNEL.replace(" ", ""):
+    if not name.startswith(DOMINANT_KERNEL.replace(" ", "")):
         raise SystemExit("bench.py: %s describes kernel %r, the timed dominant kernel is %r: re-run tools/run_pmc.sh and "
                          "tools/pmc_summary.py --dominant-json" % (PMC_DOMINANT_FILE, rec["kernel"], DOMINANT_KERNEL))
     return rec
@@ -138,35 +141,42 @@ def _quad_gather_tile(mout, in_w, out_h, out_w, pad):
     return "64x256" if tile64 else "128x128"
 
 
-# second-tier MFMA kernel classes reported next to the dominant one (roofline_by_kernel): the template each class runs
+# MFMA kernel classes of roofline_by_kernel: the template each class runs.  FLOPs are ALGORITHMIC (the direct convolution's, SURVEY
+# 8d); the Winograd classes also carry the FLOPs they EXECUTE (16 multiply-adds per 2x2 output tile and channel pair = direct / 2.25)
 KERNEL_CLASSES = {
-    "dominant": ("conv 3x3 s1 gather on maps >= 128 wide: 64 x 256 tile, quad staging (forward, fused bias+lrelu forward, s1 data "
-                 "gradient)", DOMINANT_KERNEL),
-    "s1_gather_128": ("conv 3x3 s1 gather on smaller maps: 128 x 128 tile, quad staging", "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"),
+    "dominant": ("conv 3x3 s1 forward / data gradient on the one-kernel Winograd F(2x2,3x3) route", "wino_fused_kernel<*>"),
+    "wino_wgrad": ("conv 3x3 s1 weight gradient on the one-kernel Winograd route (+ slice reduction)", "wino_fused_wgrad_kernel<*>"),
+    "wino_unfused": ("conv 3x3 s1 on the three-kernel Winograd route (transform / sixteen 1x1 products / transform)",
+                     "wino_input* / conv_igemm_kernel<1,1,*> batched / wino_output*"),
+    "s1_gather_256": ("conv 3x3 s1 direct gather on maps >= 128 wide: 64 x 256 tile, quad staging", "conv_igemm_kernel<3,1,2,2,1,4,8,false,true>"),
+    "s1_gather_128": ("conv 3x3 s1 direct gather on smaller maps: 128 x 128 tile, quad staging", "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"),
     "s2_dgrad": ("conv 3x3 s2 data gradient / transposed conv (plain + modulated)", "conv_igemm_tr2_kernel<2,16,*> / conv_igemm_tr_kernel"),
     "s2_fwd": ("conv 3x3 s2 forward gather (plain + modulated)", "conv_igemm_kernel<3,2,*>"),
-    "s1_wgrad": ("conv 3x3 s1 weight gradient (plain + modulated)", "conv_wgrad16_kernel<1> (fallback conv_wgrad_kernel<3,1,*>)"),
+    "s1_wgrad": ("conv 3x3 s1 weight gradient, direct (plain + modulated)", "conv_wgrad16_kernel<1> (fallback conv_wgrad_kernel<3,1,*>)"),
     "s2_wgrad": ("conv 3x3 s2 weight gradient (plain + modulated)", "conv_wgrad_kernel<3,2,*> (<= 64 gradient channels: conv_wgrad16_kernel<2>)"),
 }
+WINO_CLASSES = ("dominant", "wino_wgrad", "wino_unfused")
 
 
 class DominantKernelTimer:
-    """Brackets every launch of the dominant kernel (the quad-staged 3x3 stride-1 gather on the 64 x 256 tile,
-    conv_igemm_kernel<3,1,2,2,1,4,8,false,true>: the wide layers on maps at least 128 wide, reached from conv2d forward and
-    stride-1 dgrad; _quad_gather_tile repeats the library's dispatch rule so that exactly that instantiation is counted)
-    and of the second-tier MFMA classes with HIP events on the launch stream; durations are read after the final
-    synchronise."""
+    """Brackets, with HIP events on the launch stream, every launch of the 3x3 conv classes of KERNEL_CLASSES: the Winograd
+    routes at stylegan2_op.winograd.conv / wgrad (which the conv wrappers reach before any direct launch), the direct kernels at
+    conv2d_gemm._launch / _launch_fused / _launch_mod for the launches winograd.route() leaves to them (_quad_gather_tile repeats
+    the library's dispatch rule so that the two gather tiles are told apart).  Records (class, algorithmic FLOPs, executed FLOPs,
+    events); durations are read after the final synchronise."""
 
     def __init__(self):
         self.records = []
         self.active = False
 
-    def classify(self, cg, op, geom, activation_factor):
-        """Class key of a conv launch, or None.  'dominant' is exactly the instantiation named above (un-modulated
-        activation, wide layer, quad-staged rows); the other classes are the 3x3 kernels the review tracks."""
+    def classify(self, cg, wino, op, geom, activation_factor):
+        """Class key of a DIRECT conv launch, or None (also None when the launch belongs to the Winograd route, which is
+        bracketed where it is taken)."""
         if not self.active or geom.k != 3:
             return None
         if geom.stride == 1:
+            if wino.route(geom, {cg.SAE_CONV_FWD: wino.FWD, cg.SAE_CONV_DGRAD: wino.DGRAD, cg.SAE_CONV_WGRAD: wino.WGRAD}[op]) is not None:
+                return None
             if op == cg.SAE_CONV_WGRAD:
                 return "s1_wgrad" if max(geom.m, geom.c) > 32 else None
             if activation_factor:
@@ -176,34 +186,36 @@ class DominantKernelTimer:
                 tile = _quad_gather_tile(geom.m, geom.w, geom.oh, geom.ow, geom.pad)
             elif op == cg.SAE_CONV_DGRAD:
                 tile = _quad_gather_tile(geom.c, geom.ow, geom.h, geom.w, 2 - geom.pad)
-            return {"64x256": "dominant", "128x128": "s1_gather_128"}.get(tile)
+            return {"64x256": "s1_gather_256", "128x128": "s1_gather_128"}.get(tile)
         return {cg.SAE_CONV_FWD: "s2_fwd", cg.SAE_CONV_DGRAD: "s2_dgrad", cg.SAE_CONV_WGRAD: "s2_wgrad"}.get(op)
 
     def install(self):
         import torch
         from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as cg
+        from swapping_autoencoder_pytorch_amd.stylegan2_op import winograd as wino
         timer = self
 
-        def bracket(key, geom, call):
+        def bracket(key, geom, call, executed_ratio=1.0):
             if key is None:
                 return call()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = call()
             e1.record()
-            timer.records.append((key, 2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9, e0, e1))
+            fl = 2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9
+            timer.records.append((key, fl, fl * executed_ratio, e0, e1))
             return out
 
         orig_launch = cg._launch
 
         def launch(name, op, geom, a, b, out_shape, out=None):
-            return bracket(timer.classify(cg, op, geom, False), geom, lambda: orig_launch(name, op, geom, a, b, out_shape, out=out))
+            return bracket(timer.classify(cg, wino, op, geom, False), geom, lambda: orig_launch(name, op, geom, a, b, out_shape, out=out))
 
         cg._launch = launch
         orig_fused = cg._launch_fused
 
         def launch_fused(geom, x, w, bias, slope, scale):     # forward with the fused bias + leaky-ReLU epilogue
-            return bracket(timer.classify(cg, cg.SAE_CONV_FWD, geom, False), geom,
+            return bracket(timer.classify(cg, wino, cg.SAE_CONV_FWD, geom, False), geom,
                            lambda: orig_fused(geom, x, w, bias, slope, scale))
 
         cg._launch_fused = launch_fused
@@ -212,57 +224,76 @@ class DominantKernelTimer:
         def launch_mod(name, op, geom, a, b, out_shape, x_scale=None, y_scale=None, wm_scale=None, wc_scale=None, **kw):
             # a modulated-conv call whose ACTIVATION carries no factor runs the un-modulated kernel instantiation (weight
             # factors ride in the weight re-layout): the data gradient of the generator's plain modulated convs
-            key = timer.classify(cg, op, geom, x_scale is not None or y_scale is not None)
+            key = timer.classify(cg, wino, op, geom, x_scale is not None or y_scale is not None)
             return bracket(key, geom, lambda: orig_mod(name, op, geom, a, b, out_shape, x_scale, y_scale, wm_scale, wc_scale, **kw))
 
         cg._launch_mod = launch_mod
+        # the Winograd routes: 16 multiply-adds per 2x2 output tile and channel pair instead of 36
+        orig_conv, orig_wgrad = wino.conv, wino.wgrad
+
+        def wino_conv(x, w, geom, transpose=False, **kw):
+            kind = kw.get("kind") or wino.route(geom, wino.DGRAD if transpose else wino.FWD) or "unfused"
+            key = ("dominant" if kind == "fused" else "wino_unfused") if timer.active else None
+            return bracket(key, geom, lambda: orig_conv(x, w, geom, transpose=transpose, **kw), 4.0 / 9.0)
+
+        def wino_wgrad(x, gy, geom, **kw):
+            kind = kw.get("kind") or wino.route(geom, wino.WGRAD) or "unfused"
+            key = ("wino_wgrad" if kind == "fused" else "wino_unfused") if timer.active else None
+            return bracket(key, geom, lambda: orig_wgrad(x, gy, geom, **kw), 4.0 / 9.0)
+
+        wino.conv, wino.wgrad = wino_conv, wino_wgrad
 
     def summary(self, conv_math="f32", steps=1):
-        """(roofline of the dominant kernel, roofline_by_kernel list) from the event brackets of the timed region."""
-        # (bf16x6 keeps one tile for all wide layers: both exact-fp32 gather classes are its dominant kernel)
-        dom_keys = ("dominant",) if conv_math == "f32" else ("dominant", "s1_gather_128")
-        dom = [r for r in self.records if r[0] in dom_keys]
-        if not dom:
-            return None, None
-        ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in dom)
-        fl = sum(f for _, f, _, _ in dom)
-        n = len(dom)
-        achieved = fl / (ms * 1e-3) / 1e12
-        note = "event bracket includes the <1% weight re-layout launch that precedes each conv"
-        if conv_math == "bf16x6":
-            # algorithmic fp32 FLOPs against the bf16 matrix peak divided by the 6 bf16 products one fp32
-            # product costs in this arithmetic
-            peak = MFMA_BF16_PEAK_TFLOPS / 6.0
-            kernel = "conv_igemm_bx_kernel<2,2,2,2>"
-            note += "; peak = 2500 TFLOP/s dense bf16 / 6 split products per fp32 product"
-        else:
-            peak = MFMA_F32_PEAK_TFLOPS
-            kernel = DOMINANT_KERNEL
-        traffic = None
-        if conv_math == "f32":
+        """(roofline of the dominant kernel, roofline_by_kernel list) from the event brackets of the kernel pass."""
+        dom = [r for r in self.records if r[0] == "dominant"]
+        if not dom or conv_math != "f32":
+            # (bf16x6 runs no Winograd route: its line carries the by-class table only)
+            dom = []
+        peak = MFMA_F32_PEAK_TFLOPS if conv_math == "f32" else MFMA_BF16_PEAK_TFLOPS / 6.0
+        roof = None
+        if dom:
+            ms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in dom)
+            fl = sum(f for _, f, _, _, _ in dom)
+            fx = sum(f for _, _, f, _, _ in dom)
+            n = len(dom)
             pmc = load_pmc_dominant()
-            scale = (fl / n / 1e9) / pmc["gflop"]
-            traffic = round((pmc["read_bytes"] + pmc["write_bytes"]) * scale)
-            note += ("; traffic = HBM-side bytes per average launch from the PMC passes (%s: %.0f MB read + %.0f MB written per "
-                     "%.0f GFLOP reference launch against %.0f MB algorithmic), scaled by FLOPs"
-                     % (os.path.relpath(PMC_DOMINANT_FILE, ROOT), pmc["read_bytes"] / 1e6, pmc["write_bytes"] / 1e6, pmc["gflop"],
-                        pmc["algorithmic_bytes"] / 1e6))
-        roof = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2),
-                "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                "traffic": traffic, "launches": n, "avg_launch_ms": round(ms / n, 4),
-                "avg_launch_gflop": round(fl / n / 1e9, 2), "note": note}
+            scale = (fx / n / 1e9) / pmc["gflop"]
+            roof = {"bound": "mfma", "kernel": DOMINANT_KERNEL + "<*> (csrc/winograd_fused.hip)",
+                    "achieved": round(fx / (ms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(fx / (ms * 1e-3) / 1e12 / peak, 4),
+                    "achieved_algorithmic": round(fl / (ms * 1e-3) / 1e12, 2),
+                    "frac_algorithmic": round(fl / (ms * 1e-3) / 1e12 / peak, 4),
+                    "traffic": round((pmc["read_bytes"] + pmc["write_bytes"]) * scale), "launches": n,
+                    "avg_launch_ms": round(ms / n, 4), "avg_launch_gflop": round(fx / n / 1e9, 2),
+                    "avg_launch_gflop_algorithmic": round(fl / n / 1e9, 2),
+                    "note": ("achieved / frac = the FLOPs the kernel EXECUTES (Winograd F(2x2,3x3): 16 multiply-adds per 2x2 output tile "
+                             "and channel pair) over the mean launch duration, against the fp32 MFMA peak: the utilisation of the "
+                             "matrix pipe.  achieved_algorithmic / frac_algorithmic = the ALGORITHMIC FLOPs of the direct convolution "
+                             "(SURVEY 8d: 2 N M OH OW C 9), Winograd route -- 2.25x the executed ones, so it can exceed the peak.  The "
+                             "event bracket includes the transform-domain weight preparation when the parameter changed since the "
+                             "last launch (once per optimiser step).  traffic = HBM-side bytes per average launch from the PMC "
+                             "passes (%s: %.0f MB read + %.0f MB written per %.0f GFLOP executed on the reference launch against "
+                             "%.0f MB algorithmic), scaled by FLOPs"
+                             % (os.path.relpath(PMC_DOMINANT_FILE, ROOT), pmc["read_bytes"] / 1e6, pmc["write_bytes"] / 1e6,
+                                pmc["gflop"], pmc["algorithmic_bytes"] / 1e6))}
         by_kernel = []
         for key, (what, template) in KERNEL_CLASSES.items():
             rec = [r for r in self.records if r[0] == key]
             if not rec:
                 continue
-            kms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in rec)
-            kfl = sum(f for _, f, _, _ in rec)
-            by_kernel.append({"class": what, "kernel": template if conv_math == "f32" else "bf16x6 counterpart of " + template,
-                              "launches": len(rec), "ms_per_step": round(kms / steps, 3),
-                              "achieved": round(kfl / (kms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                              "frac": round(kfl / (kms * 1e-3) / 1e12 / peak, 4)})
-        return roof, by_kernel
+            kms = sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in rec)
+            kfl = sum(f for _, f, _, _, _ in rec)
+            kfx = sum(f for _, _, f, _, _ in rec)
+            row = {"class": what, "kernel": template if conv_math == "f32" else "bf16x6 counterpart of " + template,
+                   "launches": len(rec), "ms_per_step": round(kms / steps, 3),
+                   "achieved": round(kfx / (kms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                   "frac": round(kfx / (kms * 1e-3) / 1e12 / peak, 4)}
+            if key in WINO_CLASSES:
+                row["achieved_algorithmic"] = round(kfl / (kms * 1e-3) / 1e12, 2)
+                row["frac_algorithmic"] = round(kfl / (kms * 1e-3) / 1e12 / peak, 4)
+                row["flops"] = "achieved = executed FLOPs (algorithmic / 2.25); *_algorithmic = the direct convolution's"
+            by_kernel.append(row)
+        return roof, (by_kernel or None)
 
 
 class HbmKernelTimer:
@@ -840,7 +871,9 @@ def main():
                             "(SAE_TWO_STREAMS=0, %.1f ms per step) -- in the timed region the step's branches run on two streams and "
                             "kernels overlap; " % (args.kernel_steps, kernel_ms_per_step)) + roof["note"]
             line["roofline"] = roof
+        if by_kernel:
             line["roofline_by_kernel"] = by_kernel
+        if kernel_ms_per_step is not None:
             line["ms_per_step_one_stream"] = round(kernel_ms_per_step, 3)
             hbm_total, hbm_rows = hbm_timer.summary(max(args.kernel_steps, 1))
             if hbm_total:

@@ -38,6 +38,7 @@ struct WinoFusedParams {
     int bw_log2, bh_log2;      // tile block = BN x BH x BW, BN * BH * BW = 64
     int blocks_x, blocks_y;    // tile blocks per image row / column
     int chunks;                // ceil(C / 8)
+    unsigned x_bytes;          // bytes of x (< 2^31: per-lane byte offsets are 32-bit, 0x80000000 = "outside": reads as zero)
     const float* x_scale;      // [N * C] or null: the style modulation of the input
     const float* out_scale;    // [N * M] or null
     const float* noise;        // [N][OH][OW] or null
@@ -123,76 +124,102 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
     const int bn = b / p.blocks_y;
     const int mb = blockIdx.y;
 
-    // ---- the thread's role in staging: tile `lane` of the block, channels 2 wid and 2 wid + 1 of a chunk.  Branch-free: every
-    // row of the 4x4 patch is ONE 16-byte load (4-byte aligned) from a window clamped into the row, shifted into place and
-    // zeroed outside the image by selects, so that the loop body is one basic block the scheduler can interleave with the MFMAs.
+    // ---- the thread's role in staging: tile `lane` of the block, channels 2 wid and 2 wid + 1 of a chunk.  Every row of the 4x4
+    // patch is ONE 16-byte buffer load whose per-lane offset never changes (image + row + column of the tile; the channel rides
+    // in the scalar offset): rows outside the image, and tiles outside the map, carry an out-of-range offset and read as zeros
+    // (the descriptor's range check), a window starting left of the tensor wraps to an out-of-range offset too.  What is left
+    // for the ALU is the zeroing of patch COLUMNS outside the image (the neighbouring row's data): blocks that touch the left /
+    // right border only.  On this chip every VALU instruction of a wave costs its SIMD ~7 cycles of fp32-MFMA issue
+    // (profiles/r5_pmc_wino_fused.txt), so the staging is built to need as few as possible.
     const int s_tx = bx * BW + (lane & (BW - 1));
     const int s_ty = by * BH + ((lane >> p.bw_log2) & (BH - 1));
     const int s_n = bn * BN + (lane >> bshift);
     const bool s_valid = s_tx < p.TW && s_ty < p.TH && s_n < p.N;
     const int iy0 = 2 * s_ty - p.pad, ix0 = 2 * s_tx - p.pad;
-    int cx = ix0 < 0 ? 0 : ix0;
-    if (cx > p.W - 4) cx = p.W - 4;
-    const int shift = s_valid ? ix0 - cx : 0;          // -2 .. 2: wanted element q is loaded element q + shift
     const int64_t HW = (int64_t)p.H * p.W;
-    const float* xt = x + ((int64_t)(s_valid ? s_n : 0) * p.C) * HW + (s_valid ? cx : 0);
-    int rowoff[4];
-    bool rowok[4];
+    // The block that holds the tensor's first row (block 0) cannot start a window one float left of it: an offset of -4 wraps to
+    // 4 GiB - 4 and the WHOLE 16-byte load reads as zeros.  Its windows are clamped into the row and shifted into place by
+    // selects (mode 2: one workgroup per channel block); every other block takes the unclamped window (modes 0 / 1).
+    const bool first_block = blockIdx.x == 0;
+    int cx = ix0;
+    if (first_block) {
+        cx = ix0 < 0 ? 0 : ix0;
+        if (cx > p.W - 4) cx = p.W - 4;
+    }
+    const int shift = ix0 - cx;            // mode 2: wanted element q is loaded element q + shift (-2 .. 2)
+    unsigned rowv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int iy = iy0 + r;
-        rowok[r] = s_valid && iy >= 0 && iy < p.H;
-        rowoff[r] = (rowok[r] ? iy : 0) * p.W;
+        const bool ok = s_valid && iy >= 0 && iy < p.H;
+        rowv[r] = ok ? (unsigned)(((int64_t)s_n * p.C * HW + (int64_t)iy * p.W + cx) * 4) : 0x80000000u;
     }
+    bool colok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) colok[q] = ix0 + q >= 0 && ix0 + q < p.W;
+    // does any tile of this block have a patch column outside the image?  (uniform)
+    const int tx_lo = bx * BW, tx_hi = (bx + 1) * BW - 1;
+    const bool x_interior = 2 * tx_lo - p.pad >= 0 && 2 * tx_hi - p.pad + 3 < p.W && tx_hi < p.TW;
+    const unsigned plane_bytes = (unsigned)(HW * 4);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Uf + (int64_t)mb * p.chunks * kWfStage), 0, (unsigned)(p.chunks * kWfStage * 4), 0x00020000);
+    const unsigned uoff = tid * 16;
 
-    f32x4 dreg[2][4];          // the two channels' 4x4 patches of the NEXT chunk (raw windows, then the patches themselves)
+    f32x4 dreg[2][4];          // the two channels' 4x4 patches of the NEXT chunk
     f32x4 ureg[8];             // this thread's 8 quads of the next chunk's weights
     f32x2 vreg[16];            // B^T d B of both channels, as written to LDS
     float xsc[2] = {1.0f, 1.0f};
 
     // ---- the staging of a chunk, in pieces the main loop spreads over the sixteen MFMA groups of the previous chunk
-    auto load_x = [&](int chunk, int c2) {                     // 4 global 16-byte loads
+    auto load_x = [&](int chunk, int c2) {                     // 4 buffer loads, no vector ALU
         int ch = chunk * kWfCK + 2 * wid + c2;                 // wave-uniform
-        if (ch > p.C - 1) ch = p.C - 1;                        // (a channel beyond C: its patch is zeroed in `window`)
-        const float* xp = xt + (int64_t)ch * HW;
+        if (ch > p.C - 1) ch = p.C - 1;                        // (a channel beyond C meets zero weights)
+        const unsigned soff = (unsigned)ch * plane_bytes;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dreg[c2][r] = *reinterpret_cast<const f32x4u*>(xp + rowoff[r]);
+        for (int r = 0; r < 4; ++r) dreg[c2][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, rowv[r], soff, 0));
         if (XS) xsc[c2] = p.x_scale[(int64_t)(s_valid ? s_n : 0) * p.C + ch];
     };
-    auto load_u = [&](int chunk, int lo) {                     // 4 global 16-byte loads
-        const f32x4* up = reinterpret_cast<const f32x4*>(Uf + ((int64_t)mb * p.chunks + chunk) * kWfStage) + tid;
+    auto load_u = [&](int chunk, int lo) {                     // 4 buffer loads, no vector ALU
 #pragma unroll
-        for (int j = lo; j < lo + 4; ++j) ureg[j] = up[j * kBlock];
+        for (int j = lo; j < lo + 4; ++j)
+            ureg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uoff, (unsigned)(chunk * kWfStage * 4 + j * 4096), 0));
     };
-    auto window = [&](int chunk, int c2, int r) {              // row r of the patch out of the loaded window: ~10 VALU
-        const bool ok = rowok[r] && (chunk * kWfCK + 2 * wid + c2 < p.C);
-        const f32x4 l = dreg[c2][r];
-        f32x4 w;
-        if (PAD2) {                // windows of the data gradient of a valid layer: shift -2 .. 2 (sequential selects)
+    auto transform = [&](auto mode_tag, int c2) {              // B^T d B of one channel
+        constexpr int MODE = decltype(mode_tag)::value;        // 0: all columns inside, 1: zero the outside columns, 2: shifted windows
+        f32x4 d[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float t = 0.0f;
-#pragma unroll
-                for (int k = -2; k <= 2; ++k)
-                    if (q + k >= 0 && q + k < 4) t = (shift == k) ? l[q + k] : t;
-                w[q] = t;
-            }
-        } else {                   // shift -1 .. 1
-            w[0] = shift == 0 ? l[0] : shift > 0 ? l[1] : 0.0f;
-            w[1] = shift == 0 ? l[1] : shift > 0 ? l[2] : l[0];
-            w[2] = shift == 0 ? l[2] : shift > 0 ? l[3] : l[1];
-            w[3] = shift == 0 ? l[3] : shift > 0 ? 0.0f : l[2];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = ok ? w[q] : 0.0f;
-        dreg[c2][r] = XS ? w * xsc[c2] : w;
-    };
-    auto transform = [&](int c2) {                             // B^T d B of one channel: 32 VALU
+        for (int r = 0; r < 4; ++r) d[r] = XS ? dreg[c2][r] * xsc[c2] : dreg[c2][r];
         f32x4 e[4];
-        e[0] = dreg[c2][0] - dreg[c2][2];
-        e[1] = dreg[c2][1] + dreg[c2][2];
-        e[2] = dreg[c2][2] - dreg[c2][1];
-        e[3] = dreg[c2][1] - dreg[c2][3];
+        e[0] = d[0] - d[2];
+        e[1] = d[1] + d[2];
+        e[2] = d[2] - d[1];
+        e[3] = d[1] - d[3];
+        if (MODE == 2) {           // (the row transform acts column by column, so the shift can follow it)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 l = e[a];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int k = -2; k <= 2; ++k)
+                        if (q + k >= 0 && q + k < 4) t = (shift == k) ? l[q + k] : t;
+                    e[a][q] = colok[q] ? t : 0.0f;
+                }
+            }
+        }
+        if (MODE == 1) {           // columns of the patch outside the image hold the neighbouring row's data: zero them
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                e[a][0] = colok[0] ? e[a][0] : 0.0f;
+                e[a][3] = colok[3] ? e[a][3] : 0.0f;
+                if (PAD2) {
+                    e[a][1] = colok[1] ? e[a][1] : 0.0f;
+                    e[a][2] = colok[2] ? e[a][2] : 0.0f;
+                }
+            }
+        }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             vreg[4 * a + 0][c2] = e[a][0] - e[a][2];
@@ -221,9 +248,9 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
 
     // One pass over the staged chunk `cur`: sixteen groups of four MFMAs (one point each); the operands of point xi + 1 are
     // read while the MFMAs of point xi run, and with STAGE the pieces of the next chunk's staging ride in the groups' shadows --
-    // x first (its windows are needed by group 6), the weights last (written by groups 14, 15).  sched_barrier keeps the
-    // pieces in their groups; inside a group the scheduler is free.
-    auto pass = [&](auto stage_tag, int cur, int chunk) {
+    // x first (transformed by groups 8, 9), the weights last (written by groups 14, 15).  sched_barrier keeps the pieces in
+    // their groups; inside a group the scheduler is free.
+    auto pass = [&](auto stage_tag, auto mode_tag, int cur, int chunk) {
         constexpr bool STAGE = decltype(stage_tag)::value;
         const f32x4* ua = reinterpret_cast<const f32x4*>(Us[cur]) + (half * 64 + wm * 32 + l31);
         const f32x2* vb = reinterpret_cast<const f32x2*>(Vs[cur]) + (half * 128 + wt * 32 + l31);
@@ -249,12 +276,8 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
             acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b23[0], acc[xi], 0, 0, 0);
             acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b23[1], acc[xi], 0, 0, 0);
             if (STAGE) {
-                if (xi >= 6 && xi <= 9) {
-                    window(chunk + 1, (xi - 6) >> 1, 2 * ((xi - 6) & 1));
-                    window(chunk + 1, (xi - 6) >> 1, 2 * ((xi - 6) & 1) + 1);
-                }
-                if (xi == 10) transform(0);
-                if (xi == 11) transform(1);
+                if (xi == 8) transform(mode_tag, 0);
+                if (xi == 9) transform(mode_tag, 1);
                 if (xi == 12) write_v(cur ^ 1, 0);
                 if (xi == 13) write_v(cur ^ 1, 8);
                 if (xi == 14) write_u(cur ^ 1, 0);
@@ -267,30 +290,34 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
         }
     };
 
-    // prologue: chunk 0
-    load_x(0, 0);
-    load_x(0, 1);
-    load_u(0, 0);
-    load_u(0, 4);
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) window(0, c2, r);
-        transform(c2);
-    }
-    write_v(0, 0);
-    write_v(0, 8);
-    write_u(0, 0);
-    write_u(0, 4);
-    __syncthreads();
-
-    int cur = 0;
-    for (int chunk = 0; chunk + 1 < p.chunks; ++chunk) {
-        pass(std::true_type{}, cur, chunk);
+    auto run = [&](auto mode_tag) {
+        // prologue: chunk 0
+        load_x(0, 0);
+        load_x(0, 1);
+        load_u(0, 0);
+        load_u(0, 4);
+        transform(mode_tag, 0);
+        transform(mode_tag, 1);
+        write_v(0, 0);
+        write_v(0, 8);
+        write_u(0, 0);
+        write_u(0, 4);
         __syncthreads();
-        cur ^= 1;
-    }
-    pass(std::false_type{}, cur, 0);
+        // (ONE instantiation of the pass: the last chunk stages itself again into the buffer nobody reads -- a second, staging-free
+        // copy of the pass costs 300 accumulator moves between the two register assignments)
+        int cur = 0;
+        for (int chunk = 0; chunk < p.chunks; ++chunk) {
+            pass(std::true_type{}, mode_tag, cur, chunk + 1 < p.chunks ? chunk : chunk - 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    };
+    if (first_block)
+        run(std::integral_constant<int, 2>{});
+    else if (x_interior)
+        run(std::integral_constant<int, 0>{});
+    else
+        run(std::integral_constant<int, 1>{});
 
     // ---- output transform, lane-local: acc[4 a + b][r] of (m = ... r ..., tile = wt * 32 + l31)
     const int ot = wt * 32 + l31;
@@ -357,6 +384,7 @@ struct WinoWgradParams {
     int cpr;                   // chunks per tile row = TW / 8
     int chunks, chunks_per_slice;
     int Mp, Cp;                // slab dims (M, C padded to 64)
+    unsigned x_bytes, gy_bytes; // < 2^31: per-lane byte offsets are 32-bit, 0x80000000 = "outside": reads as zero
     const float* x_scale;      // [N * C] or null
     const float* y_scale;      // [N * M] or null
 };
@@ -376,17 +404,26 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
     const int wm = wid >> 1, wt = wid & 1;
     const int cb = blockIdx.x, mb = blockIdx.y, slice = blockIdx.z;
 
-    // ---- staging role: channel `ch` of both 64-channel blocks, tiles 4 hf + 2 q1 and + 1 of a chunk (hf wave-uniform)
+    // ---- staging role: channel `ch` of both 64-channel blocks, tiles 4 hf + 2 q1 and + 1 of a chunk (hf wave-uniform).  All
+    // loads are buffer loads: the per-lane offset (channel plane + the pair's column) never changes, the chunk's position (image,
+    // tile row, 8-tile group) is scalar; window rows outside the image get an out-of-range offset and read as zeros.  Channels
+    // beyond M / C are clamped to the last one: their products land in slab rows / columns nobody reads.
     const int q1 = lane & 1;
     const int ch = (wid & 1) * 32 + (lane >> 1);
     const int hf = wid >> 1;
     const int kk0 = 4 * hf + 2 * q1;
-    const bool m_ok = mb * kWfM + ch < p.M, c_ok = cb * kWfM + ch < p.C;
-    const int m_ch = m_ok ? mb * kWfM + ch : p.M - 1;
-    const int c_ch = c_ok ? cb * kWfM + ch : p.C - 1;
+    const int m_ch = mb * kWfM + ch < p.M ? mb * kWfM + ch : p.M - 1;
+    const int c_ch = cb * kWfM + ch < p.C ? cb * kWfM + ch : p.C - 1;
     const int64_t HW = (int64_t)p.H * p.W, OHW = (int64_t)p.OH * p.OW;
-    const float* px = (MOD && p.x_scale) ? p.x_scale : x;          // (a valid address either way: the loop body stays branch-free)
-    const float* py = (MOD && p.y_scale) ? p.y_scale : gy;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, p.gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sxr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MOD && p.x_scale ? p.x_scale : x), 0,
+                                                                       (unsigned)(p.N * p.C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t syr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(MOD && p.y_scale ? p.y_scale : gy), 0,
+                                                                       (unsigned)(p.N * p.M * 4), 0x00020000);
+    const unsigned g_lane = (unsigned)(((int64_t)m_ch * OHW + 2 * kk0) * 4);
+    const unsigned x_lane = (unsigned)(((int64_t)c_ch * HW + 2 * kk0 - p.pad) * 4);      // (-4 at most: wraps, with the scalar part, to "outside")
+    const unsigned ow_bytes = (unsigned)(p.OW * 4);
 
     const int ch_begin = slice * p.chunks_per_slice;
     int ch_end = ch_begin + p.chunks_per_slice;
@@ -399,38 +436,37 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
     f32x4 greg[2];             // gy rows 2 ty, 2 ty + 1: two tiles x two columns
     f32x4 xr4[4];              // window rows: columns 0 .. 3
     f32x2 xr2[4];              //              columns 4, 5
-    int rowmask = 0, shift = 0;
+    bool zl = false, zr = false, edge = false;      // the pair's window sticks out of the image on the left / right; the chunk has such a pair
     float sx = 1.0f, sy = 1.0f;
     f32x2 ev[16], vv[16];      // A e A^T and B^T d B of the two tiles, as written to LDS
-    float d6[4][6];            // the 4 x 6 patch of the two tiles
 
     auto load_gy = [&]() {
-        const int tx = ld_txb * 8 + kk0;
-        const float* gp = gy + ((int64_t)ld_n * p.M + m_ch) * OHW + (int64_t)(2 * ld_ty) * p.OW + 2 * tx;
-        greg[0] = *reinterpret_cast<const f32x4*>(gp);
-        greg[1] = *reinterpret_cast<const f32x4*>(gp + p.OW);
+        const unsigned soff = (unsigned)((((int64_t)ld_n * p.M) * OHW + (int64_t)(2 * ld_ty) * p.OW + 16 * ld_txb) * 4);
+        greg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, g_lane, soff, 0));
+        greg[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, g_lane + ow_bytes, soff, 0));
         if (MOD) {
-            sx = px[(int64_t)ld_n * p.C + c_ch];
-            sy = py[(int64_t)ld_n * p.M + m_ch];
+            sx = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sxr, (unsigned)(c_ch * 4), (unsigned)(ld_n * p.C * 4), 0));
+            sy = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(syr, (unsigned)(m_ch * 4), (unsigned)(ld_n * p.M * 4), 0));
             sx = p.x_scale ? sx : 1.0f;
             sy = p.y_scale ? sy : 1.0f;
         }
     };
     auto load_x = [&](int r0) {            // window rows r0, r0 + 1
-        const int tx = ld_txb * 8 + kk0;
-        const int ix0 = 2 * tx - p.pad;
-        int cx = ix0 < 0 ? 0 : ix0;
-        if (cx > p.W - 6) cx = p.W - 6;
-        if (r0 == 0) { shift = ix0 - cx; rowmask = 0; }
-        const float* xp = x + ((int64_t)ld_n * p.C + c_ch) * HW + cx;
+        if (r0 == 0) {
+            edge = p.pad == 1 && (ld_txb == 0 || ld_txb == p.cpr - 1);      // uniform: this chunk touches the left / right border
+            zl = p.pad == 1 && ld_txb == 0 && kk0 == 0;
+            zr = p.pad == 1 && ld_txb == p.cpr - 1 && kk0 == 6;
+        }
 #pragma unroll
         for (int r = r0; r < r0 + 2; ++r) {
             const int iy = 2 * ld_ty - p.pad + r;
-            const bool ok = iy >= 0 && iy < p.H;
-            rowmask |= ok ? (1 << r) : 0;
-            const float* rp = xp + (int64_t)(ok ? iy : 0) * p.W;
-            xr4[r] = *reinterpret_cast<const f32x4u*>(rp);
-            xr2[r] = *reinterpret_cast<const f32x2u*>(rp + 4);
+            const bool ok = iy >= 0 && iy < p.H;                 // uniform
+            const unsigned up = ok ? (unsigned)((((int64_t)ld_n * p.C) * HW + (int64_t)iy * p.W + 16 * ld_txb) * 4) : 0x80000000u;
+            // the pair at the left border starts its window AT column 0 (one float further left would be offset -4 in the
+            // tensor's first row: it wraps and the whole load reads as zeros) and is shifted into place in transform_v
+            const unsigned v = x_lane + up + (zl ? 4u : 0u);
+            xr4[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, v, 0, 0));
+            xr2[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, v + 16, 0, 0));
         }
     };
     auto advance = [&]() {
@@ -446,7 +482,6 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
         for (int t = 0; t < 2; ++t) {
             float e00 = greg[0][2 * t], e01 = greg[0][2 * t + 1], e10 = greg[1][2 * t], e11 = greg[1][2 * t + 1];
             if (MOD) { e00 *= sy; e01 *= sy; e10 *= sy; e11 *= sy; }
-            if (!m_ok) { e00 = 0.0f; e01 = 0.0f; e10 = 0.0f; e11 = 0.0f; }
             float r[4][2];
             r[0][0] = e00;       r[0][1] = e01;
             r[1][0] = e00 + e10; r[1][1] = e01 + e11;
@@ -461,33 +496,41 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
             }
         }
     };
-    auto window = [&](int r) {             // row r of the 4 x 6 patch out of the loaded window (shift -1 .. 1)
-        const bool ok = c_ok && ((rowmask >> r) & 1);
-        float l[6] = {xr4[r][0], xr4[r][1], xr4[r][2], xr4[r][3], xr2[r][0], xr2[r][1]};
+    auto transform_v = [&]() {             // B^T d B of both tiles (columns 0 .. 3 and 2 .. 5 of the 4 x 6 window)
+        float e[4][6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
-            const float lo = q > 0 ? l[q - 1] : 0.0f, hi = q < 5 ? l[q + 1] : 0.0f;
-            float v = shift == 0 ? l[q] : shift > 0 ? hi : lo;
-            v = ok ? v : 0.0f;
-            d6[r][q] = MOD ? v * sx : v;
+            float d0 = q < 4 ? xr4[0][q] : xr2[0][q - 4], d1 = q < 4 ? xr4[1][q] : xr2[1][q - 4];
+            float d2 = q < 4 ? xr4[2][q] : xr2[2][q - 4], d3 = q < 4 ? xr4[3][q] : xr2[3][q - 4];
+            if (MOD) { d0 *= sx; d1 *= sx; d2 *= sx; d3 *= sx; }
+            e[0][q] = d0 - d2;
+            e[1][q] = d1 + d2;
+            e[2][q] = d2 - d1;
+            e[3][q] = d1 - d3;
         }
-    };
-    auto transform_v = [&](int t) {        // B^T d B of tile t (columns 2 t .. 2 t + 3 of the patch)
-        float e[4][4];
+        if (edge) {                        // (uniform branch: chunks at the left / right border of the map only)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            e[0][q] = d6[0][2 * t + q] - d6[2][2 * t + q];
-            e[1][q] = d6[1][2 * t + q] + d6[2][2 * t + q];
-            e[2][q] = d6[2][2 * t + q] - d6[1][2 * t + q];
-            e[3][q] = d6[1][2 * t + q] - d6[3][2 * t + q];
+            for (int a = 0; a < 4; ++a) {
+                // left: the window was loaded from column 0 -> shift right by one, column -1 is padding;
+                // right: the last column holds the next row's first element -> padding
+                const float l0 = e[a][0], l1 = e[a][1], l2 = e[a][2], l3 = e[a][3], l4 = e[a][4];
+                e[a][0] = zl ? 0.0f : l0;
+                e[a][1] = zl ? l0 : l1;
+                e[a][2] = zl ? l1 : l2;
+                e[a][3] = zl ? l2 : l3;
+                e[a][4] = zl ? l3 : l4;
+                e[a][5] = zl ? l4 : (zr ? 0.0f : e[a][5]);
+            }
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            vv[4 * a + 0][t] = e[a][0] - e[a][2];
-            vv[4 * a + 1][t] = e[a][1] + e[a][2];
-            vv[4 * a + 2][t] = e[a][2] - e[a][1];
-            vv[4 * a + 3][t] = e[a][1] - e[a][3];
-        }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                vv[4 * a + 0][t] = e[a][2 * t + 0] - e[a][2 * t + 2];
+                vv[4 * a + 1][t] = e[a][2 * t + 1] + e[a][2 * t + 2];
+                vv[4 * a + 2][t] = e[a][2 * t + 2] - e[a][2 * t + 1];
+                vv[4 * a + 3][t] = e[a][2 * t + 1] - e[a][2 * t + 3];
+            }
     };
     auto write_e = [&](int buf, int lo) {
         f32x2* d = reinterpret_cast<f32x2*>(Es[buf]) + ((hf * 64 + ch) * 2 + q1);
@@ -506,8 +549,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[xi][r] = 0.0f;
 
-    auto pass = [&](auto stage_tag, int cur) {
-        constexpr bool STAGE = decltype(stage_tag)::value;
+    auto pass = [&](int cur, bool more) {
         const f32x4* ea = reinterpret_cast<const f32x4*>(Es[cur]) + (half * 64 + wm * 32 + l31);
         const f32x4* vb = reinterpret_cast<const f32x4*>(Vs[cur]) + (half * 64 + wt * 32 + l31);
         f32x4 a = ea[0], b = vb[0];
@@ -518,23 +560,20 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
                 an = ea[(xi + 1) * 128];
                 bn = vb[(xi + 1) * 128];
             }
-            if (STAGE) {
-                if (xi == 0) load_gy();
-                if (xi == 1) load_x(0);
-                if (xi == 2) { load_x(2); advance(); }
+            if (xi == 0) load_gy();
+            if (xi == 1) load_x(0);
+            if (xi == 2) {
+                load_x(2);
+                if (more) advance();       // (the last chunk of the slice stages itself again into the buffer nobody reads)
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], acc[xi], 0, 0, 0);
-            if (STAGE) {
-                if (xi == 5) transform_e();
-                if (xi >= 6 && xi <= 9) window(xi - 6);
-                if (xi == 10) transform_v(0);
-                if (xi == 11) transform_v(1);
-                if (xi == 12) write_e(cur ^ 1, 0);
-                if (xi == 13) write_e(cur ^ 1, 8);
-                if (xi == 14) write_v(cur ^ 1, 0);
-                if (xi == 15) write_v(cur ^ 1, 8);
-            }
+            if (xi == 7) transform_e();
+            if (xi == 9) transform_v();
+            if (xi == 12) write_e(cur ^ 1, 0);
+            if (xi == 13) write_e(cur ^ 1, 8);
+            if (xi == 14) write_v(cur ^ 1, 0);
+            if (xi == 15) write_v(cur ^ 1, 8);
             a = an;
             b = bn;
             __builtin_amdgcn_sched_barrier(0);
@@ -545,24 +584,20 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
         load_gy();
         load_x(0);
         load_x(2);
-        advance();
         transform_e();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) window(r);
-        transform_v(0);
-        transform_v(1);
+        transform_v();
         write_e(0, 0);
         write_e(0, 8);
         write_v(0, 0);
         write_v(0, 8);
+        if (ch_begin + 1 < ch_end) advance();
         __syncthreads();
         int cur = 0;
-        for (int chunk = ch_begin; chunk + 1 < ch_end; ++chunk) {
-            pass(std::true_type{}, cur);
+        for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
+            pass(cur, chunk + 2 < ch_end);
             __syncthreads();
             cur ^= 1;
         }
-        pass(std::false_type{}, cur);
     }
 
     // ---- G^T gU G, lane-local: acc[4 a + b][r] of (m = wm * 32 + row(r, half), c = wt * 32 + l31) -> slab[slice][m][tap][c]
@@ -658,6 +693,9 @@ extern "C" int sae_wino_fused_conv_f32(const float* x, const float* x_scale, con
     if (n == 0) return SAE_OK;
     if (!x || !uf || !y) return fail(SAE_EINVAL, "sae_wino_fused_conv_f32: null tensor");
     if (w < 4) return fail(SAE_EINVAL, "sae_wino_fused_conv_f32: rows of at least 4 floats (the patch rows are 16-byte loads), got %lld", (long long)w);
+    if (n * c * h * w * 4 >= ((int64_t)1 << 31))
+        return fail(SAE_EINVAL, "sae_wino_fused_conv_f32: x of %lld bytes; the kernel addresses it with 32-bit byte offsets (< 2 GiB)",
+                    (long long)(n * c * h * w * 4));
     if (!aligned16(uf) || (reinterpret_cast<uintptr_t>(y) & 7) != 0)
         return fail(SAE_EINVAL, "sae_wino_fused_conv_f32: uf must be 16-byte and y 8-byte aligned");
     if (noise && (!act || !noise_weight))
@@ -678,6 +716,7 @@ extern "C" int sae_wino_fused_conv_f32(const float* x, const float* x_scale, con
     const int64_t blocks = (int64_t)p.blocks_x * p.blocks_y * ceil_div64(n, BN);
     if (blocks >= ((int64_t)1 << 31)) return fail(SAE_EINVAL, "sae_wino_fused_conv_f32: too many tile blocks");
     p.chunks = (int)ceil_div64(c, kWfCK);
+    p.x_bytes = (unsigned)(n * c * h * w * 4);
     p.x_scale = x_scale; p.out_scale = out_scale; p.noise = noise; p.noise_w = noise_weight; p.bias = bias;
     p.act = act ? 1 : 0; p.slope = slope; p.act_scale = act_scale;
     const dim3 grid((unsigned)blocks, (unsigned)ceil_div64(m, kWfM));
@@ -720,6 +759,8 @@ extern "C" int sae_wino_fused_wgrad_f32(const float* x, const float* x_scale, co
                     (long long)ow);
     if (!x || !gy || !gw || !workspace) return fail(SAE_EINVAL, "sae_wino_fused_wgrad_f32: null tensor");
     if (!aligned16(gy)) return fail(SAE_EINVAL, "sae_wino_fused_wgrad_f32: gy must be 16-byte aligned");
+    if (n * c * h * w * 4 >= ((int64_t)1 << 31) || n * m * oh * ow * 4 >= ((int64_t)1 << 31))
+        return fail(SAE_EINVAL, "sae_wino_fused_wgrad_f32: the kernel addresses x and gy with 32-bit byte offsets (< 2 GiB each)");
     const int64_t need = sae_wino_fused_wgrad_workspace(n, c, m, h, w, pad);
     if (workspace_floats < need)
         return fail(SAE_EINVAL, "sae_wino_fused_wgrad_f32: workspace of %lld floats, %lld needed", (long long)workspace_floats,
@@ -734,6 +775,7 @@ extern "C" int sae_wino_fused_wgrad_f32(const float* x, const float* x_scale, co
     const int slices = wgrad_slices(mbs, cbs, chunks);
     p.chunks_per_slice = (int)ceil_div64(chunks, slices);
     p.Mp = (int)(mbs * kWfM); p.Cp = (int)(cbs * kWfM);
+    p.x_bytes = (unsigned)(n * c * h * w * 4); p.gy_bytes = (unsigned)(n * m * oh * ow * 4);
     p.x_scale = x_scale; p.y_scale = y_scale;
     const dim3 grid((unsigned)cbs, (unsigned)mbs, (unsigned)slices);
     const hipStream_t st = (hipStream_t)stream;

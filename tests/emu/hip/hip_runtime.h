@@ -351,6 +351,40 @@ static inline void __syncthreads() { hipemu::block_barrier(); }
 #define __builtin_amdgcn_sched_group_barrier(mask, n, id) ((void)0)
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 
+
+// ---- raw buffer loads (buffer_load_dword* through a V# descriptor): address = base + soffset + voffset; every dword whose
+// voffset-relative position lies at or beyond num_records reads as zero (the hardware's per-dword range check of raw buffers;
+// soffset takes no part in the check).  A "negative" voffset is a huge unsigned one: out of range.
+struct hipemu_rsrc {
+    const char* base;
+    unsigned num_records;
+};
+typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
+namespace hipemu {
+template <typename V, int N>
+inline V raw_buffer_load(hipemu_rsrc r, unsigned voffset, unsigned soffset) {
+    V out;
+    for (int i = 0; i < N; ++i) {
+        unsigned v = 0;
+        const unsigned long long off = (unsigned long long)voffset + 4ull * i;
+        if (off + 4 <= r.num_records) std::memcpy(&v, r.base + soffset + off, 4);
+        out[i] = v;
+    }
+    return out;
+}
+inline unsigned raw_buffer_load1(hipemu_rsrc r, unsigned voffset, unsigned soffset) {
+    unsigned v = 0;
+    if ((unsigned long long)voffset + 4 <= r.num_records) std::memcpy(&v, r.base + soffset + voffset, 4);
+    return v;
+}
+}  // namespace hipemu
+#define __amdgpu_buffer_rsrc_t hipemu_rsrc
+#define __builtin_amdgcn_make_buffer_rsrc(p, stride, num, flags) (hipemu_rsrc{(const char*)(p), (unsigned)(num)})
+#define __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, aux) hipemu::raw_buffer_load<hipemu_u32x4, 4>((r), (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, aux) hipemu::raw_buffer_load<hipemu_u32x2, 2>((r), (unsigned)(voff), (unsigned)(soff))
+#define __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, aux) hipemu::raw_buffer_load1((r), (unsigned)(voff), (unsigned)(soff))
+
 template <typename T>
 static inline T __shfl_xor(T v, int mask, int width = 64) {
     const int l = hipemu::lane_id();

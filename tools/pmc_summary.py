@@ -14,10 +14,14 @@ def short(n):
     return re.sub(r"\(.*", "", n)[:60]
 
 
-DOMINANT = "conv_igemm_kernel<3,1,2,2,1,4,8,false,true>"
-# tools/pmc_kernels.py's reference launch of it: 128 -> 128 3x3 @256x256, B = 16 (forward and stride-1 data gradient)
-DOMINANT_REF = {"gflop": 2.0 * 16 * 128 * 256 * 256 * 128 * 9 / 1e9, "algorithmic_bytes": 2.0 * 16 * 128 * 256 * 256 * 4,
-                "launch": "128 -> 128 3x3 stride 1 @256x256, B = 16 (tools/pmc_kernels.py)"}
+# Round 5: the dominant kernel is the one-kernel Winograd convolution; tools/pmc_wino_fused.py's reference launch of it is
+# 512 -> 512 3x3 @64x64, B = 16 (grid 2048 workgroups).  gflop = the FLOPs it EXECUTES (16 multiply-adds per 2x2 tile and channel
+# pair); algorithmic bytes = x and y once + the prepared weights once.
+DOMINANT = "wino_fused_kernel<false,false,false>"
+DOMINANT_REF = {"gflop": 32.0 * 16 * 512 * 512 * 32 * 32 / 1e9,
+                "algorithmic_bytes": 2.0 * 16 * 512 * 64 * 64 * 4 + 16.0 * 512 * 512 * 4,
+                "launch": "512 -> 512 3x3 stride 1 @64x64, B = 16, forward (tools/pmc_wino_fused.py)"}
+# (rounds 2-4: conv_igemm_kernel<3,1,2,2,1,4,8,false,true> on 128 -> 128 @256x256, B = 16: profiles/r4_pmc_dominant.json)
 
 
 def dominant_record(agg, source):

@@ -10,7 +10,7 @@ from swapping_autoencoder_pytorch_amd import hip_lib  # noqa: E402
 from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as cg, winograd  # noqa: E402
 
 hip_lib.get()
-for n, c, side in [(16, 512, 64), (8, 128, 256)]:
+for n, c, side in [(16, 512, 64), (2, 128, 256)]:          # the first one is tools/pmc_summary.py's reference launch (the larger grid)
     g = cg._Geom(n, c, side, side, c, 3, 1, 1, False, 1.0 / (c * 9) ** 0.5)
     x = torch.randn(n, c, side, side, device="cuda")
     gy = torch.randn(n, c, side, side, device="cuda")
