@@ -117,12 +117,23 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
     const int BW = 1 << p.bw_log2, BH = 1 << p.bh_log2;
     const int bshift = p.bw_log2 + p.bh_log2;
     const int BN = kWfT >> bshift;
-    int b = blockIdx.x;
+    // Workgroup order.  Ids go round the 8 XCDs (id % 8), each with its own L2, in dispatch order.  Re-labelled so that an XCD
+    // walks a CONTIGUOUS eighth of the tile blocks (neighbouring blocks share the halo rows / columns of their patches: fetched
+    // once per L2 instead of once per XCD) and all XCDs work on the same channel block at a time (its 0.5 - 2 MB of prepared
+    // weights stay in every L2 while the activations stream through).  Needs tile blocks % 8 == 0; otherwise launch order.
+    int b = blockIdx.x, mb = blockIdx.y;
+    if ((gridDim.x & 7) == 0) {
+        const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+        const int per = gridDim.x >> 3;
+        const int j = lin >> 3;
+        mb = j / per;
+        b = (lin & 7) * per + (j - mb * per);
+    }
+    const bool first_block = b == 0;
     const int bx = b % p.blocks_x;
     b /= p.blocks_x;
     const int by = b % p.blocks_y;
     const int bn = b / p.blocks_y;
-    const int mb = blockIdx.y;
 
     // ---- the thread's role in staging: tile `lane` of the block, channels 2 wid and 2 wid + 1 of a chunk.  Every row of the 4x4
     // patch is ONE 16-byte buffer load whose per-lane offset never changes (image + row + column of the tile; the channel rides
@@ -140,7 +151,6 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
     // The block that holds the tensor's first row (block 0) cannot start a window one float left of it: an offset of -4 wraps to
     // 4 GiB - 4 and the WHOLE 16-byte load reads as zeros.  Its windows are clamped into the row and shifted into place by
     // selects (mode 2: one workgroup per channel block); every other block takes the unclamped window (modes 0 / 1).
-    const bool first_block = blockIdx.x == 0;
     int cx = ix0;
     if (first_block) {
         cx = ix0 < 0 ? 0 : ix0;

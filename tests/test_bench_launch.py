@@ -71,8 +71,10 @@ def test_pmc_record_of_another_kernel_is_refused(tmp_path, monkeypatch):
     import json
     bench = _bench()
     rec = bench.load_pmc_dominant()
-    assert rec["kernel"].replace(" ", "") == bench.DOMINANT_KERNEL and rec["read_bytes"] > 0 and rec["write_bytes"] > 0
-    assert 0.9 < (rec["read_bytes"] + rec["write_bytes"]) / rec["algorithmic_bytes"] < 3.0
+    assert rec["kernel"].replace(" ", "").startswith(bench.DOMINANT_KERNEL) and rec["read_bytes"] > 0 and rec["write_bytes"] > 0
+    # (the one-kernel Winograd convolution reads x once per 64-channel output block: 8 passes over x at 512 channels, through the
+    # 256 MB Infinity Cache -- the request-level figure is L2 -> fabric traffic, 4.3x the algorithmic bytes at the very least)
+    assert 0.9 < (rec["read_bytes"] + rec["write_bytes"]) / rec["algorithmic_bytes"] < 12.0
     other = tmp_path / "pmc.json"
     other.write_text(json.dumps(dict(rec, kernel="conv_igemm_kernel<3,1,2,2,2,2,8,false,false>")))
     monkeypatch.setattr(bench, "PMC_DOMINANT_FILE", str(other))
@@ -80,25 +82,36 @@ def test_pmc_record_of_another_kernel_is_refused(tmp_path, monkeypatch):
         bench.load_pmc_dominant()
 
 
-def test_kernel_class_of_a_launch():
-    """The event timer's classes (roofline_by_kernel) follow the library's dispatch: the dominant instantiation only for wide,
-    quad-staged, un-modulated 3x3 stride-1 gathers; the four second-tier classes by operation and stride."""
+def test_kernel_class_of_a_launch(oracle_lib):
+    """The event timer's classes (roofline_by_kernel) follow the routing: a launch winograd.route() takes is bracketed at the
+    route (class None here); what it leaves to the direct kernels is classed by the library's dispatch -- the two quad-staged
+    gather tiles, the weight gradients, the stride-2 classes by operation."""
     bench = _bench()
-    from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as cg
+    from parity_common import backend
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as cg, winograd as wino
     t = bench.DominantKernelTimer()
     t.active = True
     g = cg._Geom(16, 128, 256, 256, 128, 3, 1, 1, False, 1.0)
-    assert t.classify(cg, cg.SAE_CONV_FWD, g, False) == "dominant" and t.classify(cg, cg.SAE_CONV_DGRAD, g, False) == "dominant"
     small = cg._Geom(16, 512, 64, 64, 512, 3, 1, 1, False, 1.0)       # maps under 128 wide keep the 128 x 128 tile
-    assert t.classify(cg, cg.SAE_CONV_FWD, small, False) == "s1_gather_128"
+    narrow = cg._Geom(128, 32, 128, 128, 32, 3, 1, 1, False, 1.0)
+    s2 = cg._Geom(16, 128, 257, 257, 256, 3, 2, 0, False, 1.0)
+    with backend(oracle_lib):
+        with wino.override(enabled=True):
+            assert wino.route(g, wino.FWD) == "fused" and wino.route(small, wino.DGRAD) == "fused" and wino.route(g, wino.WGRAD) == "fused"
+            assert wino.route(narrow, wino.FWD) is None and wino.route(s2, wino.FWD) is None
+            assert wino.route(cg._Geom(4, 64, 32, 32, 64, 3, 1, 1, False, 1.0), wino.FWD) is None      # the small presets stay direct
+            for op in (cg.SAE_CONV_FWD, cg.SAE_CONV_DGRAD, cg.SAE_CONV_WGRAD):
+                assert t.classify(cg, wino, op, g, False) is None          # bracketed at winograd.conv / wgrad instead
+            assert [t.classify(cg, wino, op, s2, False) for op in (cg.SAE_CONV_FWD, cg.SAE_CONV_DGRAD, cg.SAE_CONV_WGRAD)] == [
+                "s2_fwd", "s2_dgrad", "s2_wgrad"]
+        with wino.override(enabled=False):
+            assert t.classify(cg, wino, cg.SAE_CONV_FWD, g, False) == "s1_gather_256"
+            assert t.classify(cg, wino, cg.SAE_CONV_DGRAD, g, False) == "s1_gather_256"
+            assert t.classify(cg, wino, cg.SAE_CONV_FWD, small, False) == "s1_gather_128"
+            assert t.classify(cg, wino, cg.SAE_CONV_FWD, g, True) is None and t.classify(cg, wino, cg.SAE_CONV_WGRAD, g, True) == "s1_wgrad"
+            assert t.classify(cg, wino, cg.SAE_CONV_FWD, narrow, False) is None and t.classify(cg, wino, cg.SAE_CONV_WGRAD, narrow, False) is None
+            assert t.classify(cg, wino, cg.SAE_CONV_FWD, cg._Geom(16, 128, 64, 64, 256, 1, 1, 0, False, 1.0), False) is None
+            t.active = False
+            assert t.classify(cg, wino, cg.SAE_CONV_FWD, g, False) is None
     assert bench._quad_gather_tile(409, 128, 128, 128, 1) == "64x256" and bench._quad_gather_tile(409, 64, 64, 64, 1) == "64x256"
     assert bench._quad_gather_tile(128, 130, 128, 128, 1) is None          # rows not a multiple of four floats
-    assert t.classify(cg, cg.SAE_CONV_FWD, g, True) is None and t.classify(cg, cg.SAE_CONV_WGRAD, g, True) == "s1_wgrad"
-    narrow = cg._Geom(128, 32, 128, 128, 32, 3, 1, 1, False, 1.0)
-    assert t.classify(cg, cg.SAE_CONV_FWD, narrow, False) is None and t.classify(cg, cg.SAE_CONV_WGRAD, narrow, False) is None
-    s2 = cg._Geom(16, 128, 257, 257, 256, 3, 2, 0, False, 1.0)
-    assert [t.classify(cg, op, s2, False) for op in (cg.SAE_CONV_FWD, cg.SAE_CONV_DGRAD, cg.SAE_CONV_WGRAD)] == [
-        "s2_fwd", "s2_dgrad", "s2_wgrad"]
-    assert t.classify(cg, cg.SAE_CONV_FWD, cg._Geom(16, 128, 64, 64, 256, 1, 1, 0, False, 1.0), False) is None
-    t.active = False
-    assert t.classify(cg, cg.SAE_CONV_FWD, g, False) is None
