@@ -14,8 +14,17 @@ def sources():
     return sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".hip"))
 
 
+def includes():
+    """The parts csrc/conv2d.hip is #included from (csrc/*.inc; csrc/tuning/*.inc only exist in -DSAE_TUNING builds)."""
+    out = []
+    for d in (HERE, os.path.join(HERE, "tuning")):
+        if os.path.isdir(d):
+            out += sorted(os.path.join(d, f) for f in os.listdir(d) if f.endswith(".inc"))
+    return out
+
+
 def deps():
-    return sources() + [os.path.join(HERE, "sae_common.h"), os.path.join(ROOT, "include", "sae_hip.h")]
+    return sources() + includes() + [os.path.join(HERE, "sae_common.h"), os.path.join(ROOT, "include", "sae_hip.h")]
 
 
 def up_to_date():

@@ -49,3825 +49,21 @@ namespace {
         if (trace_knob) { fprintf(stderr, "sae-dispatch " __VA_ARGS__); fputc('\n', stderr); } \
     } while (0)
 
-// ------------------------------------------------------------------------------------------
-// weight re-layout
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void conv_wprep_kernel(const float* __restrict__ w,
-                                                            float* __restrict__ wp, int M, int C, int Mp,
-                                                            int Cp, int taps, int64_t sm, int64_t sc,
-                                                            int flip, float alpha,
-                                                            const float* __restrict__ rs_m,
-                                                            const float* __restrict__ rs_c) {
-    // rs_m[m] / rs_c[c] (either may be null): per-channel factors of the staged weight along the launch's output
-    // (m) or contraction (c) axis: the demodulation of ModulatedConv2d (stylegan2_layers.py:290-292) rides here
-    const int64_t total = (int64_t)taps * Cp * Mp;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * kBlock) {
-        const int m = (int)(i % Mp);
-        const int64_t t = i / Mp;
-        const int c = (int)(t % Cp);
-        const int tap = (int)(t / Cp);
-        float v = 0.0f;
-        if (m < M && c < C) {
-            v = alpha * w[m * sm + c * sc + (flip ? taps - 1 - tap : tap)];
-            if (rs_m) v *= rs_m[m];
-            if (rs_c) v *= rs_c[c];
-        }
-        wp[i] = v;
-    }
-}
+#include "conv2d_gather.inc"
 
-// ------------------------------------------------------------------------------------------
-// forward-type implicit GEMM (stride 1 or 2 gather)
-// ------------------------------------------------------------------------------------------
-// Profiling hook (tools/build_variant.sh ... -DSAE_CLOCK_PROBE, never in the product build): every workgroup of the
-// three fp32 MFMA kernels adds its duration in shader cycles (s_memtime) and in constant 100 MHz ticks (s_memrealtime)
-// to a device counter, from which tools/ab_conv.py --clock derives the shader clock the kernel actually ran at.
-#ifdef SAE_CLOCK_PROBE
-__device__ unsigned long long g_clock_probe[16];
-// [0] shader cycles, [1] 100 MHz ticks, [2] workgroups; phases of conv_igemm_kernel as seen by wave 0, in shader cycles:
-// [3] prologue, [4] MFMA phase, [5] wait at the barrier after it, [6] LDS stores, [7] wait at the second barrier,
-// [8] global-load issue, [9] epilogue
-#define SAE_CLOCK_BEGIN const unsigned long long cp_c0 = clock64(), cp_r0 = wall_clock64(); \
-    unsigned long long cp_t = cp_c0, cp_ph[7] = {0, 0, 0, 0, 0, 0, 0};
-#define SAE_CLOCK_PHASE(i) { const unsigned long long cp_n = clock64(); cp_ph[i] += cp_n - cp_t; cp_t = cp_n; }
-#define SAE_CLOCK_END                                                   \
-    if (threadIdx.x == 0) {                                             \
-        atomicAdd(&g_clock_probe[0], clock64() - cp_c0);                \
-        atomicAdd(&g_clock_probe[1], wall_clock64() - cp_r0);           \
-        atomicAdd(&g_clock_probe[2], 1ull);                             \
-        for (int cp_i = 0; cp_i < 7; ++cp_i) atomicAdd(&g_clock_probe[3 + cp_i], cp_ph[cp_i]); \
-    }
-#else
-#define SAE_CLOCK_BEGIN
-#define SAE_CLOCK_PHASE(i)
-#define SAE_CLOCK_END
-#endif
+#include "tuning/conv2d_ws.inc"
 
-// LDS operand reads of the gather kernels run this many (tap, channel pair) steps ahead of the MFMAs that use them
-#ifndef SAE_IGEMM_AHEAD
-#define SAE_IGEMM_AHEAD 1
-#endif
-constexpr int kIgemmAhead = SAE_IGEMM_AHEAD;
-// Workgroups per CU the 1x1 instantiations of the gather are compiled for (register budget 512 / this).  Their K loops are 4 - 16
-// chunks long and the layers are close to HBM-bound (fwd + residual 128 -> 256 @128^2 moves 1.7 GB for 43 GFLOP): a third
-// workgroup per CU hides more of each one's load -> store round trip than the dozen spilled registers cost -- same-box A/B
-// (tools/ab_conv.py, profiles/r4_ab_1x1_occupancy.txt): fwd 84 -> 92, 90 -> 93, 102 -> 111, 91 -> 101 TFLOP/s, dgrad 96 -> 104,
-// 102 -> 107, 107 -> 116, 92 -> 101; four (128 registers) spills the accumulators: 58 - 83.
-#ifndef SAE_IGEMM_1X1_WAVES
-#define SAE_IGEMM_1X1_WAVES 3
-#endif
+#include "conv2d_bx.inc"
 
-struct IgemmParams {
-    int N, C, H, W;       // input tensor; C = contraction channels
-    int M, OH, OW;        // logical output grid, M = output channels
-    int YH, YW;           // allocated output plane
-    int oys, oxs;         // output scatter multipliers (2 for the 1x1 stride-2 dgrad)
-    int Cp, Mp;           // padded dims of wp
-    int pad;              // iy = oy*S + ky - pad
-    int tw_log2, th_log2; // pixel tile = TN images x TH rows x TW cols
-    int tiles_x, tiles_y, tiles_n;
-    int chunks_per_split;   // split-K over input channels (blockIdx.z) for launches with few tiles
-    int64_t slab_stride;    // floats between the partial outputs of consecutive K slices
-    // fused epilogue (forward only): y = lrelu(acc + bias[m]) * act_scale when act != 0
-    const float* bias;
-    float act_slope, act_scale;
-    int act;
-    // fused residual merge (forward only): y = (acc + residual[same index as y]) * res_scale when residual != null -- the
-    // (out + skip) / sqrt(2) of a ResBlock (stylegan2_layers.py:689) done by the skip path's 1x1 conv on its way out
-    const float* residual;
-    float res_scale;
-    // fused NoiseInjection in front of the activation (MOD instantiations, forward only, with act != 0):
-    // y = lrelu((acc + noise_w[0] * noise[n][oy][ox]) + bias[m]) * act_scale -- StyledConv's conv -> noise -> FusedLeakyReLU
-    // (stylegan2_layers.py:398-405) without the pass over the conv's output.  noise: [N][OH][OW], noise_w: one float on the device
-    const float* noise;
-    const float* noise_w;
-    // style modulation of the INPUT (ModulatedConv2d, stylegan2_layers.py:280-286): when non-null, x[n][c][..] is
-    // multiplied by in_scale[n * C + c] on its way into LDS, so the modulated activation never exists in HBM
-    const float* in_scale;
-    // always 0.  The per-channel factor of a one-image tile is wave-uniform; indexing it with (lane & zmask) keeps the
-    // compiler from turning it into scalar-cache loads, whose out-of-order return shares the LDS wait counter
-    // (lgkmcnt) and would serialise the ds_read pipeline of the MFMA loop
-    int zmask;
-    // batched 1x1 launches (the sixteen transform-domain products of the Winograd route, csrc/winograd.hip): batch > 0 makes
-    // blockIdx.z a batch index instead of a K slice -- input, weights and output (slab_stride) advance by these many floats
-    int batch;
-    int64_t batch_x, batch_w;
-    int xcd_order;          // 1: XCD-aware tile order (see conv_igemm_kernel)
-    int vec_store;          // 1: LDS-transposed dwordx4 epilogue (see conv_igemm_kernel)
-};
-
-template <int KS, int S, int BN>
-struct PatchCap {
-    // worst case over TW,TH >= 4 (smallest tiles have the largest halo share)
-    static constexpr int value = (KS == 1) ? BN : (S == 1 ? (9 * BN) / 4 : (41 * BN) / 8);
-};
-
-// MOD: the input is style-modulated while staged (IgemmParams::in_scale); a separate instantiation, so the
-// un-modulated kernels of E / D / Dpatch carry no trace of it
-// QUAD (stride 1, rows a multiple of four floats wide; 3x3: tiles at least 16 wide, 1x1: pad 0): the input patch is staged
-// as 16-byte quads aligned in memory -- 3x3: the rows of the patch widened to [x0 - 4, x0 + TW + 4) -- CK channels' worth of quads
-// dealt out over the workgroup, so a chunk takes BN/64 dwordx4 loads and as many ds_write_b128 per thread instead of
-// 2.25 BN/32 dword ones.  A wave64 vector-memory instruction occupies the CU's address path for ~25-30 cycles whatever
-// its width (tools/probe/mfma_clock_probe.hip, profiles/r2_phase_clock_*.txt): the staging phase of a chunk is bound by the
-// NUMBER of such instructions, and the eight waves of a CU issue theirs at the same time.
-template <int KS, int S, int MI, int NI, int WM, int WN, int CK, bool MOD = false, bool QUAD = false>
-// (measured and dropped: __launch_bounds__(kBlock, 2) for the 64-accumulator tiles -- it brings the modulated stride-2
-// instantiations, 8 registers over budget, back to two waves per SIMD with 11-16 spilled registers; their time did not move
-// (5.16 ms per iteration either way) and the step got 0.7 % slower, the other instantiations' allocation changes with it)
-__global__ __launch_bounds__(kBlock, (KS == 1 ? (MOD ? 2 : SAE_IGEMM_1X1_WAVES) : 1)) void conv_igemm_kernel(const float* __restrict__ x,
-                                                            const float* __restrict__ wp,
-                                                            float* __restrict__ y, const IgemmParams p) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    static_assert(!QUAD || S == 1 || KS == 3, "quad staging: stride 1, or 3x3 stride 2");
-    // the fused residual merge (IgemmParams::residual) is compiled into the 1x1 kernels only -- the skip convs are its one
-    // use, and one register more sent the stride-2 3x3 gather from two waves per SIMD to one (27.0 -> 31.2 ms per iteration)
-    constexpr bool RESIDUAL = KS == 1;
-    constexpr int XQ0 = (KS == 3) ? 4 : 0;      // QUAD: columns added on either side of the tile
-    constexpr int T = KS * KS;
-    constexpr int BM = 32 * MI * WM;
-    constexpr int BN = 32 * NI * WN;
-    constexpr int XCAP = PatchCap<KS, S, BN>::value;
-    constexpr int PPT = QUAD ? 1 : (XCAP + kBlock - 1) / kBlock;      // patch slots per thread per channel
-    constexpr int QCAP = (S == 2) ? 5 * BN / 4 : (KS == 3) ? BN / 2 : BN / 4;   // QUAD: quads per channel accepted by the host
-    constexpr int QPT = QUAD ? (CK * QCAP + kBlock - 1) / kBlock : 1; // ... and quad slots per thread per chunk
-    constexpr int A_VEC = T * CK * BM / 4;                  // float4 per A chunk
-    constexpr int APT = (A_VEC + kBlock - 1) / kBlock;
-    // a channel row of Xs is XCAP patch floats + a 64-float dump area: threads whose slot lies beyond the patch store
-    // there, so no LDS store of the K loop is predicated (XROW = XCAP mod 64 keeps the bank pattern of the reads)
-    constexpr int XROW = XCAP + 64;
-    // one allocation: the LDS-transposed epilogue may use the whole of it (the weight tile alone is too small for the 1x1
-    // kernels' 32-channel chunks)
-    constexpr int AS = T * CK * BM, XS = CK * XROW;
-    __shared__ __attribute__((aligned(16))) float smem[AS + XS];
-    float* const As = smem;
-    float* const Xs = smem + AS;
-    // the tile's slice of the noise map (IgemmParams::noise): BN floats, shared by all BM rows of the tile, fetched once at the
-    // start (into registers, see below) and read from LDS in the epilogue -- a global load inside the store loop would make every store wait for its own
-    // round trip, and 8 - 16 quads per thread cannot be prefetched into registers (the fused residual's lesson)
-    __shared__ float zs[MOD ? BN : 1];
-
-    SAE_CLOCK_BEGIN
-    const int tid = threadIdx.x;
-    __builtin_assume(tid < kBlock);   // hipcc otherwise assumes up to 1024 and predicates the tail of the staging loops
-    const int lane = tid & 63, wid = tid >> 6;
-    const int wid_u = __builtin_amdgcn_readfirstlane(wid);   // the same value, known to be wave-uniform
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wid / WN, wn = wid % WN;
-
-    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
-    const int TN = BN >> (p.tw_log2 + p.th_log2);
-    // XCD-aware tile order: consecutive workgroup ids land on consecutive XCDs (id % 8), each with its own L2.  Giving
-    // XCD k the k-th CONTIGUOUS eighth of the tile list puts a tile and its spatial neighbours (which share halo rows
-    // and the 128-byte lines the halo columns straddle) behind the same L2, in flight at about the same time; in plain
-    // order every XCD fetched its own copy: 1.56 GB from the fabric for 0.54 GB of input (profiles/r2_pmc_f32.txt)
-    // With several M tiles (gridDim.y > 1) the M tile is the FASTEST index of the re-labelled order: the workgroups that
-    // read the same input patch run together behind one L2 (in launch order they are gridDim.x workgroups apart and each
-    // fetched its own copy from HBM: 1138 MB read for 537 MB of input with two M tiles, profiles/r3_pmc_f32.txt).
-    int bt = blockIdx.x;
-    int mt = blockIdx.y;
-    if (p.xcd_order) {
-        const int total = gridDim.x * gridDim.y;
-        if ((total & 7) == 0) {
-            const int lin = blockIdx.x + gridDim.x * blockIdx.y;           // dispatch order: x fastest
-            const int wk = (lin & 7) * (total >> 3) + (lin >> 3);
-            mt = wk % gridDim.y;
-            bt = wk / gridDim.y;
-        }
-    }
-    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
-    const int tiy = bt % p.tiles_y;
-    const int tin = bt / p.tiles_y;
-    const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
-    const int m0 = mt * BM;
-    // issued here, parked in registers across the K loop (one per thread at BN = 256) and written to LDS just before the
-    // epilogue: written to LDS right away, the wait for this load stood in front of the first chunk's loads of every workgroup
-    constexpr int ZPT = MOD ? (BN + kBlock - 1) / kBlock : 1;
-    [[maybe_unused]] float zreg[ZPT];
-    if constexpr (MOD) {
-        if (p.noise) {
-#pragma unroll
-            for (int k = 0; k < ZPT; ++k) {
-                const int pp = tid + kBlock * k;
-                const int px = pp & (TW - 1);
-                const int py = (pp >> p.tw_log2) & (TH - 1);
-                const int pn = pp >> (p.tw_log2 + p.th_log2);
-                const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
-                const bool ok = pp < BN && n < p.N && oy < p.OH && ox < p.OW;
-                const float v = p.noise[ok ? ((int64_t)n * p.OH + oy) * p.OW + ox : 0];
-                zreg[k] = ok ? v : 0.0f;
-            }
-        }
-    }
-
-    const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
-    const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
-    // QUAD, stride 2 (pad 0): rows widened to whole quads starting at column 2 x0 (4-byte aligned quads, see the wgrad
-    // kernel), kept de-interleaved in LDS like the dword path: even columns, then odd columns
-    const int RS = QUAD ? (S == 2 ? ((PW + 3) >> 2) << 2 : TW + 2 * XQ0) : PW;
-    const int HALFW = (QUAD && S == 2) ? RS >> 1 : (PW + 1) >> 1;
-    const int IP = PH * RS;
-    const int CP = TN * IP;           // staged floats per channel (<= XCAP, checked on the host)
-    const int HW = p.H * p.W;
-
-    // per-thread patch slots.  pbyte: BYTE offset of the slot's input element relative to (image n0, channel 0);
-    // padding / out-of-tile slots read element 0 instead (always valid memory) and are zeroed on their way into LDS
-    // (pok), so that no global load of the K loop sits in a divergent branch and every load is the
-    // "uniform 64-bit base + 32-bit lane offset" form with loop-invariant lane offsets.  xdst: LDS index within a
-    // channel row (the dump area for slots beyond the patch).
-    unsigned pbyte[PPT];
-    bool pok[PPT];
-    int xdst[PPT];
-    bool wave_has[PPT];     // wave-uniform: some lane of this wave has a patch element in slot s (else the slot is skipped)
-    int sidx[MOD ? (QUAD ? QPT : PPT) : 1];   // in_scale row of the slot's image
-    // QUAD: slot k of a thread is quad j = tid + kBlock * k of the chunk: channel j / QN, quad j % QN of the patch
-    // (image, row, quad column); qbyte is relative to (image n0, channel c0) and includes the channel
-    unsigned qbyte[QPT];
-    bool qok[QPT];
-    int qdst[QPT], qch[QPT];
-    [[maybe_unused]] int qdst2[(QUAD && S == 2) ? QPT : 1];   // stride 2: LDS index of the quad's odd columns
-    [[maybe_unused]] int qsh[(QUAD && S == 2) ? QPT : 1];     // ... and how far the quad was moved left to stay inside its row
-    if constexpr (QUAD) {
-        const int RQ = RS >> 2;                 // quads per patch row
-        const int QI = PH * RQ, QN = TN * QI;   // quads per image, per channel (<= QCAP, checked on the host)
-#pragma unroll
-        for (int kq = 0; kq < QPT; ++kq) {
-            const int j = tid + kBlock * kq;
-            const int ch = j / QN;
-            const int q = j - ch * QN;
-            const int pn = q / QI;
-            const int rem = q - pn * QI;
-            const int r = rem / RQ;
-            const int qc = rem - r * RQ;
-            const int iy = oy0 * S - p.pad + r, ix = (S == 2) ? ox0 * 2 + 4 * qc : ox0 - XQ0 + 4 * qc - (KS == 1 ? p.pad : 0);
-            const bool slot = ch < CK;
-            const bool in = slot && n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            qok[kq] = in;
-            qch[kq] = slot ? ch : CK - 1;
-            if constexpr (S == 2) {
-                const int ixc = ix + 4 <= p.W ? ix : p.W - 4;      // a quad that would run past its row is fetched from W - 4
-                qsh[kq] = in ? ix - ixc : 0;
-                qbyte[kq] = in ? 4u * (unsigned)((pn * p.C + ch) * HW + iy * p.W + ixc) : 0u;
-                const int d0 = slot ? ch * XROW + pn * IP + r * RS + 2 * qc
-                                    : ((tid >> 3) & (CK - 1)) * XROW + XCAP + 2 * (tid & 7);
-                qdst[kq] = d0;
-                qdst2[kq] = slot ? d0 + HALFW : d0 + 32;
-            } else {
-                qbyte[kq] = in ? 4u * (unsigned)((pn * p.C + ch) * HW + iy * p.W + ix) : 0u;
-                qdst[kq] = slot ? ch * XROW + 4 * q : ((tid >> 4) & (CK - 1)) * XROW + XCAP + 4 * (tid & 15);
-            }
-            if constexpr (MOD) sidx[kq] = in ? (n0 + pn) * p.C + ch : 0;
-        }
-        pbyte[0] = 0; pok[0] = false; xdst[0] = 0; wave_has[0] = false;
-    } else {
-        qbyte[0] = 0; qok[0] = false; qdst[0] = 0; qch[0] = 0;
-#pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-        const int e = tid + kBlock * s;
-        int off = -1;
-        if constexpr (MOD) sidx[s] = 0;
-        if (e < CP) {
-            const int pn = e / IP;
-            const int rem = e - pn * IP;
-            const int r = rem / RS;
-            const int cl = rem - r * RS;
-            int c = cl;
-            if (KS != 1 && S == 2) c = (cl < HALFW) ? 2 * cl : 2 * (cl - HALFW) + 1;
-            int iy, ix;
-            if (KS == 1) { iy = (oy0 + r) * S - p.pad; ix = (ox0 + c) * S - p.pad; }
-            else { iy = oy0 * S - p.pad + r; ix = ox0 * S - p.pad + c; }
-            if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-                off = pn * p.C * HW + iy * p.W + ix;
-                if constexpr (MOD) sidx[s] = (n0 + pn) * p.C;
-            }
-        }
-        pok[s] = off >= 0;
-        pbyte[s] = off >= 0 ? 4u * (unsigned)off : 0u;
-        xdst[s] = e < CP ? e : XCAP + (tid & 63);
-        // (not for the stride-2 gather: measured 116 vs 121 TFLOP/s with the skip, its third slot is the only sparse one)
-        wave_has[s] = (KS == 3 && S == 2) || wid_u * kWave + kBlock * s < CP;
-    }
-    }
-    // weight staging: float4 e4 = tid + kBlock * i of the chunk's [tap][ch][m] block; its byte offset relative to
-    // (channel c0, column m0) of wp is loop-invariant
-    unsigned abyte[APT];
-#pragma unroll
-    for (int i = 0; i < APT; ++i) {
-        const int e4 = tid + kBlock * i;
-        const int row = e4 / (BM / 4);       // tap*CK + ch
-        const int col4 = e4 - row * (BM / 4);
-        const int tap = (row / CK) < T ? row / CK : 0, ch = row - (row / CK) * CK;
-        abyte[i] = 4u * (unsigned)((tap * p.Cp + ch) * p.Mp + col4 * 4);
-    }
-    const bool one_image = TN == 1;          // the whole tile lies in image n0: one (uniform) factor per channel
-    float sc[MOD ? (QUAD ? QPT : CK) : 1];   // ... prefetched with the chunk (QUAD: the factor of each quad slot)
-
-    // per-lane LDS base of each N-tile pixel, and per-tap offsets
-    int pixbase[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int pp = (wn * NI + ni) * 32 + l31;
-        const int px = pp & (TW - 1);
-        const int py = (pp >> p.tw_log2) & (TH - 1);
-        const int pn = pp >> (p.tw_log2 + p.th_log2);
-        pixbase[ni] = pn * IP + ((KS == 1) ? py * RS : py * S * RS) + px + ((QUAD && KS == 3 && S == 1) ? 4 - p.pad : 0);
-    }
-    int tapoff[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int ky = t / KS, kx = t % KS;
-        tapoff[t] = (KS == 1) ? 0 : ky * RS + ((S == 2) ? (kx & 1) * HALFW + (kx >> 1) : kx);
-    }
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-    // (KS == 1 only: blockIdx.z as the batch index of a batched launch, see IgemmParams::batch)
-    int zb = 0;
-    if constexpr (KS == 1) { if (p.batch) zb = blockIdx.z; }
-    const float* xb = x + (int64_t)n0 * p.C * HW + zb * p.batch_x;
-    const float* const wpz = wp + zb * p.batch_w;
-    float xv[QUAD ? 1 : CK][PPT] = {};
-    f32x4 xq[QPT];
-    f32x4 av[APT];
-
-    auto load_chunk = [&](int c0) {
-        if constexpr (QUAD) {
-            const char* xc = reinterpret_cast<const char*>(xb + (int64_t)c0 * HW);
-#pragma unroll
-            for (int kq = 0; kq < QPT; ++kq) {
-                const bool ok = qok[kq] && c0 + qch[kq] < p.C;       // channels beyond C (last chunk): element 0, zeroed later
-                if constexpr (S == 2) {
-                    struct __attribute__((packed, aligned(4))) U4 { f32x4 v; };     // 4-byte aligned quad
-                    xq[kq] = reinterpret_cast<const U4*>(xc + (ok ? qbyte[kq] : 0u))->v;
-                } else {
-                    xq[kq] = *reinterpret_cast<const f32x4*>(xc + (ok ? qbyte[kq] : 0u));
-                }
-                if constexpr (MOD) sc[kq] = p.in_scale[ok ? sidx[kq] + c0 : 0];
-            }
-        } else {
-#pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            if (!wave_has[s]) continue;
-#pragma unroll
-            for (int ch = 0; ch < CK; ++ch) {
-                // channels beyond C (last chunk) re-read channel C - 1 and are zeroed in store_chunk
-                const int cc = (c0 + ch) < p.C ? c0 + ch : p.C - 1;
-                const char* xc = reinterpret_cast<const char*>(xb + (int64_t)cc * HW);
-                xv[ch][s] = *reinterpret_cast<const float*>(xc + pbyte[s]);
-            }
-        }
-        if constexpr (MOD) {
-            if (one_image) {
-                const float* srow = p.in_scale + n0 * p.C + (lane & p.zmask);
-#pragma unroll
-                for (int ch = 0; ch < CK; ++ch) sc[ch] = srow[(c0 + ch) < p.C ? c0 + ch : 0];
-            }
-        }
-        }
-        const char* wb = reinterpret_cast<const char*>(wpz + (int64_t)c0 * p.Mp + m0);
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e4 = tid + kBlock * i;
-            if (e4 < A_VEC) av[i] = *reinterpret_cast<const f32x4*>(wb + abyte[i]);
-        }
-    };
-    auto store_chunk = [&](int c0) {
-        if constexpr (QUAD) {
-#pragma unroll
-            for (int kq = 0; kq < QPT; ++kq) {
-                const bool ok = qok[kq] && c0 + qch[kq] < p.C;
-                f32x4 v = xq[kq];
-                if constexpr (MOD) v *= sc[kq];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
-                if constexpr (S == 2) {
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    const int sh = qsh[kq];      // fetched sh floats to the left of its place: the tail lies beyond the row
-                    const f32x4 u = v;
-                    if (sh == 1) v = f32x4{u[1], u[2], u[3], 0.0f};
-                    if (sh == 2) v = f32x4{u[2], u[3], 0.0f, 0.0f};
-                    if (sh == 3) v = f32x4{u[3], 0.0f, 0.0f, 0.0f};
-                    *reinterpret_cast<f32x2*>(Xs + qdst[kq]) = f32x2{v[0], v[2]};      // even columns
-                    *reinterpret_cast<f32x2*>(Xs + qdst2[kq]) = f32x2{v[1], v[3]};     // odd columns
-                } else {
-                    *reinterpret_cast<f32x4*>(Xs + qdst[kq]) = v;
-                }
-            }
-        } else {
-        if constexpr (MOD) {
-            if (one_image) {
-#pragma unroll
-                for (int ch = 0; ch < CK; ++ch)
-#pragma unroll
-                    for (int s = 0; s < PPT; ++s) xv[ch][s] *= sc[ch];
-            } else {     // small images, several per tile: the factor depends on the slot's image
-#pragma unroll
-                for (int ch = 0; ch < CK; ++ch) {
-                    const int cc = (c0 + ch) < p.C ? c0 + ch : 0;
-#pragma unroll
-                    for (int s = 0; s < PPT; ++s) xv[ch][s] *= p.in_scale[sidx[s] + cc];
-                }
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            if (!wave_has[s]) continue;
-#pragma unroll
-            for (int ch = 0; ch < CK; ++ch) {
-                const bool ch_ok = (c0 + ch) < p.C;
-                Xs[ch * XROW + xdst[s]] = (ch_ok && pok[s]) ? xv[ch][s] : 0.0f;
-            }
-        }
-        }
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e4 = tid + kBlock * i;
-            if (e4 < A_VEC) *reinterpret_cast<f32x4*>(As + e4 * 4) = av[i];
-        }
-    };
-
-    const int c_begin = ((KS == 1 && p.batch) ? 0 : (int)blockIdx.z) * p.chunks_per_split * CK;
-    int c_end = c_begin + p.chunks_per_split * CK;
-    if (c_end > p.Cp) c_end = p.Cp;
-    load_chunk(c_begin);
-    SAE_CLOCK_PHASE(0)
-    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
-        __syncthreads();   // everyone finished reading the previous chunk
-        SAE_CLOCK_PHASE(2)
-        store_chunk(c0);
-        SAE_CLOCK_PHASE(3)
-        __syncthreads();
-        SAE_CLOCK_PHASE(4)
-        // in flight under the MFMAs below (issuing them one per MFMA step instead measured the same or slower)
-        if (c0 + CK < c_end) load_chunk(c0 + CK);
-        SAE_CLOCK_PHASE(5)
-        // One step = one (tap, channel pair): MI x NI MFMAs on operands that were read from LDS kIgemmAhead steps
-        // earlier (a ring of register sets), so a wave's ds_reads are in flight under its own MFMAs instead of being
-        // waited for in front of each group.  The scheduling barriers keep the compiler from sinking the reads back
-        // to their first use; the accumulation order (tap-major, then channel pair) is unchanged.
-        constexpr int KK = CK / 2;
-        constexpr int NSTEP = T * KK;
-        constexpr int AH = kIgemmAhead, RING = AH + 1;
-        float ra[RING][MI], rb[RING][NI];
-        auto fetch = [&](int s, float (&a)[MI], float (&b)[NI]) {
-            const int t = s / KK, ch = 2 * (s % KK) + half;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = As[(t * CK + ch) * BM + (wm * MI + mi) * 32 + l31];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = Xs[ch * XROW + pixbase[ni] + tapoff[t]];
-        };
-#pragma unroll
-        for (int s = 0; s < AH; ++s) fetch(s, ra[s % RING], rb[s % RING]);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            if (s + AH < NSTEP) fetch(s + AH, ra[(s + AH) % RING], rb[(s + AH) % RING]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s % RING][mi], rb[s % RING][ni],
-                                                                       acc[mi][ni], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        SAE_CLOCK_PHASE(1)
-    }
-
-    // Vector epilogue (IgemmParams::vec_store; output rows a multiple of four floats, 16-byte aligned, no scatter): the
-    // accumulators go through LDS once, 32 * WM rows at a time, and leave as dwordx4 stores of four consecutive pixels --
-    // 16 instead of 64 vector-memory instructions per wave and tile (the eight waves of a CU reach their epilogues
-    // together, and a wave64 store occupies the address path as long as a load does).
-    [[maybe_unused]] float noise_wv = 0.0f;
-    if constexpr (MOD) {
-        if (p.noise) {
-            noise_wv = p.noise_w[0];
-#pragma unroll
-            for (int k = 0; k < ZPT; ++k)
-                if (tid + kBlock * k < BN) zs[tid + kBlock * k] = zreg[k];
-            __syncthreads();
-        }
-    }
-    constexpr int LDC = BN + 4;
-    constexpr bool VEC_OK = AS + XS >= 32 * WM * LDC;         // the staging buffers hold one pass
-    if constexpr (VEC_OK) {
-        if (p.vec_store) {
-            constexpr int QROW = BN / 4;                        // quads per tile row
-            constexpr int VPT = 32 * WM * QROW / kBlock;        // quads per thread per pass
-            float* Cs = As;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                // the residual of this pass is fetched BEFORE the LDS round trip (its addresses do not depend on it): issued
-                // after it, every store waited for its own load -- the 1x1 skip convs (K loops of 4-16 chunks) are all
-                // epilogue and ran at 44 TFLOP/s
-                [[maybe_unused]] f32x4 resq[RESIDUAL ? VPT : 1];
-                if (RESIDUAL && p.residual) {
-#pragma unroll
-                    for (int v = 0; v < VPT; ++v) {
-                        const int qi = tid + kBlock * v;
-                        const int row = qi / QROW, qx = qi - row * QROW;
-                        const int m = m0 + ((row >> 5) * MI + mi) * 32 + (row & 31);
-                        const int pp = 4 * qx;
-                        const int px = pp & (TW - 1);
-                        const int py = (pp >> p.tw_log2) & (TH - 1);
-                        const int pn = pp >> (p.tw_log2 + p.th_log2);
-                        const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
-                        const bool ok = m < p.M && n < p.N && oy < p.OH && ox < p.OW;
-                        const int64_t yi = ok ? (((int64_t)n * p.M + m) * p.YH + oy) * p.YW + ox : 0;
-                        resq[v] = *reinterpret_cast<const f32x4*>(p.residual + yi);
-                    }
-                }
-                __syncthreads();       // the K loop's (or the previous pass's) readers are done with As
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + (wn * NI + ni) * 32 + l31] = acc[mi][ni][r];
-                __syncthreads();
-#pragma unroll
-                for (int v = 0; v < VPT; ++v) {
-                    const int qi = tid + kBlock * v;
-                    const int row = qi / QROW, qx = qi - row * QROW;
-                    const int m = m0 + ((row >> 5) * MI + mi) * 32 + (row & 31);
-                    const int pp = 4 * qx;
-                    const int px = pp & (TW - 1);
-                    const int py = (pp >> p.tw_log2) & (TH - 1);
-                    const int pn = pp >> (p.tw_log2 + p.th_log2);
-                    const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
-                    if (m < p.M && n < p.N && oy < p.OH && ox < p.OW) {
-                        f32x4 c = *reinterpret_cast<const f32x4*>(Cs + row * LDC + 4 * qx);
-                        if (p.act) {   // bias + leaky-ReLU of the following FusedLeakyReLU, fused_bias_act_kernel.cu:30,47
-                            const float bv = p.bias ? p.bias[m] : 0.0f;
-                            if constexpr (MOD) {
-                                if (p.noise) {   // (image + weight * noise) + bias, the reference's association (:340-351)
-                                    const f32x4 z = *reinterpret_cast<const f32x4*>(zs + 4 * qx);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) c[e] = c[e] + noise_wv * z[e];
-                                }
-                            }
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float t = c[e] + bv;
-                                c[e] = ((t > 0.0f) ? t : t * p.act_slope) * p.act_scale;
-                            }
-                        }
-                        const int64_t yi = (((int64_t)n * p.M + m) * p.YH + oy) * p.YW + ox;
-                        if constexpr (RESIDUAL)
-                            if (p.residual) c = (c + resq[v]) * p.res_scale;
-                        *reinterpret_cast<f32x4*>(y + (int64_t)blockIdx.z * p.slab_stride + yi) = c;
-                    }
-                }
-            }
-            SAE_CLOCK_PHASE(6)
-            SAE_CLOCK_END
-            return;
-        }
-    }
-    // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
-    float bv[MI][16];        // bias of the rows this lane holds (fetched once, not per pixel tile)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            bv[mi][r] = (p.act && p.bias && m < p.M) ? p.bias[m] : 0.0f;
-        }
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int pp = (wn * NI + ni) * 32 + l31;
-        const int px = pp & (TW - 1);
-        const int py = (pp >> p.tw_log2) & (TH - 1);
-        const int pn = pp >> (p.tw_log2 + p.th_log2);
-        const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
-        if (n < p.N && oy < p.OH && ox < p.OW) {
-            float* yb = y + (int64_t)blockIdx.z * p.slab_stride +
-                        ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                // the 16 residual values of this accumulator tile are fetched together, branch-free (rows beyond M re-read
-                // row M - 1), before any of them is used: a load inside the store loop made every store wait for its own
-                // round trip (the 1x1 skip convs ran at 40 TFLOP/s)
-                [[maybe_unused]] float rv[RESIDUAL ? 16 : 1];
-                if (RESIDUAL && p.residual) {     // (only with oys == oxs == 1 and no K split: y and residual share indices)
-                    const float* rb = p.residual + ((int64_t)n * p.M * p.YH + oy) * p.YW + ox;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        rv[r] = rb[(int64_t)(m < p.M ? m : p.M - 1) * p.YH * p.YW];
-                    }
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (m < p.M) {
-                        float v = acc[mi][ni][r];
-                        if (p.act) {   // bias + leaky-ReLU of the following FusedLeakyReLU, fused_bias_act_kernel.cu:30,47
-                            if constexpr (MOD) {
-                                if (p.noise) v = v + noise_wv * zs[pp];
-                            }
-                            v += bv[mi][r];
-                            v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
-                        }
-                        if constexpr (RESIDUAL)
-                            if (p.residual) v = (v + rv[r]) * p.res_scale;
-                        yb[(int64_t)m * p.YH * p.YW] = v;
-                    }
-                }
-            }
-        }
-    }
-    SAE_CLOCK_PHASE(6)
-    SAE_CLOCK_END
-}
+#include "conv2d_bx8.inc"
 
 #ifdef SAE_TUNING
-// ------------------------------------------------------------------------------------------
-// Wave-specialised form of the quad-staged 3x3 stride-1 gather ("ws"): six waves per workgroup -- four CONSUMER waves with the
-// K loop of conv_igemm_kernel and not one vector-memory instruction in it, two PRODUCER waves that do nothing but move the next
-// chunk global -> LDS by DMA (global_load_lds_dwordx4) into the other of two staging buffers.  One barrier per chunk.
-//
-// Why: in conv_igemm_kernel every wave issues its share of the chunk's loads (9 - 11 dwordx4 per 144 MFMAs) between two
-// barriers; a wave64 vector-memory instruction occupies the CU's one address path for ~28 cycles and the eight waves of a CU
-// issue theirs together, so a wave spends 14 - 17 % of its time in that phase and 4 - 5 % writing LDS
-// (profiles/r2_phase_clock_quad.txt); the probe kernel loses 8 % of the matrix pipe to the loads alone
-// (profiles/r2_mfma_clock_probe.txt: barrier only 0.977, loads + barrier 0.899).  The 8-wave kernel of round 2
-// (conv_igemm_f8_kernel) moved the weights to DMA but left every wave its input loads and ran one workgroup per CU: 3 % slower.
-// Here the MFMA waves wait for nothing but the barrier, and two workgroups per CU (3 waves per SIMD, 168 registers) still
-// cover each other's prologue and epilogue.
-//
-//   * LDS: two buffers of [A: 9 taps x 8 channels x BM][X: 8 channel rows of XCAP + 64], the layouts of conv_igemm_kernel
-//     (QUAD): 2 x 38.9 KB for the 64 x 256 tile, two workgroups per CU = 156 of the 160 KB;
-//   * DMA data lands lane-linear (lane l of an instruction writes 16 bytes at base + 16 l): an A instruction is 64 consecutive
-//     quads of the chunk's [tap][channel][BM] block, an X instruction 64 consecutive quads of one channel's patch.  Padding
-//     quads (outside the image or the batch) are MASKED lanes: the patch areas are zeroed once and those cells never written;
-//     the rows of channels beyond C (last chunk) are zero-filled by the producer with LDS stores;
-//   * ordering: the producer waits for its own vmcnt(0), then the barrier; a consumer that has passed the barrier reads landed
-//     data.  The buffer a producer overwrites during chunk c is the one every consumer finished before the previous barrier;
-//   * MFMA operand order, accumulation order and the LDS-transposed epilogue are those of conv_igemm_kernel: bit-identical
-//     results (tests/test_ws_gather.py).  The producers take part in the epilogue's barriers and nothing else of it.
-// Plain (not style-modulated) launches with the vector epilogue and no K split; everything else stays on conv_igemm_kernel.
-//
-// MEASURED (same box, tools/ab_conv.py, profiles/r4_ab_wave_specialised.txt): 128 -> 128 @256^2 125.2 vs 131.0 TFLOP/s, 256 -> 256
-// @128^2 128.4 vs 134.1, 64 -> 64 @64^2 (128 images) 117.4 vs 124.1: 4 - 5 % SLOWER than conv_igemm_kernel.  (A first version that
-// computed both roles' state up front needed 168 registers; six waves of that size do not fit a CU twice whatever the SIMD
-// placement, one workgroup per CU ran: 116.4.  With the roles as two programs it is 95.)  The loads the MFMA waves no longer issue
-// were not what held the matrix pipe at 0.83: two workgroups per CU already cover each other's staging, and this form adds a
-// barrier that couples six waves per chunk.  A recorded experiment like conv_igemm_f8_kernel: compiled into tuning builds only
-// (-DSAE_TUNING, SAE_WS=1); the product library does not contain it.
-// ------------------------------------------------------------------------------------------
-constexpr int kBlockWs = 384;
-#ifndef SAE_WS_WAVES
-#define SAE_WS_WAVES 3          // waves per SIMD the kernel is compiled for (512 / this registers)
+#include "tuning/conv2d_f8.inc"
 #endif
-template <int MI, int NI, int WM, int WN>
-__global__ __launch_bounds__(kBlockWs, SAE_WS_WAVES) void conv_igemm_ws_kernel(const float* __restrict__ x,
-                                                                  const float* __restrict__ wp,
-                                                                  float* __restrict__ y, const IgemmParams p) {
-    static_assert(WM * WN == 4, "4 consumer waves per workgroup");
-    constexpr int T = 9, CK = 8, NPROD = 2;
-    constexpr int BM = 32 * MI * WM;
-    constexpr int BN = 32 * NI * WN;
-    constexpr int XCAP = PatchCap<3, 1, BN>::value;
-    constexpr int QCAP = BN / 2;                               // quads per channel accepted by the host
-    constexpr int XK = QCAP / kWave;                           // X DMA instructions per channel
-    constexpr int XROW = XCAP + 64;
-    constexpr int AS = T * CK * BM, XS = CK * XROW, BUF = AS + XS;
-    constexpr int A_INSTR = AS / 4 / kWave;                    // A DMA instructions per chunk
-    constexpr int APW = (A_INSTR + NPROD - 1) / NPROD;         // ... per producer wave
-    static_assert((AS / 4) % kWave == 0 && QCAP % kWave == 0 && XCAP % 4 == 0 && BUF % 4 == 0, "whole wave DMAs");
-    __shared__ __attribute__((aligned(16))) float smem[2 * BUF];
 
-    const int tid = threadIdx.x;
-    __builtin_assume(tid < kBlockWs);
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool producer = wid >= 4;
-    const int pw = wid - 4;                                    // producer index (0, 1)
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = (wid & 3) / WN, wn = (wid & 3) % WN;
+#include "conv2d_transposed.inc"
 
-    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
-    const int TN = BN >> (p.tw_log2 + p.th_log2);
-    int bt = blockIdx.x;
-    int mt = blockIdx.y;
-    if (p.xcd_order) {                                         // see conv_igemm_kernel
-        const int total = gridDim.x * gridDim.y;
-        if ((total & 7) == 0) {
-            const int lin = blockIdx.x + gridDim.x * blockIdx.y;
-            const int wk = (lin & 7) * (total >> 3) + (lin >> 3);
-            mt = wk % gridDim.y;
-            bt = wk / gridDim.y;
-        }
-    }
-    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
-    const int tiy = bt % p.tiles_y;
-    const int tin = bt / p.tiles_y;
-    const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
-    const int m0 = mt * BM;
-
-    const int PH = TH + 2;
-    const int RS = TW + 8;                                     // patch row = input columns [x0 - 4, x0 + TW + 4)
-    const int RQ = RS >> 2;
-    const int IP = PH * RS;
-    const int QI = PH * RQ, QN = TN * QI;                      // quads per image, per channel (<= QCAP, host)
-    const int HW = p.H * p.W;
-
-    // the patch areas of both buffers start as zeros: a padding quad is a masked DMA lane, its cell is never written
-    for (int i = tid; i < 2 * (XS / 4); i += kBlockWs) {
-        const int b = i / (XS / 4), e = i - b * (XS / 4);
-        *reinterpret_cast<f32x4*>(smem + b * BUF + AS + 4 * e) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    }
-
-    __syncthreads();                             // the zeros are in place
-
-    // The two roles are two straight-line programs with the same sequence of barriers (one per chunk, then two per epilogue
-    // pass); nothing computed for one role is live in the other, so the register allocation is the larger of the two, not their sum.
-    if (producer) {
-        // where this lane's cell of each DMA instruction comes from
-        unsigned qoff[XK];           // X: float offset of quad q = lane + 64 k relative to (image n0, the channel's plane)
-        bool qok[XK];
-        unsigned aoff[APW];          // A: float offset of cell e = 64 j + lane (j = pw + NPROD i) relative to (channel c0, column m0) of wp
-#pragma unroll
-        for (int k = 0; k < XK; ++k) {
-            const int q = lane + kWave * k;
-            const int pn = q / QI;
-            const int rem = q - pn * QI;
-            const int r = rem / RQ;
-            const int qc = rem - r * RQ;
-            const int iy = oy0 - p.pad + r, ix = ox0 - 4 + 4 * qc;
-            const bool in = q < QN && n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            qok[k] = in;
-            qoff[k] = in ? (unsigned)(pn * p.C * HW + iy * p.W + ix) : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < APW; ++i) {
-            const int e = (pw + NPROD * i) * kWave + lane;
-            const int row = e / (BM / 4), col4 = e - row * (BM / 4);
-            const int tap = (row / CK) < T ? row / CK : 0, ch = row - (row / CK) * CK;
-            aoff[i] = (unsigned)((tap * p.Cp + ch) * p.Mp + col4 * 4);
-        }
-        const float* xb = x + (int64_t)n0 * p.C * HW;
-        // iteration c0 (from -CK) stages chunk c0 + CK into the buffer the consumers are NOT reading
-        int buf = 0;                             // the buffer of chunk c0
-        for (int c0 = -CK; c0 < p.Cp; c0 += CK) {
-            const int cn = c0 + CK;
-            if (cn < p.Cp) {
-                float* Ab = smem + (c0 < 0 ? 0 : buf ^ 1) * BUF;
-                float* Xb = Ab + AS;
-                const float* wb = wp + (int64_t)cn * p.Mp + m0;
-#pragma unroll
-                for (int i = 0; i < APW; ++i) {
-                    const int j = pw + NPROD * i;
-                    // (source and destination through local pointers of non-dependent type: with `wb + aoff[i]` as the argument --
-                    // an element of an array whose size depends on the template parameters -- the HOST pass of hipcc drops the
-                    // kernel's stub without a diagnostic and the library fails to load with an undefined symbol)
-                    const float* src = wb + aoff[i];
-                    float* dst = Ab + j * kWave * 4;
-                    if (j < A_INSTR)
-                        __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                }
-#pragma unroll
-                for (int h = 0; h < CK / NPROD; ++h) {
-                    const int ch = NPROD * h + pw;
-                    float* row = Xb + ch * XROW;
-                    if (cn + ch < p.C) {
-                        const float* xc = xb + (int64_t)(cn + ch) * HW;
-#pragma unroll
-                        for (int k = 0; k < XK; ++k) {
-                            const float* src = xc + qoff[k];
-                            float* dst = row + kWave * 4 * k;
-                            if (qok[k])
-                                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-                        }
-                    } else {        // a channel beyond C (the last chunk's tail): zeros, whatever an earlier chunk left there
-#pragma unroll
-                        for (int k = 0; k < XK; ++k)
-                            *reinterpret_cast<f32x4*>(row + 4 * (lane + kWave * k)) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                    }
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's DMA has landed (the barrier publishes it)
-            __syncthreads();
-            if (c0 >= 0) buf ^= 1;
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {        // the consumers' epilogue passes
-            __syncthreads();
-            __syncthreads();
-        }
-        return;
-    }
-
-    // ---- consumer (conv_igemm_kernel, QUAD)
-    int pixbase[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int pp = (wn * NI + ni) * 32 + l31;
-        const int px = pp & (TW - 1);
-        const int py = (pp >> p.tw_log2) & (TH - 1);
-        const int pn = pp >> (p.tw_log2 + p.th_log2);
-        pixbase[ni] = pn * IP + py * RS + px + 4 - p.pad;
-    }
-    int tapoff[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) tapoff[t] = (t / 3) * RS + (t % 3);
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-    __syncthreads();                             // chunk 0 is staged (the producers' iteration c0 = -CK)
-    int buf = 0;
-    for (int c0 = 0; c0 < p.Cp; c0 += CK) {
-        const float* As = smem + buf * BUF;
-        const float* Xs = As + AS;
-        constexpr int KK = CK / 2;
-        constexpr int NSTEP = T * KK;
-        constexpr int AH = kIgemmAhead, RING = AH + 1;
-        float ra[RING][MI], rb[RING][NI];
-        auto fetch = [&](int s, float (&a)[MI], float (&b)[NI]) {
-            const int t = s / KK, ch = 2 * (s % KK) + half;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = As[(t * CK + ch) * BM + (wm * MI + mi) * 32 + l31];
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = Xs[ch * XROW + pixbase[ni] + tapoff[t]];
-        };
-#pragma unroll
-        for (int s = 0; s < AH; ++s) fetch(s, ra[s % RING], rb[s % RING]);
-#pragma unroll
-        for (int s = 0; s < NSTEP; ++s) {
-            if (s + AH < NSTEP) fetch(s + AH, ra[(s + AH) % RING], rb[(s + AH) % RING]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[s % RING][mi], rb[s % RING][ni],
-                                                                       acc[mi][ni], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        buf ^= 1;
-    }
-
-    // ---- epilogue (conv_igemm_kernel's vector epilogue; p.vec_store is a launch condition)
-    constexpr int LDC = BN + 4;
-    static_assert(BUF >= 32 * WM * LDC, "one epilogue pass fits a staging buffer");
-    constexpr int QROW = BN / 4;
-    constexpr int VPT = 32 * WM * QROW / kBlock;
-    float* Cs = smem;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        __syncthreads();
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + (wn * NI + ni) * 32 + l31] = acc[mi][ni][r];
-        __syncthreads();
-#pragma unroll
-        for (int v = 0; v < VPT; ++v) {
-            const int qi = tid + kBlock * v;
-            const int row = qi / QROW, qx = qi - row * QROW;
-            const int m = m0 + ((row >> 5) * MI + mi) * 32 + (row & 31);
-            const int pp = 4 * qx;
-            const int px = pp & (TW - 1);
-            const int py = (pp >> p.tw_log2) & (TH - 1);
-            const int pn = pp >> (p.tw_log2 + p.th_log2);
-            const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
-            if (m < p.M && n < p.N && oy < p.OH && ox < p.OW) {
-                f32x4 c = *reinterpret_cast<const f32x4*>(Cs + row * LDC + 4 * qx);
-                if (p.act) {
-                    const float bv = p.bias ? p.bias[m] : 0.0f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float t = c[e] + bv;
-                        c[e] = ((t > 0.0f) ? t : t * p.act_slope) * p.act_scale;
-                    }
-                }
-                const int64_t yi = (((int64_t)n * p.M + m) * p.YH + oy) * p.YW + ox;
-                *reinterpret_cast<f32x4*>(y + yi) = c;
-            }
-        }
-    }
-}
-
-#endif   // SAE_TUNING
-
-// ------------------------------------------------------------------------------------------
-// "bx" arithmetic (opt-in, sae_set_conv_math(1)): fp32 products on the bf16 matrix cores.
-//
-// Every fp32 operand is split exactly into three bf16 pieces a = a0 + a1 + a2 (round-to-nearest
-// residual chain: |a1| <= 2^-9 |a|, |a2| <= 2^-18 |a|, remainder <= 2^-27 |a|).  A product block is
-// six v_mfma_f32_32x32x16_bf16 (a0b2, a2b0, a1b1, a0b1, a1b0, a0b0; the three dropped cross terms are
-// <= 2^-26 |ab|) accumulated in fp32: measured error against fp64 equals the exact-fp32 MFMA chain
-// (5.0e-7 vs 6.0e-7 rel-L2 at K = 1152, tools/probe/bf16x6_probe.hip) at 6/16 of its matrix-pipe time.
-//
-// Layout: a 16-byte LDS/global cell holds the 8 channels of one K-chunk for one (tap, split, m) of A
-// or one (split, patch position) of B, i.e. exactly one lane's MFMA operand.  The 16 k of an
-// instruction are 8 channels x 2 taps (lanes 0-31 tap 2g, lanes 32-63 tap 2g+1); the ninth tap pairs
-// with an all-zero A cell.  Weights are split once per call by conv_wprep_bx_kernel into
-// wpb[m-tile][chunk][tap][split][m][8 ch], so A staging is a linear 16-byte copy; input patch
-// elements are split when they are written to LDS.
-// ------------------------------------------------------------------------------------------
-__device__ inline void split3_bf16(const float (&v)[8], bf16x8& s0, bf16x8& s1, bf16x8& s2) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const __bf16 h = (__bf16)v[e];
-        float r = v[e] - (float)h;
-        const __bf16 m = (__bf16)r;
-        r -= (float)m;
-        s0[e] = h; s1[e] = m; s2[e] = (__bf16)r;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void conv_wprep_bx_kernel(const float* __restrict__ w,
-                                                               u32x4* __restrict__ wpb, int M, int C, int Mp,
-                                                               int Cp, int BM, int64_t sm, int64_t sc, int flip,
-                                                               float alpha, const float* __restrict__ rs_m,
-                                                               const float* __restrict__ rs_c) {
-    const int nchunks = Cp / 8;
-    const int64_t total = (int64_t)(Mp / BM) * nchunks * 9 * BM;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * kBlock) {
-        const int ml = (int)(i % BM);
-        int64_t t = i / BM;
-        const int tap = (int)(t % 9); t /= 9;
-        const int chunk = (int)(t % nchunks);
-        const int mtile = (int)(t / nchunks);
-        const int m = mtile * BM + ml;
-        float v[8];
-#pragma unroll
-        for (int ch = 0; ch < 8; ++ch) {
-            const int c = chunk * 8 + ch;
-            v[ch] = (m < M && c < C) ? alpha * w[m * sm + c * sc + (flip ? 8 - tap : tap)] : 0.0f;
-            if (m < M && c < C) {
-                if (rs_m) v[ch] *= rs_m[m];
-                if (rs_c) v[ch] *= rs_c[c];
-            }
-        }
-        bf16x8 s0, s1, s2;
-        split3_bf16(v, s0, s1, s2);
-        u32x4* cell = wpb + (((int64_t)mtile * nchunks + chunk) * 9 + tap) * 3 * BM + ml;
-        cell[0] = __builtin_bit_cast(u32x4, s0);
-        cell[BM] = __builtin_bit_cast(u32x4, s1);
-        cell[2 * BM] = __builtin_bit_cast(u32x4, s2);
-    }
-}
-
-template <int S, int MI, int NI, int WM, int WN>
-__global__ __launch_bounds__(kBlock) void conv_igemm_bx_kernel(const float* __restrict__ x,
-                                                               const u32x4* __restrict__ wpb,
-                                                               float* __restrict__ y, const IgemmParams p) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int T = 9, CK = 8;
-    constexpr int BM = 32 * MI * WM;
-    constexpr int BN = 32 * NI * WN;
-    constexpr int XCAP = PatchCap<3, S, BN>::value;
-    constexpr int PPT = (XCAP + kBlock - 1) / kBlock;      // patch positions per thread
-    constexpr int A_CELLS = T * 3 * BM;                     // 16-byte cells per A chunk
-    constexpr int APT = (A_CELLS + kBlock - 1) / kBlock;
-    __shared__ u32x4 As[A_CELLS + 1];                       // + the all-zero cell
-    __shared__ u32x4 Xs[3 * XCAP];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wid / WN, wn = wid % WN;
-
-    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
-    const int TN = BN >> (p.tw_log2 + p.th_log2);
-    int bt = blockIdx.x;
-    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
-    const int tiy = bt % p.tiles_y;
-    const int tin = bt / p.tiles_y;
-    const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
-    const int m0 = blockIdx.y * BM;
-
-    const int PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3;
-    const int HALFW = (PW + 1) >> 1;      // stride 2: patch columns are stored de-interleaved, even | odd
-    const int IP = PH * PW;
-    const int CP = TN * IP;           // staged positions (<= XCAP, checked on the host)
-    const int HW = p.H * p.W;
-
-    int poff[PPT];
-#pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-        const int e = tid + kBlock * s;
-        int off = -1;
-        if (e < CP) {
-            const int pn = e / IP;
-            const int rem = e - pn * IP;
-            const int r = rem / PW;
-            const int cl = rem - r * PW;
-            const int c = (S == 2) ? (cl < HALFW ? 2 * cl : 2 * (cl - HALFW) + 1) : cl;
-            const int iy = oy0 * S - p.pad + r, ix = ox0 * S - p.pad + c;
-            if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                off = pn * p.C * HW + iy * p.W + ix;
-        }
-        poff[s] = off;
-    }
-
-    // per-lane LDS cell of each N-tile pixel; per-lane tap offset of each tap pair
-    int pixbase[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int pp = (wn * NI + ni) * 32 + l31;
-        const int px = pp & (TW - 1);
-        const int py = (pp >> p.tw_log2) & (TH - 1);
-        const int pn = pp >> (p.tw_log2 + p.th_log2);
-        pixbase[ni] = pn * IP + py * S * PW + px;
-    }
-    int boff[5], aoff[5];
-#pragma unroll
-    for (int g = 0; g < 5; ++g) {
-        const int t = (g < 4) ? 2 * g + half : 8;
-        boff[g] = (t / 3) * PW + ((S == 2) ? ((t % 3) & 1) * HALFW + ((t % 3) >> 1) : (t % 3));
-        aoff[g] = (g == 4 && half) ? A_CELLS : t * 3 * BM + wm * MI * 32 + l31;
-    }
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-    const float* xb = x + (int64_t)n0 * p.C * HW;
-    const u32x4* wt = wpb + (int64_t)blockIdx.y * (p.Cp / CK) * A_CELLS;
-    float xv[CK][PPT];
-    u32x4 av[APT];
-
-    auto load_chunk = [&](int c0) {
-#pragma unroll
-        for (int ch = 0; ch < CK; ++ch) {
-            const bool ch_ok = (c0 + ch) < p.C;
-            const float* xc = xb + (int64_t)(c0 + ch) * HW;
-#pragma unroll
-            for (int s = 0; s < PPT; ++s) xv[ch][s] = (ch_ok && poff[s] >= 0) ? xc[poff[s]] : 0.0f;
-        }
-        const u32x4* wc = wt + (int64_t)(c0 / CK) * A_CELLS;
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e = tid + kBlock * i;
-            if (e < A_CELLS) av[i] = wc[e];
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const int e = tid + kBlock * s;
-            if (e < CP) {
-                float v[CK];
-#pragma unroll
-                for (int ch = 0; ch < CK; ++ch) v[ch] = xv[ch][s];
-                bf16x8 s0, s1, s2;
-                split3_bf16(v, s0, s1, s2);
-                Xs[e] = __builtin_bit_cast(u32x4, s0);
-                Xs[XCAP + e] = __builtin_bit_cast(u32x4, s1);
-                Xs[2 * XCAP + e] = __builtin_bit_cast(u32x4, s2);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e = tid + kBlock * i;
-            if (e < A_CELLS) As[e] = av[i];
-        }
-    };
-
-    if (tid == 0) As[A_CELLS] = u32x4{0u, 0u, 0u, 0u};
-    const int c_begin = blockIdx.z * p.chunks_per_split * CK;
-    int c_end = c_begin + p.chunks_per_split * CK;
-    if (c_end > p.Cp) c_end = p.Cp;
-    load_chunk(c_begin);
-    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
-        __syncthreads();   // everyone finished reading the previous chunk
-        store_chunk();
-        __syncthreads();
-        if (c0 + CK < c_end) load_chunk(c0 + CK);   // in flight under the MFMAs below
-#pragma unroll
-        for (int g = 0; g < 5; ++g) {
-            bf16x8 a[MI][3], b[NI][3];
-            // the zero cell has no split planes: its lanes read it for every split
-            const int astep = (g == 4 && half) ? 0 : BM;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
-                    a[mi][sp] = __builtin_bit_cast(bf16x8, As[aoff[g] + sp * astep + ((g == 4 && half) ? 0 : mi * 32)]);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
-                    b[ni][sp] = __builtin_bit_cast(bf16x8, Xs[sp * XCAP + pixbase[ni] + boff[g]]);
-            // smallest terms first
-            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][TA[q]], b[ni][TB[q]],
-                                                                              acc[mi][ni], 0, 0, 0);
-        }
-    }
-
-    // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int pp = (wn * NI + ni) * 32 + l31;
-        const int px = pp & (TW - 1);
-        const int py = (pp >> p.tw_log2) & (TH - 1);
-        const int pn = pp >> (p.tw_log2 + p.th_log2);
-        const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
-        if (n < p.N && oy < p.OH && ox < p.OW) {
-            float* yb = y + (int64_t)blockIdx.z * p.slab_stride +
-                        ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (m < p.M) {
-                        float v = acc[mi][ni][r];
-                        if (p.act) {
-                            if (p.bias) v += p.bias[m];
-                            v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
-                        }
-                        yb[(int64_t)m * p.YH * p.YW] = v;
-                    }
-                }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// "bx" gather, 8 waves, LDS-DMA weights (128 x 256-pixel tile, one 512-thread workgroup per CU).
-// conv_igemm_bx_kernel loses ~20 % to its staging phase (with the staging removed it runs 245 TFLOP/s-eq):
-// two 4-wave workgroups per CU drift into phase and then both sit in store-wait-barrier while the matrix
-// pipe idles.  Here the whole CU is ONE workgroup with everything double buffered in its 160 KB of LDS:
-//   * the split weights of chunk k+1 go global -> LDS by DMA (global_load_lds_dwordx4: the wpb tile is a
-//     linear image of the LDS tile, lane l lands at base + 16 l), no registers, no ds_write pass;
-//   * the input patch of chunk k+1 is loaded to registers (one position per thread), split and written to
-//     the other Xs buffer after the MFMAs of chunk k;
-//   * one barrier per chunk (s_waitcnt vmcnt(0) first: DMA data is ordered for other waves' ds_reads only
-//     by the issuer's vmcnt followed by a barrier the reader has passed).
-// The A tile is shared by 8 waves instead of 4, halving its L2 traffic per MFMA.
-// ------------------------------------------------------------------------------------------
-constexpr int kBlock8 = 512;
-
-template <int MI, int NI, int WM, int WN>
-__global__ __launch_bounds__(kBlock8) void conv_igemm_bx8_kernel(const float* __restrict__ x,
-                                                                 const u32x4* __restrict__ wpb,
-                                                                 float* __restrict__ y, const IgemmParams p) {
-    static_assert(WM * WN == 8, "8 waves per workgroup");
-    constexpr int T = 9, CK = 8;
-    constexpr int BM = 32 * MI * WM;
-    constexpr int BN = 32 * NI * WN;
-    constexpr int XCAP = 2 * BN;                            // patch positions (host-checked): one per thread
-    static_assert(XCAP == kBlock8, "one patch position per thread");
-    constexpr int A_CELLS = T * 3 * BM;                     // 16-byte cells per A chunk
-    constexpr int A_INSTR = A_CELLS / kWave;                // DMA instructions per chunk (64 cells each)
-    static_assert(A_CELLS % kWave == 0, "A tile is a whole number of wave DMAs");
-    __shared__ u32x4 As[2][A_CELLS];
-    __shared__ u32x4 Xs[2][3 * XCAP];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wid / WN, wn = wid % WN;
-
-    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
-    const int TN = BN >> (p.tw_log2 + p.th_log2);
-    int bt = blockIdx.x;
-    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
-    const int tiy = bt % p.tiles_y;
-    const int tin = bt / p.tiles_y;
-    const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
-    const int m0 = blockIdx.y * BM;
-
-    const int PH = TH + 2, PW = TW + 2;
-    const int IP = PH * PW;
-    const int CP = TN * IP;           // staged positions (<= XCAP, checked on the host)
-    const int HW = p.H * p.W;
-
-    int poff = -1;
-    if (tid < CP) {
-        const int pn = tid / IP;
-        const int rem = tid - pn * IP;
-        const int r = rem / PW;
-        const int c = rem - r * PW;
-        const int iy = oy0 - p.pad + r, ix = ox0 - p.pad + c;
-        if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-            poff = pn * p.C * HW + iy * p.W + ix;
-    }
-
-    int pixbase[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int pp = (wn * NI + ni) * 32 + l31;
-        const int px = pp & (TW - 1);
-        const int py = (pp >> p.tw_log2) & (TH - 1);
-        const int pn = pp >> (p.tw_log2 + p.th_log2);
-        pixbase[ni] = pn * IP + py * PW + px;
-    }
-    int boff[5], aoff[5];
-#pragma unroll
-    for (int g = 0; g < 5; ++g) {
-        const int t = (g < 4) ? 2 * g + half : 8;
-        boff[g] = (t / 3) * PW + (t % 3);
-        aoff[g] = t * 3 * BM + wm * MI * 32 + l31;
-    }
-    // The ninth tap has no partner inside a chunk.  Instead of pairing it with zeros (10 % of all MFMAs), the
-    // lower half-wave keeps the tap-8 operands of every EVEN chunk in registers and the upper half-wave loads
-    // those of the following ODD chunk: one MFMA group per chunk pair whose 16 k are 8 channels of each chunk.
-    bf16x8 a8[MI][3], b8[NI][3];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) a8[mi][sp] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) b8[ni][sp] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-    bool odd = false;
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-    const float* xb = x + (int64_t)n0 * p.C * HW;
-    const u32x4* wt = wpb + (int64_t)blockIdx.y * (p.Cp / CK) * A_CELLS;
-    float xv[CK];
-
-    auto dma_a = [&](int c0, int buf) {
-        const u32x4* wc = wt + (int64_t)(c0 / CK) * A_CELLS + lane;
-        for (int j = wid; j < A_INSTR; j += WM * WN)
-            __builtin_amdgcn_global_load_lds(wc + j * kWave, (__attribute__((address_space(3))) void*)(&As[buf][j * kWave]),
-                                             16, 0, 0);
-    };
-    auto load_x = [&](int c0) {
-#pragma unroll
-        for (int ch = 0; ch < CK; ++ch) {
-            // branch-free: invalid positions read element 0 of the tile's first image and are zeroed in store_x
-            const bool ok = (c0 + ch) < p.C && poff >= 0;
-            xv[ch] = xb[ok ? (int64_t)(c0 + ch) * HW + poff : 0];
-        }
-    };
-    auto store_x = [&](int c0, int buf) {
-        if (tid < CP) {
-            float v[CK];
-#pragma unroll
-            for (int ch = 0; ch < CK; ++ch) v[ch] = ((c0 + ch) < p.C && poff >= 0) ? xv[ch] : 0.0f;
-            bf16x8 s0, s1, s2;
-            split3_bf16(v, s0, s1, s2);
-            Xs[buf][tid] = __builtin_bit_cast(u32x4, s0);
-            Xs[buf][XCAP + tid] = __builtin_bit_cast(u32x4, s1);
-            Xs[buf][2 * XCAP + tid] = __builtin_bit_cast(u32x4, s2);
-        }
-    };
-
-    const int c_begin = blockIdx.z * p.chunks_per_split * CK;
-    int c_end = c_begin + p.chunks_per_split * CK;
-    if (c_end > p.Cp) c_end = p.Cp;
-    dma_a(c_begin, 0);
-    load_x(c_begin);
-    store_x(c_begin, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA has landed
-    __syncthreads();
-    int buf = 0;
-    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
-        const bool more = c0 + CK < c_end;
-        if (more) {
-            dma_a(c0 + CK, buf ^ 1);         // lands in the other buffer under the MFMAs below
-            load_x(c0 + CK);
-        }
-        const u32x4* Ac = As[buf];
-        const u32x4* Xc = Xs[buf];
-        constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
-        constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            // the split + LDS write of the next patch sits in the middle of the MFMA stream (same basic block:
-            // its VALU / ds_write instructions issue in the shadow of the matrix pipe)
-            if (g == 3 && more) store_x(c0 + CK, buf ^ 1);
-            bf16x8 a[MI][3], b[NI][3];
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) a[mi][sp] = __builtin_bit_cast(bf16x8, Ac[aoff[g] + sp * BM + mi * 32]);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
-                    b[ni][sp] = __builtin_bit_cast(bf16x8, Xc[sp * XCAP + pixbase[ni] + boff[g]]);
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][TA[q]], b[ni][TB[q]],
-                                                                              acc[mi][ni], 0, 0, 0);
-        }
-        // tap 8: even chunk -> the lower half-wave latches its operands; odd chunk -> the upper half-wave loads
-        // its own and the pair is multiplied
-        if (!odd || half) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) a8[mi][sp] = __builtin_bit_cast(bf16x8, Ac[aoff[4] + sp * BM + mi * 32]);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
-                    b8[ni][sp] = __builtin_bit_cast(bf16x8, Xc[sp * XCAP + pixbase[ni] + boff[4]]);
-        }
-        if (odd) {
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[mi][TA[q]], b8[ni][TB[q]],
-                                                                              acc[mi][ni], 0, 0, 0);
-        }
-        odd = !odd;
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) before the barrier: see the header comment
-        __syncthreads();
-        buf ^= 1;
-    }
-
-    if (odd) {   // odd number of chunks: the last tap-8 operands pair with zeros in the upper half-wave
-        constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
-        constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
-        if (half) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) a8[mi][sp] = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[mi][TA[q]], b8[ni][TB[q]], acc[mi][ni],
-                                                                          0, 0, 0);
-    }
-
-    // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int pp = (wn * NI + ni) * 32 + l31;
-        const int px = pp & (TW - 1);
-        const int py = (pp >> p.tw_log2) & (TH - 1);
-        const int pn = pp >> (p.tw_log2 + p.th_log2);
-        const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
-        if (n < p.N && oy < p.OH && ox < p.OW) {
-            float* yb = y + (int64_t)blockIdx.z * p.slab_stride +
-                        ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (m < p.M) {
-                        float v = acc[mi][ni][r];
-                        if (p.act) {
-                            if (p.bias) v += p.bias[m];
-                            v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
-                        }
-                        yb[(int64_t)m * p.YH * p.YW] = v;
-                    }
-                }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// fp32 3x3 stride-1 gather on 8 waves with LDS-DMA weights: 128 x 256-pixel tile, ONE 512-thread workgroup per CU.
-// conv_igemm_kernel<3,1,2,2,2,2,8> keeps the matrix pipe 80 % busy: each of its two workgroups per CU stops at two
-// barriers per 8-channel chunk, writes the chunk to LDS from registers in between, and the two drift into phase.
-// Here (the structure of conv_igemm_bx8_kernel, in exact fp32):
-//   * the weight tile of chunk k+1 goes global -> LDS by DMA (global_load_lds_dwordx4, 16 B per lane: two rows
-//     [tap][channel][128 m] of the re-laid weights per wave instruction, landing lane-linear in the other buffer):
-//     no registers, no ds_write pass;
-//   * the input patch of chunk k+1 (one position per thread, 8 channels) is loaded to registers before the MFMAs of
-//     chunk k and written to the other buffer in the middle of them;
-//   * ONE barrier per chunk (vmcnt(0) first: DMA data is ordered for other waves' ds_reads only by the issuer's
-//     vmcnt followed by a barrier the reader has passed);
-//   * the weight tile is shared by 8 waves instead of 4: half the L2 -> LDS weight traffic per MFMA.
-// MFMA operand order, accumulation order per output element and the epilogue are those of conv_igemm_kernel, so the
-// two kernels produce bit-identical results.  It measured 3 % SLOWER than the 4-wave kernel: a recorded experiment, compiled
-// only into tuning builds (-DSAE_TUNING, selected there with SAE_F8=1); the product library does not contain it.
-// ------------------------------------------------------------------------------------------
-template <int MI, int NI, int WM, int WN, bool MOD = false>
-__global__ __launch_bounds__(kBlock8) void conv_igemm_f8_kernel(const float* __restrict__ x,
-                                                                const float* __restrict__ wp,
-                                                                float* __restrict__ y, const IgemmParams p) {
-    static_assert(WM * WN == 8, "8 waves per workgroup");
-    constexpr int T = 9, CK = 8;
-    constexpr int BM = 32 * MI * WM;
-    constexpr int BN = 32 * NI * WN;
-    constexpr int XCAP = 2 * BN;                            // patch positions (host-checked): one per thread
-    static_assert(XCAP == kBlock8, "one patch position per thread");
-    constexpr int A_FLOATS = T * CK * BM;                   // weight tile of one chunk
-    constexpr int A_INSTR = A_FLOATS / 4 / kWave;           // DMA instructions per chunk (64 16-byte cells each)
-    static_assert((A_FLOATS / 4) % kWave == 0 && BM % 4 == 0, "A tile is a whole number of wave DMAs");
-    __shared__ float As[2][A_FLOATS];
-    __shared__ float Xs[2][CK * XCAP];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wid / WN, wn = wid % WN;
-
-    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
-    const int TN = BN >> (p.tw_log2 + p.th_log2);
-    int bt = blockIdx.x;
-    if (p.xcd_order && (gridDim.x & 7) == 0) bt = (bt & 7) * (gridDim.x >> 3) + (bt >> 3);   // see conv_igemm_kernel
-    const int tix = bt % p.tiles_x; bt /= p.tiles_x;
-    const int tiy = bt % p.tiles_y;
-    const int tin = bt / p.tiles_y;
-    const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
-    const int m0 = blockIdx.y * BM;
-
-    const int PH = TH + 2, PW = TW + 2;
-    const int IP = PH * PW;
-    const int CP = TN * IP;           // staged positions (<= XCAP, checked on the host)
-    const int HW = p.H * p.W;
-
-    int poff = -1;
-    [[maybe_unused]] int sidx = 0;    // in_scale row of this thread's patch position
-    if (tid < CP) {
-        const int pn = tid / IP;
-        const int rem = tid - pn * IP;
-        const int r = rem / PW;
-        const int c = rem - r * PW;
-        const int iy = oy0 - p.pad + r, ix = ox0 - p.pad + c;
-        if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-            poff = pn * p.C * HW + iy * p.W + ix;
-            if constexpr (MOD) sidx = (n0 + pn) * p.C;
-        }
-    }
-
-    int pixbase[NI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int pp = (wn * NI + ni) * 32 + l31;
-        const int px = pp & (TW - 1);
-        const int py = (pp >> p.tw_log2) & (TH - 1);
-        const int pn = pp >> (p.tw_log2 + p.th_log2);
-        pixbase[ni] = pn * IP + py * PW + px;
-    }
-    int tapoff[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) tapoff[t] = (t / 3) * PW + (t % 3);
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
-    const float* xb = x + (int64_t)n0 * p.C * HW;
-    float xv[CK];
-    [[maybe_unused]] float sv[MOD ? CK : 1];
-
-    // lane's 16-byte cell of DMA instruction j: cell e = 64 j + lane = row (tap * CK + ch) * (BM / 4) + col4
-    auto dma_a = [&](int c0, int buf) {
-        for (int j = wid; j < A_INSTR; j += WM * WN) {
-            const int e = j * kWave + lane;
-            const int row = e / (BM / 4), col4 = e - row * (BM / 4);
-            const int tap = row / CK, ch = row - tap * CK;
-            const float* src = wp + ((int64_t)tap * p.Cp + c0 + ch) * p.Mp + m0 + col4 * 4;
-            __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void*)(&As[buf][j * kWave * 4]), 16, 0, 0);
-        }
-    };
-    auto load_x = [&](int c0) {
-#pragma unroll
-        for (int ch = 0; ch < CK; ++ch) {
-            // branch-free: invalid positions read element 0 of the tile's first image and are zeroed in store_x
-            const bool ok = (c0 + ch) < p.C && poff >= 0;
-            xv[ch] = xb[ok ? (int64_t)(c0 + ch) * HW + poff : 0];
-            if constexpr (MOD) sv[ch] = p.in_scale[sidx + ((c0 + ch) < p.C ? c0 + ch : 0)];
-        }
-    };
-    auto store_x = [&](int c0, int buf) {
-        if (tid < CP) {
-#pragma unroll
-            for (int ch = 0; ch < CK; ++ch) {
-                float v = ((c0 + ch) < p.C && poff >= 0) ? xv[ch] : 0.0f;
-                if constexpr (MOD) v *= sv[ch];
-                Xs[buf][ch * XCAP + tid] = v;
-            }
-        }
-    };
-
-    const int c_begin = blockIdx.z * p.chunks_per_split * CK;
-    int c_end = c_begin + p.chunks_per_split * CK;
-    if (c_end > p.Cp) c_end = p.Cp;
-    dma_a(c_begin, 0);
-    load_x(c_begin);
-    store_x(c_begin, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA has landed
-    __syncthreads();
-    int buf = 0;
-    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
-        const bool more = c0 + CK < c_end;
-        if (more) {
-            dma_a(c0 + CK, buf ^ 1);         // lands in the other buffer under the MFMAs below
-            load_x(c0 + CK);
-        }
-        const float* Ac = As[buf];
-        const float* Xc = Xs[buf];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            // the LDS write of the next patch sits in the middle of the MFMA stream (same basic block: its ds_write
-            // instructions issue in the shadow of the matrix pipe)
-            if (t == 6 && more) store_x(c0 + CK, buf ^ 1);
-#pragma unroll
-            for (int kk = 0; kk < CK / 2; ++kk) {
-                const int ch = 2 * kk + half;
-                float a[MI], b[NI];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a[mi] = Ac[(t * CK + ch) * BM + (wm * MI + mi) * 32 + l31];
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) b[ni] = Xc[ch * XCAP + pixbase[ni] + tapoff[t]];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) before the barrier: see the header comment
-        __syncthreads();
-        buf ^= 1;
-    }
-
-    // epilogue: D row = (r&3) + 8*(r>>2) + 4*half, col = l31
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-        const int pp = (wn * NI + ni) * 32 + l31;
-        const int px = pp & (TW - 1);
-        const int py = (pp >> p.tw_log2) & (TH - 1);
-        const int pn = pp >> (p.tw_log2 + p.th_log2);
-        const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
-        if (n < p.N && oy < p.OH && ox < p.OW) {
-            float* yb = y + (int64_t)blockIdx.z * p.slab_stride +
-                        ((int64_t)n * p.M * p.YH + (int64_t)oy * p.oys) * p.YW + (int64_t)ox * p.oxs;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (m < p.M) {
-                        float v = acc[mi][ni][r];
-                        if (p.act) {
-                            if (p.bias) v += p.bias[m];
-                            v = ((v > 0.0f) ? v : v * p.act_slope) * p.act_scale;
-                        }
-                        yb[(int64_t)m * p.YH * p.YW] = v;
-                    }
-                }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// stride-2 transposed gather ("tr"): out[m][o] = sum_{c,k : o + pad = 2 i + k} wp[k][c][m] * in[c][i]
-// 3x3 taps only.  N-tiles of a wave = the 4 parity classes of the same 32 q positions.
-// ------------------------------------------------------------------------------------------
-struct TrRegion {
-    int QH, QW;           // half-resolution rectangle [qy_base, QH) x [qx_base, QW)
-    int qy_base, qx_base;
-    int tw, th, tn;       // q tile = TN images x TH x TW positions (any sizes with TN*TH*TW <= BQ: the
-                          // transposed problems have 2^k + 1 wide grids, power-of-two tiles waste 25-90 %)
-    int tiles_x, tiles_y, tiles_n;
-    int blocks;           // tiles_x * tiles_y * tiles_n
-    int flat;             // tr2: tiles are runs of 128 consecutive positions of the WHOLE grid in row-major order (tiles_x per image)
-};
-struct TrParams {
-    int N, C, IH, IW;     // input tensor (the small, "y side" image)
-    int M, OH, OW;        // output tensor (the large, "x side" image)
-    int debug_skip_store;   // profiling aid of tuning builds (SAE_TR_NOSTORE): results are NOT written; ignored by the product
-    int Cp, Mp;
-    int pad;
-    const float* in_scale;  // [N][C] or null: style modulation of the input, applied while staging (see IgemmParams)
-    int zmask;              // always 0 (see IgemmParams)
-    int mtiles, main_items, strip_items;  // tr2: M tiles; (q tile, M tile) items of region 0 and of regions 1 + 2
-    // conv_igemm_tr_kernel, split K (blockIdx.z): chunks per slice and the distance between the partial outputs
-    int chunks_per_split;
-    int64_t slab_stride;
-    // main region + right / bottom strips, all in ONE launch (blockIdx.x runs through the regions):
-    // launched one after the other the two thin strips cost a full K loop of latency each on a
-    // nearly empty GPU
-    TrRegion reg[3];
-};
-
-// WM x WN = 4 or 8 waves.  The 8-wave form (128 rows x 128 q positions) halves the weight traffic per MFMA -- a tap of the
-// transposed problem feeds only one of the four output parity classes, so the 128 x 64q tile needs twice the weight bytes
-// per MFMA of the forward gather, and the issue of those loads was 33-39 % of the kernel (profiles/r2_phase_clock_*.txt).
-template <int MI, int WM, int WN, int CK, bool MOD = false>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_tr_kernel(const float* __restrict__ x,
-                                                               const float* __restrict__ wp,
-                                                               float* __restrict__ y, const TrParams p) {
-    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
-    constexpr int NT = 64 * WM * WN;
-    constexpr int T = 9;
-    constexpr int BM = 32 * MI * WM;
-    constexpr int BQ = 32 * WN;                  // q positions per workgroup
-    constexpr int XCAP = (25 * BQ) / 16;         // (TW+1)(TH+1)/(TW*TH) <= 25/16 for TW,TH >= 4
-    constexpr int PPT = (XCAP + NT - 1) / NT;
-    constexpr int A_VEC = T * CK * BM / 4;
-    constexpr int APT = (A_VEC + NT - 1) / NT;
-    __shared__ float As[T * CK * BM];
-    __shared__ float Xs[CK * XCAP];
-
-    SAE_CLOCK_BEGIN
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wid / WN, wn = wid % WN;
-
-    int bt = blockIdx.x;
-    int ridx = 0;
-    if (bt >= p.reg[0].blocks) {
-        bt -= p.reg[0].blocks; ridx = 1;
-        if (bt >= p.reg[1].blocks) { bt -= p.reg[1].blocks; ridx = 2; }
-    }
-    const TrRegion g = p.reg[ridx];
-    const int TW = g.tw, TH = g.th, TN = g.tn;
-    const int tix = bt % g.tiles_x; bt /= g.tiles_x;
-    const int tiy = bt % g.tiles_y;
-    const int tin = bt / g.tiles_y;
-    const int qx0 = g.qx_base + tix * TW, qy0 = g.qy_base + tiy * TH, n0 = tin * TN;
-    const int m0 = blockIdx.y * BM;
-
-    const int PH = TH + 1, PW = TW + 1;          // patch row r <-> input row qy0 - 1 + r
-    const int RS = PW;
-    const int IP = PH * RS;
-    const int CP = TN * IP;
-    const int HW = p.IH * p.IW;
-
-    int poff[PPT];
-    int sidx[MOD ? PPT : 1];   // in_scale row of the slot's image (tiles that span several images only)
-#pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-        const int e = tid + NT * s;
-        int off = -1;
-        if constexpr (MOD) sidx[s] = 0;
-        if (e < CP) {
-            const int pn = e / IP;
-            const int rem = e - pn * IP;
-            const int r = rem / RS;
-            const int c = rem - r * RS;
-            const int iy = qy0 - 1 + r, ix = qx0 - 1 + c;
-            if (n0 + pn < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW) {
-                off = pn * p.C * HW + iy * p.IW + ix;
-                if constexpr (MOD) sidx[s] = (n0 + pn) * p.C;
-            }
-        }
-        poff[s] = off;
-    }
-    const bool one_image = TN == 1;
-    float sc[MOD ? CK : 1];
-
-    const int pp = wn * 32 + l31;
-    const int pn = pp / (TW * TH);
-    const int prem = pp - pn * (TW * TH);
-    const int py = prem / TW;
-    const int px = prem - py * TW;
-    const bool lane_ok = pn < TN;                 // lanes beyond TN*TH*TW positions idle
-    const int pixbase = lane_ok ? pn * IP + py * RS + px : 0;
-    int tapoff[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int ky = t / 3, kx = t % 3;
-        // tap k contributes from input index q - (k == 2 ? 1 : 0); patch row of input q is q - q0 + 1
-        tapoff[t] = ((ky == 2) ? 0 : 1) * RS + ((kx == 2) ? 0 : 1);
-    }
-
-    f32x16 acc[MI][4];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][cl][r] = 0.0f;
-
-    const float* xb = x + (int64_t)n0 * p.C * HW;
-    float xv[CK][PPT];
-    f32x4 av[APT];
-
-    auto load_chunk = [&](int c0) {
-#pragma unroll
-        for (int ch = 0; ch < CK; ++ch) {
-            const bool ch_ok = (c0 + ch) < p.C;
-            const float* xc = xb + (int64_t)(c0 + ch) * HW;
-#pragma unroll
-            for (int s = 0; s < PPT; ++s) xv[ch][s] = (ch_ok && poff[s] >= 0) ? xc[poff[s]] : 0.0f;
-        }
-        if constexpr (MOD) {
-            if (one_image) {
-                const float* srow = p.in_scale + n0 * p.C + (lane & p.zmask);
-#pragma unroll
-                for (int ch = 0; ch < CK; ++ch) sc[ch] = srow[(c0 + ch) < p.C ? c0 + ch : 0];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e4 = tid + NT * i;
-            if (e4 < A_VEC) {
-                const int row = e4 / (BM / 4);
-                const int col4 = e4 - row * (BM / 4);
-                const int tap = row / CK, ch = row - tap * CK;
-                av[i] = *reinterpret_cast<const f32x4*>(
-                    wp + ((int64_t)tap * p.Cp + c0 + ch) * p.Mp + m0 + col4 * 4);
-            }
-        }
-    };
-    auto store_chunk = [&](int c0) {
-        if constexpr (MOD) {
-            if (one_image) {
-#pragma unroll
-                for (int ch = 0; ch < CK; ++ch)
-#pragma unroll
-                    for (int s = 0; s < PPT; ++s) xv[ch][s] *= sc[ch];
-            } else {     // small images, several per tile: the factor depends on the slot's image
-#pragma unroll
-                for (int ch = 0; ch < CK; ++ch) {
-                    const int cc = (c0 + ch) < p.C ? c0 + ch : 0;
-#pragma unroll
-                    for (int s = 0; s < PPT; ++s) xv[ch][s] *= p.in_scale[sidx[s] + cc];
-                }
-            }
-        }
-#pragma unroll
-        for (int ch = 0; ch < CK; ++ch)
-#pragma unroll
-            for (int s = 0; s < PPT; ++s) {
-                const int e = tid + NT * s;
-                if (e < CP) Xs[ch * XCAP + e] = xv[ch][s];
-            }
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e4 = tid + NT * i;
-            if (e4 < A_VEC) *reinterpret_cast<f32x4*>(As + e4 * 4) = av[i];
-        }
-    };
-
-    // split K over blockIdx.z (launches with few workgroups and long channel loops: the 4 x 4 ... 17 x 17 tails and the
-    // encoder's 1024-channel 7 x 7 layer); the partial outputs go to slabs that conv_splitk_reduce_kernel sums in fixed order
-    const int c_begin = blockIdx.z * p.chunks_per_split * CK;
-    int c_end = c_begin + p.chunks_per_split * CK;
-    if (c_end > p.Cp) c_end = p.Cp;
-    y += (int64_t)blockIdx.z * p.slab_stride;
-    load_chunk(c_begin);
-    SAE_CLOCK_PHASE(0)
-    for (int c0 = c_begin; c0 < c_end; c0 += CK) {
-        __syncthreads();
-        SAE_CLOCK_PHASE(2)
-        store_chunk(c0);
-        SAE_CLOCK_PHASE(3)
-        __syncthreads();
-        SAE_CLOCK_PHASE(4)
-        if (c0 + CK < c_end) load_chunk(c0 + CK);
-        SAE_CLOCK_PHASE(5)
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int cls = ((t / 3) & 1) * 2 + ((t % 3) & 1);   // parity class fed by this tap
-#pragma unroll
-            for (int kk = 0; kk < CK / 2; ++kk) {
-                const int ch = 2 * kk + half;
-                const float b = Xs[ch * XCAP + pixbase + tapoff[t]];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const float a = As[(t * CK + ch) * BM + (wm * MI + mi) * 32 + l31];
-                    // cls is a compile-time constant after unrolling t
-                    if (cls == 0) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][0], 0, 0, 0);
-                    else if (cls == 1) acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][1], 0, 0, 0);
-                    else if (cls == 2) acc[mi][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][2], 0, 0, 0);
-                    else acc[mi][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][3], 0, 0, 0);
-                }
-            }
-        }
-        SAE_CLOCK_PHASE(1)
-    }
-
-    const int n = n0 + pn, qy = qy0 + py, qx = qx0 + px;
-#ifdef SAE_TUNING
-    if (p.debug_skip_store) {   // keep the accumulators alive without the store traffic
-        float keep = 0.0f;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int cl = 0; cl < 4; ++cl) keep += acc[mi][cl][0] + acc[mi][cl][15];
-        if (keep == 12345.678f) y[0] = keep;
-        return;
-    }
-#endif
-    if (lane_ok && n < p.N && qy < g.QH && qx < g.QW) {   // q beyond this launch's region belongs to another launch
-        // (pairing the two x-classes of a lane into one 4-byte-aligned 8-byte store was measured
-        // slower, 87 vs 94 TFLOP/s: the rows are 2^k + 1 wide, so half of those stores are misaligned)
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
-            const int oy = 2 * qy + (cl >> 1) - p.pad;
-            const int ox = 2 * qx + (cl & 1) - p.pad;
-            if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
-                float* yb = y + ((int64_t)n * p.M * p.OH + oy) * p.OW + ox;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (m < p.M) yb[(int64_t)m * p.OH * p.OW] = acc[mi][cl][r];
-                    }
-            }
-        }
-    }
-    SAE_CLOCK_PHASE(6)
-    SAE_CLOCK_END
-}
-
-// ------------------------------------------------------------------------------------------
-// transposed gather, second generation ("tr2"): 32*MI rows x 128 q positions, CK = 16 or 8 channels per chunk.
-//
-// Same arithmetic in the same order as conv_igemm_tr_kernel (8-channel sub-chunks, tap-major, channel pairs), so its
-// results are BIT-identical; what changes is how operands reach LDS and how results leave the registers:
-//  * the input patch rows are widened to whole 16-byte quads [qx0 - 4, qx0 + TW) (TW a multiple of 4, input rows a multiple
-//    of four floats wide) and a chunk's quads are dealt out over the workgroup: 3 dwordx4 per thread and 16-channel chunk
-//    instead of 8 dword loads per 8 channels.  With the 9 weight quads that is 12 vector-memory instructions per 144 MFMAs
-//    of a wave (13 per 72 before); their issue was 33-39 % of the kernel (profiles/r2_phase_clock_*.txt);
-//  * 1-D grid in XCD-aware order with the M tile as the FASTEST index: the workgroups that share an input patch (all M
-//    tiles of a q tile) and its spatial neighbours run at the same time behind the same L2 (the plain order read the
-//    input 6.1x from the fabric, profiles/r2_pmc_f32_quad.txt);
-//  * the epilogue goes through LDS wave by wave: a lane holds both x-classes of a q position, i.e. two adjacent output
-//    columns, so the four classes of a wave's 32 positions are two complete output rows of 64 consecutive columns; they
-//    leave as 4-byte aligned dwordx4 stores (32 per lane instead of 128 stride-2 dword stores that wrote every 64-byte
-//    line twice);
-//  * the style factors of a modulated launch are fetched once into LDS (tiles never span images then).
-// Tiles are TN x TH x TW positions with TN (TH + 1) (TW + 4) <= kTr2Cap, chosen per region on the host.
-// ------------------------------------------------------------------------------------------
-constexpr int kTr2Cap = 192;        // patch floats per channel (rectangular tiles)
-constexpr int kTr2FlatCap = 288;    // ... of a flat tile: the rows a run of 128 positions touches, full width (65-wide grids: 4 x 72)
-constexpr int kTr2MaxC = 2048;      // style factors held in LDS (modulated launches)
-
-// FLAT (small 2^k + 1 grids: 17, 33, 65 wide): a tile is a run of 128 consecutive positions of the whole q grid of one image in
-// row-major order -- no main region + strips (a 33 x 33 grid is 1024 + 65 positions: the strips were separate tiles with one
-// active wave and a scalar epilogue, 15 - 30 % of these launches) and no padded tile rows: 94 % of the lanes carry a position
-// (9 tiles of 128 for 1089).  The patch is the 3 - 9 full-width input rows the run touches; a lane's two x-classes are two
-// adjacent output columns and leave as one 8-byte store.  Same arithmetic per output in the same order: bit-identical.
-template <int MI, int CK, bool MOD = false, bool FLAT = false>
-__global__ __launch_bounds__(kBlock, 2) void conv_igemm_tr2_kernel(const float* __restrict__ x,
-                                                                const float* __restrict__ wp,
-                                                                float* __restrict__ y, const TrParams p) {
-    static_assert(CK == 8 || CK == 16, "8- or 16-channel chunks");
-    constexpr int T = 9;
-    constexpr int BM = 32 * MI;
-    constexpr int XCAP = FLAT ? kTr2FlatCap : kTr2Cap;
-    constexpr int QCAP = XCAP / 4;
-    constexpr int QPT = (CK * QCAP + kBlock - 1) / kBlock;       // quad slots per thread per chunk
-    constexpr int A_VEC = T * CK * BM / 4;
-    constexpr int APT = (A_VEC + kBlock - 1) / kBlock;
-    constexpr int XS = CK * XCAP + 4 * kBlock;                   // + a dump area for the slots beyond the patch
-    constexpr int AS = T * CK * BM;
-    constexpr int CS = 4 * 8 * 128;                              // epilogue: 8 rows x 128 floats per wave and pass
-    constexpr int LDSF = (AS + XS > CS) ? AS + XS : CS;
-    __shared__ __attribute__((aligned(16))) float smem[LDSF];
-    __shared__ float Ss[MOD ? kTr2MaxC : 1];
-    float* As = smem;
-    float* Xs = smem + AS;
-
-    SAE_CLOCK_BEGIN
-    const int tid = threadIdx.x;
-    __builtin_assume(tid < kBlock);
-    const int lane = tid & 63, wn = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-
-    // Work items = (q tile, M tile), M tile fastest.  XCD k (= workgroup id % 8) takes the k-th contiguous eighth of the strip
-    // items and then the k-th contiguous eighth of the main region's: the thin strip tiles (one active wave, latency-bound
-    // K loop) run FIRST, next to main tiles on the same CUs, instead of alone on an emptying GPU at the end of the launch
-    const int xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
-    const int ps = (p.strip_items + 7) >> 3, pm = (p.main_items + 7) >> 3;
-    int wk;
-    if (slot < ps) {
-        wk = xcd * ps + slot;
-        if (wk >= p.strip_items) return;
-        wk += p.main_items;
-    } else {
-        wk = xcd * pm + slot - ps;
-        if (wk >= p.main_items) return;
-    }
-    const int mt = wk % p.mtiles;
-    int bt = wk / p.mtiles;
-    int ridx = 0;
-    if (bt >= p.reg[0].blocks) {
-        bt -= p.reg[0].blocks; ridx = 1;
-        if (bt >= p.reg[1].blocks) { bt -= p.reg[1].blocks; ridx = 2; }
-    }
-    const TrRegion g = p.reg[ridx];
-    const int TW = g.tw, TH = g.th, TN = g.tn;
-    const int tix = bt % g.tiles_x; bt /= g.tiles_x;
-    const int tiy = bt % g.tiles_y;
-    const int tin = bt / g.tiles_y;
-    // FLAT: tile tix of image tin starts at position 128 tix = (row qy0, column s0) of the grid; TW = the grid's width, TH the
-    // most rows a run can touch (patch rows beyond the image are zero-filled like any padding)
-    const int qx0 = FLAT ? 0 : g.qx_base + tix * TW;
-    const int qy0 = FLAT ? (128 * tix) / TW : g.qy_base + tiy * TH;
-    const int n0 = tin * TN;
-    [[maybe_unused]] const int s0 = FLAT ? 128 * tix - qy0 * TW : 0;
-    const int m0 = mt * BM;
-
-    const int PH = TH + 1;                 // patch row r <-> input row qy0 - 1 + r
-    const int RS = ((TW + 3) & ~3) + 4;    // patch column c <-> input column qx0 - 4 + c (qx0 is a multiple of 4)
-    const int RQ = RS >> 2;
-    const int IP = PH * RS;
-    const int QI = PH * RQ, QN = TN * QI;  // quads per image, per channel
-    const int HW = p.IH * p.IW;
-
-    // quad slot k of a thread = quad j = tid + kBlock * k of the chunk: channel j / QN, quad j % QN of the patch.  Slots
-    // outside the image (zero padding) or beyond the chunk fetch element 0 and are zeroed / dumped at the LDS write, so the
-    // K loop has no divergent branch and every load is "uniform 64-bit base + loop-invariant 32-bit lane offset"
-    unsigned qbyte[QPT];
-    int qdst[QPT], qch[QPT];       // qch < 0: never valid
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-        const int j = tid + kBlock * k;
-        const int ch = j / QN;
-        const int q = j - ch * QN;
-        const int pn = q / QI;
-        const int rem = q - pn * QI;
-        const int r = rem / RQ;
-        const int qc = rem - r * RQ;
-        const int iy = qy0 - 1 + r, ix = qx0 - 4 + 4 * qc;
-        const bool slot = ch < CK;
-        const bool in = slot && n0 + pn < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW;
-        qbyte[k] = in ? 4u * (unsigned)((pn * p.C + ch) * HW + iy * p.IW + ix) : 0u;
-        qch[k] = in ? ch : -1;
-        qdst[k] = slot ? ch * XCAP + 4 * q : CK * XCAP + 4 * tid;
-    }
-    unsigned abyte[APT];
-#pragma unroll
-    for (int i = 0; i < APT; ++i) {
-        const int e4 = tid + kBlock * i;
-        const int row = e4 / (BM / 4);
-        const int col4 = e4 - row * (BM / 4);
-        const int tap = (row / CK) < T ? row / CK : 0, ch = row - (row / CK) * CK;
-        abyte[i] = 4u * (unsigned)((tap * p.Cp + ch) * p.Mp + col4 * 4);
-    }
-    if constexpr (MOD) {    // tiles of a modulated launch lie inside one image (host)
-        for (int c = tid; c < p.C; c += kBlock) Ss[c] = p.in_scale[(int64_t)n0 * p.C + c];
-    }
-
-    const int pp = wn * 32 + l31;
-    const int npos = FLAT ? (g.QH * TW - 128 * tix < 128 ? g.QH * TW - 128 * tix : 128) : TN * TH * TW;
-    const int pn_l = FLAT ? 0 : pp / (TW * TH);
-    const int prem = FLAT ? pp + s0 : pp - pn_l * (TW * TH);
-    const int py = prem / TW;
-    const int px = prem - py * TW;
-    const int pixbase = pp < npos ? pn_l * IP + py * RS + px : 0;     // lanes beyond the tile compute on position 0
-    const bool wave_active = wn * 32 < npos;                          // (whole waves beyond it skip their MFMAs: strip tiles)
-    int tapoff[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int ky = t / 3, kx = t % 3;
-        // tap k contributes from input index q - (k == 2 ? 1 : 0)
-        tapoff[t] = ((ky == 2) ? 0 : 1) * RS + ((kx == 2) ? 3 : 4);
-    }
-
-    f32x16 acc[MI][4];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][cl][r] = 0.0f;
-
-    const float* xb = x + (int64_t)n0 * p.C * HW;
-    f32x4 xq[QPT];
-    f32x4 av[APT];
-
-    auto load_chunk = [&](int c0) {
-        const char* xc = reinterpret_cast<const char*>(xb + (int64_t)c0 * HW);
-#pragma unroll
-        for (int k = 0; k < QPT; ++k) {
-            const bool ok = qch[k] >= 0 && c0 + qch[k] < p.C;      // channels beyond C (last chunk): element 0, zeroed later
-            xq[k] = *reinterpret_cast<const f32x4*>(xc + (ok ? qbyte[k] : 0u));
-        }
-        const char* wb = reinterpret_cast<const char*>(wp + (int64_t)c0 * p.Mp + m0);
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e4 = tid + kBlock * i;
-            if (e4 < A_VEC) av[i] = *reinterpret_cast<const f32x4*>(wb + abyte[i]);
-        }
-    };
-    auto store_chunk = [&](int c0) {
-#pragma unroll
-        for (int k = 0; k < QPT; ++k) {
-            const bool ok = qch[k] >= 0 && c0 + qch[k] < p.C;
-            f32x4 v = xq[k];
-            if constexpr (MOD) v *= Ss[ok ? c0 + qch[k] : 0];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
-            *reinterpret_cast<f32x4*>(Xs + qdst[k]) = v;
-        }
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e4 = tid + kBlock * i;
-            if (e4 < A_VEC) *reinterpret_cast<f32x4*>(As + e4 * 4) = av[i];
-        }
-    };
-
-    load_chunk(0);
-    SAE_CLOCK_PHASE(0)
-    for (int c0 = 0; c0 < p.Cp; c0 += CK) {
-        __syncthreads();
-        SAE_CLOCK_PHASE(2)
-        store_chunk(c0);
-        SAE_CLOCK_PHASE(3)
-        __syncthreads();
-        SAE_CLOCK_PHASE(4)
-        if (c0 + CK < p.Cp) load_chunk(c0 + CK);
-        SAE_CLOCK_PHASE(5)
-        if (wave_active)
-#pragma unroll
-        for (int sub = 0; sub < CK / 8; ++sub)
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int cls = ((t / 3) & 1) * 2 + ((t % 3) & 1);   // parity class fed by this tap
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int ch = sub * 8 + 2 * kk + half;
-                    const float b = Xs[ch * XCAP + pixbase + tapoff[t]];
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) {
-                        const float a = As[(t * CK + ch) * BM + mi * 32 + l31];
-                        // cls is a compile-time constant after unrolling t
-                        if (cls == 0) acc[mi][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][0], 0, 0, 0);
-                        else if (cls == 1) acc[mi][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][1], 0, 0, 0);
-                        else if (cls == 2) acc[mi][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][2], 0, 0, 0);
-                        else acc[mi][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[mi][3], 0, 0, 0);
-                    }
-                }
-            }
-        SAE_CLOCK_PHASE(1)
-    }
-
-    // ---- epilogue.  Per pass a wave parks 8 rows (m) x [cy][32 positions][cx] in its own LDS block; lane (cy = bit 4,
-    // k = lane & 15) then owns the quad of positions 2k, 2k + 1 = four consecutive columns of output row 2 qy + cy - pad
-    // for rows m8 = 2 v + (lane >> 5).
-    __syncthreads();                  // every wave is done with As / Xs
-    if (!wave_active) return;
-    if constexpr (FLAT) {
-        // a lane's classes (cy, 0) and (cy, 1) are output columns 2 qx - pad and 2 qx - pad + 1 of row 2 qy + cy - pad: one 8-byte
-        // store (rows are 2^k + 1 floats: 4-byte aligned); a wave instruction writes 2 x 256 contiguous bytes
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        struct __attribute__((packed, aligned(4))) U2 { f32x2 v; };
-        const int qy = qy0 + py, qx = px;
-        const int ox = 2 * qx - p.pad;
-        const bool live = pp < npos;
-        const bool c0 = live && ox >= 0 && ox < p.OW, c1 = live && ox + 1 >= 0 && ox + 1 < p.OW;
-        const int64_t plane = (int64_t)p.OH * p.OW;
-#pragma unroll
-        for (int cy = 0; cy < 2; ++cy) {
-            const int oy = 2 * qy + cy - p.pad;
-            if (oy < 0 || oy >= p.OH || !(c0 || c1)) continue;
-            float* yb = y + ((int64_t)n0 * p.M * p.OH + oy) * p.OW + ox;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (m < p.M) {
-                        float* yp = yb + (int64_t)m * plane;
-                        if (c0 && c1) reinterpret_cast<U2*>(yp)->v = f32x2{acc[mi][2 * cy][r], acc[mi][2 * cy + 1][r]};
-                        else if (c0) yp[0] = acc[mi][2 * cy][r];
-                        else yp[1] = acc[mi][2 * cy + 1][r];
-                    }
-                }
-        }
-        SAE_CLOCK_PHASE(6)
-        SAE_CLOCK_END
-        return;
-    }
-    if (TW & 1) {                     // one-column strips: positions 2k, 2k + 1 are not neighbours; plain stores
-        const int n = n0 + pn_l, qy = qy0 + py, qx = qx0 + px;
-        if (pp < npos && n < p.N && qy < g.QH && qx < g.QW) {
-#pragma unroll
-            for (int cl = 0; cl < 4; ++cl) {
-                const int oy = 2 * qy + (cl >> 1) - p.pad;
-                const int ox = 2 * qx + (cl & 1) - p.pad;
-                if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
-                    float* yb = y + ((int64_t)n * p.M * p.OH + oy) * p.OW + ox;
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int m = m0 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                            if (m < p.M) yb[(int64_t)m * p.OH * p.OW] = acc[mi][cl][r];
-                        }
-                }
-            }
-        }
-        return;
-    }
-    float* Cw = smem + wn * (8 * 128);
-    const int ecy = (lane >> 4) & 1, ek = lane & 15;
-    const int epp = wn * 32 + 2 * ek;
-    const int epn = epp / (TW * TH);
-    const int eprem = epp - epn * (TW * TH);
-    const int epy = eprem / TW;
-    const int epx = eprem - epy * TW;                 // even; position 2k + 1 is its right neighbour (TW is even)
-    const int en = n0 + epn, eqy = qy0 + epy, eqx = qx0 + epx;
-    const int oy = 2 * eqy + ecy - p.pad;
-    const int ox = 2 * eqx - p.pad;
-    unsigned emask = 0;               // bit e: output column ox + e exists and belongs to this tile's region
-    if (epp < npos && en < p.N && eqy < g.QH && oy >= 0 && oy < p.OH) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (eqx + (e >> 1) < g.QW && ox + e >= 0 && ox + e < p.OW) emask |= 1u << e;
-    }
-    const int64_t plane = (int64_t)p.OH * p.OW;
-    float* yb = y + (int64_t)en * p.M * plane + (int64_t)oy * p.OW + ox;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    struct __attribute__((packed, aligned(4))) U4 { f32x4 v; };     // 4-byte aligned quad (rows are 2^k + 1 wide)
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int cy = 0; cy < 2; ++cy)
-                    *reinterpret_cast<f32x2*>(Cw + (4 * half + i) * 128 + cy * 64 + 2 * l31) =
-                        f32x2{acc[mi][cy * 2][4 * j + i], acc[mi][cy * 2 + 1][4 * j + i]};
-            wave_sync();
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int m8 = 2 * v + half;
-                const f32x4 c = *reinterpret_cast<const f32x4*>(Cw + m8 * 128 + (lane & 31) * 4);
-                const int m = m0 + mi * 32 + 8 * j + m8;
-                if (m < p.M) {
-                    float* yp = yb + (int64_t)m * plane;
-                    if (emask == 15u) reinterpret_cast<U4*>(yp)->v = c;
-                    else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (emask & (1u << e)) yp[e] = c[e];
-                    }
-                }
-            }
-            wave_sync();
-        }
-    SAE_CLOCK_PHASE(6)
-    SAE_CLOCK_END
-}
-
-// ------------------------------------------------------------------------------------------
-// "bx" arithmetic of the transposed gather (128 x 64q tile).  Same cell layouts as
-// conv_igemm_bx_kernel.  The 16 k of an MFMA are 8 channels x the two taps of a pair that feed
-// the SAME parity class: (0,2) (6,8) -> class 0, (1,7) -> 1, (3,5) -> 2, (4, zero cell) -> 3.
-// ------------------------------------------------------------------------------------------
-template <int MI, int WM, int WN>
-__global__ __launch_bounds__(kBlock) void conv_igemm_tr_bx_kernel(const float* __restrict__ x,
-                                                                  const u32x4* __restrict__ wpb,
-                                                                  float* __restrict__ y, const TrParams p) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int T = 9, CK = 8;
-    constexpr int BM = 32 * MI * WM;
-    constexpr int BQ = 32 * WN;
-    constexpr int XCAP = (25 * BQ) / 16;
-    constexpr int PPT = (XCAP + kBlock - 1) / kBlock;
-    constexpr int A_CELLS = T * 3 * BM;
-    constexpr int APT = (A_CELLS + kBlock - 1) / kBlock;
-    __shared__ u32x4 As[A_CELLS + 1];
-    __shared__ u32x4 Xs[3 * XCAP];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wm = wid / WN, wn = wid % WN;
-
-    int bt = blockIdx.x;
-    int ridx = 0;
-    if (bt >= p.reg[0].blocks) {
-        bt -= p.reg[0].blocks; ridx = 1;
-        if (bt >= p.reg[1].blocks) { bt -= p.reg[1].blocks; ridx = 2; }
-    }
-    const TrRegion g = p.reg[ridx];
-    const int TW = g.tw, TH = g.th, TN = g.tn;
-    const int tix = bt % g.tiles_x; bt /= g.tiles_x;
-    const int tiy = bt % g.tiles_y;
-    const int tin = bt / g.tiles_y;
-    const int qx0 = g.qx_base + tix * TW, qy0 = g.qy_base + tiy * TH, n0 = tin * TN;
-    const int m0 = blockIdx.y * BM;
-
-    const int PH = TH + 1, PW = TW + 1;
-    const int IP = PH * PW;
-    const int CP = TN * IP;
-    const int HW = p.IH * p.IW;
-
-    int poff[PPT];
-#pragma unroll
-    for (int s = 0; s < PPT; ++s) {
-        const int e = tid + kBlock * s;
-        int off = -1;
-        if (e < CP) {
-            const int pn = e / IP;
-            const int rem = e - pn * IP;
-            const int r = rem / PW;
-            const int c = rem - r * PW;
-            const int iy = qy0 - 1 + r, ix = qx0 - 1 + c;
-            if (n0 + pn < p.N && iy >= 0 && iy < p.IH && ix >= 0 && ix < p.IW)
-                off = pn * p.C * HW + iy * p.IW + ix;
-        }
-        poff[s] = off;
-    }
-
-    const int pp = wn * 32 + l31;
-    const int pn = pp / (TW * TH);
-    const int prem = pp - pn * (TW * TH);
-    const int py = prem / TW;
-    const int px = prem - py * TW;
-    const bool lane_ok = pn < TN;
-    const int pixbase = lane_ok ? pn * IP + py * PW + px : 0;
-    constexpr int TLO[5] = {0, 6, 1, 3, 4};
-    constexpr int THI[5] = {2, 8, 7, 5, 4};
-    constexpr int GCLS[5] = {0, 0, 1, 2, 3};
-    int boff[5], aoff[5];
-#pragma unroll
-    for (int g = 0; g < 5; ++g) {
-        const int t = half ? THI[g] : TLO[g];
-        const int ky = t / 3, kx = t % 3;
-        boff[g] = ((ky == 2) ? 0 : 1) * PW + ((kx == 2) ? 0 : 1);
-        aoff[g] = (g == 4 && half) ? A_CELLS : t * 3 * BM + wm * MI * 32 + l31;
-    }
-    const int astep4 = half ? 0 : BM, mstep4 = half ? 0 : 32;   // the zero cell has no planes
-
-    f32x16 acc[MI][4];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][cl][r] = 0.0f;
-
-    const float* xb = x + (int64_t)n0 * p.C * HW;
-    const u32x4* wt = wpb + (int64_t)blockIdx.y * (p.Cp / CK) * A_CELLS;
-    float xv[CK][PPT];
-    u32x4 av[APT];
-
-    auto load_chunk = [&](int c0) {
-#pragma unroll
-        for (int ch = 0; ch < CK; ++ch) {
-            const bool ch_ok = (c0 + ch) < p.C;
-            const float* xc = xb + (int64_t)(c0 + ch) * HW;
-#pragma unroll
-            for (int s = 0; s < PPT; ++s) xv[ch][s] = (ch_ok && poff[s] >= 0) ? xc[poff[s]] : 0.0f;
-        }
-        const u32x4* wc = wt + (int64_t)(c0 / CK) * A_CELLS;
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e = tid + kBlock * i;
-            if (e < A_CELLS) av[i] = wc[e];
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int s = 0; s < PPT; ++s) {
-            const int e = tid + kBlock * s;
-            if (e < CP) {
-                float v[CK];
-#pragma unroll
-                for (int ch = 0; ch < CK; ++ch) v[ch] = xv[ch][s];
-                bf16x8 s0, s1, s2;
-                split3_bf16(v, s0, s1, s2);
-                Xs[e] = __builtin_bit_cast(u32x4, s0);
-                Xs[XCAP + e] = __builtin_bit_cast(u32x4, s1);
-                Xs[2 * XCAP + e] = __builtin_bit_cast(u32x4, s2);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < APT; ++i) {
-            const int e = tid + kBlock * i;
-            if (e < A_CELLS) As[e] = av[i];
-        }
-    };
-
-    if (tid == 0) As[A_CELLS] = u32x4{0u, 0u, 0u, 0u};
-    load_chunk(0);
-    for (int c0 = 0; c0 < p.Cp; c0 += CK) {
-        __syncthreads();
-        store_chunk();
-        __syncthreads();
-        if (c0 + CK < p.Cp) load_chunk(c0 + CK);
-#pragma unroll
-        for (int g = 0; g < 5; ++g) {
-            bf16x8 a[MI][3], b[3];
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) b[sp] = __builtin_bit_cast(bf16x8, Xs[sp * XCAP + pixbase + boff[g]]);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp)
-                    a[mi][sp] = __builtin_bit_cast(
-                        bf16x8, As[aoff[g] + ((g == 4) ? sp * astep4 + mi * mstep4 : sp * BM + mi * 32)]);
-            constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
-            constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
-#pragma unroll
-            for (int q = 0; q < 6; ++q)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    acc[mi][GCLS[g]] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi][TA[q]], b[TB[q]],
-                                                                               acc[mi][GCLS[g]], 0, 0, 0);
-        }
-    }
-
-    const int n = n0 + pn, qy = qy0 + py, qx = qx0 + px;
-    if (lane_ok && n < p.N && qy < g.QH && qx < g.QW) {
-#pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
-            const int oy = 2 * qy + (cl >> 1) - p.pad;
-            const int ox = 2 * qx + (cl & 1) - p.pad;
-            if (oy >= 0 && oy < p.OH && ox >= 0 && ox < p.OW) {
-                float* yb = y + ((int64_t)n * p.M * p.OH + oy) * p.OW + ox;
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        if (m < p.M) yb[(int64_t)m * p.OH * p.OW] = acc[mi][cl][r];
-                    }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// wgrad: slab[slice][tap][a][b] = sum over the slice's pixels of  S[a][pix] * L[b][pix*stride + tap - pad]
-//   S = gy (a = y-side channel m), L = x (b = x-side channel c)
-// ------------------------------------------------------------------------------------------
-struct WgradParams {
-    int N, C, H, W;       // L tensor (x side)
-    int M, OH, OW;        // S tensor (y side)
-    int pad;
-    int tw_log2, th_log2; // pixel chunk = TN x TH x TW = 64 pixels of the y side
-    int tiles_x, tiles_y, tiles_n;
-    int chunks, chunks_per_slice;
-    int Ap, Bp;           // slab dims (padded M, C)
-    // style modulation of either operand (null = none): L[n][c][..] * l_scale[n * C + c] (the input of a modulated
-    // forward conv) or S[n][m][..] * s_scale[n * M + m] (the input of a modulated TRANSPOSED conv, which is the
-    // y side of the forward-orientation problem), applied while the operand is written to LDS
-    const float* l_scale;
-    const float* s_scale;
-    int zmask;            // always 0 (see IgemmParams)
-    int xcd_order;        // 1: XCD-aware workgroup order (see conv_wgrad_kernel)
-};
-
-constexpr int kWgPix = 64;
-
-template <int KS, int S>
-struct WgPatchCap {
-    static constexpr int value = (KS == 1) ? 65 : (S == 1 ? 145 : 325);   // odd strides
-};
-
-// MODE 0: the 4 waves tile the (a, b) plane WA x WB, every wave walks all 64 pixels of a chunk.
-// MODE 1: narrow layers (M, C <= 32): ONE 32 x 32 x taps tile per workgroup; the 4 waves split the
-//         pixels of a chunk (k-pairs w, w+4, ...) and are summed through LDS before the slab store,
-//         so no wave multiplies padding.
-// MODE 2: MODE 1 with the B-tile lanes enumerating (channel, tap) pairs (C * taps <= 32: the RGB
-//         stems): one MFMA per k-pair instead of one per tap.
-// MOD: an operand is style-modulated while staged (WgradParams::l_scale / s_scale); a separate instantiation
-// WQ (stride 1, one image per 64-pixel chunk, rows of both tensors a multiple of four floats): both operands are staged as
-// aligned 16-byte quads -- a wave loads the 64 pixels of FOUR gy channels with one dwordx4 instruction, and the widened
-// x patch [x0 - 4, x0 + TW + 4) of one channel with one (3x3; 1x1: four channels) -- 20 (3x3) or 16 (1x1) vector-memory
-// instructions per wave and chunk instead of 64.  At one wave per SIMD the issue of those instructions is not hidden by
-// anything (profiles/r2_phase_clock_*.txt: 21 % of the kernel for 3x3, 54-61 % for 1x1).  LDS rows are 66 (S, 1x1 L) or
-// 162 (3x3 L) floats: 8-byte aligned for ds_write_b64 and conflict-free across the 32 channels of an MFMA operand read.
-// Stride 2 (3x3, pad 0): the x rows are 2^k + 1 floats, so the patch [2 x0, 2 x0 + 2 TW] is fetched as quads that are only
-// 4-byte aligned (global_load_dwordx4 takes them, tools/probe/unaligned_x4_probe.hip) -- 85 quads per channel, two loads
-// per channel and wave instead of six; a quad that would run past the end of its row is fetched from W - 4 and shifted,
-// so nothing is read outside the tensor.  24 instead of 80 vector-memory instructions per wave and chunk.
-template <int KS, int S, int TA, int TB, int WA, int WB, int MODE, bool MOD = false, bool WQ = false>
-__global__ __launch_bounds__(kBlock) void conv_wgrad_kernel(const float* __restrict__ xl,
-                                                            const float* __restrict__ gs,
-                                                            float* __restrict__ slab, const WgradParams p) {
-    constexpr bool PIXSPLIT = MODE == 1 || MODE == 2;
-    constexpr bool PACKCT = MODE == 2;     // MODE 4 = MODE 0 with the operand double buffer forced on
-    static_assert(PIXSPLIT ? (WA == 1 && WB == 1 && TA == 1 && TB == 1) : (WA * WB == 4), "wave arrangement");
-    static_assert(!WQ || (!PIXSPLIT && !MOD && (S == 1 || KS == 3)), "quad staging: MODE 0 / 4, operands not modulated in the kernel");
-    constexpr int T = KS * KS;
-    constexpr int TT = PACKCT ? 1 : T;      // accumulator tap-tiles per (ta, tb)
-    constexpr int BA = 32 * TA * WA, BB = 32 * TB * WB;
-    constexpr int PK = kWgPix;
-    constexpr int SLD = WQ ? PK + 2 : PK + 1;
-    constexpr int LP = WQ ? (KS == 1 ? PK + 2 : (S == 1 ? 162 : 342)) : WgPatchCap<KS, S>::value;
-    __shared__ float Ss[BA * SLD];
-    __shared__ float Ls[BB * LP];
-    __shared__ float red[PIXSPLIT ? 4 * 32 * 33 : 1];
-
-    SAE_CLOCK_BEGIN
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    // the wave index is wave-uniform: say so, or every per-wave base address lives in VGPRs
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wa = PIXSPLIT ? 0 : wid / WB, wb = PIXSPLIT ? 0 : wid % WB;
-    // XCD-aware order: the (a, b) tiles of one pixel slice read the same pixels; workgroup ids go round the 8 XCDs
-    // (id % 8), so in launch order they sit behind 8 different L2s and each fetches its own copy.  Re-labelled so that
-    // all tiles of a slice share an XCD and are dispatched together (needs slices % 8 == 0).
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (p.xcd_order && (gridDim.z & 7) == 0) {
-        const int mn = gridDim.x * gridDim.y;
-        const int lin = bx + gridDim.x * (by + gridDim.y * bz);
-        const int j = lin >> 3;
-        const int tile = j % mn;
-        bz = (j / mn) * 8 + (lin & 7);
-        bx = tile % gridDim.x;
-        by = tile / gridDim.x;
-    }
-    const int b0 = bx * BB, a0 = by * BA, slice = bz;
-
-    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
-    const int TN = PK >> (p.tw_log2 + p.th_log2);
-    const int PH = (KS == 1) ? TH : (TH - 1) * S + KS;
-    const int PW = (KS == 1) ? TW : (TW - 1) * S + KS;
-    const int RS = (WQ && KS == 3) ? (S == 1 ? TW + 8 : ((PW + 3) >> 2) << 2) : PW;      // WQ: patch rows widened to whole quads
-    const int IP = PH * RS;
-    const int CPs = TN * IP;
-    const int HWl = p.H * p.W, HWs = p.OH * p.OW;
-
-    int tapoff[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int ky = t / KS, kx = t % KS;
-        tapoff[t] = (KS == 1) ? 0 : ky * RS + kx;
-    }
-
-    f32x16 acc[TA][TB][TT];
-#pragma unroll
-    for (int ta = 0; ta < TA; ++ta)
-#pragma unroll
-        for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-            for (int t = 0; t < TT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[ta][tb][t][r] = 0.0f;
-
-    // MODE 2: lane j of the B tile stands for (channel j / T, tap j % T)
-    int pk_row = 0, pk_tapoff = 0;
-    if (PACKCT) {
-        const int ch = l31 / T, t = l31 - ch * T;
-        const int ky = t / KS, kx = t % KS;
-        pk_row = (ch < BB ? ch : BB - 1) * LP;
-        pk_tapoff = (KS == 1) ? 0 : ky * RS + kx;
-    }
-
-    const int ch_begin = slice * p.chunks_per_slice;
-    int ch_end = ch_begin + p.chunks_per_slice;
-    if (ch_end > p.chunks) ch_end = p.chunks;
-
-    // Register prefetch (software pipeline): the global loads of chunk k+1 are issued before the
-    // MFMA loop of chunk k and written to LDS after the barrier that ends it, so HBM/L2 latency
-    // hides under the matrix pipe even at one workgroup per CU.
-    //   S: thread (wave w, lane l) holds pixel l of channels a = w, w+4, ...
-    //   L: wave w holds channels b = w, w+4, ...; lane l holds patch elements l, l+64, ...
-    constexpr int NS = BA / 4;
-    constexpr int NLB = BB / 4;
-    constexpr int LS = (KS == 1) ? 1 : (LP + kWave - 1) / kWave;
-    float sv[WQ ? 1 : NS];
-    float lv[WQ ? 1 : NLB][LS];
-    // WQ: S quads: lane = (channel sub-index cs = lane / 16, quad q = lane % 16), load i covers channels 16 i + 4 wid + cs;
-    // L quads (3x3): lane = quad of the widened patch, load j is channel wid + 4 j; (1x1): the S mapping
-    constexpr int NSQ = BA / 16;
-    constexpr int NLQ = (KS == 1) ? BB / 16 : (S == 1 ? BB / 4 : BB / 2);   // stride 2: two loads per channel
-    f32x4 sq[WQ ? NSQ : 1];
-    f32x4 lq[WQ ? NLQ : 1];
-    bool sq_ok = false, lq_ok = false;
-    [[maybe_unused]] bool lq_ok2 = false;          // stride 2: validity of the second quad of a channel
-    [[maybe_unused]] int lq_sh[2] = {0, 0};        // ... and how far each was moved left to stay inside its row
-    constexpr bool BRANCHFREE = KS == 3 && S == 2 && !PIXSPLIT;
-    bool s_ok = false;      // validity of the prefetched chunk's elements (applied in store_chunk)
-    int l_okmask = 0;
-    [[maybe_unused]] int pf_n0 = 0;   // first image of the prefetched chunk (operand modulation)
-    // factors of the prefetched chunk when it lies in one image (TN == 1: every layer with >= 64 pixels per image),
-    // fetched with the chunk so their latency hides under the MFMAs like the operands' own
-    [[maybe_unused]] float ssc[MOD ? NS : 1];
-    [[maybe_unused]] float lsc[MOD ? NLB : 1];
-
-    auto load_chunk = [&](int chunk) {
-        int bt = chunk;
-        const int tix = bt % p.tiles_x; bt /= p.tiles_x;
-        const int tiy = bt % p.tiles_y;
-        const int tin = bt / p.tiles_y;
-        const int ox0 = tix * TW, oy0 = tiy * TH, n0 = tin * TN;
-        if constexpr (MOD) {
-            pf_n0 = n0;
-            if (TN == 1) {
-                const int z = lane & p.zmask;
-                if (p.s_scale) {
-#pragma unroll
-                    for (int i = 0; i < NS; ++i) {
-                        const int a = a0 + wid + 4 * i;
-                        ssc[i] = p.s_scale[n0 * p.M + (a < p.M ? a : 0) + z];
-                    }
-                }
-                if (p.l_scale) {
-#pragma unroll
-                    for (int j = 0; j < NLB; ++j) {
-                        const int b = b0 + wid + 4 * j;
-                        lsc[j] = p.l_scale[n0 * p.C + (b < p.C ? b : 0) + z];
-                    }
-                }
-            }
-        }
-        if constexpr (WQ) {
-            const int q = lane & 15, cs = lane >> 4;
-            const int py = (4 * q) >> p.tw_log2, px = (4 * q) & (TW - 1);
-            {   // S: gy[n0][a0 + a][oy0 + py][ox0 + px .. + 3]
-                const int oy = oy0 + py, ox = ox0 + px;
-                sq_ok = oy < p.OH && ox < p.OW;
-                const char* sbase = reinterpret_cast<const char*>(gs + ((int64_t)n0 * p.M + a0) * HWs);
-                const unsigned pix = sq_ok ? (unsigned)(oy * p.OW + ox) : 0u;
-#pragma unroll
-                for (int i = 0; i < NSQ; ++i) {
-                    const int a = 16 * i + 4 * wid + cs;
-                    const unsigned off = (a0 + a < p.M) ? 4u * ((unsigned)(a * HWs) + pix) : 0u;
-                    sq[i] = *reinterpret_cast<const f32x4*>(sbase + off);
-                }
-            }
-            const char* lbase = reinterpret_cast<const char*>(xl + ((int64_t)n0 * p.C + b0) * HWl);
-            if constexpr (KS == 1) {   // L: x at the same pixels (1x1, stride 1, pad 0)
-                const int iy = oy0 + py - p.pad, ix = ox0 + px - p.pad;
-                lq_ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                const unsigned pix = lq_ok ? (unsigned)(iy * p.W + ix) : 0u;
-#pragma unroll
-                for (int j = 0; j < NLQ; ++j) {
-                    const int b = 16 * j + 4 * wid + cs;
-                    const unsigned off = (b0 + b < p.C) ? 4u * ((unsigned)(b * HWl) + pix) : 0u;
-                    lq[j] = *reinterpret_cast<const f32x4*>(lbase + off);
-                }
-            } else if constexpr (S == 2) {   // L: quads lane, lane + 64 of the patch of channel wid + 4 j (pad 0)
-                const int RQ = RS >> 2;
-                unsigned pix[2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int qi = lane + 64 * h;
-                    const int r = qi / RQ, qc = qi - r * RQ;
-                    const int iy = oy0 * 2 + r, ix = ox0 * 2 + 4 * qc;
-                    const bool ok = r < PH && iy < p.H && ix < p.W;
-                    const int ixc = ix + 4 <= p.W ? ix : p.W - 4;       // keep the quad inside its row
-                    lq_sh[h] = ok ? ix - ixc : 0;
-                    pix[h] = ok ? (unsigned)(iy * p.W + ixc) : 0u;
-                    if (h == 0) lq_ok = ok; else lq_ok2 = ok;
-                }
-#pragma unroll
-                for (int j = 0; j < NLQ; ++j) {
-                    const int b = wid + 4 * (j >> 1);
-                    const unsigned off = (b0 + b < p.C) ? 4u * ((unsigned)(b * HWl) + pix[j & 1]) : 0u;
-                    struct __attribute__((packed, aligned(4))) U4 { f32x4 v; };     // 4-byte aligned quad
-                    lq[j] = reinterpret_cast<const U4*>(lbase + off)->v;
-                }
-            } else {                   // L: quad `lane` of the widened patch of channel wid + 4 j
-                const int RQ = RS >> 2;
-                const int r = lane / RQ, qc = lane - r * RQ;
-                const int iy = oy0 - p.pad + r, ix = ox0 - 4 + 4 * qc;
-                lq_ok = r < PH && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                const unsigned pix = lq_ok ? (unsigned)(iy * p.W + ix) : 0u;
-#pragma unroll
-                for (int j = 0; j < NLQ; ++j) {
-                    const int b = wid + 4 * j;
-                    const unsigned off = (b0 + b < p.C) ? 4u * ((unsigned)(b * HWl) + pix) : 0u;
-                    lq[j] = *reinterpret_cast<const f32x4*>(lbase + off);
-                }
-            }
-        } else {
-        // addressing: one wave-uniform 64-bit base per tensor + 32-bit (lane + channel) offsets,
-        // so loads use the SGPR-base form and no per-channel pointer is kept in registers
-        {
-            const int px = lane & (TW - 1);
-            const int py = (lane >> p.tw_log2) & (TH - 1);
-            const int pn = lane >> (p.tw_log2 + p.th_log2);
-            const int n = n0 + pn, oy = oy0 + py, ox = ox0 + px;
-            const bool ok = n < p.N && oy < p.OH && ox < p.OW;
-            const float* sbase = gs + ((int64_t)n0 * p.M + a0) * HWs;
-            const int lane_off = pn * p.M * HWs + oy * p.OW + ox;
-            // BRANCHFREE: no load sits in a divergent branch (hipcc drains vmcnt at the join, which serialised
-            // the loads of the register-starved stride-2 instantiation: 78 -> 98 TFLOP/s); invalid elements
-            // read element 0 of the block's tile and are zeroed in store_chunk.  The stride-1 kernel keeps
-            // predicated loads (measured 111 vs 102 TFLOP/s with the select-and-mask form).
-            s_ok = ok;
-#pragma unroll
-            for (int i = 0; i < NS; ++i) {
-                const int a = wid + 4 * i;
-                if constexpr (BRANCHFREE) sv[i] = sbase[(ok && a0 + a < p.M) ? lane_off + a * HWs : 0];
-                else sv[i] = (ok && a0 + a < p.M) ? sbase[lane_off + a * HWs] : 0.0f;
-            }
-        }
-        {
-            int poff[LS];
-#pragma unroll
-            for (int s = 0; s < LS; ++s) {
-                const int e = lane + kWave * s;
-                int off = -1;
-                if (e < CPs) {
-                    const int pn = e / IP;
-                    const int rem = e - pn * IP;
-                    const int r = rem / RS;
-                    const int cl = rem - r * RS;
-                    int c = cl;
-                    // natural column order: lanes of a wgrad B-read differ in CHANNEL, not pixel, so the
-                    // stride-2 pixel walk causes no bank conflict and the global loads stay contiguous
-                    int iy, ix;
-                    if (KS == 1) { iy = (oy0 + r) * S - p.pad; ix = (ox0 + c) * S - p.pad; }
-                    else { iy = oy0 * S - p.pad + r; ix = ox0 * S - p.pad + c; }
-                    if (n0 + pn < p.N && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                        off = pn * p.C * HWl + iy * p.W + ix;
-                }
-                poff[s] = off;
-            }
-            const float* lbase = xl + ((int64_t)n0 * p.C + b0) * HWl;
-            l_okmask = 0;
-#pragma unroll
-            for (int s = 0; s < LS; ++s) l_okmask |= (poff[s] >= 0 ? 1 : 0) << s;
-#pragma unroll
-            for (int j = 0; j < NLB; ++j) {
-                const int b = wid + 4 * j;
-                const bool ch_ok = (b0 + b) < p.C;
-#pragma unroll
-                for (int s = 0; s < LS; ++s) {
-                    if constexpr (BRANCHFREE) lv[j][s] = lbase[(ch_ok && poff[s] >= 0) ? poff[s] + b * HWl : 0];
-                    else lv[j][s] = (ch_ok && poff[s] >= 0) ? lbase[poff[s] + b * HWl] : 0.0f;
-                }
-            }
-        }
-        }
-    };
-    auto store_chunk = [&]() {
-        if constexpr (WQ) {
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const int q = lane & 15, cs = lane >> 4;
-#pragma unroll
-            for (int i = 0; i < NSQ; ++i) {
-                const int a = 16 * i + 4 * wid + cs;
-                f32x4 v = sq[i];
-                const bool ok = sq_ok && a0 + a < p.M;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
-                float* dst = Ss + a * SLD + 4 * q;
-                *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
-                *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
-            }
-            if constexpr (KS == 3 && S == 2) {
-#pragma unroll
-                for (int j = 0; j < NLQ; ++j) {
-                    const int b = wid + 4 * (j >> 1);
-                    const int sh = lq_sh[j & 1];
-                    const f32x4 u = lq[j];
-                    // a quad fetched `sh` floats to the left of its place: drop the first sh, the tail lies beyond the row
-                    f32x4 v = u;
-                    if (sh == 1) v = f32x4{u[1], u[2], u[3], 0.0f};
-                    if (sh == 2) v = f32x4{u[2], u[3], 0.0f, 0.0f};
-                    if (sh == 3) v = f32x4{u[3], 0.0f, 0.0f, 0.0f};
-                    const bool ok = ((j & 1) ? lq_ok2 : lq_ok) && b0 + b < p.C;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
-                    const int slot = 4 * (lane + 64 * (j & 1));
-                    if (slot + 3 < LP) {
-                        float* dst = Ls + b * LP + slot;
-                        *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
-                        *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
-                    }
-                }
-                return;
-            }
-#pragma unroll
-            for (int j = 0; j < NLQ; ++j) {
-                const int b = (KS == 1) ? 16 * j + 4 * wid + cs : wid + 4 * j;
-                f32x4 v = lq[j];
-                const bool ok = lq_ok && b0 + b < p.C;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
-                // 3x3: lanes beyond the patch (r >= PH) have lq_ok false and still own a distinct slot < 64 quads = 256
-                // floats: keep them inside the row by folding onto the last quad slots of the row's spare space
-                const int slot = (KS == 1) ? 4 * q : 4 * lane;
-                if (KS == 1 || 4 * lane + 3 < LP) {
-                    float* dst = Ls + b * LP + slot;
-                    *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
-                    *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
-                }
-            }
-            return;
-        }
-        if (MOD && p.s_scale) {        // modulated S operand: factor of (image of this lane's pixel, channel a)
-            if (TN == 1) {
-#pragma unroll
-                for (int i = 0; i < NS; ++i) sv[i] *= ssc[i];
-            } else {
-                const int n = pf_n0 + (lane >> (p.tw_log2 + p.th_log2));
-#pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    const int a = a0 + wid + 4 * i;
-                    sv[i] *= p.s_scale[(n < p.N ? n : 0) * p.M + (a < p.M ? a : 0)];
-                }
-            }
-        }
-        if (MOD && p.l_scale) {        // modulated L operand: factor of (image of the patch element, channel b)
-            if (TN == 1) {
-#pragma unroll
-                for (int j = 0; j < NLB; ++j)
-#pragma unroll
-                    for (int s = 0; s < LS; ++s) lv[j][s] *= lsc[j];
-            } else {
-#pragma unroll
-                for (int s = 0; s < LS; ++s) {
-                    const int e = lane + kWave * s;
-                    const int n = pf_n0 + (e < CPs ? e / IP : 0);
-                    const int row = (n < p.N ? n : 0) * p.C;
-#pragma unroll
-                    for (int j = 0; j < NLB; ++j) {
-                        const int b = b0 + wid + 4 * j;
-                        lv[j][s] *= p.l_scale[row + (b < p.C ? b : 0)];
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NS; ++i)
-            Ss[(wid + 4 * i) * SLD + lane] = (!BRANCHFREE || (s_ok && a0 + wid + 4 * i < p.M)) ? sv[i] : 0.0f;
-#pragma unroll
-        for (int j = 0; j < NLB; ++j) {
-            const bool ch_ok = (b0 + wid + 4 * j) < p.C;
-#pragma unroll
-            for (int s = 0; s < LS; ++s) {
-                const int e = lane + kWave * s;
-                if (e < CPs)
-                    Ls[(wid + 4 * j) * LP + e] = (!BRANCHFREE || (ch_ok && ((l_okmask >> s) & 1))) ? lv[j][s] : 0.0f;
-            }
-        }
-    };
-
-    if (ch_begin < ch_end) load_chunk(ch_begin);
-    SAE_CLOCK_PHASE(0)
-    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
-        __syncthreads();   // previous chunk fully consumed
-        SAE_CLOCK_PHASE(2)
-        store_chunk();
-        SAE_CLOCK_PHASE(3)
-        __syncthreads();
-        SAE_CLOCK_PHASE(4)
-        if (chunk + 1 < ch_end) load_chunk(chunk + 1);   // in flight under the MFMAs below
-        SAE_CLOCK_PHASE(5)
-
-        // ---- MFMA over the 64 pixels, two per instruction.  The LDS operands of k-pair i+1 are
-        // fetched into a second register set before the MFMAs of k-pair i issue (explicit
-        // double buffering): with one wave per SIMD nothing else hides the ds_read latency.
-        constexpr int KSTEP = PIXSPLIT ? 4 : 1;
-        constexpr int KITER = (PK / 2) / KSTEP;           // k-pairs per wave per chunk (even)
-        static_assert(KITER % 2 == 0, "k-pair loop is unrolled by two");
-        constexpr int NB = PACKCT ? 1 : TB * T;
-        auto fetch = [&](int kp, float (&a)[TA], float (&b)[NB]) {
-            const int pk = 2 * kp + half;
-            const int px = pk & (TW - 1);
-            const int py = (pk >> p.tw_log2) & (TH - 1);
-            const int pn = pk >> (p.tw_log2 + p.th_log2);
-            const int pbase = pn * IP + ((KS == 1) ? py * RS + px : py * S * RS + px * S) + ((WQ && KS == 3 && S == 1) ? 4 - p.pad : 0);
-#pragma unroll
-            for (int ta = 0; ta < TA; ++ta) a[ta] = Ss[((wa * TA + ta) * 32 + l31) * SLD + pk];
-            if constexpr (PACKCT) {
-                b[0] = Ls[pk_row + pbase + pk_tapoff];
-            } else {
-#pragma unroll
-                for (int tb = 0; tb < TB; ++tb) {
-                    const float* lrow = Ls + ((wb * TB + tb) * 32 + l31) * LP + pbase;
-#pragma unroll
-                    for (int t = 0; t < T; ++t) b[tb * T + t] = lrow[tapoff[t]];
-                }
-            }
-        };
-        auto mma = [&](const float (&a)[TA], const float (&b)[NB]) {
-            if constexpr (PACKCT) {
-                acc[0][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b[0], acc[0][0][0], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-                    for (int t = 0; t < T; ++t)
-#pragma unroll
-                        for (int ta = 0; ta < TA; ++ta)
-                            acc[ta][tb][t] =
-                                __builtin_amdgcn_mfma_f32_32x32x2f32(a[ta], b[tb * T + t], acc[ta][tb][t], 0, 0, 0);
-            }
-        };
-        const int kp0 = PIXSPLIT ? wid : 0;
-        // the stride-2 instantiation already sits at the register ceiling (80 prefetch + 144
-        // accumulator registers): it keeps a single operand set
-        constexpr bool DOUBLE_BUFFER = (MODE == 4) || !(KS == 3 && S == 2 && MODE == 0);
-        if constexpr (DOUBLE_BUFFER) {
-            float a_even[TA], b_even[NB], a_odd[TA], b_odd[NB];
-            fetch(kp0, a_even, b_even);
-            for (int it = 0; it < KITER; it += 2) {
-                const int kp = kp0 + it * KSTEP;
-                fetch(kp + KSTEP, a_odd, b_odd);
-                mma(a_even, b_even);
-                if (it + 2 < KITER) fetch(kp + 2 * KSTEP, a_even, b_even);
-                mma(a_odd, b_odd);
-            }
-        } else {
-#pragma unroll 2
-            for (int it = 0; it < KITER; ++it) {
-                float a_cur[TA], b_cur[NB];
-                fetch(kp0 + it * KSTEP, a_cur, b_cur);
-                mma(a_cur, b_cur);
-            }
-        }
-        SAE_CLOCK_PHASE(1)
-    }
-
-    // ---- slab store: rows = a (m), cols = b (c)
-    if constexpr (PIXSPLIT) {
-        // sum the four waves' partial tiles through LDS (fixed order), one tap-tile at a time
-#pragma unroll
-        for (int t = 0; t < TT; ++t) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                red[(wid * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l31] = acc[0][0][t][r];
-            __syncthreads();
-            for (int e = tid; e < 32 * 32; e += kBlock) {
-                const int i = e >> 5, j = e & 31;
-                const float v = (red[(0 * 32 + i) * 33 + j] + red[(1 * 32 + i) * 33 + j]) +
-                                (red[(2 * 32 + i) * 33 + j] + red[(3 * 32 + i) * 33 + j]);
-                int tap = t, bcol = b0 + j;
-                if (PACKCT) { bcol = j / T; tap = j - bcol * T; }
-                if (bcol < p.Bp && (!PACKCT || bcol < p.C))
-                    slab[(((int64_t)slice * T + tap) * p.Ap + a0 + i) * p.Bp + bcol] = v;
-            }
-        }
-    } else {
-#pragma unroll
-        for (int ta = 0; ta < TA; ++ta)
-#pragma unroll
-            for (int tb = 0; tb < TB; ++tb)
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    const int bcol = b0 + (wb * TB + tb) * 32 + l31;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int arow = a0 + (wa * TA + ta) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        slab[(((int64_t)slice * T + t) * p.Ap + arow) * p.Bp + bcol] = acc[ta][tb][t][r];
-                    }
-                }
-    }
-    SAE_CLOCK_PHASE(6)
-    SAE_CLOCK_END
-}
-
-// ------------------------------------------------------------------------------------------
-// wgrad, second generation ("wg16"): 64 a x 32 b x 9 taps per workgroup on v_mfma_f32_16x16x4_f32, two or three
-// workgroups per CU.
-//
-// conv_wgrad_kernel<3, S, ..., WQ> gives every wave a 32 x 32 x 9-tap tile: 144 accumulator registers + the chunk's
-// prefetch registers = one wave per SIMD, and nothing overlaps its staging phases (profiles/r2_phase_clock_*.txt: 70 % of
-// the wave's time in the MFMA loop; 0.73 of peak in the step).  Here a wave owns 32 a x 16 b x 9 taps as 2 x 9 tiles of the
-// 16 x 16 x 4 instruction (same FLOP rate, 4 accumulator registers per tile): 72 accumulator registers, 36 (stride 2: 60)
-// prefetch registers, so two independent workgroups share a CU and one's MFMAs cover the other's staging, as in the gather.
-//  * operands: lane l supplies A[a = l & 15][k = l >> 4] and B[k][b = l & 15], k = four consecutive pixels of the chunk; the
-//    32 lanes of an LDS access group read 16 channel rows x 2 adjacent pixels.  Row pitches 66 (S) and 162 (L, stride 1) are
-//    = 2 (mod 32): banks 2 r + {0, 1}, conflict-free (the 32 x 32 form read 32 rows per group: r and r + 16 collided,
-//    SQ_LDS_BANK_CONFLICT = 48 % of the LDS cycles, profiles/r3_pmc_f32.txt).  Stride 2 (pitch 342, pixel offsets even)
-//    keeps two-way conflicts on its L reads.
-//  * staging: S as in the WQ path (a wave loads the 64 pixels of four gy channels per dwordx4); the L patch quads of the 32
-//    channels are dealt out over the workgroup (quad j = tid + 256 k: channel j / QN, quad j % QN), 5 (stride 2: 11) per
-//    thread -- 9 (15) vector-memory instructions per thread and chunk.  Stride 2 fetches 4-byte aligned quads and moves a
-//    quad that would cross its row's end to W - 4, as the WQ path does.
-//  * the k of an instruction sums 4 pixels, so the summation ORDER differs from conv_wgrad_kernel (not bit-identical to it;
-//    both are checked against the oracle).  Slab layout and the fixed-order reduction are unchanged: deterministic.
-// Taken for 3 x 3 layers with one image per 64-pixel chunk under the WQ path's conditions (host: conv_wgrad_impl).
-// ------------------------------------------------------------------------------------------
-// (measured and dropped: __launch_bounds__(kBlock, 3) -- 168 registers with 27 spilled dwords, 83 - 102 instead of 130 TFLOP/s;
-// stride 2 with the L operand read as conflict-free 8-byte pairs on a pitch of 388 floats: 109.8 vs 111.4, the two-way
-// conflicts of its dword reads are not what bounds it)
-template <int S>
-__global__ __launch_bounds__(kBlock, 2) void conv_wgrad16_kernel(const float* __restrict__ xl,
-                                                                 const float* __restrict__ gs,
-                                                                 float* __restrict__ slab, const WgradParams p) {
-    constexpr int T = 9, BA = 64, BB = 32, PK = kWgPix;
-    constexpr int SLD = PK + 2;
-    constexpr int LP = (S == 1) ? 162 : 342;
-    constexpr int QCAP = (S == 1) ? 40 : 85;                       // quads per channel of the widened patch (host-checked)
-    constexpr int QPT = (BB * QCAP + kBlock - 1) / kBlock;          // L quad slots per thread and chunk
-    constexpr int NSQ = BA / 16;
-    constexpr int NB = T;                                           // operand registers of the L side per step
-    __shared__ __attribute__((aligned(16))) float Ss[BA * SLD];
-    __shared__ __attribute__((aligned(16))) float Ls[BB * LP + 4 * kBlock];   // + a dump area for the slots beyond the patch
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-    SAE_CLOCK_BEGIN
-    const int tid = threadIdx.x;
-    __builtin_assume(tid < kBlock);
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, k4 = lane >> 4;
-    const int wa = wid >> 1, wb = wid & 1;
-    // XCD-aware order: all (a, b) tiles of a pixel slice behind one L2 (see conv_wgrad_kernel)
-    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (p.xcd_order && (gridDim.z & 7) == 0) {
-        const int mn = gridDim.x * gridDim.y;
-        const int lin = bx + gridDim.x * (by + gridDim.y * bz);
-        const int j = lin >> 3;
-        const int tile = j % mn;
-        bz = (j / mn) * 8 + (lin & 7);
-        bx = tile % gridDim.x;
-        by = tile / gridDim.x;
-    }
-    const int b0 = bx * BB, a0 = by * BA, slice = bz;
-
-    const int TW = 1 << p.tw_log2, TH = 1 << p.th_log2;
-    const int PH = (TH - 1) * S + 3;
-    const int PW = (TW - 1) * S + 3;
-    const int RS = (S == 1) ? TW + 8 : ((PW + 3) >> 2) << 2;      // patch rows widened to whole quads
-    const int RQ = RS >> 2, QN = PH * RQ;                          // quads per row, per channel (<= QCAP)
-    const int HWl = p.H * p.W, HWs = p.OH * p.OW;
-
-    f32x4 acc[2][T];
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int t = 0; t < T; ++t) acc[ta][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    // chunk-invariant part of the L quad slots: patch row, first column relative to the tile's origin, byte offset relative
-    // to (image n0, channel b0, row oy0 * S - pad, column ox0 * S), LDS index.  lrc < 0: the slot never holds data.
-    int lrc[QPT], lbyte[QPT], ldst[QPT];
-#pragma unroll
-    for (int k = 0; k < QPT; ++k) {
-        const int j = tid + kBlock * k;
-        const int ch = j / QN;
-        const int q = j - ch * QN;
-        const int r = q / RQ;
-        const int qc = q - r * RQ;
-        const int col = (S == 1) ? 4 * qc - 4 : 4 * qc;
-        const bool slot = ch < BB;
-        lrc[k] = (slot && b0 + ch < p.C) ? (r << 16) | (col + 4) : -1;
-        lbyte[k] = 4 * (ch * HWl + r * p.W + col);
-        ldst[k] = slot ? ch * LP + 4 * q : BB * LP + 4 * tid;
-    }
-    // S quads: lane = (channel sub-index cs = lane / 16, quad q = lane % 16), load i covers channel 16 i + 4 wid + cs
-    const int sq_q = lane & 15, sq_cs = lane >> 4;
-    const int sq_py = (4 * sq_q) >> p.tw_log2, sq_px = (4 * sq_q) & (TW - 1);
-
-    const int ch_begin = slice * p.chunks_per_slice;
-    int ch_end = ch_begin + p.chunks_per_slice;
-    if (ch_end > p.chunks) ch_end = p.chunks;
-
-    f32x4 sq[NSQ], lq[QPT];
-    bool sq_ok = false;
-    unsigned lq_ok = 0;                     // bit k: slot k of the prefetched chunk holds image data
-    [[maybe_unused]] unsigned lq_sh = 0;    // stride 2, two bits per slot: how far the quad was moved left to stay inside its row
-
-    auto load_chunk = [&](int chunk) {
-        int bt = chunk;
-        const int tix = bt % p.tiles_x; bt /= p.tiles_x;
-        const int tiy = bt % p.tiles_y;
-        const int n0 = bt / p.tiles_y;
-        const int ox0 = tix * TW, oy0 = tiy * TH;
-        {
-            const int oy = oy0 + sq_py, ox = ox0 + sq_px;
-            sq_ok = oy < p.OH && ox < p.OW;
-            const char* sbase = reinterpret_cast<const char*>(gs + ((int64_t)n0 * p.M + a0) * HWs);
-            const unsigned pix = sq_ok ? (unsigned)(oy * p.OW + ox) : 0u;
-#pragma unroll
-            for (int i = 0; i < NSQ; ++i) {
-                const int a = 16 * i + 4 * wid + sq_cs;
-                const unsigned off = (a0 + a < p.M) ? 4u * ((unsigned)(a * HWs) + pix) : 0u;
-                sq[i] = *reinterpret_cast<const f32x4*>(sbase + off);
-            }
-        }
-        const char* lbase = reinterpret_cast<const char*>(xl + ((int64_t)n0 * p.C + b0) * HWl);
-        const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S;
-        const int rel = 4 * (iy0 * p.W + ix0);
-        lq_ok = 0;
-        if constexpr (S == 2) lq_sh = 0;
-#pragma unroll
-        for (int k = 0; k < QPT; ++k) {
-            const int iy = iy0 + (lrc[k] >> 16), ix = ix0 + (lrc[k] & 0xffff) - 4;
-            const bool ok = lrc[k] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            int off = lbyte[k] + rel;
-            if constexpr (S == 2) {
-                const int sh = (ok && ix + 4 > p.W) ? ix + 4 - p.W : 0;       // keep the quad inside its row
-                off -= 4 * sh;
-                lq_sh |= (unsigned)sh << (2 * k);
-                struct __attribute__((packed, aligned(4))) U4 { f32x4 v; };     // 4-byte aligned quad
-                lq[k] = reinterpret_cast<const U4*>(lbase + (ok ? off : 0))->v;
-            } else {
-                lq[k] = *reinterpret_cast<const f32x4*>(lbase + (ok ? off : 0));
-            }
-            lq_ok |= (ok ? 1u : 0u) << k;
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < NSQ; ++i) {
-            const int a = 16 * i + 4 * wid + sq_cs;
-            f32x4 v = sq[i];
-            const bool ok = sq_ok && a0 + a < p.M;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
-            float* dst = Ss + a * SLD + 4 * sq_q;
-            *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
-            *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
-        }
-#pragma unroll
-        for (int k = 0; k < QPT; ++k) {
-            f32x4 v = lq[k];
-            if constexpr (S == 2) {
-                const int sh = (lq_sh >> (2 * k)) & 3;     // fetched sh floats to the left of its place: the tail lies beyond the row
-                const f32x4 u = v;
-                if (sh == 1) v = f32x4{u[1], u[2], u[3], 0.0f};
-                if (sh == 2) v = f32x4{u[2], u[3], 0.0f, 0.0f};
-                if (sh == 3) v = f32x4{u[3], 0.0f, 0.0f, 0.0f};
-            }
-            const bool ok = (lq_ok >> k) & 1u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.0f;
-            float* dst = Ls + ldst[k];
-            *reinterpret_cast<f32x2*>(dst) = f32x2{v[0], v[1]};
-            *reinterpret_cast<f32x2*>(dst + 2) = f32x2{v[2], v[3]};
-        }
-    };
-
-    const float* const srow = Ss + (wa * 32 + l15) * SLD + k4;
-    const float* const lrow = Ls + (wb * 16 + l15) * LP + ((S == 1) ? 4 - p.pad : 0);
-    if (ch_begin < ch_end) load_chunk(ch_begin);
-    SAE_CLOCK_PHASE(0)
-    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
-        __syncthreads();   // previous chunk fully consumed
-        SAE_CLOCK_PHASE(2)
-        store_chunk();
-        SAE_CLOCK_PHASE(3)
-        __syncthreads();
-        SAE_CLOCK_PHASE(4)
-        if (chunk + 1 < ch_end) load_chunk(chunk + 1);   // in flight under the MFMAs below
-        SAE_CLOCK_PHASE(5)
-        // 16 steps of 4 pixels: 2 + 9 operand reads, 18 MFMAs; the operands of step i + 1 are read before the MFMAs of step i
-        auto fetch = [&](int step, float (&a)[2], float (&b)[NB]) {
-            const int pk = 4 * step + k4;
-            const int px = pk & (TW - 1), py = pk >> p.tw_log2;
-            const float* lp = lrow + py * S * RS + px * S;
-            a[0] = srow[4 * step];
-            a[1] = srow[16 * SLD + 4 * step];
-#pragma unroll
-            for (int t = 0; t < T; ++t) b[t] = lp[(t / 3) * RS + (t % 3)];
-        };
-        auto mma = [&](const float (&a)[2], const float (&b)[NB]) {
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int ta = 0; ta < 2; ++ta)
-                    acc[ta][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], b[t], acc[ta][t], 0, 0, 0);
-        };
-        float a_even[2], b_even[NB], a_odd[2], b_odd[NB];
-        fetch(0, a_even, b_even);
-        for (int it = 0; it < PK / 4; it += 2) {
-            fetch(it + 1, a_odd, b_odd);
-            mma(a_even, b_even);
-            if (it + 2 < PK / 4) fetch(it + 2, a_even, b_even);
-            mma(a_odd, b_odd);
-        }
-        SAE_CLOCK_PHASE(1)
-    }
-
-    // ---- slab store: D row = 4 * (lane >> 4) + r (a), column = lane & 15 (b)
-    const int bcol = b0 + wb * 16 + l15;
-#pragma unroll
-    for (int ta = 0; ta < 2; ++ta)
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int arow = a0 + wa * 32 + ta * 16 + 4 * k4 + r;
-                slab[(((int64_t)slice * T + t) * p.Ap + arow) * p.Bp + bcol] = acc[ta][t][r];
-            }
-    SAE_CLOCK_PHASE(6)
-    SAE_CLOCK_END
-}
-
-// ------------------------------------------------------------------------------------------
-// "bx" arithmetic of the 3x3 wgrad (see conv_igemm_bx_kernel for the split).  K = pixels: the 16 k
-// of an MFMA are two OCTETS, an octet = 8 consecutive pixels of one row of the y side, held as one
-// 16-byte cell per (split, channel).  S (gy) cells are staged as they lie; the x-side operand of tap
-// (ky, kx) is the octet shifted by kx columns: for stride 1 the lane reads the aligned cell plus the
-// first dword of its right neighbour and forms kx = 1 by a 16-bit funnel shift (v_alignbit) and
-// kx = 2 by dropping a dword; for stride 2 the patch columns are stored de-interleaved (even cells,
-// odd cells) so kx = 0 / 1 / 2 = even / odd / even shifted by one element.
-// One workgroup per CU (accumulators: 9 tap tiles = 144 AGPRs per wave), register prefetch of the
-// next chunk; operand splitting happens when the prefetched fp32 values are written to LDS.
-// ------------------------------------------------------------------------------------------
-struct WgBxParams {
-    int N, C, H, W;       // L tensor (x side)
-    int M, OH, OW;        // S tensor (y side), OW % 8 == 0
-    int pad;
-    int tw8_log2, th_log2; // y-side tile: TH rows x (8 << tw8_log2) columns x TN images = 8 * NO pixels
-    int tiles_x, tiles_y, tiles_n;
-    int chunks, chunks_per_slice;
-    int Ap, Bp;
-};
-
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned 16-byte global access
-
-template <int S>
-struct WgBx {
-    static constexpr int NO = (S == 1) ? 16 : 8;      // octets per chunk
-    static constexpr int SOS = NO + 1;                // odd cell strides: conflict-free 16-byte reads across channels
-    static constexpr int LCAP = (S == 1) ? 30 : 45;   // x-side cells per channel
-    static constexpr int LOS = (S == 1) ? 31 : 45;
-    static constexpr int UCAP = (S == 1) ? 30 : 27;   // staging units per channel (s2: a unit = 16 columns = even + odd cell)
-};
-
-template <int S, int WA, int WB>
-__global__ __launch_bounds__(kBlock) void conv_wgrad_bx_kernel(const float* __restrict__ xl,
-                                                               const float* __restrict__ gs,
-                                                               float* __restrict__ slab, const WgBxParams p) {
-    static_assert(WA * WB == 4, "4 waves per workgroup");
-    constexpr int T = 9;
-    constexpr int BA = 32 * WA, BB = 32 * WB;
-    constexpr int NO = WgBx<S>::NO, SOS = WgBx<S>::SOS, LOS = WgBx<S>::LOS;
-    constexpr int SPT = BA * NO / kBlock;
-    constexpr int LPT = (BB * WgBx<S>::UCAP + kBlock - 1) / kBlock;
-    constexpr int UW = (S == 1) ? 8 : 16;              // columns per staging unit
-    static_assert(BA * NO % kBlock == 0, "S cells per thread");
-    __shared__ u32x4 Ss[3 * BA * SOS];
-    __shared__ u32x4 Ls[3 * BB * LOS];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int wa = wid / WB, wb = wid % WB;
-    const int b0 = blockIdx.x * BB, a0 = blockIdx.y * BA, slice = blockIdx.z;
-
-    const int TWO = 1 << p.tw8_log2, TH = 1 << p.th_log2;
-    const int TN = NO >> (p.tw8_log2 + p.th_log2);
-    const int PH = (TH - 1) * S + 3;
-    const int NOLE = TWO + 1;                           // stride 1: cells per patch row; stride 2: even cells per row
-    const int RC = (S == 1) ? NOLE : 2 * TWO + 1;       // cells per patch row
-    const int UPC = TN * PH * NOLE;                     // staging units per channel
-    const int HWl = p.H * p.W, HWs = p.OH * p.OW;
-
-    // chunk-independent part of the staging maps (kept packed: these live across the whole kernel)
-    //   S: cell e = tid + 256 i -> channel a = e / NO, octet o = e % NO; 256 % NO == 0, so a thread's
-    //      cells share the octet (same pixel position) and differ by 256 / NO channels
-    constexpr int SA = kBlock / NO;
-    const int s_o = tid % NO, s_a = tid / NO;
-    const int s_ox = 8 * (s_o & (TWO - 1));
-    const int s_oy = (s_o >> p.tw8_log2) & (TH - 1);
-    const int s_n = s_o >> (p.tw8_log2 + p.th_log2);
-    const int s_off = (s_n * p.M + s_a) * HWs + s_oy * p.OW + s_ox;
-    const int s_cell = s_a * SOS + s_o;
-    //   L: unit u = tid + 256 i -> (channel, image, patch row, unit column); meta = cell | row << 12 |
-    //      column << 17 | image << 24 | single-column unit << 30
-    int l_off[LPT], l_meta[LPT];
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-        const int u = tid + kBlock * i;
-        const int ub = u / UPC, ur = u - ub * UPC;
-        const int j = ur % NOLE;
-        const int rr = ur / NOLE;
-        const int r = rr % PH, pn = rr / PH;
-        const bool ok = ub < BB && b0 + ub < p.C;
-        l_off[i] = ok ? (pn * p.C + ub) * HWl + r * p.W + UW * j : -1;
-        const int cell = (ub < BB) ? ub * LOS + (pn * PH + r) * RC + j : 0xfff;   // 0xfff: writes nothing
-        l_meta[i] = cell | (r << 12) | ((UW * j) << 17) | (pn << 24) | ((S == 2 && j == TWO) ? (1 << 30) : 0);
-    }
-
-    f32x16 acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-
-    const int ch_begin = slice * p.chunks_per_slice;
-    int ch_end = ch_begin + p.chunks_per_slice;
-    if (ch_end > p.chunks) ch_end = p.chunks;
-
-    float sv[SPT][8];
-    float lv[LPT][UW];      // raw windows as loaded; the border fix-up waits until store_chunk so that
-    int lcode[LPT];         // nothing in load_chunk depends on a load (its latency hides under the MFMAs)
-    int s_okmask = 0;
-    bool chunk_border = false;   // workgroup-uniform: the prefetched chunk needs the border fix-up
-    float ltail[(S == 2) ? LPT : 1];
-
-    auto load_chunk = [&](int chunk) {
-        int bt = chunk;
-        const int tix = bt % p.tiles_x; bt /= p.tiles_x;
-        const int tiy = bt % p.tiles_y;
-        const int tin = bt / p.tiles_y;
-        const int ox0 = tix * 8 * TWO, oy0 = tiy * TH, n0 = tin * TN;
-        chunk_border = ox0 == 0 || ox0 + 8 * TWO >= p.OW || oy0 == 0 || oy0 + TH >= p.OH || n0 + TN > p.N ||
-                       a0 + BA > p.M || b0 + BB > p.C;
-        {
-            const float* sbase = gs + ((int64_t)n0 * p.M + a0) * HWs + oy0 * p.OW + ox0;
-            const bool pos_ok = n0 + s_n < p.N && oy0 + s_oy < p.OH && ox0 + s_ox < p.OW;
-            s_okmask = 0;
-#pragma unroll
-            for (int i = 0; i < SPT; ++i) {
-                const bool ok = pos_ok && a0 + s_a + SA * i < p.M;
-                s_okmask |= (ok ? 1 : 0) << i;
-                const f32x4u* g = reinterpret_cast<const f32x4u*>(ok ? sbase + s_off + SA * i * HWs : gs);
-                const f32x4 v0 = g[0], v1 = g[1];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { sv[i][e] = v0[e]; sv[i][4 + e] = v1[e]; }
-            }
-        }
-        // x side.  No branch may contain a load here: hipcc drains vmcnt at every control-flow join, which
-        // would serialise the chunk's loads.  Every unit reads a full window from an address that is always
-        // inside the tensor (clamped into its row, or the tensor base for rows that do not exist) and the
-        // border cases are resolved with selects afterwards.
-        const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
-        const float* lbase = xl + ((int64_t)n0 * p.C + b0) * HWl + iy0 * p.W + ix0;
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int m = l_meta[i];
-            const int iy = iy0 + ((m >> 12) & 31), ix = ix0 + ((m >> 17) & 127);
-            const bool row_ok = l_off[i] >= 0 && n0 + ((m >> 24) & 63) < p.N && iy >= 0 && iy < p.H;
-            if constexpr (S == 1) {
-                // window [ixc, ixc + 8) with ixc = clamp(ix, 0, W - 8); d = ix - ixc is -1 at the left image
-                // border (pad 1), 0 inside, > 0 at the right border, where only the row's last cell can be
-                // and only its elements 0 and 1 are ever read (host: OW % tile width == 0)
-                int ixc = ix < 0 ? 0 : ix;
-                if (ixc > p.W - 8) ixc = p.W - 8;
-                const int d = row_ok ? ix - ixc : 64;
-                const f32x4u* g = reinterpret_cast<const f32x4u*>(row_ok ? lbase + l_off[i] + (ixc - ix) : xl);
-                const f32x4 v0 = g[0], v1 = g[1];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { lv[i][e] = v0[e]; lv[i][4 + e] = v1[e]; }
-                lcode[i] = d;
-            } else {
-                // stride 2, pad 0 (host): 16-column units are inside their row; the single-column tail unit
-                // (even cell of column 2 TW) reads one element
-                const bool single = (m >> 30) & 1;
-                const bool vec = row_ok && !single;
-                const float* gu = lbase + l_off[i];
-                const f32x4u* g = reinterpret_cast<const f32x4u*>(vec ? gu : xl);
-                ltail[i] = *((row_ok && single) ? gu : xl);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = g[q];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) lv[i][4 * q + e] = v[e];
-                }
-                lcode[i] = vec ? 1 : ((row_ok && single) ? 2 : 0);
-            }
-        }
-    };
-    // Border fix-up happens on the packed bf16 cells (dword funnel shifts and selects, no arrays) and only
-    // in chunks that touch an image border or a channel / batch tail (workgroup-uniform branch).
-    //   stride 1: code = window shift d: -1 -> the window starts one column right of the cell (left border),
-    //             6 / 7 -> right border cell, whose elements 0, 1 are window elements d, d + 1; 64 -> dead row
-    //   stride 2: code 1 = 16 columns, 2 = single-column tail unit, 0 = dead row
-    auto put3 = [&](u32x4* base, int plane, int c, const bf16x8& s0, const bf16x8& s1, const bf16x8& s2, int code) {
-        u32x4 v[3] = {__builtin_bit_cast(u32x4, s0), __builtin_bit_cast(u32x4, s1), __builtin_bit_cast(u32x4, s2)};
-        if (chunk_border && S == 1) {
-#pragma unroll
-            for (int sp = 0; sp < 3; ++sp) {
-                const u32x4 q = v[sp];
-                const u32x4 sh = {q[0] << 16, (q[0] >> 16) | (q[1] << 16), (q[1] >> 16) | (q[2] << 16),
-                                  (q[2] >> 16) | (q[3] << 16)};
-                u32x4 r = (code == -1) ? sh : q;
-                if (code > 0) r[0] = (code == 6) ? q[3] : (q[3] >> 16);
-                if (code > 7) r = u32x4{0u, 0u, 0u, 0u};
-                v[sp] = r;
-            }
-        }
-        base[c] = v[0];
-        base[plane + c] = v[1];
-        base[2 * plane + c] = v[2];
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < SPT; ++i) {
-            float fx[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) fx[e] = (!chunk_border || ((s_okmask >> i) & 1)) ? sv[i][e] : 0.0f;
-            bf16x8 s0, s1, s2;
-            split3_bf16(fx, s0, s1, s2);
-            put3(Ss, BA * SOS, s_cell + SA * SOS * i, s0, s1, s2, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int c = l_meta[i] & 0xfff;
-            if (c == 0xfff) continue;
-            if constexpr (S == 1) {
-                bf16x8 s0, s1, s2;
-                split3_bf16(lv[i], s0, s1, s2);
-                put3(Ls, BB * LOS, c, s0, s1, s2, lcode[i]);
-            } else {
-                const int code = lcode[i];
-                float ev[8], od[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    ev[e] = (code == 1) ? lv[i][2 * e] : 0.0f;
-                    od[e] = (code == 1) ? lv[i][2 * e + 1] : 0.0f;
-                }
-                if (code == 2) ev[0] = ltail[i];
-                bf16x8 s0, s1, s2;
-                split3_bf16(ev, s0, s1, s2);
-                put3(Ls, BB * LOS, c, s0, s1, s2, 0);
-                if (!((l_meta[i] >> 30) & 1)) {
-                    split3_bf16(od, s0, s1, s2);
-                    put3(Ls, BB * LOS, c + NOLE, s0, s1, s2, 0);
-                }
-            }
-        }
-    };
-
-    // operands: A cells of one K block (two octets); per (K block, ky) the aligned x-side cell(s) + the
-    // first dword of the right neighbour.  One wave per SIMD: the LDS reads of step (kb, ky) + 1 are
-    // issued before the 18 MFMAs of step (kb, ky) (two alternating register sets).
-    struct FragA { u32x4 a[3]; };
-    struct FragB {
-        u32x4 be[3];
-        unsigned bn[3];
-        u32x4 bo[(S == 2) ? 3 : 1];
-    };
-    const int a_row = (wa * 32 + l31) * SOS;
-    const int b_row = (wb * 32 + l31) * LOS;
-    auto fetchA = [&](int kb, FragA& f) {
-        const int o = 2 * kb + half;
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) f.a[sp] = Ss[sp * BA * SOS + a_row + o];
-    };
-    auto fetchB = [&](int kb, int ky, FragB& f) {
-        const int o = 2 * kb + half;
-        const int poct = o & (TWO - 1);
-        const int py = (o >> p.tw8_log2) & (TH - 1);
-        const int pn = o >> (p.tw8_log2 + p.th_log2);
-        const int c0 = b_row + (pn * PH + py * S + ky) * RC + poct;
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) {
-            f.be[sp] = Ls[sp * BB * LOS + c0];
-            f.bn[sp] = Ls[sp * BB * LOS + c0 + 1][0];
-            if constexpr (S == 2) f.bo[sp] = Ls[sp * BB * LOS + c0 + NOLE];
-        }
-    };
-    auto shift1 = [](const u32x4& c, unsigned n) {
-        u32x4 r;
-        r[0] = (c[0] >> 16) | (c[1] << 16);
-        r[1] = (c[1] >> 16) | (c[2] << 16);
-        r[2] = (c[2] >> 16) | (c[3] << 16);
-        r[3] = (c[3] >> 16) | (n << 16);
-        return r;
-    };
-    auto mma = [&](const FragA& fa, const FragB& f, auto KY) {
-        constexpr int ky = decltype(KY)::value;
-        constexpr int TA[6] = {0, 2, 1, 0, 1, 0};
-        constexpr int TB[6] = {2, 0, 1, 1, 0, 0};
-        bf16x8 a[3], b[3][3];     // b[kx][split]
-#pragma unroll
-        for (int sp = 0; sp < 3; ++sp) {
-            a[sp] = __builtin_bit_cast(bf16x8, fa.a[sp]);
-            const u32x4 e = f.be[sp];
-            b[0][sp] = __builtin_bit_cast(bf16x8, e);
-            if constexpr (S == 1) {
-                b[1][sp] = __builtin_bit_cast(bf16x8, shift1(e, f.bn[sp]));
-                const u32x4 d = {e[1], e[2], e[3], f.bn[sp]};
-                b[2][sp] = __builtin_bit_cast(bf16x8, d);
-            } else {
-                b[1][sp] = __builtin_bit_cast(bf16x8, f.bo[sp]);
-                b[2][sp] = __builtin_bit_cast(bf16x8, shift1(e, f.bn[sp]));
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-                acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[q]], b[kx][TB[q]],
-                                                                           acc[ky * 3 + kx], 0, 0, 0);
-    };
-    using K0 = std::integral_constant<int, 0>;
-    using K1 = std::integral_constant<int, 1>;
-    using K2 = std::integral_constant<int, 2>;
-
-    if (ch_begin < ch_end) load_chunk(ch_begin);
-    for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
-        __syncthreads();
-        store_chunk();
-        __syncthreads();
-        if (chunk + 1 < ch_end) load_chunk(chunk + 1);
-        constexpr int KB = NO / 2;
-        static_assert(KB % 2 == 0, "K-block loop is unrolled by two");
-        FragA a0, a1;
-        FragB f0, f1;
-        fetchA(0, a0);
-        fetchB(0, 0, f0);
-        for (int kb = 0; kb < KB; kb += 2) {
-            fetchB(kb, 1, f1); mma(a0, f0, K0{});
-            fetchB(kb, 2, f0); mma(a0, f1, K1{});
-            fetchA(kb + 1, a1); fetchB(kb + 1, 0, f1); mma(a0, f0, K2{});
-            fetchB(kb + 1, 1, f0); mma(a1, f1, K0{});
-            fetchB(kb + 1, 2, f1); mma(a1, f0, K1{});
-            if (kb + 2 < KB) { fetchA(kb + 2, a0); fetchB(kb + 2, 0, f0); }
-            mma(a1, f1, K2{});
-        }
-    }
-
-    // slab store: rows = a (m), cols = b (c)
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int bcol = b0 + wb * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int arow = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            slab[(((int64_t)slice * T + t) * p.Ap + arow) * p.Bp + bcol] = acc[t][r];
-        }
-    }
-}
-
-// Weight gradient of the 1x1 layers with at most four channels on one side (FromRGB 3 -> C, ToRGB C -> 3, stride 1, pad 0):
-//   gw[m][c] = alpha * sum_n f[n] sum_pix gy[n][m][pix] x[n][c][pix]
-// a streaming reduction -- the "big" tensor (128 channels) is read ONCE as 16-byte quads, four of its channels per workgroup
-// against all (<= 4) channels of the "small" one (re-read from L2), 16 fp32 sums per thread, reduced through the wave and LDS.
-// On the MFMA path the 3-channel side pads to a 32- or 128-wide tile (> 90 % zeros) and the kernel ran at 1.6 - 3 TB/s
-// (0.33 ms for the 537 MB of ToRGB's input at B = 16, 0.46 ms for FromRGB's 1.34 GB at B = 40; the bytes need 0.11 / 0.28).
-// Partials per (image, pixel slice) in a fixed order, second stage below: deterministic.
-struct ThinWgParams {
-    int N, CB, CS, split;
-    int64_t HW;
-    int quads_per_slice;           // 16-byte quads of a plane handled by one workgroup
-    const float* big_scale;        // [N][CB] activation factor of the big side (modulated conv) or null
-    const float* small_scale;      // [N][CS] ... of the small side or null
-};
-
-__global__ __launch_bounds__(kBlock) void conv1x1_thin_wgrad_kernel(const float* __restrict__ big, const float* __restrict__ small,
-                                                                    float* __restrict__ partial, const ThinWgParams p) {
-    __shared__ float red[kBlock / kWave][16];
-    const int cb0 = blockIdx.x * 4, n = blockIdx.y, sp = blockIdx.z;
-    const float* bp = big + ((int64_t)n * p.CB + cb0) * p.HW;
-    const float* sp_ = small + (int64_t)n * p.CS * p.HW;
-    const int64_t q_begin = (int64_t)sp * p.quads_per_slice;
-    int64_t q_end = q_begin + p.quads_per_slice;
-    if (q_end > p.HW / 4) q_end = p.HW / 4;
-    float acc[4][4] = {};
-    for (int64_t q = q_begin + threadIdx.x; q < q_end; q += kBlock) {
-        f32x4 bv[4], sv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {       // rows beyond the channel count re-read row 0 and are dropped at the end
-            bv[i] = *reinterpret_cast<const f32x4*>(bp + (int64_t)(cb0 + i < p.CB ? i : 0) * p.HW + 4 * q);
-            sv[i] = *reinterpret_cast<const f32x4*>(sp_ + (int64_t)(i < p.CS ? i : 0) * p.HW + 4 * q);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                acc[i][k] += (bv[i][0] * sv[k][0] + bv[i][1] * sv[k][1]) + (bv[i][2] * sv[k][2] + bv[i][3] * sv[k][3]);
-    }
-    const int lane = threadIdx.x & (kWave - 1), wid = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float v = acc[i][k];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0) red[wid][i * 4 + k] = v;
-        }
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        const int i = threadIdx.x >> 2, k = threadIdx.x & 3;
-        float v = 0.0f;
-#pragma unroll
-        for (int w = 0; w < kBlock / kWave; ++w) v += red[w][threadIdx.x];
-        if (cb0 + i < p.CB && k < p.CS) {
-            if (p.big_scale) v *= p.big_scale[(int64_t)n * p.CB + cb0 + i];
-            if (p.small_scale) v *= p.small_scale[(int64_t)n * p.CS + k];
-        }
-        // partial[(n * split + sp)][cb][k]
-        partial[(((int64_t)n * p.split + sp) * gridDim.x * 4 + cb0 + i) * 4 + k] = v;
-    }
-}
-
-// gw[m * sm + c * sc] = alpha * sum over the (image, slice) partials, one wave per output element: lane l sums parts l, l + 64,
-// ..., then the wave's shuffle tree (fixed order; one thread per element walked up to 1 024 partials as a dependent chain)
-__global__ __launch_bounds__(kBlock) void conv1x1_thin_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ gw,
-                                                                           int CB, int CBp, int CS, int parts, int big_is_m,
-                                                                           int64_t sm, int64_t sc, float alpha) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int e = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
-    const bool live = e < CB * CS;
-    const int cb = live ? e / CS : 0, k = live ? e - cb * CS : 0;
-    float v = 0.0f;
-    for (int t = lane; t < parts; t += kWave) v += partial[((int64_t)t * CBp + cb) * 4 + k];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (live && lane == 0) {
-        const int m = big_is_m ? cb : k, c = big_is_m ? k : cb;
-        gw[m * sm + c * sc] = alpha * v;
-    }
-}
-
-// l_scale / s_scale / spi (slices per image, 0 = none): operand modulation applied per K-slice.  When every slice
-// of the pixel range lies inside one image n, the factor of a modulated operand, l_scale[n][c] or s_scale[n][m], is
-// constant over the slice and can multiply the slice's partial sum here instead of every staged operand element
-// in the main kernel (host: conv_wgrad_impl), which then runs its un-modulated instantiation.
-__global__ __launch_bounds__(kBlock) void conv_wgrad_reduce_kernel(const float* __restrict__ slab,
-                                                                   float* __restrict__ gw, int M, int C,
-                                                                   int Ap, int Bp, int taps, int slices,
-                                                                   int64_t sm, int64_t sc, float alpha,
-                                                                   const float* __restrict__ l_scale,
-                                                                   const float* __restrict__ s_scale, int spi) {
-    // Four lanes per output element, each summing every fourth slice with eight loads in flight, combined in a
-    // fixed order ((q0 + q1) + (q2 + q3)): a chain of `slices` dependent loads per thread on ~2 workgroups per CU
-    // ran at 1.2 TB/s.  Deterministic (the order depends only on `slices`).
-    const int64_t total = (int64_t)taps * M * C;
-    const int64_t slice_stride = (int64_t)taps * Ap * Bp;
-    const int q = threadIdx.x & 3;
-    for (int64_t i0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 2; i0 < ((total + 63) & ~(int64_t)63);
-         i0 += ((int64_t)gridDim.x * kBlock) >> 2) {
-        const bool live = i0 < total;          // whole quads stay together for the shuffles
-        const int64_t i = live ? i0 : 0;
-        const int c = (int)(i % C);
-        const int64_t t = i / C;
-        const int m = (int)(t % M);
-        const int tap = (int)(t / M);
-        const float* s = slab + ((int64_t)tap * Ap + m) * Bp + c;
-        float acc = 0.0f;
-        int sl = q;
-        if (spi > 0) {       // per-slice operand factors (same slice order as below: the sum stays deterministic)
-            for (; sl < slices; sl += 4) {
-                const int n = sl / spi;
-                float f = 1.0f;
-                if (l_scale) f *= l_scale[(int64_t)n * C + c];
-                if (s_scale) f *= s_scale[(int64_t)n * M + m];
-                acc += s[sl * slice_stride] * f;
-            }
-        }
-        for (; sl + 28 < slices; sl += 32) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = s[(sl + 4 * u) * slice_stride];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) acc += v[u];
-        }
-        for (; sl < slices; sl += 4) acc += s[sl * slice_stride];
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        if (live && q == 0) gw[m * sm + c * sc + tap] = alpha * acc;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// host side: planning and dispatch
-// ------------------------------------------------------------------------------------------
-bool desc_ok(const sae_conv2d_desc* d, const char* who) {
-    if (!d) { fail(SAE_EINVAL, "%s: null descriptor", who); return false; }
-    if (d->n < 0 || d->c < 1 || d->m < 1 || d->h < 1 || d->w < 1) {
-        fail(SAE_EINVAL, "%s: bad tensor dims", who); return false;
-    }
-    if (d->kh != d->kw || (d->kh != 1 && d->kh != 3) || (d->stride != 1 && d->stride != 2) || d->pad < 0 ||
-        d->pad >= d->kh) {
-        fail(SAE_EINVAL, "%s: unsupported geometry k=%dx%d stride=%d pad=%d (k in {1,3}, stride in {1,2}, pad < k)",
-             who, d->kh, d->kw, d->stride, d->pad);
-        return false;
-    }
-    if (d->oh != (d->h + 2 * d->pad - d->kh) / d->stride + 1 || d->ow != (d->w + 2 * d->pad - d->kw) / d->stride + 1 ||
-        d->oh < 1 || d->ow < 1) {
-        fail(SAE_EINVAL, "%s: oh/ow do not match the conv formula", who); return false;
-    }
-    const int64_t lim = (int64_t)1 << 31;
-    if (d->n * d->c * d->h * d->w >= lim * 4 || d->n * d->m * d->oh * d->ow >= lim * 4 || d->c * d->h * d->w >= lim ||
-        d->m * d->oh * d->ow >= lim || d->n >= (1 << 24) || d->c >= (1 << 24) || d->m >= (1 << 24)) {
-        fail(SAE_EINVAL, "%s: tensor too large for 32-bit tile arithmetic", who); return false;
-    }
-    return true;
-}
-
-inline int round_up(int v, int q) { return (v + q - 1) / q * q; }
-
-// tile shape of a forward-type launch producing `mout` channels
-struct FwdShape { int cfg; int bm, bn; int ck; };   // cfg 0: 128x128, 1: 64x256, 2: 32x512
-FwdShape fwd_shape(int mout, int ks, int stride, int ow) {
-    FwdShape s{};
-    // tuning knob (benchmarks only): SAE_IGEMM_WIDE=1 gives 3x3 stride-1 layers a 128 x 256 tile
-    static const int wide_knob = tuning_knob("SAE_IGEMM_WIDE", 0);
-    // exact fp32, 3x3 stride 1, maps at least 128 wide: the 64 x 256 tile for wide layers too -- a 32 x 8 pixel tile has less
-    // halo and 30 % less staging traffic per MFMA than 128 x 128 on 16 x 8 pixels (9 instead of 11 vector-memory instructions
-    // per chunk); same-box A/B (tools/ab_conv.py): 128 -> 128 @256^2 128.1 -> 130.9 TFLOP/s, 256 -> 256 @128^2 131.5 -> 136.1;
-    // at 64^2 and below (long K loops, few tiles) the 128-row tile stays ahead by up to 1 %.  Bit-identical results.
-    static const int prefer64_knob = tuning_knob("SAE_IGEMM_PREFER64", 1);
-    const bool wide_map_64 = prefer64_knob && conv_math() == 0 && ks == 3 && stride == 1 && ow >= 128;
-    static const int bx_s2_knob = tuning_knob("SAE_BX_S2", 1);
-    if (mout > 64 && wide_knob && ks == 3 && stride == 1) { s.cfg = 3; s.bm = 128; s.bn = 256; }
-    else if (mout > 32 && ks == 3 && stride == 2 && conv_math() == 1 && bx_s2_knob) { s.cfg = 6; s.bm = 64; s.bn = 128; }   // bf16x6 stride 2
-    else if (mout > 64 && round_up(mout, 64) * 100 >= round_up(mout, 128) * 92 && !wide_map_64) { s.cfg = 0; s.bm = 128; s.bn = 128; }
-    else if (mout > 64) { s.cfg = 1; s.bm = 64; s.bn = 256; }    // e.g. 409 -> 448 instead of 512 padded rows
-    else if (mout > 32 || stride == 2) { s.cfg = 1; s.bm = 64; s.bn = 256; }
-    else {
-        // narrow layers (M <= 32).  a 32 x 256 tile at three workgroups per CU
-        // (SAE_IGEMM_NARROW=0, tuning knob: 32 x 512 at one)
-        // measured on 32->32 3x3 @128x128 B=128: 104 TFLOP/s (32 x 256) vs 81 (32 x 512)
-        static const int narrow_knob = tuning_knob("SAE_IGEMM_NARROW", 1);
-        if (narrow_knob && ks == 3 && stride == 1) { s.cfg = 4; s.bm = 32; s.bn = 256; }
-        else { s.cfg = 2; s.bm = 32; s.bn = 512; }
-    }
-    // channels per K-chunk: 3x3 -> 8 (72 k per chunk); 1x1 -> 32, 16 for the 512-pixel tile (LDS)
-    s.ck = (ks == 1) ? (s.cfg == 2 ? 16 : 32) : 8;
-    return s;
-}
-
-// choose TW/TH (powers of two >= 4) for a tile of `bn` pixels over an oh x ow grid
-void pick_tile(int bn, int oh, int ow, int max_tw, int* tw_log2, int* th_log2) {
-    int tw = 1 << ilog2_ceil(ow);
-    if (tw < 4) tw = 4;
-    if (tw > max_tw) tw = max_tw;
-    int th = 1 << ilog2_ceil(oh);
-    if (th < 4) th = 4;
-    while (tw * th > bn) th >>= 1;
-    if (th < 1) th = 1;
-    *tw_log2 = ilog2_ceil(tw);
-    *th_log2 = ilog2_ceil(th);
-}
-
-struct TrShape { int cfg; int bm, bq; int ck; };   // cfg 0: 128 x 64q, 1: 64 x 128q, 2: 32 x 128q, 3: 64 x 128q with 16-channel chunks,
-                                                      // 4: 128 x 128q on 8 waves
-TrShape tr_shape(int mout) {
-    TrShape s{};
-    s.ck = 8;
-    static const int cfg_knob = tuning_knob("SAE_TR_CFG", -1);
-    if (mout > 32 && cfg_knob == 3) { s.cfg = 3; s.bm = 64; s.bq = 128; s.ck = 16; }
-    // (cfg 4, one 8-wave workgroup per CU, measured 73-93 TFLOP/s against 92-104 for two independent 4-wave workgroups:
-    // the second workgroup's MFMAs are what covers the staging phases; kept behind the knob)
-    else if (mout > 64 && cfg_knob == 4 && conv_math() == 0) { s.cfg = 4; s.bm = 128; s.bq = 128; }
-    // exact fp32: the 64 x 128q tile also for wide layers -- a weight element then serves 128 q positions instead of 64 (a tap
-    // of the transposed problem feeds one output parity class only, so the weights are the larger share of the staging):
-    // 106.6 / 107.9 / 94.6 vs 103.5 / 103.3 / 92.6 TFLOP/s on the three D shapes.  bf16x6 keeps its 128 x 64q kernel.
-    else if (mout > 64 && cfg_knob != 1 && (cfg_knob == 0 || conv_math() == 1)) { s.cfg = 0; s.bm = 128; s.bq = 64; }
-    else if (mout > 32) { s.cfg = 1; s.bm = 64; s.bq = 128; }
-    else { s.cfg = 2; s.bm = 32; s.bq = 128; }
-    return s;
-}
-
-struct WgShape { int ba, bb; int mode; };
-WgShape wg_shape(int m, int c, int ks, int stride) {
-    if (c * ks * ks <= 32) return {32, 32, 2};                       // RGB stems: (channel, tap) packed
-    if (m <= 32 && c <= 32 && ks == 3 && stride == 1) return {32, 32, 1};
-    if (ks == 1) return {128, 128, 0};
-    if (stride == 1) return {64, 64, 0};
-    return {128, 32, 0};
-}
-
-struct WgPlan {
-    WgShape sh; int tw_log2, th_log2; int tiles_x, tiles_y, tiles_n; int chunks, cps, slices; int Ap, Bp; int taps;
-    bool bx; int tw8_log2;   // bf16-split arithmetic: tiles of TH rows x (8 << tw8_log2) columns
-};
-// Number of K slices of a weight-gradient launch.  "Fill the chip once" (256 / tiles, 512 / tiles for the kernel that runs two
-// workgroups per CU) is right when the tile count divides the slots; Dpatch's 384- and 768-channel layers have 24 ... 144 tiles
-// and it is not: 256 -> 384 @8^2, 384 images: 24 tiles x 11 slices = 264 workgroups = one full round of the 256 CUs and a
-// second one for the last eight (0.39 of peak, profiles/r4_roofline_by_shape_church256.txt).  The candidates are priced in
-// microseconds -- rounds of workgroups x chunks per slice x one chunk (4.7 MFLOP on a CU's matrix cores at the 0.8 the kernels
-// reach), plus the slabs written and read back by the fixed-order reduction at 4 TB/s -- and the cheapest one runs, if it
-// is at least 7 % cheaper than the plain rule's.  A last round with at most one workgroup per CU of the two-per-CU kernel is
-// priced at 0.6 (a workgroup that has its CU to itself runs that much faster; 384 -> 384 @8^2: 576 workgroups, model 0.71 ms,
-// measured 0.70).
-int wg_pick_slices(int tiles, int chunks, bool two_per_cu, int64_t slab_floats, int plain) {
-    static const int knob = tuning_knob("SAE_WGRAD_SLICE_MODEL", 1);
-    if (!knob || tiles < 1 || chunks < 2) return plain;
-    const int slots = two_per_cu ? 512 : 256;
-    constexpr double kChunkUs = 9.4;
-    auto cost = [&](int s) {
-        const int cps = ceil_div(chunks, s);
-        const int eff = ceil_div(chunks, cps);            // slices that exist with this length
-        const int64_t wgs = (int64_t)tiles * eff;
-        const int64_t full = wgs / slots, rem = wgs - full * slots;
-        double rounds = (double)full;
-        if (rem > 0) rounds += (two_per_cu && rem <= 256) ? 0.6 : 1.0;
-        double us = rounds * cps * kChunkUs + (2.0 * eff + 1.0) * 4.0 * (double)slab_floats / 4e6;
-        if (two_per_cu && (eff & 7) != 0) us *= 1.02;     // the XCD-aware order of that kernel wants a multiple of eight
-        return us;
-    };
-    int best = plain;
-    double best_us = cost(plain);
-    const int hi = chunks < 96 ? chunks : 96;
-    for (int s = 1; s <= hi; ++s) {
-        const double us = cost(s);
-        if (us < best_us) { best_us = us; best = s; }
-    }
-    return best_us < 0.93 * cost(plain) ? best : plain;
-}
-
-// wg16: the plan of conv_wgrad16_kernel (64 a x 32 b workgroup tiles, two workgroups per CU) for a 3 x 3 layer
-WgPlan wg_plan(const sae_conv2d_desc* d, bool wg16 = false) {
-    WgPlan w{};
-    w.sh = wg_shape((int)d->m, (int)d->c, d->kh, d->stride);
-    if (wg16) w.sh = {64, 32, 5};
-    w.taps = d->kh * d->kw;
-    pick_tile(kWgPix, (int)d->oh, (int)d->ow, 32, &w.tw_log2, &w.th_log2);
-    int tw = 1 << w.tw_log2, th = 1 << w.th_log2, tn = kWgPix / (tw * th);
-    w.bx = false;
-    if (!wg16 && conv_math() == 1 && d->kh == 3 && w.sh.mode == 0 && d->ow % 8 == 0 && d->ow >= 16) {
-        // octet tiles: 128 (stride 1) / 64 (stride 2) pixels per chunk, rows of 16 or 32 columns
-        const int no = (d->stride == 1) ? 16 : 8;
-        const int two = (d->ow > 16) ? 4 : 2;
-        int bth = 1 << ilog2_ceil(d->oh);
-        if (bth > no / two) bth = no / two;
-        const int btn = no / (two * bth);
-        const int ph = (bth - 1) * d->stride + 3;
-        bool fits = (d->stride == 1) ? btn * ph * (two + 1) <= 30
-                                     : (btn * ph * (2 * two + 1) <= 45 && btn * ph * (two + 1) <= 27);
-        // border handling of the staging loads: whole tiles only; stride 2 with pad 0 only
-        if (d->ow % (8 * two) != 0 || (d->stride == 2 && d->pad != 0)) fits = false;
-        if (fits) {
-            w.bx = true;
-            w.tw8_log2 = (two == 4) ? 2 : 1;
-            w.th_log2 = ilog2_ceil(bth);
-            tw = 8 * two; th = bth; tn = btn;
-        }
-    }
-    w.tiles_x = ceil_div((int)d->ow, tw);
-    w.tiles_y = ceil_div((int)d->oh, th);
-    w.tiles_n = ceil_div((int)d->n, tn);
-    w.chunks = w.tiles_x * w.tiles_y * w.tiles_n;
-    w.Ap = round_up((int)d->m, w.sh.ba);
-    w.Bp = round_up((int)d->c, w.sh.bb);
-    const int mn_tiles = (w.Ap / w.sh.ba) * (w.Bp / w.sh.bb);
-    // MODE 0 runs one workgroup per CU (register prefetch): one full wave of 256 workgroups; the
-    // narrow modes co-reside 2-3 per CU
-    int slices = ceil_div(w.sh.mode == 0 ? 256 : 512, mn_tiles);
-    if (wg16) slices = round_up(slices, 8);       // (the XCD-aware order needs slices % 8 == 0)
-    if (slices > w.chunks) slices = w.chunks;
-    if (slices < 1) slices = 1;
-    if ((w.sh.mode == 0 || wg16) && !w.bx && w.taps == 9)     // (the 1x1 layers are HBM-bound: another model)
-        slices = wg_pick_slices(mn_tiles, w.chunks, wg16, (int64_t)w.taps * w.Ap * w.Bp, slices);
-    w.cps = ceil_div(w.chunks, slices);
-    // keep a K slice inside one image where the images are large (>= 32 chunks of 64 pixels): the factors of a
-    // style-modulated operand can then be applied per slice in the reduction and the main kernel stays the plain
-    // (quad-staged) one.  Costs more, smaller slabs only for the generator's 512-channel 64 x 64 layers (4 -> 8 / 16 slices).
-    if ((w.sh.mode == 0 || wg16) && !w.bx && tn == 1) {
-        const int cpi = w.tiles_x * w.tiles_y;
-        // (batches of at most 16 images only: the generator's; for D / Dpatch at 24 ... 384 images 40 slabs of 9 MB cost
-        // more, and moving cps to a divisor of the image breaks the one-workgroup-per-CU balance: 26.9 -> 30.6 ms measured)
-        if (cpi >= 32 && w.tiles_n <= 16) {
-            if (w.cps > cpi) w.cps = cpi;
-            else while (cpi % w.cps != 0) --w.cps;
-        }
-    }
-    w.slices = ceil_div(w.chunks, w.cps);
-    return w;
-}
-
-// sum of the K-slice partial outputs (fixed order -> deterministic), then the optional fused
-// bias + leaky-ReLU epilogue (hw = OH*OW, channels = M locate the bias of a flat element)
-__global__ __launch_bounds__(kBlock) void conv_splitk_reduce_kernel(const float* __restrict__ slab,
-                                                                    float* __restrict__ y, int64_t numel4,
-                                                                    int64_t slab_stride, int ksplit,
-                                                                    const float* __restrict__ bias, int act,
-                                                                    float act_slope, float act_scale, int hw,
-                                                                    int channels, const float* __restrict__ residual,
-                                                                    float res_scale, const float* __restrict__ noise,
-                                                                    const float* __restrict__ noise_w) {
-    const float nwv = noise ? noise_w[0] : 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < numel4; i += (int64_t)gridDim.x * kBlock) {
-        f32x4 acc = *reinterpret_cast<const f32x4*>(slab + i * 4);
-        for (int s = 1; s < ksplit; ++s) acc += *reinterpret_cast<const f32x4*>(slab + s * slab_stride + i * 4);
-        if (act) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = acc[e];
-                if (noise) {        // element (n, m, pix) takes noise[n][pix]
-                    const int64_t f = i * 4 + e, plane = f / hw;
-                    v = v + nwv * noise[(plane / channels) * hw + (f - plane * hw)];
-                }
-                if (bias) v += bias[((i * 4 + e) / hw) % channels];
-                acc[e] = ((v > 0.0f) ? v : v * act_slope) * act_scale;
-            }
-        }
-        if (residual) acc = (acc + *reinterpret_cast<const f32x4*>(residual + i * 4)) * res_scale;
-        *reinterpret_cast<f32x4*>(y + i * 4) = acc;
-    }
-}
+#include "conv2d_wgrad.inc"
 
 #ifndef SAE_IGEMM_SPLIT_MODEL_DEFAULT
 #define SAE_IGEMM_SPLIT_MODEL_DEFAULT 1

@@ -25,8 +25,9 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = sources() + [os.path.join(CSRC, "sae_common.h"), os.path.join(ROOT, "include", "sae_hip.h"),
-                        os.path.join(HERE, "hip", "hip_runtime.h")]
+    incs = [os.path.join(d, f) for d in (CSRC, os.path.join(CSRC, "tuning")) if os.path.isdir(d) for f in os.listdir(d) if f.endswith(".inc")]
+    deps = sources() + incs + [os.path.join(CSRC, "sae_common.h"), os.path.join(ROOT, "include", "sae_hip.h"),
+                               os.path.join(HERE, "hip", "hip_runtime.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -18,7 +18,8 @@ def sources():
 
 
 def up_to_date():
-    deps = sources() + [os.path.join(CSRC, "sae_common.h"), os.path.join(ROOT, "include", "sae_hip.h")]
+    incs = [os.path.join(d, f) for d in (CSRC, os.path.join(CSRC, "tuning")) if os.path.isdir(d) for f in os.listdir(d) if f.endswith(".inc")]
+    deps = sources() + incs + [os.path.join(CSRC, "sae_common.h"), os.path.join(ROOT, "include", "sae_hip.h")]
     return os.path.exists(OUT) and all(os.path.getmtime(d) <= os.path.getmtime(OUT) for d in deps)
 
 
