@@ -25,13 +25,6 @@
 namespace sae {
 namespace {
 
-// Tuning variants (tools/build_wf_variant.sh; the product build uses the defaults):
-//   SAE_WF_U_DMA  1: the prepared weights of the next chunk go global -> LDS by DMA (global_load_lds_dwordx4) instead of through
-//                    registers (8 buffer loads + 8 LDS writes per thread and chunk)
-#ifndef SAE_WF_U_DMA
-#define SAE_WF_U_DMA 0
-#endif
-
 constexpr int kWfM = 64;       // output channels per workgroup
 constexpr int kWfT = 64;       // 2x2 output tiles per workgroup
 constexpr int kWfCK = 8;       // input channels per chunk
@@ -197,22 +190,12 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
         for (int r = 0; r < 4; ++r) dreg[c2][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, rowv[r], soff, 0));
         if (XS) xsc[c2] = p.x_scale[(int64_t)(s_valid ? s_n : 0) * p.C + ch];
     };
-    auto load_u = [&](int chunk, int lo, int buf) {            // 4 buffer loads, no vector ALU
-#if SAE_WF_U_DMA
-        const f32x4* up = reinterpret_cast<const f32x4*>(Uf + ((int64_t)mb * p.chunks + chunk) * kWfStage) + tid;
-#pragma unroll
-        for (int j = lo; j < lo + 4; ++j)
-            __builtin_amdgcn_global_load_lds(up + j * kBlock, (__attribute__((address_space(3))) void*)(&Us[buf][(j * kBlock + 64 * wid) * 4]),
-                                             16, 0, 0);
-#else
-        (void)buf;
+    auto load_u = [&](int chunk, int lo) {                     // 4 buffer loads, no vector ALU
 #pragma unroll
         for (int j = lo; j < lo + 4; ++j)
             ureg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uoff, (unsigned)(chunk * kWfStage * 4 + j * 4096), 0));
-#endif
     };
-    f32x4 ereg[2][4];          // B^T d of both channels (rows transformed, columns not yet)
-    auto transform_rows = [&](auto mode_tag, int c2) {         // B^T d, + the column border of modes 1 / 2
+    auto transform = [&](auto mode_tag, int c2) {              // B^T d B of one channel
         constexpr int MODE = decltype(mode_tag)::value;        // 0: all columns inside, 1: zero the outside columns, 2: shifted windows
         f32x4 d[4];
 #pragma unroll
@@ -248,16 +231,11 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
             }
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a) ereg[c2][a] = e[a];
-    };
-    auto transform_cols = [&](int c2) {                        // (B^T d) B
-#pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const f32x4 e = ereg[c2][a];
-            vreg[4 * a + 0][c2] = e[0] - e[2];
-            vreg[4 * a + 1][c2] = e[1] + e[2];
-            vreg[4 * a + 2][c2] = e[2] - e[1];
-            vreg[4 * a + 3][c2] = e[1] - e[3];
+            vreg[4 * a + 0][c2] = e[a][0] - e[a][2];
+            vreg[4 * a + 1][c2] = e[a][1] + e[a][2];
+            vreg[4 * a + 2][c2] = e[a][2] - e[a][1];
+            vreg[4 * a + 3][c2] = e[a][1] - e[a][3];
         }
     };
     // channel 2 wid + c2 of the chunk = (half = wid >> 1, s = 2 (wid & 1) + c2): both channels share one 8-byte slot
@@ -267,13 +245,9 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
         for (int xi = lo; xi < lo + 8; ++xi) vd[xi * 256] = vreg[xi];
     };
     auto write_u = [&](int buf, int lo) {                      // 4 LDS 16-byte writes
-#if !SAE_WF_U_DMA
         f32x4* ud = reinterpret_cast<f32x4*>(Us[buf]) + tid;
 #pragma unroll
         for (int j = lo; j < lo + 4; ++j) ud[j * kBlock] = ureg[j];
-#else
-        (void)buf; (void)lo;
-#endif
     };
 
     f32x16 acc[16];
@@ -283,86 +257,68 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
         for (int r = 0; r < 16; ++r) acc[xi][r] = 0.0f;
 
     // One pass over the staged chunk `cur`: sixteen groups of four MFMAs (one point each); the operands of point xi + 1 are
-    // read while the MFMAs of point xi run, and the pieces of the next chunk's staging ride in the groups' shadows -- x first
-    // (transformed by groups 6 .. 9, a quarter each), the weights last (written by groups 14, 15).  sched_barrier keeps the
-    // pieces in their groups; inside a group the scheduler is free.  The MFMAs of the LAST point are issued after the barrier
-    // that ends the pass, behind the first operand reads of the next chunk: they cover that read's latency (one wave per SIMD:
-    // nothing else would).
-    f32x4 a_nx;
-    f32x2 b01_nx, b23_nx;      // operands of point 0 of the chunk about to be processed
-    auto read0 = [&](int cur) {
+    // read while the MFMAs of point xi run, and with STAGE the pieces of the next chunk's staging ride in the groups' shadows --
+    // x first (transformed by groups 8, 9), the weights last (written by groups 14, 15).  sched_barrier keeps the pieces in
+    // their groups; inside a group the scheduler is free.
+    auto pass = [&](auto stage_tag, auto mode_tag, int cur, int chunk) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
         const f32x4* ua = reinterpret_cast<const f32x4*>(Us[cur]) + (half * 64 + wm * 32 + l31);
         const f32x2* vb = reinterpret_cast<const f32x2*>(Vs[cur]) + (half * 128 + wt * 32 + l31);
-        a_nx = ua[0];
-        b01_nx = vb[0];
-        b23_nx = vb[64];
-    };
-    auto mfma4 = [&](int xi, const f32x4& a, const f32x2& b01, const f32x2& b23) {
-        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b01[0], acc[xi], 0, 0, 0);
-        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b01[1], acc[xi], 0, 0, 0);
-        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b23[0], acc[xi], 0, 0, 0);
-        acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b23[1], acc[xi], 0, 0, 0);
-    };
-    auto pass = [&](auto mode_tag, int cur, int chunk) {
-        const f32x4* ua = reinterpret_cast<const f32x4*>(Us[cur]) + (half * 64 + wm * 32 + l31);
-        const f32x2* vb = reinterpret_cast<const f32x2*>(Vs[cur]) + (half * 128 + wt * 32 + l31);
-        f32x4 a = a_nx;
-        f32x2 b01 = b01_nx, b23 = b23_nx;
+        f32x4 a = ua[0];
+        f32x2 b01 = vb[0], b23 = vb[64];
 #pragma unroll
-        for (int xi = 0; xi < 15; ++xi) {
-            const f32x4 an = ua[(xi + 1) * 128];
-            const f32x2 b01n = vb[(xi + 1) * 256], b23n = vb[(xi + 1) * 256 + 64];
-            if (xi == 0) load_x(chunk + 1, 0);
-            if (xi == 1) load_x(chunk + 1, 1);
-            if (xi == 2) load_u(chunk + 1, 0, cur ^ 1);
-            if (xi == 3) load_u(chunk + 1, 4, cur ^ 1);
-            mfma4(xi, a, b01, b23);
-            if (xi == 6) transform_rows(mode_tag, 0);
-            if (xi == 7) transform_cols(0);
-            if (xi == 8) transform_rows(mode_tag, 1);
-            if (xi == 9) transform_cols(1);
-            if (xi == 11) write_v(cur ^ 1, 0);
-            if (xi == 12) write_v(cur ^ 1, 8);
-            if (xi == 13) write_u(cur ^ 1, 0);
-            if (xi == 14) write_u(cur ^ 1, 4);
+        for (int xi = 0; xi < 16; ++xi) {
+            f32x4 an = a;
+            f32x2 b01n = b01, b23n = b23;
+            if (xi < 15) {
+                an = ua[(xi + 1) * 128];
+                b01n = vb[(xi + 1) * 256];
+                b23n = vb[(xi + 1) * 256 + 64];
+            }
+            if (STAGE) {
+                if (xi == 0) load_x(chunk + 1, 0);
+                if (xi == 1) load_x(chunk + 1, 1);
+                if (xi == 2) load_u(chunk + 1, 0);
+                if (xi == 3) load_u(chunk + 1, 4);
+            }
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b01[0], acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b01[1], acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b23[0], acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b23[1], acc[xi], 0, 0, 0);
+            if (STAGE) {
+                if (xi == 8) transform(mode_tag, 0);
+                if (xi == 9) transform(mode_tag, 1);
+                if (xi == 12) write_v(cur ^ 1, 0);
+                if (xi == 13) write_v(cur ^ 1, 8);
+                if (xi == 14) write_u(cur ^ 1, 0);
+                if (xi == 15) write_u(cur ^ 1, 4);
+            }
             a = an;
             b01 = b01n;
             b23 = b23n;
             __builtin_amdgcn_sched_barrier(0);
         }
-#if SAE_WF_U_DMA
-        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): this wave's DMA has landed (the barrier publishes it)
-#endif
-        __syncthreads();
-        read0(cur ^ 1);
-        mfma4(15, a, b01, b23);
-        __builtin_amdgcn_sched_barrier(0);
     };
 
     auto run = [&](auto mode_tag) {
         // prologue: chunk 0
         load_x(0, 0);
         load_x(0, 1);
-        load_u(0, 0, 0);
-        load_u(0, 4, 0);
-        transform_rows(mode_tag, 0);
-        transform_cols(0);
-        transform_rows(mode_tag, 1);
-        transform_cols(1);
+        load_u(0, 0);
+        load_u(0, 4);
+        transform(mode_tag, 0);
+        transform(mode_tag, 1);
         write_v(0, 0);
         write_v(0, 8);
         write_u(0, 0);
         write_u(0, 4);
-#if SAE_WF_U_DMA
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
         __syncthreads();
-        read0(0);
         // (ONE instantiation of the pass: the last chunk stages itself again into the buffer nobody reads -- a second, staging-free
         // copy of the pass costs 300 accumulator moves between the two register assignments)
         int cur = 0;
         for (int chunk = 0; chunk < p.chunks; ++chunk) {
-            pass(mode_tag, cur, chunk + 1 < p.chunks ? chunk : chunk - 1);
+            pass(std::true_type{}, mode_tag, cur, chunk + 1 < p.chunks ? chunk : chunk - 1);
+            __syncthreads();
             cur ^= 1;
         }
     };
@@ -603,20 +559,17 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[xi][r] = 0.0f;
 
-    f32x4 a_nx, b_nx;          // operands of point 0 of the chunk about to be processed
-    auto read0 = [&](int cur) {
-        a_nx = (reinterpret_cast<const f32x4*>(Es[cur]) + (half * 64 + wm * 32 + l31))[0];
-        b_nx = (reinterpret_cast<const f32x4*>(Vs[cur]) + (half * 64 + wt * 32 + l31))[0];
-    };
-    // (the MFMAs of the last point are issued after the barrier that ends the pass, behind the first operand reads of the next
-    // chunk: see wino_fused_kernel)
     auto pass = [&](int cur, bool more) {
         const f32x4* ea = reinterpret_cast<const f32x4*>(Es[cur]) + (half * 64 + wm * 32 + l31);
         const f32x4* vb = reinterpret_cast<const f32x4*>(Vs[cur]) + (half * 64 + wt * 32 + l31);
-        f32x4 a = a_nx, b = b_nx;
+        f32x4 a = ea[0], b = vb[0];
 #pragma unroll
-        for (int xi = 0; xi < 15; ++xi) {
-            const f32x4 an = ea[(xi + 1) * 128], bn = vb[(xi + 1) * 128];
+        for (int xi = 0; xi < 16; ++xi) {
+            f32x4 an = a, bn = b;
+            if (xi < 15) {
+                an = ea[(xi + 1) * 128];
+                bn = vb[(xi + 1) * 128];
+            }
             if (xi == 0) load_gy();
             if (xi == 1) load_x(0);
             if (xi == 2) {
@@ -625,21 +578,16 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], acc[xi], 0, 0, 0);
-            if (xi == 6) transform_e();
-            if (xi == 8) transform_v();
-            if (xi == 11) write_e(cur ^ 1, 0);
-            if (xi == 12) write_e(cur ^ 1, 8);
-            if (xi == 13) write_v(cur ^ 1, 0);
-            if (xi == 14) write_v(cur ^ 1, 8);
+            if (xi == 7) transform_e();
+            if (xi == 9) transform_v();
+            if (xi == 12) write_e(cur ^ 1, 0);
+            if (xi == 13) write_e(cur ^ 1, 8);
+            if (xi == 14) write_v(cur ^ 1, 0);
+            if (xi == 15) write_v(cur ^ 1, 8);
             a = an;
             b = bn;
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
-        read0(cur ^ 1);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4) acc[15] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], acc[15], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
     };
 
     if (ch_begin < ch_end) {
@@ -654,10 +602,10 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
         write_v(0, 8);
         if (ch_begin + 1 < ch_end) advance();
         __syncthreads();
-        read0(0);
         int cur = 0;
         for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
             pass(cur, chunk + 2 < ch_end);
+            __syncthreads();
             cur ^= 1;
         }
     }
