@@ -43,4 +43,22 @@ def run():
     for name, got, want in zip(("act", "grad_bias", "grad_input", "grad_weight"), outs[0], outs[1]):
         err = H.rel_err(got, want)
         assert err < 1e-4, (name, err)
-    print("smoke ok: blur -> conv3x3/s2 -> bias+lrelu fwd/bwd on cuda:0 within 1e-4 of the oracle")
+    # the step's dominant kernels: a 3x3 stride-1 layer on the one-kernel Winograd route (forward with bias + leaky-ReLU, data
+    # gradient, weight gradient) against the oracle's DIRECT convolution
+    x1 = rng.standard_normal((2, 24, 16, 16)).astype(np.float32)
+    w1 = rng.standard_normal((40, 24, 3, 3)).astype(np.float32)
+    b1 = rng.standard_normal(40).astype(np.float32)
+    g1 = rng.standard_normal((2, 40, 16, 16)).astype(np.float32)
+    d1 = H.conv_desc(2, 24, 16, 16, 40, 3, 1, 1)
+    al = 1.0 / (24 * 9) ** 0.5
+    checks = (("winograd forward + bias + lrelu", H.wino_fused_conv(hip, x1, w1, alpha=al, bias=b1, act=(0.2, 2 ** 0.5), device=dev),
+               H.conv_bias_act(ora, d1, x1, w1, b1, alpha=al)),
+              ("winograd data gradient", H.wino_fused_conv(hip, g1, w1, alpha=al, transpose=True, device=dev),
+               H.conv(ora, 1, d1, g1, w1, x1.shape, alpha=al)),
+              ("winograd weight gradient", H.wino_fused_wgrad(hip, x1, g1, alpha=al, device=dev),
+               H.conv(ora, 2, d1, x1, g1, w1.shape, alpha=al)))
+    for name, got, want in checks:
+        err = H.rel_err(got, want)
+        assert err < 1e-4, (name, err)
+    print("smoke ok: blur -> conv3x3/s2 -> bias+lrelu fwd/bwd and the one-kernel Winograd 3x3/s1 fwd / dgrad / wgrad on cuda:0 within "
+          "1e-4 of the oracle")
