@@ -438,10 +438,26 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
     const int ch_begin = slice * p.chunks_per_slice;
     int ch_end = ch_begin + p.chunks_per_slice;
     if (ch_end > p.chunks) ch_end = p.chunks;
-    // position of the chunk being LOADED: image n, tile row ty, chunk txb of the row
+    // position of the chunk being LOADED: image n, tile row ty, chunk txb of the row -- and the scalar byte offsets that go with
+    // it, kept RUNNING (+ 64 bytes per chunk, a row / image step at the wraps): recomputed from (n, ty, txb) per chunk they were
+    // 120 scalar instructions per 64 MFMAs, and every instruction of the wave takes an issue slot from the matrix pipe
     int ld_txb = ch_begin % p.cpr;
     int ld_ty = (ch_begin / p.cpr) % p.TH;
     int ld_n = ch_begin / (p.cpr * p.TH);
+    unsigned g_soff = 0, x_soff = 0, up_row[4] = {0, 0, 0, 0};
+    auto place = [&]() {                   // offsets of (ld_n, ld_ty, ld_txb) from scratch: slice start and image wraps
+        g_soff = (unsigned)((((int64_t)ld_n * p.M) * OHW + (int64_t)(2 * ld_ty) * p.OW + 16 * ld_txb) * 4);
+        x_soff = (unsigned)((((int64_t)ld_n * p.C) * HW + (int64_t)(2 * ld_ty - p.pad) * p.W + 16 * ld_txb) * 4);
+    };
+    auto rows = [&]() {                    // per tile row: which of the four window rows lie inside the image (uniform)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int iy = 2 * ld_ty - p.pad + r;
+            up_row[r] = (iy >= 0 && iy < p.H) ? (unsigned)(r * p.W * 4) : 0x80000000u;
+        }
+    };
+    place();
+    rows();
 
     f32x4 greg[2];             // gy rows 2 ty, 2 ty + 1: two tiles x two columns
     f32x4 xr4[4];              // window rows: columns 0 .. 3
@@ -451,9 +467,8 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
     f32x2 ev[16], vv[16];      // A e A^T and B^T d B of the two tiles, as written to LDS
 
     auto load_gy = [&]() {
-        const unsigned soff = (unsigned)((((int64_t)ld_n * p.M) * OHW + (int64_t)(2 * ld_ty) * p.OW + 16 * ld_txb) * 4);
-        greg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, g_lane, soff, 0));
-        greg[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, g_lane + ow_bytes, soff, 0));
+        greg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, g_lane, g_soff, 0));
+        greg[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, g_lane + ow_bytes, g_soff, 0));
         if (MOD) {
             sx = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sxr, (unsigned)(c_ch * 4), (unsigned)(ld_n * p.C * 4), 0));
             sy = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(syr, (unsigned)(m_ch * 4), (unsigned)(ld_n * p.M * 4), 0));
@@ -467,24 +482,33 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
             zl = p.pad == 1 && ld_txb == 0 && kk0 == 0;
             zr = p.pad == 1 && ld_txb == p.cpr - 1 && kk0 == 6;
         }
+        // the pair at the left border starts its window AT column 0 (one float further left would be offset -4 in the tensor's
+        // first row: it wraps and the whole load reads as zeros) and is shifted into place in transform_v.  A window row
+        // outside the image adds 0x80000000: out of range whatever the rest is (x is smaller than 2 GiB).
+        const unsigned vl = x_lane + (zl ? 4u : 0u);
 #pragma unroll
         for (int r = r0; r < r0 + 2; ++r) {
-            const int iy = 2 * ld_ty - p.pad + r;
-            const bool ok = iy >= 0 && iy < p.H;                 // uniform
-            const unsigned up = ok ? (unsigned)((((int64_t)ld_n * p.C) * HW + (int64_t)iy * p.W + 16 * ld_txb) * 4) : 0x80000000u;
-            // the pair at the left border starts its window AT column 0 (one float further left would be offset -4 in the
-            // tensor's first row: it wraps and the whole load reads as zeros) and is shifted into place in transform_v
-            const unsigned v = x_lane + up + (zl ? 4u : 0u);
+            const unsigned v = vl + x_soff + up_row[r];
             xr4[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, v, 0, 0));
             xr2[r] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(xrs, v + 16, 0, 0));
         }
     };
     auto advance = [&]() {
         ++ld_txb;
+        g_soff += 64;
+        x_soff += 64;
         if (ld_txb == p.cpr) {
             ld_txb = 0;
             ++ld_ty;
-            if (ld_ty == p.TH) { ld_ty = 0; ++ld_n; }
+            if (ld_ty == p.TH) {
+                ld_ty = 0;
+                ++ld_n;
+                place();
+            } else {
+                g_soff += (unsigned)((2 * p.OW - 16 * p.cpr) * 4);
+                x_soff += (unsigned)((2 * p.W - 16 * p.cpr) * 4);
+            }
+            rows();
         }
     };
     auto transform_e = [&]() {             // A e A^T of both tiles
@@ -643,8 +667,17 @@ __global__ __launch_bounds__(kBlock) void wino_fused_wgrad_reduce_kernel(const f
     const int m = (int)(i / ((int64_t)C * 9));
     const float* sp = slab + ((int64_t)m * 9 + tap) * Cp + c;
     const int64_t stride = (int64_t)Mp * 9 * Cp;
+    // eight loads in flight, added in slice order (a chain of `slices` dependent loads per thread ran at 1.4 TB/s)
     float acc = 0.0f;
-    for (int s = 0; s < slices; ++s) acc += sp[s * stride];
+    int s = 0;
+    for (; s + 8 <= slices; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sp[(s + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; s < slices; ++s) acc += sp[s * stride];
     gw[m * sm + c * sc + tap] = alpha * acc;
 }
 

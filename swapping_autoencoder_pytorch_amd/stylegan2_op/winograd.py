@@ -99,19 +99,21 @@ def _route_of(geom, op):
         return None
     cmin = min(geom.c, geom.m)
     tiles = (geom.oh >> 1) * (geom.ow >> 1)
+    # the one-kernel forms address their activations with 32-bit byte offsets
+    fused_ok = _CFG.fused and max(geom.n * geom.c * geom.h * geom.w, geom.n * geom.m * geom.oh * geom.ow) * 4 < (1 << 31)
     if _CFG.min_c is not None:                        # explicit threshold (tests): everything at least that wide
         if cmin < _CFG.min_c:
             return None
-        if op != WGRAD and _CFG.fused and (geom.ow if op == DGRAD else geom.w) >= 4:
+        if op != WGRAD and fused_ok and (geom.ow if op == DGRAD else geom.w) >= 4:
             return "fused"
-        if op == WGRAD and _CFG.fused and geom.ow % 16 == 0:
+        if op == WGRAD and fused_ok and geom.ow % 16 == 0:
             return "fused"
         return "unfused"
     if op == WGRAD:
         # three-kernel form (two transforms + sixteen K-sliced 1x1 weight gradients): from 256 channels on enough pixels;
         # one-kernel form (sae_wino_fused_wgrad_f32): output rows a multiple of 16 pixels, enough 8-tile chunks for whole
         # rounds of 64 x 64-channel workgroups with slices of >= 8 chunks
-        if _CFG.fused and geom.ow % 16 == 0 and cmin >= 64 and geom.n * tiles >= 4096:
+        if fused_ok and geom.ow % 16 == 0 and cmin >= 64 and geom.n * tiles >= 4096:
             return "fused"
         return "unfused" if (cmin >= 256 and geom.n * tiles * cmin >= (4 << 20)) else None
     direct = max(2.0 * geom.n * geom.m * geom.oh * geom.ow * geom.c * 9 / 130e9, 0.035)
@@ -120,7 +122,7 @@ def _route_of(geom, op):
         est = direct * (0.62 if cmin >= 512 else 0.66 if cmin >= 384 else 0.78)
         if est < cost:
             best, cost = "unfused", est
-    if _CFG.fused:
+    if fused_ok:
         # the product that is computed: forward c -> m on the oh x ow grid; data gradient m -> c on the h x w grid
         cin, cout, th, tw, in_w = ((geom.m, geom.c, geom.h >> 1, geom.w >> 1, geom.ow) if op == DGRAD else
                                    (geom.c, geom.m, geom.oh >> 1, geom.ow >> 1, geom.w))

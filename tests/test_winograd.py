@@ -416,3 +416,16 @@ def test_python_route_one_kernel_weight_gradient(oracle_lib, monkeypatch):
         assert got.data_ptr() == out.data_ptr() and not torch.isnan(out).any()
     for a, o in zip(routed, direct):
         assert float((a - o).abs().max() / o.abs().max()) < TOL
+
+
+def test_route_keeps_activations_over_2_gib_off_the_one_kernel_forms(oracle_lib, monkeypatch):
+    """The one-kernel kernels address x / gy with 32-bit byte offsets (the C-ABI refuses larger tensors): the router must not pick
+    them there, whatever the estimates say."""
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as G, winograd
+    monkeypatch.setattr(hip_lib, "_LIB", oracle_lib)
+    big = G._Geom(64, 256, 512, 512, 256, 3, 1, 1, False, 1.0)          # 17 GB of input
+    ok = G._Geom(16, 256, 128, 128, 256, 3, 1, 1, False, 1.0)
+    with winograd.override(enabled=True):
+        assert [winograd.route(ok, op) for op in (winograd.FWD, winograd.DGRAD, winograd.WGRAD)] == ["fused"] * 3
+        assert all(winograd.route(big, op) != "fused" for op in (winograd.FWD, winograd.DGRAD, winograd.WGRAD))
