@@ -447,13 +447,13 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
     unsigned g_soff = 0, x_soff = 0, up_row[4] = {0, 0, 0, 0};
     auto place = [&]() {                   // offsets of (ld_n, ld_ty, ld_txb) from scratch: slice start and image wraps
         g_soff = (unsigned)((((int64_t)ld_n * p.M) * OHW + (int64_t)(2 * ld_ty) * p.OW + 16 * ld_txb) * 4);
-        x_soff = (unsigned)((((int64_t)ld_n * p.C) * HW + (int64_t)(2 * ld_ty - p.pad) * p.W + 16 * ld_txb) * 4);
+        x_soff = (unsigned)((((int64_t)ld_n * p.C) * HW + 16 * ld_txb) * 4);         // image + column; the row is in up_row
     };
-    auto rows = [&]() {                    // per tile row: which of the four window rows lie inside the image (uniform)
+    auto rows = [&]() {                    // per tile row: the four window rows, "outside" for those not in the image (uniform)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int iy = 2 * ld_ty - p.pad + r;
-            up_row[r] = (iy >= 0 && iy < p.H) ? (unsigned)(r * p.W * 4) : 0x80000000u;
+            up_row[r] = (iy >= 0 && iy < p.H) ? (unsigned)(iy * p.W * 4) : 0x80000000u;
         }
     };
     place();
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
         }
         // the pair at the left border starts its window AT column 0 (one float further left would be offset -4 in the tensor's
         // first row: it wraps and the whole load reads as zeros) and is shifted into place in transform_v.  A window row
-        // outside the image adds 0x80000000: out of range whatever the rest is (x is smaller than 2 GiB).
+        // outside the image adds 0x80000000 to a sum that is non-negative and below 2 GiB: out of range.
         const unsigned vl = x_lane + (zl ? 4u : 0u);
 #pragma unroll
         for (int r = r0; r < r0 + 2; ++r) {
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
                 place();
             } else {
                 g_soff += (unsigned)((2 * p.OW - 16 * p.cpr) * 4);
-                x_soff += (unsigned)((2 * p.W - 16 * p.cpr) * 4);
+                x_soff -= (unsigned)(16 * p.cpr * 4);
             }
             rows();
         }

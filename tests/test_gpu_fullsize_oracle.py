@@ -157,6 +157,73 @@ def test_conv_fullsize_vs_oracle(hip_lib, oracle_lib, case):
         del y, gx, gw
 
 
+# the 3x3 stride-1 layers the step runs on the ONE-kernel Winograd route (csrc/winograd_fused.hip), at their real shapes:
+# (role, n, c, h, w, m, pad).  The same slices as above against the oracle's DIRECT convolution: all pixels of the first and last
+# image for the channels either side of every 32 / 64-channel boundary, the weight gradient with the full batch-and-pixel reduction
+# (every pixel slice of the kernel) for a seam subset of gradient channels.
+WINO_FULL = [
+    ("church256 D 128->128 @256 (16 chunks, interior + border blocks)", 16, 128, 256, 256, 128, 1),
+    ("church256 D 256->256 @128", 16, 256, 128, 128, 256, 1),
+    ("church256 G 512->512 @64 (every block touches a border)", 16, 512, 64, 64, 512, 1),
+    ("church256 Dpatch 64->64 @64, B=128 (one channel block)", 128, 64, 64, 64, 64, 1),
+    ("church256 E valid 256->256 @34 -> 32 (its data gradient pads by 2)", 16, 256, 34, 34, 256, 0),
+    ("ffhq1024 G 409->409 @128 (channels no multiple of 8 or 64)", 4, 409, 128, 128, 409, 1),
+]
+
+
+@pytest.mark.parametrize("case", WINO_FULL, ids=lambda c: c[0].split(" (")[0].replace(" ", "_"))
+def test_one_kernel_winograd_fullsize_vs_oracle(hip_lib, oracle_lib, case):
+    name, n, c, h, w, m, p = case
+    d = H.conv_desc(n, c, h, w, m, 3, 1, p)
+    gen = torch.Generator(device=DEV).manual_seed(4321)
+    x = torch.randn(n, c, h, w, device=DEV, generator=gen)
+    wt = torch.randn(m, c, 3, 3, device=DEV, generator=gen)
+    gy = torch.randn(n, m, d.oh, d.ow, device=DEV, generator=gen)
+    bias = torch.randn(m, device=DEV, generator=gen)
+    alpha = float(1.0 / np.sqrt(c * 9))
+    imgs = sorted({0, n - 1})
+    msel, csel, wsub = seam_channels(m), seam_channels(c), seam_channels(m, cap=12)
+    t0 = time.time()
+    d_f = H.conv_desc(len(imgs), c, h, w, len(msel), 3, 1, p)
+    o_fwd = H.conv_bias_act(oracle_lib, d_f, _np(x[imgs]), _np(wt[msel]), _np(bias[msel]), alpha=alpha)
+    d_d = H.conv_desc(len(imgs), len(csel), h, w, m, 3, 1, p)
+    o_dg = H.conv(oracle_lib, 1, d_d, _np(gy[imgs]), _np(wt[:, csel]), (len(imgs), len(csel), h, w), alpha=alpha)
+    d_w = H.conv_desc(n, c, h, w, len(wsub), 3, 1, p)
+    o_wg = H.conv(oracle_lib, 2, d_w, _np(x), _np(gy[:, wsub]), (len(wsub), c, 3, 3), alpha=alpha)
+    t_oracle = time.time() - t0
+    st = torch.cuda.current_stream().cuda_stream
+
+    def fused_conv(inp, cin, cout, ih, iw, pad, sm, sc, flip, b, act):
+        uf = torch.empty(hip_lib.query("wino_fused_weights_floats", cout, cin), device=DEV)
+        hip_lib.call("wino_fused_weights_f32", wt.data_ptr(), None, None, uf.data_ptr(), cout, cin, sm, sc, flip, alpha, st)
+        out = torch.full((n, cout, ih + 2 * pad - 2, iw + 2 * pad - 2), float("nan"), device=DEV)
+        hip_lib.call("wino_fused_conv_f32", inp.data_ptr(), None, uf.data_ptr(), None, None, None, b.data_ptr() if b is not None else None,
+                     out.data_ptr(), n, cin, cout, ih, iw, pad, 1 if act else 0, 0.2, 2 ** 0.5, st)
+        return out
+
+    y = fused_conv(x, c, m, h, w, p, c * 9, 9, 0, bias, True)
+    gx = fused_conv(gy, m, c, d.oh, d.ow, 2 - p, 9, c * 9, 1, None, False)
+    e_wg = None
+    if d.ow % 16 == 0:
+        n_ws = hip_lib.query("wino_fused_wgrad_workspace", n, c, m, h, w, p)
+        ws = torch.empty(max(n_ws, 1), device=DEV)
+        gw = torch.full((m, c, 3, 3), float("nan"), device=DEV)
+        hip_lib.call("wino_fused_wgrad_f32", x.data_ptr(), None, gy.data_ptr(), None, gw.data_ptr(), n, c, m, h, w, p, c * 9, 9, alpha,
+                     ws.data_ptr(), n_ws, st)
+        torch.cuda.synchronize()
+        assert not torch.isnan(gw).any()
+        e_wg = H.rel_err(_np(gw[wsub]), o_wg)
+    torch.cuda.synchronize()
+    assert not torch.isnan(y).any() and not torch.isnan(gx).any()
+    e_fwd = H.rel_err(_np(y[imgs][:, msel]), o_fwd)
+    e_dg = H.rel_err(_np(gx[imgs][:, csel]), o_dg)
+    _record(test="one-kernel winograd", case=name, geom=[n, c, h, w, m, 3, 1, p], math="f32", fwd_bias_act=e_fwd, dgrad=e_dg, wgrad=e_wg,
+            oracle_s=round(t_oracle, 2))
+    assert e_fwd < TOL, ("fwd + bias + lrelu", e_fwd)
+    assert e_dg < TOL, ("dgrad", e_dg)
+    assert e_wg is None or e_wg < TOL, ("wgrad", e_wg)
+
+
 @pytest.mark.parametrize("case", [
     ("church256 D 128->128 @256 fused bias+lrelu", 16, 128, 256, 256, 128, 3, 1, 1),
     ("church256 D 128->256 s2 @257 fused bias+lrelu", 16, 128, 257, 257, 256, 3, 2, 0),
