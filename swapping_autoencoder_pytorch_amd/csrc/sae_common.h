@@ -66,4 +66,33 @@ __device__ __forceinline__ void wave_sync() {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Packed fp32 adds with the operand-select / negate modifiers of VOP3P, which hipcc does not emit for pairs it has to build
+// (it negates and moves instead: two instructions more per pair).  On pairs p = (p.x, p.y):
+//   pk_sub(a, b)  = (a.x - b.x, a.y - b.y)
+//   pk_c01(e01, e23) = (e01.x - e23.x, e01.y + e23.x)      columns 0, 1 of  e B  for a row e = (e0, e1, e2, e3), B of Winograd F(2x2,3x3)
+//   pk_c23(e01, e23) = (e23.x - e01.y, e01.y - e23.y)      columns 2, 3
+// (the emulator of tests/emu models them in plain C++: HIPEMU is defined by its hip_runtime.h)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifdef HIPEMU
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return f32x2{a[0] - b[0], a[1] - b[1]}; }
+__device__ __forceinline__ f32x2 pk_c01(f32x2 e01, f32x2 e23) { return f32x2{e01[0] - e23[0], e01[1] + e23[0]}; }
+__device__ __forceinline__ f32x2 pk_c23(f32x2 e01, f32x2 e23) { return f32x2{e23[0] - e01[1], e01[1] - e23[1]}; }
+#else
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_c01(f32x2 e01, f32x2 e23) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(e01), "v"(e23));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_c23(f32x2 e01, f32x2 e23) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(d) : "v"(e23), "v"(e01));
+    return d;
+}
+#endif
+
 }  // namespace sae
