@@ -128,6 +128,12 @@ def work_of(name, a):
         if BY_SHAPE:
             return "winograd fused conv n%-3d %4d->%-4d %3dx%-3d tiles" % (n, c, m, th, tw), "mfma", 32.0 * n * c * m * th * tw
         return "winograd fused conv (one kernel; executed FLOPs = direct / 2.25)", "mfma", 32.0 * n * c * m * th * tw
+    if name == "wino_fused_wgrad_f32":
+        n, c, m, h, w, pad = a[5], a[6], a[7], a[8], a[9], a[10]
+        th, tw = (h + 2 * pad - 2) // 2, (w + 2 * pad - 2) // 2
+        if BY_SHAPE:
+            return "winograd fused wgrad n%-3d %4d->%-4d %3dx%-3d tiles" % (n, c, m, th, tw), "mfma", 32.0 * n * c * m * th * tw
+        return "winograd fused weight gradient (one kernel + slice reduction; executed FLOPs = direct / 2.25)", "mfma", 32.0 * n * c * m * th * tw
     if name == "wino_fused_weights_f32":
         return "winograd weight transform", "hbm", 100.0 * a[4] * a[5]
     if name in ("wino_input_f32", "wino_gy_f32"):
@@ -179,6 +185,8 @@ def main():
     global BY_SHAPE
     BY_SHAPE = args.by_shape
     sys.path.insert(0, ROOT)
+    # ONE stream: the step's two branches otherwise overlap and the bracketed times of concurrent calls add up to more than the wall
+    os.environ["SAE_TWO_STREAMS"] = "0"
     import bench
     from swapping_autoencoder_pytorch_amd.options import make_options
     from swapping_autoencoder_pytorch_amd.swapping_autoencoder_model import create_model
@@ -215,7 +223,7 @@ def main():
         r[2] += work
         r[3] += e0.elapsed_time(e1)
     k = args.steps
-    print("# per-kernel-class roofline, %s preset, %dx%d, B=%d, conv math %s, %d timed iterations%s (event-bracketed C-ABI calls)"
+    print("# per-kernel-class roofline, %s preset, %dx%d, B=%d, conv math %s, %d timed iterations%s (event-bracketed C-ABI calls, the step on ONE stream: SAE_TWO_STREAMS=0)"
           % (args.preset, size, size, batch, args.conv_math, k, " incl. one lazy-R1 call" if args.with_r1 else ", no R1 call"))
     print("# bound peaks: fp32 MFMA 157.3 TFLOP/s, HBM 8.0 TB/s (spec; ~6.3 achievable).  Work is ALGORITHMIC (SURVEY 8d).")
     print("%-52s %5s %8s %12s %10s %9s %6s" % ("kernel class", "bound", "calls/it", "work/it", "ms/it", "achieved", "frac"))
