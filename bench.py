@@ -79,6 +79,10 @@ def parse():
     ap.add_argument("--force-allreduce", action="store_true",
                     help="with --gpus 1: run the multi-GPU gradient path (buckets, grad-ready hooks, asynchronous RCCL "
                          "all-reduce, per-bucket Adam) on the single rank -- the cost of that machinery, NOT a scaling number")
+    ap.add_argument("--ring-rehearsal", type=int, default=0, metavar="N",
+                    help="with --force-allreduce: behind every bucket's (empty, one-rank) all-reduce, put on a side stream the memory "
+                         "traffic and kernel launches a RING all-reduce over N GPUs costs THIS GPU -- 2 (N - 1) steps of a 1/N slice, "
+                         "read + reduce + write -- concurrent with the backward pass.  A rehearsal of the contention, NOT a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-cpu-baseline", action="store_true",
                     help="cpu_baseline.value from ONE whole iteration of the preset on the host (a discriminator call + a "
@@ -636,6 +640,45 @@ def via_dropin_leg(args, line):
     return leg
 
 
+def _install_ring_rehearsal(n_gpus):
+    """RCCL launches nothing for an all-reduce over ONE rank, so the single-rank rehearsal of the gradient path says nothing about what
+    the collective's kernels take from the backward pass.  This stands in for them: behind every bucket's all-reduce a side stream
+    runs what a ring over `n_gpus` costs the local GPU -- N - 1 reduce-scatter steps (read the local 1/N slice and the received
+    one, write the sum) and N - 1 all-gather steps (write the received slice, read it to send it on) -- as elementwise kernels over
+    slices of the bucket itself, concurrent with whatever the step runs.  The link time is NOT modelled (nothing leaves the GPU)."""
+    import torch
+    import torch.distributed as dist
+    real = dist.all_reduce
+    # SAE_RING_REHEARSAL_STREAM: "own" (default: a stream of its own, as RCCL's kernels have), "high" (the same, high priority),
+    # "launch" (no further stream: behind the collective on the stream it was launched from)
+    where = os.environ.get("SAE_RING_REHEARSAL_STREAM", "own")
+    # "nowait": a stream of its own that does NOT wait for the bucket (is it the dependency or the kernels?)
+    side = None if where == "launch" else torch.cuda.Stream(priority=-1 if where == "high" else 0)
+    scratch = {}
+
+    def rehearsed(tensor, *a, **kw):
+        work = real(tensor, *a, **kw)
+        flat = tensor.view(-1)
+        n = flat.numel() // n_gpus
+        if n == 0:
+            return work
+        if side is not None and where != "nowait":
+            side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side if side is not None else torch.cuda.current_stream()):
+            buf = scratch.get(n)
+            if buf is None:
+                buf = scratch[n] = torch.zeros(n, device=tensor.device)
+            for s in range(2 * (n_gpus - 1)):
+                seg = flat[(s % n_gpus) * n:(s % n_gpus + 1) * n]
+                if s < n_gpus - 1:
+                    torch.add(buf, seg, out=buf)     # reduce-scatter step
+                else:
+                    buf.copy_(seg)                   # all-gather step
+        return work
+
+    dist.all_reduce = rehearsed
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -690,6 +733,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus
         world = dist.get_world_size()
+    if args.ring_rehearsal:
+        if not args.force_allreduce or args.ring_rehearsal < 2:
+            raise SystemExit("bench.py: --ring-rehearsal N (N >= 2) goes with --force-allreduce")
+        _install_ring_rehearsal(args.ring_rehearsal)
     dev = torch.device("cuda", local_rank)
 
     from swapping_autoencoder_pytorch_amd import hip_lib
@@ -820,6 +867,9 @@ def main():
                                    "every 16th D iteration" % (args.preset, size, size, batch),
                        "global_batch": world * batch, "parallelism": "dp%d" % world, "conv_math": args.conv_math},
         }
+        from swapping_autoencoder_pytorch_amd import streams
+        line["config"]["streams"] = ("the step's independent branches on two HIP streams" if streams.enabled() else
+                                     "the step on one HIP stream (streams.enabled(): the default for a rank of a multi-rank job, or SAE_TWO_STREAMS=0)")
         line["config"]["winograd"] = (
             "off: every 3x3 stride-1 layer on the direct MFMA kernels" if not winograd.enabled() else
             "3x3 stride-1 launches selected by stylegan2_op/winograd.route() run as Winograd F(2x2,3x3) (%s): 2.25x fewer "
@@ -828,6 +878,10 @@ def main():
         if args.force_allreduce:
             line["config"]["force_allreduce"] = ("single-rank rehearsal of the multi-GPU gradient path: %d + %d buckets all-reduced over "
                                                  "RCCL per iteration" % (len(optimizer.reducer_D.buckets), len(optimizer.reducer_G.buckets)))
+            if args.ring_rehearsal:
+                line["config"]["ring_rehearsal"] = ("behind every bucket: the reads / writes and launches of a ring all-reduce over %d GPUs "
+                                                    "(2 x %d steps of a 1/%d slice) on a side stream, concurrent with the step; no link time"
+                                                    % (args.ring_rehearsal, args.ring_rehearsal - 1, args.ring_rehearsal))
         if alt:
             line["alt_conv_math"] = alt
         if per_image:

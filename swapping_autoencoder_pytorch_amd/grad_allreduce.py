@@ -148,9 +148,12 @@ class GradAllReducer:
     def _launch_stragglers(self):
         """Buckets whose last gradient never arrived (some parameter got no gradient in this pass) still take part
         in the collective, with zeros in the missing slots, so its shape is identical on every rank."""
+        from .streams import collective_launch
         for b in self.buckets:
             if b.work is None:
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                # (with the step on two streams the bucket's gradients may come from either: ordered after both)
+                with collective_launch(b.flat):
+                    b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     # called after loss.backward(), before optimizer.step()
     def finish(self):

@@ -13,7 +13,8 @@ profiles/r4_ab_async_wgrad.txt: with two branches in flight the chip has no idle
 
 Values do not change: every kernel is deterministic and sees the same inputs (tests/test_gpu_determinism.py compares the two
 modes bit for bit); the host enqueues the branches in the order the single-stream code ran them, so the random draws (Philox
-offsets are advanced at enqueue time) are the same too.  ``SAE_TWO_STREAMS=0`` keeps everything on the current stream."""
+offsets are advanced at enqueue time) are the same too.  ``SAE_TWO_STREAMS=0`` keeps everything on the current stream (the default
+for a rank of a multi-rank job: ``enabled()``)."""
 import os
 
 import torch
@@ -24,7 +25,15 @@ _MAIN = {}      # the stream the step itself runs on, as seen at the last fork
 
 
 def enabled():
-    return os.environ.get("SAE_TWO_STREAMS", "1") != "0"
+    """``SAE_TWO_STREAMS=1`` / ``0`` decides; unset: two streams in a single-rank process, ONE when the process is a rank of a
+    multi-rank job.  There the gradient all-reduce adds a stream whose kernels wait for the buckets: rehearsed on one GPU with
+    stand-in kernels for a ring's steps (``bench.py --force-allreduce --ring-rehearsal 8``, profiles/r5_ring_rehearsal.txt), that
+    costs the two-stream step 20 ms of its 217 -- more than the second stream gains -- and the one-stream step 1.3 of its 227."""
+    v = os.environ.get("SAE_TWO_STREAMS")
+    if v is not None:
+        return v != "0"
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
 
 def side_stream(device):

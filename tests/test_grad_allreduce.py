@@ -55,6 +55,7 @@ def _worker(rank, world, port, tmp):
     red_a = GradAllReducer(group_a, bucket_bytes=256)      # tiny buckets -> several collectives
     red_b = GradAllReducer(group_b, bucket_bytes=256)
     assert red_a.enabled and len(red_a.buckets) > 1
+    launched_in_backward = []
     results = {}
     for tag, params, frozen, red, fn in (("a", group_a, group_b, red_a, _loss), ("b", group_b, group_a, red_b, _loss),
                                          ("b_r1", group_b, group_a, red_b, _r1)):
@@ -65,8 +66,12 @@ def _worker(rank, world, port, tmp):
             p.requires_grad_(False)
         red.arm()
         fn(net, shard).mean().backward()
+        launched_in_backward.append(sum(b.work is not None for b in red.buckets))
         red.finish()
         results[tag] = [None if p.grad is None else p.grad.clone() for p in params]
+    # complete buckets are in flight when backward returns (launched from the grad-ready hooks); the one holding the parameter that
+    # never gets a gradient is launched by finish()
+    assert max(launched_in_backward) > 0, launched_in_backward
     state = {k: v.clone() for k, v in net.state_dict().items()}
     # finish_into: the multi-tensor Adam reads the summed buckets in place (oracle bound behind the C-ABI: test only)
     from swapping_autoencoder_pytorch_amd import hip_lib
