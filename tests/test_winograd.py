@@ -288,7 +288,8 @@ def test_wide_rows_take_the_four_tile_kernels():
 # chunk and the 64-channel block, maps that fill a 4 x 16 tile block, spill over it, or leave most of it empty, several images per block
 FUSED_CASES = [(2, 12, 8, 8, 20, False, 1), (1, 40, 6, 10, 70, False, 1), (3, 9, 4, 4, 70, True, 1), (1, 5, 16, 36, 8, False, 1),
                (2, 16, 10, 10, 20, False, 0), (5, 24, 4, 4, 16, False, 0), (1, 9, 6, 8, 33, True, 0), (1, 8, 40, 12, 64, False, 1),
-               (1, 8, 8, 100, 16, False, 1)]      # 50 tiles per row: four blocks, the middle two touch no border (the select-free loop)
+               (1, 8, 8, 100, 16, False, 1),      # 50 tiles per row: four blocks, the middle two touch no border (the select-free loop)
+               (3, 10, 20, 40, 12, False, 1)]     # 3 images x 3 block rows x 2 block columns (16 x 4 tiles each, ragged in both directions)
 
 
 def _fused_route(lib, oracle_lib, dev):

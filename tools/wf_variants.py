@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from swapping_autoencoder_pytorch_amd import hip_lib  # noqa: E402
 from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as cg, winograd  # noqa: E402
 
-SHAPES = [(16, 512, 64), (16, 256, 128), (16, 128, 256), (128, 128, 32)]
+SHAPES = [(16, 512, 64), (16, 256, 128), (16, 128, 256), (128, 128, 32), (40, 128, 256), (8, 256, 128), (40, 512, 64), (128, 64, 64)]
 
 
 def timed(fn, reps=10):
