@@ -655,12 +655,36 @@ def _install_ring_rehearsal(n_gpus):
     # "nowait": a stream of its own that does NOT wait for the bucket (is it the dependency or the kernels?)
     side = None if where == "launch" else torch.cuda.Stream(priority=-1 if where == "high" else 0)
     scratch = {}
+    # SAE_RING_REHEARSAL_KERNEL=persistent:CHANNELS:HOLD_US -- ONE kernel per bucket, CHANNELS persistent workgroups that walk the
+    # 2 (N - 1) steps and take at least HOLD_US per step (tools/probe/ring_standin.hip): the shape of RCCL's ring kernel.  Default:
+    # a chain of 2 (N - 1) ATen elementwise kernels over the slices (whole-GPU grids, a few microseconds each)
+    form = os.environ.get("SAE_RING_REHEARSAL_KERNEL", "")
+    standin = None
+    if form.startswith("persistent"):
+        import ctypes
+        _, channels, hold_us = (form.split(":") + ["32", "0"])[:3]
+        lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "probe", "libring_standin.so"))
+        lib.ring_standin_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_void_p]
+        standin = (lib, int(channels), int(hold_us))
 
     def rehearsed(tensor, *a, **kw):
         work = real(tensor, *a, **kw)
         flat = tensor.view(-1)
         n = flat.numel() // n_gpus
         if n == 0:
+            return work
+        if standin is not None:
+            if side is not None and where != "nowait":
+                side.wait_stream(torch.cuda.current_stream())
+            st = side if side is not None else torch.cuda.current_stream()
+            with torch.cuda.stream(st):
+                buf = scratch.get(n)
+                if buf is None:
+                    buf = scratch[n] = torch.zeros(n, device=tensor.device)
+                rc = standin[0].ring_standin_launch(flat.data_ptr(), buf.data_ptr(), flat.numel(), n_gpus, standin[1], standin[2],
+                                                    st.cuda_stream)
+                assert rc == 0, rc
             return work
         if side is not None and where != "nowait":
             side.wait_stream(torch.cuda.current_stream())
