@@ -659,6 +659,7 @@ def _install_ring_rehearsal(n_gpus):
     # 2 (N - 1) steps and take at least HOLD_US per step (tools/probe/ring_standin.hip): the shape of RCCL's ring kernel.  Default:
     # a chain of 2 (N - 1) ATen elementwise kernels over the slices (whole-GPU grids, a few microseconds each)
     form = os.environ.get("SAE_RING_REHEARSAL_KERNEL", "")
+    host = [0.0, 0.0, 0]
     standin = None
     if form.startswith("persistent"):
         import ctypes
@@ -675,8 +676,10 @@ def _install_ring_rehearsal(n_gpus):
         if n == 0:
             return work
         if standin is not None:
+            t0 = time.perf_counter()
             if side is not None and where != "nowait":
                 side.wait_stream(torch.cuda.current_stream())
+            t1 = time.perf_counter()
             st = side if side is not None else torch.cuda.current_stream()
             with torch.cuda.stream(st):
                 buf = scratch.get(n)
@@ -685,6 +688,11 @@ def _install_ring_rehearsal(n_gpus):
                 rc = standin[0].ring_standin_launch(flat.data_ptr(), buf.data_ptr(), flat.numel(), n_gpus, standin[1], standin[2],
                                                     st.cuda_stream)
                 assert rc == 0, rc
+            t2 = time.perf_counter()
+            host[0] += t1 - t0; host[1] += t2 - t1; host[2] += 1
+            if host[2] % 8 == 0 and os.environ.get("SAE_RING_REHEARSAL_HOST_TIMES"):
+                print("ring rehearsal, host side: wait_stream %.3f ms, launch %.3f ms per collective (%d collectives)"
+                      % (host[0] / host[2] * 1e3, host[1] / host[2] * 1e3, host[2]), file=sys.stderr, flush=True)
             return work
         if side is not None and where != "nowait":
             side.wait_stream(torch.cuda.current_stream())

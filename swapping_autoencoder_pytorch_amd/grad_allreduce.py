@@ -28,7 +28,7 @@ import os
 import torch
 import torch.distributed as dist
 
-BUCKET_BYTES = 32 * 1024 * 1024
+BUCKET_BYTES = int(os.environ.get("SAE_ALLREDUCE_BUCKET_MB", "32")) * 1024 * 1024
 SLOT_ALIGN = 64          # floats: every parameter's slot starts on a 256-byte boundary
 
 # data_ptr of a parameter -> its slot in an armed reducer's flat bucket, handed out ONCE per backward pass
