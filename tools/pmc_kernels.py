@@ -68,6 +68,11 @@ if __name__ == "__main__":
         conv(16, 128, 257, 257, 256, 3, 2, 0, ops=(1,))
         conv(16, 256, 129, 129, 512, 3, 2, 0, ops=(1,))
         sys.exit(0)
+    if "--s2" in sys.argv:      # the stride-2 family at the step's three wide shapes: gather / transposed gather / weight gradient
+        conv(16, 128, 257, 257, 256, 3, 2, 0)
+        conv(16, 256, 129, 129, 512, 3, 2, 0)
+        conv(16, 512, 65, 65, 512, 3, 2, 0)
+        sys.exit(0)
     calibrate()
     conv(16, 128, 256, 256, 128, 3, 1, 1)          # igemm s1 / dgrad s1 / wgrad s1
     conv(16, 128, 257, 257, 256, 3, 2, 0)          # igemm s2 / tr / wgrad s2
