@@ -21,7 +21,10 @@ EMU = [(2, 20, 16, 16, 130, 3, 1, 1), (1, 12, 20, 36, 70, 3, 1, 0), (3, 20, 12, 
        (2, 12, 21, 41, 70, 3, 2, 0), (1, 6, 33, 33, 130, 3, 2, 0),
        # stride-2 data gradient through conv_igemm_tr2_kernel (input rows a multiple of 4 wide): M / channel tails, strips,
        # pad 1, 32-row tile, several images per tile
-       (2, 40, 17, 33, 20, 3, 2, 0), (1, 36, 16, 24, 12, 3, 2, 1), (3, 20, 17, 17, 40, 3, 2, 0), (1, 70, 9, 65, 9, 3, 2, 0)]
+       (2, 40, 17, 33, 20, 3, 2, 0), (1, 36, 16, 24, 12, 3, 2, 1), (3, 20, 17, 17, 40, 3, 2, 0), (1, 70, 9, 65, 9, 3, 2, 0),
+       # stride 2 with INTERIOR tiles and full channel blocks (137 wide: two of three tile columns touch no border; 128 x 32
+       # channels): the select-free staging of the gather and of the weight gradient, next to the masked one in the same launch
+       (1, 32, 9, 137, 128, 3, 2, 0), (2, 40, 13, 137, 136, 3, 2, 0)]
 GPU = EMU + [(4, 128, 64, 64, 128, 3, 1, 1), (2, 512, 32, 32, 512, 3, 1, 1), (8, 32, 64, 64, 32, 3, 1, 1), (4, 64, 65, 65, 128, 3, 2, 0),
              (4, 128, 64, 64, 256, 1, 1, 0), (2, 256, 129, 129, 512, 3, 2, 0)]
 
