@@ -55,6 +55,13 @@ def _worker(rank, world, port, tmp):
     red_a = GradAllReducer(group_a, bucket_bytes=256)      # tiny buckets -> several collectives
     red_b = GradAllReducer(group_b, bucket_bytes=256)
     assert red_a.enabled and len(red_a.buckets) > 1
+    # a rank of a multi-rank job runs the step on ONE stream unless told otherwise (streams.enabled)
+    from swapping_autoencoder_pytorch_amd import streams
+    os.environ.pop("SAE_TWO_STREAMS", None)
+    assert not streams.enabled()
+    os.environ["SAE_TWO_STREAMS"] = "1"
+    assert streams.enabled()
+    os.environ.pop("SAE_TWO_STREAMS")
     launched_in_backward = []
     results = {}
     for tag, params, frozen, red, fn in (("a", group_a, group_b, red_a, _loss), ("b", group_b, group_a, red_b, _loss),
@@ -140,8 +147,14 @@ def test_two_rank_gradient_allreduce(tmp_path):
         assert torch.allclose(r0["after_adam"][k], v, rtol=1e-5, atol=2e-6), k
 
 
-def test_single_process_is_a_noop():
+def test_single_process_is_a_noop(monkeypatch):
+    from swapping_autoencoder_pytorch_amd import streams
     from swapping_autoencoder_pytorch_amd.grad_allreduce import GradAllReducer
+    monkeypatch.delenv("SAE_TWO_STREAMS", raising=False)
+    assert streams.enabled()                    # single rank: the step's branches on two streams
+    monkeypatch.setenv("SAE_TWO_STREAMS", "0")
+    assert not streams.enabled()
+    monkeypatch.delenv("SAE_TWO_STREAMS")
     net = Net()
     red = GradAllReducer(list(net.parameters()))
     assert not red.enabled
