@@ -38,16 +38,48 @@ def hipcc():
     raise RuntimeError("hipcc not found: cannot build the gfx950 hot-path library")
 
 
+def _source_deps(src):
+    """What one source is rebuilt for: itself, the two headers, and -- for the file that #includes them -- the .inc parts."""
+    d = [src, os.path.join(HERE, "sae_common.h"), os.path.join(ROOT, "include", "sae_hip.h")]
+    with open(src) as f:
+        if ".inc\"" in f.read():
+            d += includes()
+    return d
+
+
+def compile_and_link(out, objdir, extra_flags=(), force=False, verbose=False, jobs=None):
+    """One object per source (stale ones only, compiled side by side), then one link.  Shared with tests/tuning/build_tuning.py.
+    Objects live under a git-ignored build/ directory; only the linked library travels to the GPU box."""
+    from concurrent.futures import ThreadPoolExecutor
+    cc = hipcc()
+    os.makedirs(objdir, exist_ok=True)
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"),
+             "-I", HERE] + list(extra_flags)
+    todo, objs = [], []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in _source_deps(src)):
+            todo.append((src, obj))
+
+    def one(job):
+        cmd = [cc] + flags + ["-c", job[0], "-o", job[1]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(6, os.cpu_count() or 1)) as ex:
+            list(ex.map(one, todo))
+    subprocess.check_call([cc, "--offload-arch=" + ARCH, "-shared", "-fPIC"] + objs + ["-o", out])
+    verify_loads(out)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and up_to_date():
         return OUT
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I", os.path.join(ROOT, "include"), "-I", HERE] + sources() + ["-o", OUT]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    verify_loads(OUT)
-    return OUT
+    return compile_and_link(OUT, os.path.join(HERE, "build", "product"), force=force, verbose=verbose)
 
 
 def verify_loads(path):

@@ -51,7 +51,9 @@ namespace {
 
 #include "conv2d_gather.inc"
 
+#ifdef SAE_TUNING
 #include "tuning/conv2d_ws.inc"
+#endif
 
 #include "conv2d_bx.inc"
 

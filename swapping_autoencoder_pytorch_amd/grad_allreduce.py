@@ -91,7 +91,7 @@ class GradAllReducer:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
     # called right before loss.backward()
-    def arm(self):
+    def arm(self, hand_out_slots=True):
         if not self.enabled:
             return
         self.armed = True
@@ -111,7 +111,12 @@ class GradAllReducer:
                 # conv weights: their wgrad kernels can write into the slot -- only when autograd will ADOPT the result as
                 # `.grad` (no gradient alive); otherwise it accumulates into the existing one and the hook copies the sum
                 # (ModulatedConv2d keeps its weight as [1, O, I, k, k] and convolves a 4-D view of it: same address)
-                if (p.dim() == 4 or (p.dim() == 5 and p.shape[0] == 1)) and p.is_contiguous() and p.grad is None:
+                # ``hand_out_slots=False`` (arming from inside a gradient hook, in the MIDDLE of a backward pass): no slot is
+                # registered -- the ``zero_()`` above was enqueued on the hook's stream, and with the step on two streams a
+                # weight gradient launched next on the OTHER stream would write its slot with no ordering against it.  The
+                # hooks then copy every gradient in (always correct, one copy per conv weight dearer).
+                if (hand_out_slots and (p.dim() == 4 or (p.dim() == 5 and p.shape[0] == 1)) and p.is_contiguous()
+                        and p.grad is None):
                     _DESTINATIONS[p.data_ptr()] = b.flat[off:off + p.numel()]
 
     def arm_lazily(self):
@@ -127,7 +132,9 @@ class GradAllReducer:
         if not self.armed:
             if not self._arm_pending:
                 return
-            self.arm()       # no zero_grad since the last step (gradient accumulation): the late, always-correct form
+            # no zero_grad since the last step (gradient accumulation, model.zero_grad(), p.grad = None): the late,
+            # always-correct form -- copy-in-hook only, no bucket slot handed to a producer mid-pass
+            self.arm(hand_out_slots=False)
         bi, pi = self._where[p]
         b = self.buckets[bi]
         off = b.offsets[pi]

@@ -15,7 +15,9 @@ Only ``torch.nn.Parameter`` weights (or views of one) are cached: a temporary te
 operators of the R1 penalty convolve with gradients) can be freed and its address and version recur with other contents.
 An entry holds a weak reference to its parameter and is dropped -- with its device buffer -- when the parameter dies (the
 weak reference's callback).  Memory: one padded copy per (parameter, layout) in use, i.e. the forward and the data-gradient
-layouts of every conv weight: about twice the conv weights on top of the parameters themselves (0.6 GB at the church preset)."""
+layouts of every conv weight: about twice the conv weights on top of the parameters themselves for the direct kernels; a layer
+on the Winograd route keeps its sixteen transform-domain points instead of nine taps, 16/9 x the weight (padded to 64 output
+channels and 8 contraction channels) per direction, i.e. about 3.6 x the weight for both -- 0.9 GB at the church preset."""
 import ctypes as C
 import os
 import weakref

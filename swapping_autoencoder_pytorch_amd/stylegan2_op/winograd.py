@@ -17,6 +17,10 @@ from .. import hip_lib
 from . import weight_prep
 
 FWD, DGRAD, WGRAD = "fwd", "dgrad", "wgrad"
+# The one-kernel weight gradient writes one partial gradient per K slice (slices x Mp x 9 x Cp floats: 226 MB for a 512 -> 512
+# layer cut into 24 slices) into a slab taken from torch's caching allocator for the duration of the call.  Layers whose slab
+# would exceed this take the three-kernel form instead (none of the three presets' layers comes near it).
+FUSED_WGRAD_SLAB_BYTES = 1 << 30
 
 
 class _Config:
@@ -239,11 +243,13 @@ def wgrad(x, gy, geom, out=None, x_scale=None, y_scale=None, kind=None):
         kind = route(geom, WGRAD) or "unfused"
     if kind == "fused" and (gy.data_ptr() & 15):          # the kernel fetches gy tile pairs as aligned 16-byte loads
         kind = "unfused"
+    n_ws = lib.query("wino_fused_wgrad_workspace", n, c, m, geom.h, geom.w, geom.pad) if kind == "fused" else 0
+    if n_ws * 4 > FUSED_WGRAD_SLAB_BYTES:                 # slices x Mp x 9 x Cp partial gradients: capped, not open-ended
+        kind = "unfused"
     if kind == "fused":
         d = geom.desc()
         if out is None or tuple(out.shape) != tuple(geom.weight_shape()) or not out.is_contiguous():
             out = torch.empty(geom.weight_shape(), dtype=torch.float32, device=x.device)
-        n_ws = lib.query("wino_fused_wgrad_workspace", n, c, m, geom.h, geom.w, geom.pad)
         ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=x.device)
         lib.call("wino_fused_wgrad_f32", x.data_ptr(), hip_lib.ptr(x_scale), gy.data_ptr(), hip_lib.ptr(y_scale), out.data_ptr(), n, c,
                  m, geom.h, geom.w, geom.pad, d.w_stride_m, d.w_stride_c, geom.alpha, ws.data_ptr(), n_ws, lib.stream(x))

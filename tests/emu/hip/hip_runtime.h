@@ -30,6 +30,7 @@
 #include <cstring>
 #include <functional>
 #include <vector>
+#include <atomic>
 
 // ---- keywords -------------------------------------------------------------------------------
 #define __global__
@@ -360,6 +361,16 @@ struct hipemu_rsrc {
     const char* base;
     unsigned num_records;
 };
+// Guard range (tests only): bytes a buffer load must never touch, e.g. the 64 bytes that follow a tensor.  A load that passes
+// its range check and still reads inside [lo, hi) is counted instead of performed -- what a GPU memory-access fault would be
+// when the tensor ends its allocator segment (the memcpy alone cannot see it).  hipemu_set_guard(0, 0) switches it off.
+inline const char* volatile hipemu_guard_lo = nullptr;
+inline const char* volatile hipemu_guard_hi = nullptr;
+inline std::atomic<long long> hipemu_guard_count{0};
+extern "C" inline __attribute__((visibility("default"), used)) void hipemu_set_guard(const void* lo, const void* hi) {
+    hipemu_guard_lo = (const char*)lo; hipemu_guard_hi = (const char*)hi; hipemu_guard_count = 0;
+}
+extern "C" inline __attribute__((visibility("default"), used)) long long hipemu_guard_hits() { return hipemu_guard_count.load(); }
 typedef unsigned hipemu_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned hipemu_u32x2 __attribute__((ext_vector_type(2)));
 namespace hipemu {
@@ -369,14 +380,22 @@ inline V raw_buffer_load(hipemu_rsrc r, unsigned voffset, unsigned soffset) {
     for (int i = 0; i < N; ++i) {
         unsigned v = 0;
         const unsigned long long off = (unsigned long long)voffset + 4ull * i;
-        if (off + 4 <= r.num_records) std::memcpy(&v, r.base + soffset + off, 4);
+        if (off + 4 <= r.num_records) {
+            const char* a = r.base + soffset + off;
+            if (a + 4 > hipemu_guard_lo && a < hipemu_guard_hi) ++hipemu_guard_count;
+            else std::memcpy(&v, a, 4);
+        }
         out[i] = v;
     }
     return out;
 }
 inline unsigned raw_buffer_load1(hipemu_rsrc r, unsigned voffset, unsigned soffset) {
     unsigned v = 0;
-    if ((unsigned long long)voffset + 4 <= r.num_records) std::memcpy(&v, r.base + soffset + voffset, 4);
+    if ((unsigned long long)voffset + 4 <= r.num_records) {
+        const char* a = r.base + soffset + voffset;
+        if (a + 4 > hipemu_guard_lo && a < hipemu_guard_hi) ++hipemu_guard_count;
+        else std::memcpy(&v, a, 4);
+    }
     return v;
 }
 }  // namespace hipemu

@@ -431,3 +431,37 @@ def test_route_keeps_activations_over_2_gib_off_the_one_kernel_forms(oracle_lib,
     with winograd.override(enabled=True):
         assert [winograd.route(ok, op) for op in (winograd.FWD, winograd.DGRAD, winograd.WGRAD)] == ["fused"] * 3
         assert all(winograd.route(big, op) != "fused" for op in (winograd.FWD, winograd.DGRAD, winograd.WGRAD))
+
+
+def test_fused_conv_never_reads_past_the_input_on_the_emulator(emu_lib, oracle_lib):
+    """The channel plane of wino_fused_kernel's input loads rides in the buffer load's SCALAR offset, which the descriptor's range
+    check ignores: a right-border window in the last row of the last image used to read 4 (pad 1) or 8 (pad 2, the data gradient)
+    bytes past x for every channel but the first -- harmless values (zeroed afterwards), but a memory-access fault when x ends its
+    allocator segment.  The emulator counts loads that pass their range check and touch the 64 bytes after x."""
+    import ctypes
+    rng = np.random.default_rng(5)
+    dll = emu_lib._dll
+    dll.hipemu_set_guard.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    dll.hipemu_guard_hits.restype = ctypes.c_longlong
+    for n, c, h, w, m, ipad in [(2, 12, 8, 8, 16, 1), (1, 9, 6, 10, 70, 2), (3, 8, 16, 32, 8, 1)]:
+        x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+        wt = (0.3 * rng.standard_normal((m, c, 3, 3))).astype(np.float32)
+        # x at the front of a larger buffer: the floats behind it are NaN, so a read that escaped the guard would also show
+        store = np.full(x.size + 16, np.nan, np.float32)
+        store[:x.size] = x.reshape(-1)
+        floats = emu_lib.query("wino_fused_weights_floats", m, c)
+        u = np.zeros(floats, np.float32)
+        emu_lib.call("wino_fused_weights_f32", wt.ctypes.data, None, None, u.ctypes.data, m, c, c * 9, 9, 0, 1.0, None)
+        oh, ow = h + 2 * ipad - 2, w + 2 * ipad - 2
+        y = np.full((n, m, oh, ow), np.nan, np.float32)
+        end = store.ctypes.data + 4 * x.size
+        dll.hipemu_set_guard(end, end + 64)
+        try:
+            emu_lib.call("wino_fused_conv_f32", store.ctypes.data, None, u.ctypes.data, None, None, None, None, y.ctypes.data,
+                         n, c, m, h, w, ipad, 0, 0.0, 1.0, None)
+            hits = dll.hipemu_guard_hits()
+        finally:
+            dll.hipemu_set_guard(None, None)
+        assert hits == 0, (n, c, h, w, m, ipad, hits)
+        d = H.conv_desc(n, c, h, w, m, 3, 1, ipad, False)
+        assert H.rel_err(y, H.conv(oracle_lib, 0, d, x, wt, y.shape)) < TOL

@@ -39,12 +39,10 @@ def build(force=False):
         if os.path.exists(OUT):
             return OUT
         raise RuntimeError("hipcc not found and no prebuilt %s" % OUT)
-    subprocess.check_call([cc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
-                           "-DSAE_TUNING", "-I", os.path.join(ROOT, "include"), "-I", CSRC] + sources() + ["-o", OUT])
     if ROOT not in sys.path:
         sys.path.insert(0, ROOT)
-    from swapping_autoencoder_pytorch_amd.csrc.build import verify_loads
-    verify_loads(OUT)
+    from swapping_autoencoder_pytorch_amd.csrc.build import compile_and_link
+    compile_and_link(OUT, os.path.join(CSRC, "build", "tuning"), extra_flags=["-DSAE_TUNING"], force=force)
     return OUT
 
 
