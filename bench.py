@@ -12,15 +12,19 @@ penalty on every 16th discriminator iteration (the default K = 16 contains exact
 value = N * B * K / t   (whole-job images per second; B images per GPU -> weak scaling).
 
 Also reported on the same JSON line:
-  roofline     – dominant kernel (3x3 stride-1 implicit-GEMM conv, conv_igemm_kernel<3,1,2,2,1,4,8,false,true>):
-                 algorithmic FLOPs per launch / mean launch duration measured with HIP events on the
-                 launch stream inside the timed region, against the fp32 MFMA peak (157.3 TFLOP/s); `traffic` from the
-                 committed counter record profiles/r4_pmc_dominant.json (refused if it names another kernel);
-  roofline_by_kernel – the same event-timed fraction for the second-tier MFMA classes (stride-2 data gradient,
-                 stride-2 forward, both weight gradients) next to the dominant one;
-  cpu_baseline – the reference's CPU path (ATen on all host cores, restated in oracle/aten_cpu_path.py and pinned
-                 to the reference's own modules) timed on a bounded sample of the same workload: the image
-                 discriminator forward + backward (rank 0, N = 1 only); the C oracle's rate rides along.
+  roofline     – dominant kernel (the one-kernel Winograd F(2x2,3x3) convolution wino_fused_kernel<*> of
+                 csrc/winograd_fused.hip: forward and data gradient of the wide 3x3 stride-1 layers): FLOPs per launch
+                 -- EXECUTED (direct / 2.25) for `achieved` / `frac`, algorithmic (the direct convolution's) alongside --
+                 / mean launch duration measured with HIP events on the launch stream in the kernel pass that follows
+                 the timed region, against the fp32 MFMA peak (157.3 TFLOP/s); `traffic` from the committed counter
+                 record PMC_DOMINANT_FILE (refused if it names another kernel), scaled by FLOPs to the average launch;
+  roofline_by_kernel – the same event-timed fraction for the other MFMA classes (stride-2 family, weight gradients, 1x1);
+  hbm_by_kernel – the HBM-bound classes (upfirdn2d, bias / activation, modulation) in TB/s against 8 TB/s;
+  cpu_baseline – the reference's CPU path (ATen on the host cores, restated in oracle/aten_cpu_path.py and pinned
+                 to the reference's own modules) MEASURED on one whole iteration of the preset at B = 2 (discriminator
+                 call + generator call with their Adam updates; rank 0, N = 1 only); the D-only FLOP-scaled sample that
+                 picks the thread count and the C oracle's rate ride along;
+  other_presets – BASELINE configs 3 and 5 (ffhq512 B = 8, ffhq1024 B = 4) measured in their own processes.
 """
 import argparse
 import json
@@ -63,6 +67,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0        # same table, dense bf16 matrix; the bf16x
                                       # (20/3 with the zero-padded ninth tap) per fp32 product
 FLOPS_PER_IMAGE = {"church256": 1.815e12, "bedroom256": 1.815e12, "ffhq512": 3.91e12, "ffhq1024": 6.08e12}
 DEFAULT_BATCH = {"church256": 16, "bedroom256": 16, "ffhq512": 8, "ffhq1024": 4, "tiny32": 4}
+CPU_BASELINE_BATCH = 2                # images of the measured whole CPU iteration of the default run (cpu_baseline)
 
 
 def parse():
@@ -85,9 +90,10 @@ def parse():
                          "read + reduce + write -- concurrent with the backward pass.  A rehearsal of the contention, NOT a scaling number")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-cpu-baseline", action="store_true",
-                    help="cpu_baseline.value from ONE whole iteration of the preset on the host (a discriminator call + a "
-                         "generator call of the reference's driver through oracle/aten_cpu_path.TrainIterationCPU; several "
-                         "minutes at 256 x 256, B = 16) instead of the bounded, FLOP-scaled sample")
+                    help="cpu_baseline.value from ONE whole iteration of the preset on the host at the preset's FULL batch (a "
+                         "discriminator call + a generator call of the reference's driver through "
+                         "oracle/aten_cpu_path.TrainIterationCPU; several minutes at 256 x 256, B = 16) instead of the same whole "
+                         "iteration at B = 2 (the default: 10 - 30 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-winograd", action="store_true",
                     help="A/B only: SAE_WINOGRAD=0 -- every 3x3 stride-1 layer on the direct MFMA kernels (stylegan2_op/winograd.py "
@@ -491,10 +497,13 @@ def cpu_baseline(preset, size, batch, full=False):
                      "TFLOP/s, scaled by %.3f TFLOP/image of the full iteration" % (n, size, size, flops / 1e12, dt,
                                                                                   flops / dt / 1e12, per_image / 1e12)}
 
-    if full:
-        sampled = {k: out[k] for k in ("value", "sample", "extrapolated")}
-        out.update(cpu_baseline_full(A, preset, batch, threads))
-        out["sampled"] = sampled
+    # cpu_baseline.value is MEASURED: one whole iteration of the preset (discriminator call + generator call, Adam updates
+    # included) on the ATen CPU path -- at the preset's batch with --full-cpu-baseline (minutes), by default at B = 2, which
+    # bounds the CPU work to the 10 - 30 s SURVEY 8d asks for (the swap pairs images, so 2 is the smallest batch the step
+    # accepts).  The D-only, FLOP-scaled sample above chose the thread count and rides along as `flop_scaled_sample`.
+    scaled = {k: out[k] for k in ("value", "sample")}
+    out.update(cpu_baseline_full(A, preset, batch if full else CPU_BASELINE_BATCH, threads))
+    out["flop_scaled_sample"] = scaled
     out["config1"] = cpu_baseline_config1(A, threads)
 
     so = os.path.join(ROOT, "oracle", "libsae_oracle.so")
