@@ -95,6 +95,9 @@ def parse():
                          "oracle/aten_cpu_path.TrainIterationCPU; several minutes at 256 x 256, B = 16) instead of the same whole "
                          "iteration at B = 2 (the default: 10 - 30 s of CPU work)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="A/B only: SAE_HIP_GRAPH=0 -- every call enqueued from Python (the default on one GPU replays the "
+                         "discriminator call and the generator call as hipGraphs: swapping_autoencoder_pytorch_amd/hip_graph.py)")
     ap.add_argument("--no-winograd", action="store_true",
                     help="A/B only: SAE_WINOGRAD=0 -- every 3x3 stride-1 layer on the direct MFMA kernels (stylegan2_op/winograd.py "
                          "routes the wide ones through Winograd F(2x2,3x3) by default); `config.winograd` records it")
@@ -787,6 +790,8 @@ def main():
     from swapping_autoencoder_pytorch_amd.swapping_autoencoder_optimizer import create_optimizer
     hip_lib.get()           # fail loudly here if the HIP library is missing
     hip_lib.set_conv_math(args.conv_math)
+    if args.no_graph:
+        os.environ["SAE_HIP_GRAPH"] = "0"
     from swapping_autoencoder_pytorch_amd.stylegan2_op import winograd
     if args.no_winograd:
         winograd.configure(enabled=False)
@@ -823,8 +828,18 @@ def main():
         call_ms["d"].append((t1 - t0) * 1e3)
         call_ms["g"].append((t2 - t1) * 1e3)
 
-    for i in range(args.warmup):
+    # hipGraph mode: the third call of each kind is the capture (hip_graph.WARMUP_CALLS eager ones before it).  With fewer
+    # than three warm-up steps the capture would land in the timed region: it is set-up, like building the library, and is
+    # brought forward by as many extra untimed iterations as are missing (reported as `graph_setup_iterations`).
+    graph_setup = 0
+    if optimizer.graphs is not None:
+        from swapping_autoencoder_pytorch_amd import hip_graph
+        graph_setup = max(0, hip_graph.WARMUP_CALLS + 1 - args.warmup)
+    skew = graph_setup          # keeps the iteration numbers (batch pool index, R1 schedule bookkeeping below) in step
+    for i in range(graph_setup):
         iteration(i)
+    for i in range(args.warmup):
+        iteration(graph_setup + i)
 
     def fence():
         torch.cuda.synchronize()
@@ -835,14 +850,14 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        iteration(args.warmup + i)
+        iteration(skew + args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    done = args.warmup + args.steps
+    done = skew + args.warmup + args.steps
 
     # kernel pass (not `value`): the same iterations with everything on ONE stream and an event bracket around every launch
     # of the tracked kernels.  The timed region above runs the step's independent branches on two streams: two kernels then
@@ -856,6 +871,7 @@ def main():
             _quiet(False)
         prev = os.environ.get("SAE_TWO_STREAMS")
         os.environ["SAE_TWO_STREAMS"] = "0"
+        graphs, optimizer.graphs = optimizer.graphs, None      # eager: the brackets sit around individual launches
         try:
             iteration(done)
             fence()
@@ -867,6 +883,7 @@ def main():
             kernel_ms_per_step = (time.perf_counter() - t0) / args.kernel_steps * 1e3
             timer.active = hbm_timer.active = False
         finally:
+            optimizer.graphs = graphs
             if prev is None:
                 os.environ.pop("SAE_TWO_STREAMS", None)
             else:
@@ -878,15 +895,21 @@ def main():
     if args.alt_steps > 0:
         other = "bf16x6" if args.conv_math == "f32" else "f32"
         hip_lib.set_conv_math(other)
-        for i in range(2):                       # workspaces change size with the arithmetic: let the allocator settle
+        main_graphs = optimizer.graphs
+        settle = 2                               # workspaces change size with the arithmetic: let the allocator settle
+        if main_graphs is not None:              # the captured graphs hold the OTHER arithmetic's kernels: capture this one's
+            optimizer.graphs = hip_graph.StepGraphs(warmup=1)
+            settle = 3                           # one eager call, the capture, one replay
+        for i in range(settle):
             iteration(done + i)
         fence()
         t0 = time.perf_counter()
         for i in range(args.alt_steps):
-            iteration(done + 2 + i)
+            iteration(done + settle + i)
         fence()
         adt = time.perf_counter() - t0
         hip_lib.set_conv_math(args.conv_math)
+        optimizer.graphs = main_graphs
         if world > 1:
             t = torch.tensor([adt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -911,6 +934,12 @@ def main():
         from swapping_autoencoder_pytorch_amd import streams
         line["config"]["streams"] = ("the step's independent branches on two HIP streams" if streams.enabled() else
                                      "the step on one HIP stream (streams.enabled(): the default for a rank of a multi-rank job, or SAE_TWO_STREAMS=0)")
+        line["config"]["launch"] = (
+            "the discriminator call and the generator call replayed as hipGraphs (hip_graph.py: captured at the third call of each; "
+            "the lazy-R1 call is enqueued eagerly)" if optimizer.graphs is not None else
+            "every kernel enqueued from Python (SAE_HIP_GRAPH=0 / --no-graph, or a rank of a multi-rank job)")
+        if graph_setup:
+            line["graph_setup_iterations"] = graph_setup
         line["config"]["winograd"] = (
             "off: every 3x3 stride-1 layer on the direct MFMA kernels" if not winograd.enabled() else
             "3x3 stride-1 launches selected by stylegan2_op/winograd.route() run as Winograd F(2x2,3x3) (%s): 2.25x fewer "
@@ -930,18 +959,19 @@ def main():
             line["frac_of_mfma_f32_roofline"] = round(value / world * per_image / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
         # lazy R1 runs on every R1_once_every-th discriminator iteration (the optimizer's own counter, 1-based)
         every = opt.R1_once_every
-        r1_in_window = sum(1 for j in range(args.warmup + 1, args.warmup + args.steps + 1) if j % every == 0)
+        first = skew + args.warmup      # iterations before the timed window (the optimizer's counter is 1-based)
+        r1_in_window = sum(1 for j in range(first + 1, first + args.steps + 1) if j % every == 0)
         line["r1_iterations_in_window"] = r1_in_window
-        d_window = call_ms["d"][args.warmup:args.warmup + args.steps]
+        d_window = call_ms["d"][first:first + args.steps]
         d_calls = sorted(d_window)
-        g_calls = sorted(call_ms["g"][args.warmup:args.warmup + args.steps])
+        g_calls = sorted(call_ms["g"][first:first + args.steps])
         if d_calls and g_calls:
             # median D call (without the lazy R1 extra), median G call, and the R1 surcharge: the D calls KNOWN to carry the R1
             # penalty (the optimizer's 1-based counter is a multiple of `every`) minus the median D call
             d_med = d_calls[len(d_calls) // 2]
             line["ms_d_call_median"] = round(d_med, 2)
             line["ms_g_call_median"] = round(g_calls[len(g_calls) // 2], 2)
-            r1_calls = [d_window[j - args.warmup - 1] for j in range(args.warmup + 1, args.warmup + args.steps + 1) if j % every == 0]
+            r1_calls = [d_window[j - first - 1] for j in range(first + 1, first + args.steps + 1) if j % every == 0]
             line["metric_version"] = 2      # 2: `value` is the plain wall-clock quotient of the K timed steps (rounds 1-3 and 5); round 4's
                                             # line carried the R1-normalised figure there
             if r1_calls:

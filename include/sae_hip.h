@@ -28,7 +28,8 @@
  *   sae_l2_normalize_{,bwd_}f32 <- util.normalize                       util/util.py:18-22
  *   sae_plane_affine_{,bwd_}f32 <- GeneratorModulation.forward           models/networks/generator.py:62-67
  *   sae_softplus_mean_{,bwd_}f32 <- gan_loss                             models/networks/loss.py:10-16
- *   sae_adam_multi_f32       <- torch.optim.Adam(...).step()            optimizers/swapping_autoencoder_optimizer.py:34-42,77,95,107
+ *   sae_adam_multi_f32, sae_adam_multi_dev_f32
+ *                            <- torch.optim.Adam(...).step()            optimizers/swapping_autoencoder_optimizer.py:34-42,77,95,107
  *
  * Conventions (what the reference's pybind layer did implicitly is explicit here):
  *   - plain pointers and sizes only, no torch types; all tensors are dense fp32 in device memory
@@ -59,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 9   /* 9: sae_wino_fused_wgrad_*;  8: sae_wino_fused_* (one-kernel Winograd convolution);  7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
+#define SAE_ABI_VERSION 10  /* 10: sae_adam_multi_dev_f32 (step counts in device memory: hipGraph replays);  9: sae_wino_fused_wgrad_*;  8: sae_wino_fused_* (one-kernel Winograd convolution);  7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -392,6 +393,15 @@ int sae_softplus_mean_bwd_f32(const float* gy, const float* x, float* gx, int64_
 int sae_adam_multi_f32(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                        const int64_t* numel, const int64_t* step, int64_t count, double lr, double beta1, double beta2,
                        double eps, double grad_scale, sae_stream_t stream);
+
+/* The same update with the update counts kept in DEVICE memory: step_dev is a HOST array of `count` device pointers, each to
+ * the int64 count of its tensor BEFORE this update (0 for a fresh parameter).  The kernels read it, form the two bias
+ * corrections in double as the host form does, and a trailing launch adds 1 to every count.  Nothing about the call depends
+ * on a host-side value that changes from step to step, so a hipGraph captured around a whole train step (the eager loop of
+ * train.py:22-28 replayed as one graph launch) applies the right bias correction on every replay. */
+int sae_adam_multi_dev_f32(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                           const int64_t* numel, int64_t* const* step_dev, int64_t count, double lr, double beta1, double beta2,
+                           double eps, double grad_scale, sae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Winograd F(2x2, 3x3) transforms for the 3x3 stride-1 convolutions (pad 1 or 0) (F.conv2d at models/networks/stylegan2_layers.py:136,

@@ -42,7 +42,7 @@ typedef struct sae_conv2d_desc {
 
 static __thread char g_err[256];
 
-int oracle_abi_version(void) { return 9; }
+int oracle_abi_version(void) { return 10; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
@@ -800,6 +800,25 @@ int oracle_adam_multi_f32(float* const* params, const float* const* grads, float
         }
     }
     return SAE_OK;
+}
+
+/* sae_adam_multi_dev_f32: the same update with the counts read from (here: host) memory and advanced afterwards. */
+int oracle_adam_multi_dev_f32(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                              const int64_t* numel, int64_t* const* step_dev, int64_t count, double lr, double beta1,
+                              double beta2, double eps, double grad_scale, sae_stream_t stream) {
+    if (count < 0 || (count > 0 && !step_dev)) return set_err("oracle_adam_multi_dev_f32: null step table");
+    int64_t* step = (int64_t*)malloc(sizeof(int64_t) * (size_t)(count > 0 ? count : 1));
+    if (!step) return set_err("oracle_adam_multi_dev_f32: out of memory");
+    for (int64_t t = 0; t < count; ++t) {
+        if (!step_dev[t]) { free(step); return set_err("oracle_adam_multi_dev_f32: null step counter"); }
+        step[t] = *step_dev[t] + 1;
+    }
+    const int rc = oracle_adam_multi_f32(params, grads, exp_avg, exp_avg_sq, numel, step, count, lr, beta1, beta2, eps, grad_scale,
+                                         stream);
+    free(step);
+    if (rc == SAE_OK)
+        for (int64_t t = 0; t < count; ++t) *step_dev[t] += 1;
+    return rc;
 }
 
 /* ---- Style-modulated convolution (include/sae_hip.h: sae_modconv2d_*).  ModulatedConv2d.forward,

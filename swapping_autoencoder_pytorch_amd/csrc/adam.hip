@@ -34,6 +34,7 @@ struct AdamArgs {
     long long n[kTensors];
     float step_size[kTensors];
     float inv_bc2_sqrt[kTensors];
+    const long long* step_dev[kTensors];    // DEV: the tensor's update count BEFORE this update, in device memory
     int block_chunk[kBlocks];
     unsigned char block_tensor[kBlocks];
 };
@@ -48,8 +49,13 @@ __device__ __forceinline__ void adam_element(float& p, float g, float& m, float&
     p = p - step_size * (m / denom);
 }
 
+// DEV (sae_adam_multi_dev_f32): the step counts live in device memory, so that a captured hipGraph of the train step replays with
+// the right bias corrections -- as kernel ARGUMENTS they would be frozen at their capture-time values.  Every thread forms the
+// two scalars in double, as the host form does (two pow() per workgroup of 64 Ki elements: nothing next to the 28 bytes per
+// element the update moves).
+template <bool DEV>
 __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamArgs a, float gscale, float omb1, float beta2, float omb2,
-                                                            float eps) {
+                                                            float eps, double lr, double beta1d, double beta2d) {
     const int t = a.block_tensor[blockIdx.x];
     const long long base = (long long)a.block_chunk[blockIdx.x] * kChunk;
     const long long n = a.n[t];
@@ -58,7 +64,12 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamArgs a, float gs
     const float* __restrict__ g = a.g[t] + base;
     float* __restrict__ m = a.m[t] + base;
     float* __restrict__ v = a.v[t] + base;
-    const float ss = a.step_size[t], ib = a.inv_bc2_sqrt[t];
+    float ss = a.step_size[t], ib = a.inv_bc2_sqrt[t];
+    if constexpr (DEV) {
+        const double st = (double)(*a.step_dev[t] + 1);
+        ss = (float)(lr / (1.0 - pow(beta1d, st)));
+        ib = (float)(1.0 / sqrt(1.0 - pow(beta2d, st)));
+    }
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                        reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
     long long done = 0;
@@ -97,20 +108,53 @@ __global__ __launch_bounds__(kBlock) void adam_multi_kernel(AdamArgs a, float gs
     }
 }
 
+constexpr int kAdvance = 384;       // step counters advanced per launch (pointers in the argument block)
+struct AdvanceArgs { long long* slot[kAdvance]; };
+__global__ void adam_advance_kernel(AdvanceArgs a, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) *a.slot[i] += 1;
+}
+
 }  // namespace
 }  // namespace sae
+
+namespace {
+int adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+               const int64_t* numel, const int64_t* step, int64_t* const* step_dev, int64_t count, double lr, double beta1,
+               double beta2, double eps, double grad_scale, sae_stream_t stream);
+}
+
+extern "C" int sae_adam_multi_dev_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                                      float* const* exp_avg_sq, const int64_t* numel, int64_t* const* step_dev, int64_t count,
+                                      double lr, double beta1, double beta2, double eps, double grad_scale, sae_stream_t stream) {
+    sae::clear_stale_error();
+    if (count > 0 && !step_dev) return sae::fail(SAE_EINVAL, "sae_adam_multi_dev_f32: null step table");
+    for (int64_t i = 0; i < count; ++i)
+        if (!step_dev[i]) return sae::fail(SAE_EINVAL, "sae_adam_multi_dev_f32: tensor %lld: null step counter", (long long)i);
+    return adam_multi(params, grads, exp_avg, exp_avg_sq, numel, nullptr, step_dev, count, lr, beta1, beta2, eps, grad_scale, stream);
+}
 
 extern "C" int sae_adam_multi_f32(float* const* params, const float* const* grads, float* const* exp_avg,
                                   float* const* exp_avg_sq, const int64_t* numel, const int64_t* step, int64_t count,
                                   double lr, double beta1, double beta2, double eps, double grad_scale, sae_stream_t stream) {
     sae::clear_stale_error();
+    if (count > 0 && !step) return sae::fail(SAE_EINVAL, "sae_adam_multi_f32: null table");
+    return adam_multi(params, grads, exp_avg, exp_avg_sq, numel, step, nullptr, count, lr, beta1, beta2, eps, grad_scale, stream);
+}
+
+namespace {
+int adam_multi(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+               const int64_t* numel, const int64_t* step, int64_t* const* step_dev, int64_t count, double lr, double beta1,
+               double beta2, double eps, double grad_scale, sae_stream_t stream) {
     using namespace sae;
-    if (count < 0 || (count > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !step)))
+    const bool dev = step_dev != nullptr;
+    if (count < 0 || (count > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numel)))
         return fail(SAE_EINVAL, "sae_adam_multi_f32: null table");
     if (!(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0))
         return fail(SAE_EINVAL, "sae_adam_multi_f32: betas must be in [0, 1), eps >= 0");
     for (int64_t i = 0; i < count; ++i) {
-        if (numel[i] < 0 || step[i] < 1) return fail(SAE_EINVAL, "sae_adam_multi_f32: tensor %lld: numel < 0 or step < 1", (long long)i);
+        if (numel[i] < 0 || (!dev && step[i] < 1))
+            return fail(SAE_EINVAL, "sae_adam_multi_f32: tensor %lld: numel < 0 or step < 1", (long long)i);
         if (numel[i] > 0 && (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i]))
             return fail(SAE_EINVAL, "sae_adam_multi_f32: tensor %lld: null pointer", (long long)i);
     }
@@ -119,17 +163,24 @@ extern "C" int sae_adam_multi_f32(float* const* params, const float* const* grad
     int nt = 0, nb = 0;
     auto flush = [&]() -> int {
         if (nb == 0) { nt = 0; return SAE_OK; }
-        hipLaunchKernelGGL(adam_multi_kernel, dim3(nb), dim3(kBlock), 0, s, a, (float)grad_scale, (float)(1.0 - beta1), (float)beta2,
-                           (float)(1.0 - beta2), (float)eps);
+        if (dev)
+            hipLaunchKernelGGL(adam_multi_kernel<true>, dim3(nb), dim3(kBlock), 0, s, a, (float)grad_scale, (float)(1.0 - beta1),
+                               (float)beta2, (float)(1.0 - beta2), (float)eps, lr, beta1, beta2);
+        else
+            hipLaunchKernelGGL(adam_multi_kernel<false>, dim3(nb), dim3(kBlock), 0, s, a, (float)grad_scale, (float)(1.0 - beta1),
+                               (float)beta2, (float)(1.0 - beta2), (float)eps, lr, beta1, beta2);
         nt = nb = 0;
         return check_launch("adam_multi_kernel");
     };
     for (int64_t i = 0; i < count; ++i) {
         if (numel[i] == 0) continue;
-        const double bc1 = 1.0 - std::pow(beta1, (double)step[i]);
-        const double bc2 = 1.0 - std::pow(beta2, (double)step[i]);
-        const float step_size = (float)(lr / bc1);
-        const float inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
+        float step_size = 0.0f, inv_bc2_sqrt = 0.0f;
+        if (!dev) {
+            const double bc1 = 1.0 - std::pow(beta1, (double)step[i]);
+            const double bc2 = 1.0 - std::pow(beta2, (double)step[i]);
+            step_size = (float)(lr / bc1);
+            inv_bc2_sqrt = (float)(1.0 / std::sqrt(bc2));
+        }
         const int64_t chunks = ceil_div64(numel[i], kChunk);
         int64_t c = 0;
         while (c < chunks) {
@@ -146,6 +197,7 @@ extern "C" int sae_adam_multi_f32(float* const* params, const float* const* grad
             a.n[t] = numel[i] - c * kChunk;
             a.step_size[t] = step_size;
             a.inv_bc2_sqrt[t] = inv_bc2_sqrt;
+            a.step_dev[t] = dev ? reinterpret_cast<const long long*>(step_dev[i]) : nullptr;
             int local = 0;
             while (c < chunks && nb < kBlocks) {
                 a.block_tensor[nb] = (unsigned char)t;
@@ -155,5 +207,18 @@ extern "C" int sae_adam_multi_f32(float* const* params, const float* const* grad
             }
         }
     }
-    return flush();
+    int rc = flush();
+    if (rc != SAE_OK || !dev) return rc;
+    // every update above read the counts as they were; now they advance (tensors of zero elements included: torch counts the
+    // step of every parameter that had a gradient)
+    for (int64_t i0 = 0; i0 < count; i0 += kAdvance) {
+        AdvanceArgs adv;
+        const int nadv = (int)((count - i0 < kAdvance) ? (count - i0) : kAdvance);
+        for (int j = 0; j < nadv; ++j) adv.slot[j] = reinterpret_cast<long long*>(step_dev[i0 + j]);
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(ceil_div(nadv, 128)), dim3(128), 0, s, adv, nadv);
+        rc = check_launch("adam_advance_kernel");
+        if (rc != SAE_OK) return rc;
+    }
+    return SAE_OK;
 }
+}  // namespace

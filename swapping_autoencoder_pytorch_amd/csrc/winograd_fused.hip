@@ -181,6 +181,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
     const int tx_lo = bx * BW, tx_hi = (bx + 1) * BW - 1;
     const bool x_interior = 2 * tx_lo - p.pad >= 0 && 2 * tx_hi - p.pad + 3 < p.W && tx_hi < p.TW;
     const unsigned plane_bytes = (unsigned)(HW * 4);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(Uf + (int64_t)mb * p.chunks * kWfStage), 0, (unsigned)(p.chunks * kWfStage * 4), 0x00020000);
     const unsigned uoff = tid * 16;
@@ -195,12 +196,11 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
         int ch = chunk * kWfCK + 2 * wid + c2;                 // wave-uniform
         if (ch > p.C - 1) ch = p.C - 1;                        // (a channel beyond C meets zero weights)
         const unsigned soff = (unsigned)ch * plane_bytes;
-        // The range check of a raw buffer compares the per-lane offset alone with num_records -- the scalar offset takes no part.
-        // A right-border window in the last row of the last image lies up to 8 bytes past the tensor for every channel but the
-        // first unless the record count shrinks by what the scalar offset adds (one scalar subtraction per channel).
-        const __amdgpu_buffer_rsrc_t xrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, p.x_bytes - soff, 0x00020000);
+        // (the channel plane rides in the SCALAR offset.  gfx950 range-checks a raw buffer access as offset >= num_records -
+        // soffset -- measured in round 6: with num_records reduced by soff on top, the last image's planes read as zeros -- so a
+        // right-border window in the tensor's last row cannot reach past x for any channel)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dreg[c2][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrc, rowv[r], soff, 0));
+        for (int r = 0; r < 4; ++r) dreg[c2][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, rowv[r], soff, 0));
         if (XS) xsc[c2] = p.x_scale[(int64_t)(s_valid ? s_n : 0) * p.C + ch];
     };
     auto load_u = [&](int chunk, int lo) {                     // 4 buffer loads, no vector ALU
@@ -591,8 +591,6 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
     f32x2 ev[16], vv[16];      // A e A^T and B^T d B of the two tiles, as written to LDS
 
     auto load_gy = [&]() {
-        // (scalar offset = image + tile row + chunk of a map whose rows are whole chunks and whose height is even -- checked by
-        // the entry point -- so these loads stay inside gy although the scalar offset takes no part in the range check)
         greg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, g_lane, g_soff, 0));
         greg[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, g_lane + ow_bytes, g_soff, 0));
         if (MOD) {

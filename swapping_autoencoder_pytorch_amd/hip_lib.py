@@ -43,7 +43,7 @@ class ConvMod(C.Structure):
     _fields_ = [("x_scale", C.c_void_p), ("y_scale", C.c_void_p), ("wm_scale", C.c_void_p), ("wc_scale", C.c_void_p)]
 
 
-ABI_VERSION = 9      # include/sae_hip.h: SAE_ABI_VERSION
+ABI_VERSION = 10     # include/sae_hip.h: SAE_ABI_VERSION
 
 _SIGNATURES = {
     "abi_version": (C.c_int, []),
@@ -98,6 +98,8 @@ _SIGNATURES = {
     "softplus_mean_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _f32, _stream]),
     "adam_multi_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64, C.c_double,
                                  C.c_double, C.c_double, C.c_double, C.c_double, _stream]),
+    "adam_multi_dev_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64, C.c_double,
+                                     C.c_double, C.c_double, C.c_double, C.c_double, _stream]),
     "upsample2x_bilinear_add_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),
     "upsample2x_bilinear_bwd_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),
     "wino_gemm_workspace": (_i64, [_i64, _i64, _i64, _i64, _i64]),

@@ -13,7 +13,7 @@ they overlap the rest of backward (grad_allreduce.GradAllReducer) — the MI355X
 reference's nn.DataParallel replicate/scatter/gather/reduce (models/__init__.py:75-93)."""
 import torch
 
-from . import util
+from . import hip_graph, util
 from .fused_adam import FusedAdam
 from .grad_allreduce import GradAllReducer
 
@@ -46,6 +46,12 @@ class SwappingAutoencoderOptimizer:
         # one reducer per parameter group: the trainable set flips every call
         self.reducer_G = GradAllReducer(self.Gparams)
         self.reducer_D = GradAllReducer(self.Dparams)
+        # hipGraph replay of the two calls (hip_graph.py): single-rank GPU process with the fused Adam; SAE_HIP_GRAPH=0: eager
+        self.graphs = None
+        if hip_graph.wanted(self.Gparams + self.Dparams, [self.optimizer_G, self.optimizer_D]):
+            self.graphs = hip_graph.StepGraphs()
+            self.optimizer_G.use_device_steps()
+            self.optimizer_D.use_device_steps()
 
     def set_requires_grad(self, params, requires_grad):
         for p in params:
@@ -77,14 +83,32 @@ class SwappingAutoencoderOptimizer:
             reducer.finish()                 # waits for the in-flight buckets, grads now hold the global mean
             optimizer.step()
 
-    def train_generator_one_step(self, images):
-        """:67-79"""
-        self.set_requires_grad(self.Dparams, False)
-        self.set_requires_grad(self.Gparams, True)
+    def _generator_call(self, images):
+        """zero_grad -> losses -> backward -> Adam of :67-79: what a hipGraph of the generator call holds (hip_graph.py)"""
         self.optimizer_G.zero_grad()
         g_losses, g_metrics = self.model(images, None, None, command="compute_generator_losses")
         g_loss = sum(v.mean() for v in g_losses.values())
         self._backward_and_step(g_loss, self.optimizer_G, self.reducer_G)
+        return g_losses, g_metrics
+
+    def _discriminator_call(self, images):
+        """the same for :81-95 (without the lazy-R1 call, which stays eager)"""
+        self.optimizer_D.zero_grad()
+        d_losses, d_metrics, sp, gl = self.model(images, command="compute_discriminator_losses")
+        d_loss = sum(v.mean() for v in d_losses.values())
+        self._backward_and_step(d_loss, self.optimizer_D, self.reducer_D)
+        return d_losses, d_metrics, sp.detach(), gl.detach()
+
+    def _run(self, key, body, images):
+        if self.graphs is not None:
+            return self.graphs.run(key, images, body)
+        return body(images)
+
+    def train_generator_one_step(self, images):
+        """:67-79"""
+        self.set_requires_grad(self.Dparams, False)
+        self.set_requires_grad(self.Gparams, True)
+        g_losses, g_metrics = self._run("generator", self._generator_call, images)
         g_losses.update(g_metrics)
         return g_losses
 
@@ -96,11 +120,7 @@ class SwappingAutoencoderOptimizer:
         self.set_requires_grad(self.Dparams, True)
         self.set_requires_grad(self.Gparams, False)
         self.discriminator_iter_counter += 1
-        self.optimizer_D.zero_grad()
-        d_losses, d_metrics, sp, gl = self.model(images, command="compute_discriminator_losses")
-        self.previous_sp, self.previous_gl = sp.detach(), gl.detach()
-        d_loss = sum(v.mean() for v in d_losses.values())
-        self._backward_and_step(d_loss, self.optimizer_D, self.reducer_D)
+        d_losses, d_metrics, self.previous_sp, self.previous_gl = self._run("discriminator", self._discriminator_call, images)
 
         needs_R1 = opt.lambda_R1 > 0.0 or opt.lambda_patch_R1 > 0.0
         if needs_R1 and self.discriminator_iter_counter % opt.R1_once_every == 0:
@@ -153,6 +173,9 @@ class SwappingAutoencoderOptimizer:
         self.optimizer_D.load_state_dict(state["optimizer_D"])
         self.train_mode_counter = int(state["train_mode_counter"])
         self.discriminator_iter_counter = int(state["discriminator_iter_counter"])
+        if self.graphs is not None:
+            # torch's load_state_dict REPLACES the moment tensors: graphs captured before hold the old ones' addresses
+            self.graphs = hip_graph.StepGraphs()
 
     def load(self, resume_iter="latest"):
         """Restore what ``save`` wrote (optimiser moments + counters); returns False when there is nothing to load."""

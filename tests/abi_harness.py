@@ -290,9 +290,12 @@ def rel_err(a, b):
     return float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max() / max(float(np.abs(b).max()), 1e-30))
 
 
-def adam_multi(lib, params, grads, ms, vs, steps, lr, beta1, beta2, eps, grad_scale=1.0, device=None, offset_elems=0):
+def adam_multi(lib, params, grads, ms, vs, steps, lr, beta1, beta2, eps, grad_scale=1.0, device=None, offset_elems=0,
+               dev_steps=False):
     """Runs sae_adam_multi_f32 on lists of 1-D numpy arrays; returns updated (params, ms, vs).  offset_elems > 0
-    places every tensor that many floats into its buffer (pointers not 16-byte aligned)."""
+    places every tensor that many floats into its buffer (pointers not 16-byte aligned).  dev_steps: the same update through
+    sae_adam_multi_dev_f32 -- the counts (steps - 1, i.e. BEFORE the update) staged in device memory; returns the counts after
+    the call as a fourth value."""
     n = len(params)
 
     def stage(arrs):
@@ -305,10 +308,23 @@ def adam_multi(lib, params, grads, ms, vs, steps, lr, beta1, beta2, eps, grad_sc
     bv, pv = stage(vs)
     arr = lambda xs: (C.c_void_p * n)(*xs)
     numel = (C.c_int64 * n)(*[a.size for a in params])
+    cut = lambda bufs: [b.numpy()[offset_elems:] for b in bufs]
+    if dev_steps:
+        before = np.asarray([t - 1 for t in steps], np.int64)
+        if device is None:
+            counts = before.copy()
+            base = counts.ctypes.data
+        else:
+            import torch
+            counts = torch.from_numpy(before).to(device)
+            base = counts.data_ptr()
+        lib.call("adam_multi_dev_f32", arr(pp), arr(pg), arr(pm), arr(pv), numel, arr([base + 8 * i for i in range(n)]), n, lr,
+                 beta1, beta2, eps, grad_scale, _stream(device))
+        after = counts if device is None else counts.cpu().numpy()
+        return cut(bp), cut(bm), cut(bv), [int(v) for v in after]
     st = (C.c_int64 * n)(*steps)
     lib.call("adam_multi_f32", arr(pp), arr(pg), arr(pm), arr(pv), numel, st, n, lr, beta1, beta2, eps, grad_scale,
              _stream(device))
-    cut = lambda bufs: [b.numpy()[offset_elems:] for b in bufs]
     return cut(bp), cut(bm), cut(bv)
 
 

@@ -354,9 +354,10 @@ static inline void __syncthreads() { hipemu::block_barrier(); }
 #define __builtin_amdgcn_s_setprio(p) ((void)0)
 
 
-// ---- raw buffer loads (buffer_load_dword* through a V# descriptor): address = base + soffset + voffset; every dword whose
-// voffset-relative position lies at or beyond num_records reads as zero (the hardware's per-dword range check of raw buffers;
-// soffset takes no part in the check).  A "negative" voffset is a huge unsigned one: out of range.
+// ---- raw buffer loads (buffer_load_dword* through a V# descriptor): address = base + soffset + voffset; every dword with
+// voffset + 4 > num_records - soffset reads as zero (the hardware's per-dword range check of raw buffers; the scalar offset DOES
+// take part: measured on gfx950 in round 6 -- a descriptor whose num_records had been reduced by soffset on top zeroed valid
+// data of the last image, profiles/r6_buffer_range_check.txt).  A "negative" voffset is a huge unsigned one: out of range.
 struct hipemu_rsrc {
     const char* base;
     unsigned num_records;
@@ -380,7 +381,7 @@ inline V raw_buffer_load(hipemu_rsrc r, unsigned voffset, unsigned soffset) {
     for (int i = 0; i < N; ++i) {
         unsigned v = 0;
         const unsigned long long off = (unsigned long long)voffset + 4ull * i;
-        if (off + 4 <= r.num_records) {
+        if (off + soffset + 4 <= r.num_records) {
             const char* a = r.base + soffset + off;
             if (a + 4 > hipemu_guard_lo && a < hipemu_guard_hi) ++hipemu_guard_count;
             else std::memcpy(&v, a, 4);
@@ -391,7 +392,7 @@ inline V raw_buffer_load(hipemu_rsrc r, unsigned voffset, unsigned soffset) {
 }
 inline unsigned raw_buffer_load1(hipemu_rsrc r, unsigned voffset, unsigned soffset) {
     unsigned v = 0;
-    if ((unsigned long long)voffset + 4 <= r.num_records) {
+    if ((unsigned long long)voffset + soffset + 4 <= r.num_records) {
         const char* a = r.base + soffset + voffset;
         if (a + 4 > hipemu_guard_lo && a < hipemu_guard_hi) ++hipemu_guard_count;
         else std::memcpy(&v, a, 4);

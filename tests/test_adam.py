@@ -76,6 +76,63 @@ def test_emulated_kernel_many_tensors(emu_lib, oracle_lib):
     _check_against_oracle(emu_lib, oracle_lib, None, [257] * 60 + [3], 0)
 
 
+def _device_steps_equal_host_steps(lib, device, sizes, exact):
+    """sae_adam_multi_dev_f32 (counts in device memory, bias corrections formed by the kernel) against sae_adam_multi_f32 (counts
+    as host arguments) on the same problem; the counts come back advanced by one."""
+    lr, b1, b2, eps, scale = 0.00188, 0.0, 0.9905, 1e-8, 0.5
+    ps, gs, ms, vs, steps = _problem(sizes, 4)
+    h_p, h_m, h_v = H.adam_multi(lib, ps, gs, ms, vs, steps, lr, b1, b2, eps, scale, device=device)
+    d_p, d_m, d_v, after = H.adam_multi(lib, ps, gs, ms, vs, steps, lr, b1, b2, eps, scale, device=device, dev_steps=True)
+    assert after == steps
+    for i in range(len(sizes)):
+        assert np.array_equal(d_m[i], h_m[i]) and np.array_equal(d_v[i], h_v[i]), i      # no bias correction in the moments
+        if exact:
+            assert np.array_equal(d_p[i], h_p[i]), i
+        else:   # pow() of the device library against the host's: the two fp32 scalars may differ in their last bit
+            assert np.abs(d_p[i] - h_p[i]).max(initial=0.0) <= 2e-7 * lr + 1e-7 * np.abs(h_p[i]).max(initial=0.0), i
+
+
+def test_device_step_counts_on_the_emulator_and_the_oracle(emu_lib, oracle_lib):
+    _device_steps_equal_host_steps(emu_lib, None, SIZES, exact=True)
+    _device_steps_equal_host_steps(emu_lib, None, [257] * 400 + [3], exact=True)      # more counters than one advance launch holds
+    _device_steps_equal_host_steps(oracle_lib, None, SIZES, exact=True)
+
+
+def test_fused_adam_with_device_step_counts(oracle_lib):
+    """FusedAdam.use_device_steps(): same trajectory as the host-count form, state_dict() reports the device counts, a
+    checkpoint loads back into them."""
+    from swapping_autoencoder_pytorch_amd.fused_adam import FusedAdam
+    torch.manual_seed(1)
+    net_a = torch.nn.Sequential(torch.nn.Linear(5, 9), torch.nn.Tanh(), torch.nn.Linear(9, 2))
+    net_b = copy.deepcopy(net_a)
+    x = torch.randn(16, 5)
+    with P.backend(oracle_lib):
+        host = FusedAdam(list(net_a.parameters()), lr=0.002, betas=(0.0, 0.99))
+        dev = FusedAdam(list(net_b.parameters()), lr=0.002, betas=(0.0, 0.99))
+
+        def step_both():
+            for net, opt in ((net_a, host), (net_b, dev)):
+                opt.zero_grad()
+                net(x).pow(2).mean().backward()
+                opt.step()
+            for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+                assert torch.equal(pa, pb)
+
+        step_both()
+        dev.use_device_steps()               # switches after the first update: the counts are carried over
+        for _ in range(3):
+            step_both()
+        sd = dev.state_dict()
+        assert [float(v["step"]) for v in sd["state"].values()] == [4.0] * 4
+        assert [float(v["step"]) for v in host.state_dict()["state"].values()] == [4.0] * 4
+        again = FusedAdam(list(net_b.parameters()), lr=0.002, betas=(0.0, 0.99))
+        again.use_device_steps()
+        again.load_state_dict(copy.deepcopy(sd))
+        dev = again
+        step_both()
+        assert [float(v["step"]) for v in dev.state_dict()["state"].values()] == [5.0] * 4
+
+
 def test_bad_arguments_are_refused(oracle_lib, emu_lib):
     from swapping_autoencoder_pytorch_amd.hip_lib import SaeError
     ps, gs, ms, vs, steps = _problem([8], 3)
@@ -130,6 +187,13 @@ def test_fused_adam_follows_torch_adam_and_shares_its_state_dict(oracle_lib):
 def test_gpu_kernel_vs_oracle(oracle_lib, offset):
     from swapping_autoencoder_pytorch_amd import hip_lib
     _check_against_oracle(hip_lib.get(), oracle_lib, "cuda:0", SIZES + [3_000_001], offset)
+
+
+@pytest.mark.gpu
+def test_gpu_device_step_counts():
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    _device_steps_equal_host_steps(hip_lib.get(), "cuda:0", SIZES + [3_000_001], exact=False)
+    _device_steps_equal_host_steps(hip_lib.get(), "cuda:0", [257] * 400 + [3], exact=False)
 
 
 @pytest.mark.gpu
