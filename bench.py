@@ -88,6 +88,14 @@ def parse():
                     help="with --force-allreduce: behind every bucket's (empty, one-rank) all-reduce, put on a side stream the memory "
                          "traffic and kernel launches a RING all-reduce over N GPUs costs THIS GPU -- 2 (N - 1) steps of a 1/N slice, "
                          "read + reduce + write -- concurrent with the backward pass.  A rehearsal of the contention, NOT a scaling number")
+    ap.add_argument("--same-device", action="store_true",
+                    help="with --gpus N > 1: every rank on cuda:0 over the gloo backend -- the multi-rank code path (buckets, grad-ready "
+                         "hooks, collectives, per-bucket Adam, the line's per-rank / all-reduce fields) rehearsed on a one-GPU box.  "
+                         "NOT a scaling number: the ranks share one GPU and the collective goes through host memory")
+    ap.add_argument("--alt-streams-steps", type=int, default=8,
+                    help="multi-rank runs: steps of an extra measurement with the OTHER stream mode (streams.enabled(): one stream "
+                         "is the default for a rank of a multi-rank job, SAE_TWO_STREAMS overrides), reported as `alt_streams` so that "
+                         "one run on real hardware decides the default (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-cpu-baseline", action="store_true",
                     help="cpu_baseline.value from ONE whole iteration of the preset on the host at the preset's FULL batch (a "
@@ -743,6 +751,9 @@ def self_launch_command(args, argv):
 
 def main():
     args = parse()
+    if os.environ.get("SAE_BENCH_STACKS_AFTER_S"):      # diagnosis of a stuck multi-rank run: every thread's stack to stderr
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SAE_BENCH_STACKS_AFTER_S"]), repeat=False, exit=False)
     if args.via_dropin:
         return main_via_dropin(args)
     relaunch = self_launch_command(args, sys.argv[1:])
@@ -760,6 +771,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); one rank per GPU is the "
                          "contract" % (args.gpus, world))
+    if args.same_device:
+        local_rank = 0                       # every rank on the one GPU of the box (rehearsal of the multi-rank path)
     if torch.cuda.device_count() < min(args.gpus, local_rank + 1):
         raise SystemExit("bench.py: --gpus %d but only %d device(s) are visible" % (args.gpus, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -774,7 +787,10 @@ def main():
             launched = True
     if launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.same_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus
         world = dist.get_world_size()
     if args.ring_rehearsal:
@@ -805,6 +821,8 @@ def main():
     broadcast_parameters(model.singlegpu_model)
     optimizer = create_optimizer(opt, model)
     torch.manual_seed(1234 + rank)              # per-rank crops / noise / data
+    if world > 1 or args.force_allreduce:       # the all-reduce fields of the line (grad_allreduce.GradAllReducer.summary)
+        optimizer.reducer_D.profile = optimizer.reducer_G.profile = True
 
     size = opt.crop_size
     pool = [torch.rand(batch, 3, size, size, device=dev) * 2 - 1 for _ in range(4)]
@@ -848,16 +866,59 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    records_before = (len(optimizer.reducer_D.records), len(optimizer.reducer_G.records))     # passes of the warm-up: left out
     t0 = time.perf_counter()
     for i in range(args.steps):
         iteration(skew + args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
+    dt_by_rank = None
+    allreduce_fields = None
+    alt_streams = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every_rank, mine)
+        dt_by_rank = [float(t.item()) for t in every_rank]
+        dt = max(dt_by_rank)
+    if world > 1 or args.force_allreduce:
+        allreduce_fields = {"D": optimizer.reducer_D.summary(records_before[0]), "G": optimizer.reducer_G.summary(records_before[1])}
+        if world > 1:
+            ex = sum(v["ms_exposed"] for v in allreduce_fields.values() if v)
+            worst = torch.tensor([ex], device=dev, dtype=torch.float64)
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+            allreduce_fields["ms_exposed_per_step_max_over_ranks"] = round(float(worst.item()), 3)
+        allreduce_fields["note"] = ("per backward pass of rank 0, timed steps only: MB all-reduced, buckets, HIP-event time from the first "
+                                    "bucket's launch to the last bucket's completion, and the time the waiting stream stood idle for "
+                                    "collectives (exposed = not overlapped with backward / Adam)")
     done = skew + args.warmup + args.steps
+    if world > 1 and args.alt_streams_steps > 0:
+        # the OTHER stream mode on the same ranks, same batches: decides streams.enabled()'s multi-rank default on hardware
+        from swapping_autoencoder_pytorch_amd import streams as _streams
+        was = os.environ.get("SAE_TWO_STREAMS")
+        other_two = not _streams.enabled()
+        os.environ["SAE_TWO_STREAMS"] = "1" if other_two else "0"
+        try:
+            for i in range(2):
+                iteration(done + i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.alt_streams_steps):
+                iteration(done + 2 + i)
+            fence()
+            sdt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+            sdt = float(sdt.item())
+        finally:
+            if was is None:
+                os.environ.pop("SAE_TWO_STREAMS", None)
+            else:
+                os.environ["SAE_TWO_STREAMS"] = was
+        done += 2 + args.alt_streams_steps
+        alt_streams = {"streams": "two" if other_two else "one", "steps": args.alt_streams_steps,
+                       "value": round(world * batch * args.alt_streams_steps / sdt, 3), "unit": "images/s",
+                       "ms_per_step": round(sdt / args.alt_streams_steps * 1e3, 3),
+                       "note": "no lazy-R1 iteration in this window unless it spans a multiple of 16"}
 
     # kernel pass (not `value`): the same iterations with everything on ONE stream and an event bracket around every launch
     # of the tracked kernels.  The timed region above runs the step's independent branches on two streams: two kernels then
@@ -954,6 +1015,15 @@ def main():
                                                     % (args.ring_rehearsal, args.ring_rehearsal - 1, args.ring_rehearsal))
         if alt:
             line["alt_conv_math"] = alt
+        if dt_by_rank is not None:
+            line["ms_per_step_by_rank"] = [round(t / args.steps * 1e3, 3) for t in dt_by_rank]
+        if allreduce_fields is not None:
+            line["allreduce"] = allreduce_fields
+        if alt_streams is not None:
+            line["alt_streams"] = alt_streams
+        if args.same_device and world > 1:
+            line["config"]["same_device"] = ("REHEARSAL: all %d ranks on cuda:0 over gloo -- the ranks share one GPU, nothing here is a "
+                                             "scaling number" % world)
         if per_image:
             line["model_tflops_per_gpu"] = round(value / world * per_image / 1e12, 2)
             line["frac_of_mfma_f32_roofline"] = round(value / world * per_image / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)

@@ -22,7 +22,7 @@
  *   sae_modconv2d_{fwd,dgrad,wgrad}_f32
  *                            <- ModulatedConv2d.forward (style scale, demodulation, conv / conv_transpose) and its
  *                               ATen backward   models/networks/stylegan2_layers.py:266-325
- *   sae_gemm_f32             <- F.linear and its backward       models/networks/stylegan2_layers.py:177,186
+ *   sae_gemm_f32, sae_gemm_ws_f32 <- F.linear and its backward  models/networks/stylegan2_layers.py:177,186
  *   sae_upsample2x_bilinear_{add,bwd}_f32
  *                            <- F.interpolate(bilinear x2) + residual   models/networks/generator.py:51-53
  *   sae_l2_normalize_{,bwd_}f32 <- util.normalize                       util/util.py:18-22
@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 10  /* 10: sae_adam_multi_dev_f32 (step counts in device memory: hipGraph replays);  9: sae_wino_fused_wgrad_*;  8: sae_wino_fused_* (one-kernel Winograd convolution);  7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
+#define SAE_ABI_VERSION 11  /* 11: sae_gemm_ws_f32 (K split across workgroups);  10: sae_adam_multi_dev_f32 (step counts in device memory: hipGraph replays);  9: sae_wino_fused_wgrad_*;  8: sae_wino_fused_* (one-kernel Winograd convolution);  7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -335,6 +335,17 @@ int sae_gemm_f32(const float* a, const float* b, const float* bias, float* c,
                  int64_t m, int64_t n, int64_t k,
                  int64_t a_si, int64_t a_sk, int64_t b_sk, int64_t b_sj, int64_t ldc,
                  float alpha, sae_stream_t stream);
+
+/* The same product with the contraction split ACROSS workgroups for the skinny shapes of the linear layers (16 - 128 rows
+ * against 2048 x 2048 ... 8192 x 512 weights: F.linear of the Dpatch pair MLP, the D head and the style projections,
+ * models/networks/stylegan2_layers.py:177,186): K slices in a caller-owned workspace of sae_gemm_workspace(m, n, k) floats
+ * (0: the shape takes sae_gemm_f32's one-launch kernels, workspace may be NULL), then one reduction launch that adds the slices
+ * in order, scales and adds the bias.  Same result contract as sae_gemm_f32; the summation order differs (per slice). */
+int64_t sae_gemm_workspace(int64_t m, int64_t n, int64_t k);
+int sae_gemm_ws_f32(const float* a, const float* b, const float* bias, float* c,
+                    int64_t m, int64_t n, int64_t k,
+                    int64_t a_si, int64_t a_sk, int64_t b_sk, int64_t b_sj, int64_t ldc,
+                    float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Generator skip path: bilinear x2 upsampling (align_corners = false) fused with the residual add

@@ -256,6 +256,15 @@ class _Holder(torch.nn.Module):
         setattr(self, name, torch.nn.Parameter(value))
 
 
+def noise_map(out):
+    """A fresh N(0, 1) map for `out` ([b, c, h, w]).  On the CPU: drawn in place, as the reference does.  When the restatement
+    is moved to another device / to double for a parity run (tests/test_gpu_step_parity.py), the draw still comes from the
+    CPU generator as an fp32 map -- the stream the compared run is fed from -- and is then moved."""
+    if out.device.type == "cpu" and out.dtype == torch.float32:
+        return out.new_empty(out.shape[0], 1, out.shape[2], out.shape[3]).normal_()
+    return torch.empty(out.shape[0], 1, out.shape[2], out.shape[3]).normal_().to(out)
+
+
 class StyledConvCPU(torch.nn.Module):
     """StyledConv (stylegan2_layers.py:367-405): modulated conv -> image + weight * noise (:351) -> FusedLeakyReLU."""
 
@@ -270,7 +279,7 @@ class StyledConvCPU(torch.nn.Module):
         if noise is None and getattr(self, "fixed_noise", None) is not None:      # :343-347, the fixed map
             noise = self.fixed_noise.to(out.dtype)
         if noise is None:      # NoiseInjection.forward, stylegan2_layers.py:340-342: a fresh N(0, 1) map per call
-            noise = out.new_empty(out.shape[0], 1, out.shape[2], out.shape[3]).normal_()
+            noise = noise_map(out)
         out = out + self.noise.weight * noise
         return fused_leaky_relu(out, self.activate.bias)
 
@@ -526,12 +535,14 @@ def apply_random_crop(x, target_size, scale_range, num_crops=1):
     """util/util.py:323-343: per crop a random horizontal flip, independent x / y scale, an offset that keeps the window inside
     the image; bilinear grid_sample with zero padding, align_corners=False.  Random draws in the reference's order."""
     b = x.size(0) * num_crops
-    flip = torch.round(torch.rand(b, 1, 1, 1)) * 2 - 1.0
-    gx = torch.linspace(-1.0, 1.0, target_size)[None, None, :, None].repeat(b, target_size, 1, 1)
+    # (the draws come from the CPU generator in fp32, as in the reference; `.to(x)` is a no-op there and lets a parity run
+    # evaluate the restatement on another device / in double with the same crop windows)
+    flip = (torch.round(torch.rand(b, 1, 1, 1)) * 2 - 1.0).to(x)
+    gx = torch.linspace(-1.0, 1.0, target_size)[None, None, :, None].repeat(b, target_size, 1, 1).to(x)
     grid = torch.cat([gx * flip, gx.transpose(1, 2)], dim=3)
     x = x.unsqueeze(1).expand(-1, num_crops, -1, -1, -1).flatten(0, 1)
-    scale = torch.rand(b, 1, 1, 2) * (scale_range[1] - scale_range[0]) + scale_range[0]
-    offset = (torch.rand(b, 1, 1, 2) * 2 - 1) * (1 - scale)
+    scale = (torch.rand(b, 1, 1, 2) * (scale_range[1] - scale_range[0]) + scale_range[0]).to(x)
+    offset = ((torch.rand(b, 1, 1, 2) * 2 - 1) * (1 - scale.cpu().float())).to(x)
     crop = F.grid_sample(x, grid * scale + offset, align_corners=False)
     return crop.view(b // num_crops, num_crops, *crop.shape[1:])
 

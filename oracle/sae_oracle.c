@@ -42,7 +42,7 @@ typedef struct sae_conv2d_desc {
 
 static __thread char g_err[256];
 
-int oracle_abi_version(void) { return 10; }
+int oracle_abi_version(void) { return 11; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
@@ -420,6 +420,15 @@ int oracle_gemm_f32(const float* a, const float* b, const float* bias, float* c,
             c[i * ldc + j] = (float)acc;
         }
     return SAE_OK;
+}
+
+/* sae_gemm_ws_f32 / sae_gemm_workspace: the K split is a launch detail of the GPU; the oracle needs no workspace. */
+int64_t oracle_gemm_workspace(int64_t m, int64_t n, int64_t k) { (void)m; (void)n; (void)k; return 0; }
+int oracle_gemm_ws_f32(const float* a, const float* b, const float* bias, float* c, int64_t m, int64_t n, int64_t k,
+                       int64_t a_si, int64_t a_sk, int64_t b_sk, int64_t b_sj, int64_t ldc, float alpha, float* workspace,
+                       int64_t workspace_floats, sae_stream_t stream) {
+    (void)workspace; (void)workspace_floats;
+    return oracle_gemm_f32(a, b, bias, c, m, n, k, a_si, a_sk, b_sk, b_sj, ldc, alpha, stream);
 }
 
 /* ---------------------------------------------------------------------------------------------

@@ -179,10 +179,109 @@ __global__ __launch_bounds__(kBlock) void gemm32_splitk_kernel(const float* __re
     }
 }
 
+// K split ACROSS workgroups (sae_gemm_ws_f32): workgroup (x, y, z) multiplies the 32 x 32 tile (y, x) over K slice z -- its 4 waves
+// take the slice's chunks round-robin and meet in LDS, as above -- and writes the UNSCALED partial tile to ws[z][m][n]; the
+// reduction kernel adds the slices in order (fixed summation order: bit-reproducible), scales and adds the bias.  The skinny
+// products of the step (batch 16 - 128 rows against 2048 x 2048 ... 8192 x 512 weights) launched 16 - 256 workgroups and read
+// their weight once at 0.4 - 1.6 TB/s; split into ~768 workgroups they are a weight-bandwidth problem again.
+__global__ __launch_bounds__(kBlock) void gemm32_slice_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                              float* __restrict__ ws, const GemmParams p, int64_t chunks_per_slice) {
+    constexpr int BT = 32, LD = BT + 1;
+    __shared__ float As[4][kKc * LD];
+    __shared__ float Bs[4][kKc * LD];
+    __shared__ float red[4][32 * 33];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.y * BT, j0 = (int64_t)blockIdx.x * BT;
+    const int64_t c_begin = (int64_t)blockIdx.z * chunks_per_slice;
+    const int64_t nchunks = ceil_div64(p.k, kKc);
+    const int64_t c_end = c_begin + chunks_per_slice < nchunks ? c_begin + chunks_per_slice : nchunks;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int64_t iters = ceil_div64(c_end - c_begin, 4);
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t ck = c_begin + it * 4 + wid;
+        // a chunk beyond the slice stages zeros (kmax = the slice's end), so every wave runs the same number of iterations
+        const int64_t k0 = ck * kKc;
+        const int64_t kmax = c_end * kKc < p.k ? c_end * kKc : p.k;
+        stage_panel<BT, LD, kWave>(As[wid], a, i0, p.m, k0, ck < c_end ? kmax : 0, p.a_si, p.a_sk, lane);
+        stage_panel<BT, LD, kWave>(Bs[wid], b, j0, p.n, k0, ck < c_end ? kmax : 0, p.b_sj, p.b_sk, lane);
+        __syncthreads();
+#pragma unroll
+        for (int kp = 0; kp < kKc / 2; ++kp) {
+            const float av = As[wid][(2 * kp + half) * LD + l31];
+            const float bv = Bs[wid][(2 * kp + half) * LD + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wid][((r & 3) + 8 * (r >> 2) + 4 * half) * 33 + l31] = acc[r];
+    __syncthreads();
+    float* out = ws + (int64_t)blockIdx.z * p.m * p.n;
+    for (int e = tid; e < 32 * 32; e += kBlock) {
+        const int i = e >> 5, j = e & 31;
+        const float v = (red[0][i * 33 + j] + red[1][i * 33 + j]) + (red[2][i * 33 + j] + red[3][i * 33 + j]);
+        if (i0 + i < p.m && j0 + j < p.n) out[(i0 + i) * p.n + (j0 + j)] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gemm_slices_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                                    float* __restrict__ c, int64_t m, int64_t n, int64_t ldc,
+                                                                    int slices, float alpha) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= m * n) return;
+    const int64_t i = e / n, j = e - i * n;
+    float v = ws[e];
+    for (int s = 1; s < slices; ++s) v += ws[(int64_t)s * m * n + e];
+    c[i * ldc + j] = alpha * v + (bias ? bias[j] : 0.0f);
+}
+
+// K slices of the split form (0: the one-launch kernels are the better choice)
+inline int gemm_slices(int64_t m, int64_t n, int64_t k) {
+    const int64_t tiles64 = ceil_div64(m, 64) * ceil_div64(n, 64);
+    if (!(tiles64 < 128 && k >= 256)) return 0;                 // sae_gemm_f32's own rule for the 32 x 32 split-K kernel
+    const int64_t tiles32 = ceil_div64(m, 32) * ceil_div64(n, 32);
+    const int64_t nchunks = ceil_div64(k, kKc);
+    int64_t s = ceil_div64(768, tiles32);                       // ~3 workgroups per CU
+    const int64_t most = nchunks / 4 > 0 ? nchunks / 4 : 1;     // at least one chunk per wave and slice
+    if (s > most) s = most;
+    return s >= 2 ? (int)s : 0;
+}
+
 }  // namespace
 }  // namespace sae
 
 using namespace sae;
+
+extern "C" int64_t sae_gemm_workspace(int64_t m, int64_t n, int64_t k) {
+    if (m < 1 || n < 1 || k < 1) return 0;
+    return (int64_t)gemm_slices(m, n, k) * m * n;
+}
+
+extern "C" int sae_gemm_ws_f32(const float* a, const float* b, const float* bias, float* c, int64_t m, int64_t n, int64_t k,
+                               int64_t a_si, int64_t a_sk, int64_t b_sk, int64_t b_sj, int64_t ldc, float alpha, float* workspace,
+                               int64_t workspace_floats, sae_stream_t stream) {
+    const int slices = (m > 0 && n > 0 && k > 0) ? gemm_slices(m, n, k) : 0;
+    if (slices == 0) return sae_gemm_f32(a, b, bias, c, m, n, k, a_si, a_sk, b_sk, b_sj, ldc, alpha, stream);
+    sae::clear_stale_error();
+    if (!c || !a || !b) return fail(SAE_EINVAL, "sae_gemm_ws_f32: null matrix");
+    if (ldc < n) return fail(SAE_EINVAL, "sae_gemm_ws_f32: ldc < n");
+    if (!workspace || workspace_floats < (int64_t)slices * m * n)
+        return fail(SAE_EWORKSPACE, "sae_gemm_ws_f32: workspace %lld < %lld floats (sae_gemm_workspace)", (long long)workspace_floats,
+                    (long long)((int64_t)slices * m * n));
+    GemmParams p{m, n, k, a_si, a_sk, b_sk, b_sj, ldc, alpha};
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t cps = ceil_div64(ceil_div64(k, kKc), slices);
+    const dim3 grid((unsigned)ceil_div64(n, 32), (unsigned)ceil_div64(m, 32), (unsigned)slices);
+    hipLaunchKernelGGL(gemm32_slice_kernel, grid, dim3(kBlock), 0, s, a, b, workspace, p, cps);
+    int rc = check_launch("sae_gemm_ws_f32");
+    if (rc != SAE_OK) return rc;
+    hipLaunchKernelGGL(gemm_slices_reduce_kernel, dim3((unsigned)ceil_div64(m * n, kBlock)), dim3(kBlock), 0, s,
+                       (const float*)workspace, bias, c, m, n, ldc, slices, alpha);
+    return check_launch("sae_gemm_ws_f32 (reduce)");
+}
 
 extern "C" int sae_gemm_f32(const float* a, const float* b, const float* bias, float* c, int64_t m, int64_t n,
                             int64_t k, int64_t a_si, int64_t a_sk, int64_t b_sk, int64_t b_sj, int64_t ldc,

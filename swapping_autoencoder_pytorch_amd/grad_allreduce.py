@@ -49,6 +49,14 @@ def claim_destination(weight):
     return slot.view(weight.shape)
 
 
+class _PassRecord:
+    """One backward pass of an instrumented reducer (``GradAllReducer.profile = True``): HIP events, read after the run."""
+    __slots__ = ("bytes", "buckets", "first_launch", "last_done", "waits")
+
+    def __init__(self):
+        self.bytes, self.buckets, self.first_launch, self.last_done, self.waits = 0, 0, None, None, []
+
+
 class _Bucket:
     __slots__ = ("params", "offsets", "numel", "flat", "pending", "work")
 
@@ -71,6 +79,12 @@ class GradAllReducer:
         self._arm_pending = False
         self.buckets = []
         self._where = {}
+        # instrumentation (bench.py --gpus N): per pass the bytes all-reduced, an event at the first bucket's launch, one after
+        # the last bucket's completion was waited for, and an event pair around every wait -- the time a stream that had nothing
+        # else left to do stood waiting for a collective is the EXPOSED (non-overlapped) part of the all-reduce
+        self.profile = False
+        self.records = []
+        self._rec = None
         if not self.enabled:
             return
         cur = _Bucket()
@@ -145,6 +159,7 @@ class GradAllReducer:
         if b.pending == 0:
             from .streams import collective_launch
             with collective_launch(b.flat):     # ordered after BOTH streams of the step: the other gradients may come from either
+                self._note_launch(b)
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _release_destinations(self):
@@ -160,7 +175,51 @@ class GradAllReducer:
             if b.work is None:
                 # (with the step on two streams the bucket's gradients may come from either: ordered after both)
                 with collective_launch(b.flat):
+                    self._note_launch(b)
                     b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    # ---- instrumentation ------------------------------------------------------------------------------------------------
+    def _note_launch(self, b):
+        if not self.profile or not b.flat.is_cuda:
+            return
+        if self._rec is None:
+            self._rec = _PassRecord()
+        r = self._rec
+        r.bytes += b.flat.numel() * b.flat.element_size()
+        r.buckets += 1
+        if r.first_launch is None:
+            r.first_launch = torch.cuda.Event(enable_timing=True)
+            r.first_launch.record()              # on the launch stream, which has waited for the bucket's gradients
+
+    def _wait(self, b):
+        """``b.work.wait()`` (the current stream waits for the collective), bracketed by events when instrumented."""
+        if not self.profile or not b.flat.is_cuda or self._rec is None:
+            b.work.wait()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        b.work.wait()
+        e1.record()
+        self._rec.waits.append((e0, e1))
+        self._rec.last_done = e1
+
+    def _close_record(self):
+        if self._rec is not None:
+            self.records.append(self._rec)
+            self._rec = None
+
+    def summary(self, skip=0):
+        """Means over the recorded passes (after ``torch.cuda.synchronize()``), the first `skip` left out: MB all-reduced per
+        pass, buckets, ms from the first bucket's launch to the last bucket's completion, ms the waiting stream stood idle for
+        the collectives (exposed)."""
+        recs = [r for r in self.records[skip:] if r.first_launch is not None and r.last_done is not None]
+        if not recs:
+            return None
+        span = [r.first_launch.elapsed_time(r.last_done) for r in recs]
+        exposed = [sum(a.elapsed_time(b) for a, b in r.waits) for r in recs]
+        n = len(recs)
+        return {"passes": n, "buckets": recs[0].buckets, "mb_allreduced": round(recs[0].bytes / 1e6, 2),
+                "ms_first_launch_to_last_done": round(sum(span) / n, 3), "ms_exposed": round(sum(exposed) / n, 3)}
 
     # called after loss.backward(), before optimizer.step()
     def finish(self):
@@ -174,12 +233,13 @@ class GradAllReducer:
         inv = 1.0 / self.world
         self._launch_stragglers()
         for b in self.buckets:
-            b.work.wait()
+            self._wait(b)
             b.flat.mul_(inv)
             for p, off in zip(b.params, b.offsets):
                 if p.grad is not None and p.grad.data_ptr() != b.flat[off:off + 1].data_ptr():
                     p.grad.copy_(b.flat[off:off + p.numel()].view_as(p.grad))
             b.work = None
+        self._close_record()
 
     def finish_into(self, optimizer):
         """finish() and optimizer.step() in one: as each bucket's all-reduce completes, the multi-tensor Adam kernel
@@ -197,11 +257,12 @@ class GradAllReducer:
         inv = 1.0 / self.world
         self._launch_stragglers()
         for b in self.buckets:
-            b.work.wait()
+            self._wait(b)
             views = {p: b.flat[off:off + p.numel()] for p, off in zip(b.params, b.offsets) if p.grad is not None}
             if views:
                 optimizer.step(grad_views=views, grad_scale=inv, only=views)
             b.work = None
+        self._close_record()
 
 
 def broadcast_parameters(module, src=0, process_group=None):

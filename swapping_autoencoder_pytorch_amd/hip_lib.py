@@ -43,7 +43,7 @@ class ConvMod(C.Structure):
     _fields_ = [("x_scale", C.c_void_p), ("y_scale", C.c_void_p), ("wm_scale", C.c_void_p), ("wc_scale", C.c_void_p)]
 
 
-ABI_VERSION = 10     # include/sae_hip.h: SAE_ABI_VERSION
+ABI_VERSION = 11     # include/sae_hip.h: SAE_ABI_VERSION
 
 _SIGNATURES = {
     "abi_version": (C.c_int, []),
@@ -89,6 +89,9 @@ _SIGNATURES = {
     "modconv2d_dgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),
     "modconv2d_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, C.POINTER(ConvDesc), C.POINTER(ConvMod), _f32, _f32p, _i64, _stream]),
     "gemm_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _stream]),
+    "gemm_workspace": (_i64, [_i64, _i64, _i64]),
+    "gemm_ws_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _f32p, _i64,
+                              _stream]),
     "add_scale_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _f32, _stream]),
     "l2_normalize_f32": (C.c_int, [_f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),
     "l2_normalize_bwd_f32": (C.c_int, [_f32p, _f32p, _f32p, _i64, _i64, _i64, _f32, _stream]),

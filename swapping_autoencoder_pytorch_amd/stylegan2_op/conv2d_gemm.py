@@ -590,8 +590,11 @@ def _gemm(a, b, bias, ta, tb, alpha):
     a_si, a_sk = (1, a.shape[1]) if ta else (a.shape[1], 1)
     b_sk, b_sj = (1, b.shape[1]) if tb else (b.shape[1], 1)
     out = torch.empty((m, n), dtype=torch.float32, device=a.device)
-    lib.call("gemm_f32", a.data_ptr(), b.data_ptr(), hip_lib.ptr(bias), out.data_ptr(), m, n, k, a_si, a_sk, b_sk,
-             b_sj, n, float(alpha), lib.stream(a))
+    # skinny products (16 - 128 rows against 2048 x 2048 ... 8192 x 512 weights): the contraction split across workgroups
+    n_ws = lib.query("gemm_workspace", m, n, k)
+    ws = torch.empty(n_ws, dtype=torch.float32, device=a.device) if n_ws > 0 else None
+    lib.call("gemm_ws_f32", a.data_ptr(), b.data_ptr(), hip_lib.ptr(bias), out.data_ptr(), m, n, k, a_si, a_sk, b_sk,
+             b_sj, n, float(alpha), hip_lib.ptr(ws), n_ws, lib.stream(a))
     return out
 
 

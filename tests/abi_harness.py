@@ -167,10 +167,17 @@ def conv_residual(lib, d, x, w, residual, alpha=1.0, res_scale=0.5, device=None)
     return by.numpy()
 
 
-def gemm(lib, a, b, bias, m, n, k, a_si, a_sk, b_sk, b_sj, alpha=1.0, device=None):
+def gemm(lib, a, b, bias, m, n, k, a_si, a_sk, b_sk, b_sj, alpha=1.0, device=None, split=False):
+    """sae_gemm_f32, or (split=True) sae_gemm_ws_f32 with the workspace sae_gemm_workspace asks for -> (result, slices' floats)"""
     ba, bb = _Buf(a, device), _Buf(b, device)
     bbias = _Buf(bias, device) if bias is not None else None
     bc = _out((m, n), device)
+    if split:
+        n_ws = lib.query("gemm_workspace", m, n, k)
+        ws = _out((max(n_ws, 1),), device)
+        lib.call("gemm_ws_f32", ba.ptr, bb.ptr, bbias.ptr if bbias else None, bc.ptr, m, n, k, a_si, a_sk, b_sk, b_sj, n,
+                 alpha, ws.ptr if n_ws else None, n_ws, _stream(device))
+        return bc.numpy(), n_ws
     lib.call("gemm_f32", ba.ptr, bb.ptr, bbias.ptr if bbias else None, bc.ptr, m, n, k, a_si, a_sk, b_sk, b_sj, n,
              alpha, _stream(device))
     return bc.numpy()

@@ -124,6 +124,7 @@ def run_rank(args):
     optimizer.reducer_D = GradAllReducer(optimizer.Dparams, bucket_bytes=96 * 1024)
     assert optimizer.reducer_G.enabled and optimizer.reducer_D.enabled
     assert len(optimizer.reducer_G.buckets) > 2 and len(optimizer.reducer_D.buckets) > 2
+    optimizer.reducer_G.profile = optimizer.reducer_D.profile = True          # bench.py --gpus N reports these per pass
     if args.keep_grad:
         for o in (optimizer.optimizer_G, optimizer.optimizer_D):
             zero = o.zero_grad
@@ -143,7 +144,8 @@ def run_rank(args):
     maps = sorted({l.split("/")[-1].strip() for l in open("/proc/self/maps") if "libsae" in l})
     torch.save({"state": {k: v.detach().cpu() for k, v in net.state_dict().items()}, "losses": losses, "in_place": in_place,
                 "library": lib.path, "maps": maps, "staged_all_reduce": staged,
-                "buckets": [len(optimizer.reducer_D.buckets), len(optimizer.reducer_G.buckets)]}, args.out)
+                "buckets": [len(optimizer.reducer_D.buckets), len(optimizer.reducer_G.buckets)],
+                "allreduce": {"D": optimizer.reducer_D.summary(), "G": optimizer.reducer_G.summary()}}, args.out)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -20,6 +20,7 @@ class SavedActivations:
     def __init__(self):
         self.by_shape = {}
         self.matched = 0
+        self.elements = 0          # elements of the matched activations (the population the flip counts are out of)
         self.unmatched = []
 
     def __enter__(self):
@@ -48,6 +49,7 @@ class SavedActivations:
             self.unmatched.append((tuple(act.shape), best_err))
             return None
         self.matched += 1
+        self.elements += act.numel()
         return best > 0
 
 

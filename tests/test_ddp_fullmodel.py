@@ -92,7 +92,15 @@ def test_two_ranks_full_model_one_gpu(tmp_path, keep_grad):
         assert r["library"].endswith("libsae_hip.so") and r["maps"] == ["libsae_hip.so"], (r["library"], r["maps"])
     if not keep_grad:
         assert sum(v for v, _ in res[0]["in_place"]) > 0, res[0]["in_place"]      # bucket-view weight gradients engaged
+    # the instrumentation bench.py --gpus N puts on its line: per pass MB all-reduced, buckets, first launch -> last completion,
+    # exposed wait (D: three passes -- two D calls + one lazy-R1 pass; G: two)
+    for r in res[:2]:
+        d, g = r["allreduce"]["D"], r["allreduce"]["G"]
+        assert d["passes"] == 3 and g["passes"] == 2, r["allreduce"]
+        for v, n in ((d, r["buckets"][0]), (g, r["buckets"][1])):
+            assert v["buckets"] == n and v["mb_allreduced"] > 0
+            assert v["ms_first_launch_to_last_done"] >= v["ms_exposed"] - 1e-3 and v["ms_exposed"] >= 0.0, v
     os.makedirs(os.path.join(os.path.dirname(HERE), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(HERE), "gpurun_out", "ddp_fullmodel_one_gpu.txt"), "a") as f:
-        f.write("keep_grad=%s worst_rel_dev=%.3g staged_all_reduce=%s in_place=%s buckets=%s\n"
-                % (keep_grad, worst, res[0]["staged_all_reduce"], res[0]["in_place"], res[0]["buckets"]))
+        f.write("keep_grad=%s worst_rel_dev=%.3g staged_all_reduce=%s in_place=%s buckets=%s allreduce=%s\n"
+                % (keep_grad, worst, res[0]["staged_all_reduce"], res[0]["in_place"], res[0]["buckets"], res[0]["allreduce"]))

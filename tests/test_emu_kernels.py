@@ -151,6 +151,9 @@ def test_gemm(emu_lib, oracle_lib, mnk):
         e = H.gemm(emu_lib, *args)
         o = H.gemm(oracle_lib, *args)
         assert H.rel_err(e, o) < TOL
+        # the form the product calls: K split across workgroups where sae_gemm_workspace says so (skinny shapes)
+        es, n_ws = H.gemm(emu_lib, *args, split=True)
+        assert not np.isnan(es).any() and H.rel_err(es, o) < TOL, n_ws
 
 
 def test_argument_errors(emu_lib):

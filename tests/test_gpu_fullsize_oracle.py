@@ -168,17 +168,33 @@ WINO_FULL = [
     ("church256 Dpatch 64->64 @64, B=128 (one channel block)", 128, 64, 64, 64, 64, 1),
     ("church256 E valid 256->256 @34 -> 32 (its data gradient pads by 2)", 16, 256, 34, 34, 256, 0),
     ("ffhq1024 G 409->409 @128 (channels no multiple of 8 or 64)", 4, 409, 128, 128, 409, 1),
+    # the step's activations are not N(0, 1): they leave a FusedLeakyReLU (one-sided, mean ~0.45 of their spread) with per-channel
+    # gains that differ by orders of magnitude.  F(2x2,3x3) forms differences of neighbouring pixels before it multiplies: the case
+    # where a transform-domain algorithm could lose digits the direct convolution keeps
+    ("church256 D 128->128 @256 post-activation data, channel gains over 3 decades", 16, 128, 256, 256, 128, 1, "postact"),
+    ("church256 G 512->512 @64 post-activation data, channel gains over 3 decades", 16, 512, 64, 64, 512, 1, "postact"),
 ]
+
+
+def _post_activation(t, gen):
+    """lrelu(N(0,1) + per-channel bias) * sqrt(2) * per-channel gain, gains log-uniform over [1e-3, 1]"""
+    c = t.shape[1]
+    bias = torch.randn(1, c, 1, 1, device=t.device, generator=gen)
+    gain = torch.exp(torch.rand(1, c, 1, 1, device=t.device, generator=gen) * (-3.0 * float(np.log(10.0))))
+    return torch.nn.functional.leaky_relu(t + bias, 0.2) * (2 ** 0.5) * gain
 
 
 @pytest.mark.parametrize("case", WINO_FULL, ids=lambda c: c[0].split(" (")[0].replace(" ", "_"))
 def test_one_kernel_winograd_fullsize_vs_oracle(hip_lib, oracle_lib, case):
-    name, n, c, h, w, m, p = case
+    name, n, c, h, w, m, p = case[:7]
     d = H.conv_desc(n, c, h, w, m, 3, 1, p)
     gen = torch.Generator(device=DEV).manual_seed(4321)
     x = torch.randn(n, c, h, w, device=DEV, generator=gen)
     wt = torch.randn(m, c, 3, 3, device=DEV, generator=gen)
     gy = torch.randn(n, m, d.oh, d.ow, device=DEV, generator=gen)
+    if len(case) > 7:           # "postact": activations as the step sees them; the gradient with per-channel gains as well
+        x = _post_activation(x, gen)
+        gy = gy * torch.exp(torch.rand(1, m, 1, 1, device=DEV, generator=gen) * (-3.0 * float(np.log(10.0))))
     bias = torch.randn(m, device=DEV, generator=gen)
     alpha = float(1.0 / np.sqrt(c * 9))
     imgs = sorted({0, n - 1})
@@ -213,6 +229,13 @@ def test_one_kernel_winograd_fullsize_vs_oracle(hip_lib, oracle_lib, case):
         torch.cuda.synchronize()
         assert not torch.isnan(gw).any()
         e_wg = H.rel_err(_np(gw[wsub]), o_wg)
+        if len(case) > 7:
+            # entries of the weight gradient span six decades here (gain of the gradient channel x gain of the input channel) and
+            # Adam normalises every entry by its own magnitude: each (m, c) filter against ITS OWN scale, not the tensor's
+            a, o = _np(gw[wsub]).astype(np.float64), o_wg.astype(np.float64)
+            per_pair = np.abs(a - o).max(axis=(2, 3)) / (np.abs(o).max(axis=(2, 3)) + 1e-30)
+            _record(test="one-kernel winograd", case=name, wgrad_worst_filter_rel_to_its_own_max=float(per_pair.max()))
+            assert per_pair.max() < 1e-3, ("wgrad, worst (m, c) filter relative to its own largest tap", float(per_pair.max()))
     torch.cuda.synchronize()
     assert not torch.isnan(y).any() and not torch.isnan(gx).any()
     e_fwd = H.rel_err(_np(y[imgs][:, msel]), o_fwd)

@@ -107,7 +107,8 @@ def _grads_and_errors(ref64, ref32, ours, inputs, run_ref, run_ours, loss_weight
             errs[col][n] = _stats(a, c)
         for kind, (la, lc) in pooled.items():
             errs[col][kind] = _stats(torch.cat(la), torch.cat(lc))
-    book = {"activation calls": len(flips_o), "matched to a saved activation of this package": saved.matched,
+    book = {"activation calls": len(flips_o), "activation elements": int(saved.elements),
+            "matched to a saved activation of this package": saved.matched,
             "unmatched": saved.unmatched, "elements flipped vs the double run (ours)": int(sum(f for f in flips_o if f > 0)),
             "elements flipped vs the double run (control)": int(sum(flips_c))}
     return errs, book
@@ -142,6 +143,12 @@ def _check(case, conv_math, errs, book):
     assert book["unmatched"] == [] and book["matched to a saved activation of this package"] == book["activation calls"], book
     bad = {k: v[:2] for k, v in errs["ours"].items() if k != "output" and not v[1] <= GRAD_TOL[conv_math]}
     assert not bad, bad
+    # ... and ONE assertion on the FREE run, so that a real sign bug cannot hide behind the frozen masks: this package's forward
+    # pass may put no more leaky-ReLU inputs on the other side of zero than the double run does than twice what the stock ATen /
+    # MIOpen fp32 run does (+ a floor of one element per million for networks where the control happens to flip none).  A wrong
+    # sign, bias or scale anywhere upstream of an activation flips a sizeable FRACTION of its elements, not a handful.
+    flips, control = book["elements flipped vs the double run (ours)"], book["elements flipped vs the double run (control)"]
+    assert flips <= 2 * control + max(8, book["activation elements"] // 1000000), (flips, control, book["activation elements"])
 
 
 def test_discriminator_church256_b16_vs_aten_restatement(conv_math):
@@ -235,3 +242,40 @@ def test_encoder_generator_reconstruction_church256_b16_vs_aten_restatement(conv
     t = torch.randn(b, 3, 256, 256, generator=g).to(DEV)
     errs, book = _grads_and_errors(ref64, ref32, ours, [x], lambda m, i: m(i[0]), lambda m, i: m(i[0]), t)
     _check("Encoder -> Generator reconstruction 16x3x256x256 vs ATen restatement in double (cuda:0)", conv_math, errs, book)
+
+
+class _PatchPair(torch.nn.Module):
+    """(reference patches, target patches) -> Dpatch logits: extract_features on both (the reference side aggregated over the
+    crops of an image), then discriminate_features -- swapping_autoencoder_model.py:95-114, patch_discriminator.py:146-171"""
+
+    def __init__(self, net):
+        super().__init__()
+        self.net = net
+
+    def forward(self, ref_patches, target_patches):
+        f_ref = self.net.extract_features(ref_patches, aggregate=True)
+        f_tgt = self.net.extract_features(target_patches)
+        return self.net.discriminate_features(f_ref, f_tgt)
+
+
+def test_patch_discriminator_church256_b16_vs_aten_restatement(conv_math):
+    """The whole patch discriminator at the BASELINE configuration: 16 images x 8 crops of 128 x 128 per side (the 128-patch
+    batches of one discriminator call), aggregation over the reference crops, the pair MLP -- outputs, both patch gradients
+    (what the generator step and the patch R1 penalty consume) and every parameter gradient."""
+    import aten_cpu_path as A
+    from swapping_autoencoder_pytorch_amd.networks.patch_discriminator import StyleGAN2PatchDiscriminator
+    from swapping_autoencoder_pytorch_amd.options import make_options
+    opt = make_options("church256", batch_size=16, num_gpus=1)
+    b, t, ps = 16, opt.patch_num_crops, opt.patch_size
+    ours = _PatchPair(StyleGAN2PatchDiscriminator(opt)).to(DEV)
+    ref32 = _PatchPair(A.PatchDiscriminatorCPU(opt)).to(DEV)
+    _copy_params(ref32, ours, 17)
+    ref64 = _PatchPair(A.PatchDiscriminatorCPU(opt)).to(DEV).double()
+    ref64.load_state_dict({k: v.double() for k, v in ref32.state_dict().items()})
+    g = torch.Generator().manual_seed(19)
+    pr = (torch.rand(b, t, 3, ps, ps, generator=g) * 2 - 1).to(DEV)
+    pt = (torch.rand(b, t, 3, ps, ps, generator=g) * 2 - 1).to(DEV)
+    w = torch.linspace(0.25, 1.0, b * t, device=DEV).view(b * t, 1)       # one sign: see the discriminator test
+    run = lambda m, i: m(i[0], i[1])
+    errs, book = _grads_and_errors(ref64, ref32, ours, [pr, pt], run, run, w)
+    _check("PatchDiscriminator 2 x (16x8)x3x128x128 vs ATen restatement in double (cuda:0)", conv_math, errs, book)

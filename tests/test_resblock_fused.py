@@ -172,6 +172,35 @@ def test_non_downsampling_and_reflection_blocks_keep_the_module_path(oracle_lib)
             assert "ResBlockFunction" not in type(y.grad_fn).__name__
 
 
+def _against_the_oracle(oracle_lib, shapes, tol):
+    """The fused node on the GPU against the MODULE-BY-MODULE path on the CPU oracle (double accumulation): output, first-order
+    gradients of the input and the five parameters, the generator step's input-gradient-only pass and the lazy-R1 double
+    backward.  Relative L2 per tensor (one leaky-ReLU sign flip between an fp32 and a double run moves single elements by a
+    finite amount; it does not move the L2 norm)."""
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    for (n, cin, cout, hw) in shapes:
+        cpu_blk = _block(cin, cout, 11)
+        gpu_blk = _block(cin, cout, 11).to("cuda:0")
+        torch.manual_seed(5)
+        x = torch.randn(n, cin, hw, hw)
+        for mode in ("first", "input_only", "r1"):
+            with backend(hip_lib.get()):
+                got = _run(gpu_blk, x.to("cuda:0"), True, mode)
+            with backend(oracle_lib):
+                want = _run(cpu_blk, x, False, mode)
+            assert len(got) == len(want)
+            for i, (u, v) in enumerate(zip(got, want)):
+                u, v = u.cpu().double(), v.double()
+                err = float((u - v).pow(2).sum().sqrt() / (v.pow(2).sum().sqrt() + 1e-30))
+                assert err < tol, ((n, cin, cout, hw), mode, i, err)
+
+
+@pytest.mark.gpu
+def test_fused_resblock_on_the_gpu_against_the_oracle(oracle_lib):
+    """models/networks/stylegan2_layers.py:651-693 (ResBlock: conv1, Blur + stride-2 conv2, Blur + 1x1 stride-2 skip, merge)"""
+    _against_the_oracle(oracle_lib, [(2, 5, 6, 8), (2, 32, 64, 64), (3, 128, 256, 32)], 2e-5)
+
+
 @pytest.mark.gpu
 def test_fused_resblock_matches_the_module_path_gpu():
     from swapping_autoencoder_pytorch_amd import hip_lib

@@ -115,3 +115,65 @@ def test_a_second_consumer_of_a_merged_activation_is_refused(oracle_lib):
 def test_fused_styled_blocks_match_the_module_path_gpu():
     from swapping_autoencoder_pytorch_amd import hip_lib
     _compare(hip_lib.get(), "cuda:0", 5e-6)
+
+
+@pytest.mark.gpu
+def test_fused_styled_blocks_on_the_gpu_against_the_oracle(oracle_lib):
+    """The generator blocks' fused path on the GPU (one-kernel StyledConv forward, blur + noise + activation epilogue, the ticketed
+    backward) against the MODULE-BY-MODULE path on the CPU oracle, same weights, same explicit noise maps: output, input / style
+    gradients and every parameter gradient, relative L2 per tensor.  models/networks/generator.py:30-53,
+    stylegan2_layers.py:266-351,398-405."""
+    import copy
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    from swapping_autoencoder_pytorch_amd.networks.generator import ResolutionPreservingResnetBlock, UpsamplingResnetBlock
+    from swapping_autoencoder_pytorch_amd.stylegan2_layers import NoiseInjection
+    for make, xshape in ((lambda: ResolutionPreservingResnetBlock(None, 6, 10, 16), (2, 6, 8, 8)),
+                         (lambda: UpsamplingResnetBlock(6, 10, 16, use_noise=True), (2, 6, 8, 8)),
+                         (lambda: ResolutionPreservingResnetBlock(None, 64, 64, 32), (2, 64, 32, 32)),
+                         (lambda: UpsamplingResnetBlock(128, 64, 32, use_noise=True), (2, 128, 32, 32))):
+        torch.manual_seed(11)
+        cpu_block = make()
+        with torch.no_grad():
+            for n, p in cpu_block.named_parameters():
+                if p.dim() == 1 or n.endswith("noise.weight"):
+                    p.normal_(0.0, 0.5)
+        gpu_block = copy.deepcopy(cpu_block).to("cuda:0")
+        sdim = 16 if xshape[1] == 6 else 32
+        x, style = torch.randn(xshape), torch.randn(xshape[0], sdim)
+        with backend(oracle_lib), torch.no_grad():
+            cpu_block(x[:1], style[:1])                    # records every NoiseInjection's map size
+        g = torch.Generator().manual_seed(5)
+        for mc, mg in zip([m for m in cpu_block.modules() if isinstance(m, NoiseInjection)],
+                          [m for m in gpu_block.modules() if isinstance(m, NoiseInjection)]):
+            z = torch.randn(xshape[0], 1, mc.image_size[2], mc.image_size[3], generator=g)
+            mc.fixed_noise, mg.fixed_noise = z, z.to("cuda:0")
+        with backend(hip_lib.get()):
+            got, calls = _run_block(gpu_block, x.to("cuda:0"), style.to("cuda:0"), True, hip_lib.get())
+        with backend(oracle_lib):
+            want, _ = _run_block(cpu_block, x, style, False, oracle_lib)
+        assert "modconv2d_fwd_noise_bias_act_f32" in calls or "wino_fused_conv_f32" in calls
+        # _run_block draws the output gradient on the block's device: redo both backward passes' weights identically
+        for i, (u, v) in enumerate(zip(got[:1], want[:1])):
+            u, v = u.cpu().double(), v.double()
+            assert float((u - v).pow(2).sum().sqrt() / (v.pow(2).sum().sqrt() + 1e-30)) < 2e-5, (type(cpu_block).__name__, xshape, i)
+        # gradients under ONE common output gradient
+        torch.manual_seed(4)
+        gout = torch.randn(want[0].shape)
+        outs = []
+        for block, dev, lib, fused in ((gpu_block, "cuda:0", hip_lib.get(), True), (cpu_block, "cpu", oracle_lib, False)):
+            from swapping_autoencoder_pytorch_amd import stylegan2_layers as SL
+            prev, SL._FUSED_STYLED = SL._FUSED_STYLED, fused
+            try:
+                with backend(lib):
+                    xi, si = x.to(dev).requires_grad_(True), style.to(dev).requires_grad_(True)
+                    y = block(xi, si)
+                    grads = torch.autograd.grad(y, [xi, si] + list(block.parameters()), gout.to(dev))
+                    outs.append([t.detach().cpu().double() for t in grads])
+            finally:
+                SL._FUSED_STYLED = prev
+        names = ["grad_x", "grad_style"] + [n for n, _ in cpu_block.named_parameters()]
+        for n, u, v in zip(names, outs[0], outs[1]):
+            err = float((u - v).pow(2).sum().sqrt() / (v.pow(2).sum().sqrt() + 1e-30))
+            # (a noise strength's gradient is ONE cancelling sum over n * c * h * w terms: fp32 summation noise relative to the
+            # cancelled total is ~sqrt(terms) ulp)
+            assert err < (2e-4 if u.numel() == 1 else 2e-5), (type(cpu_block).__name__, xshape, n, err)
