@@ -731,6 +731,29 @@ def _install_ring_rehearsal(n_gpus):
     dist.all_reduce = rehearsed
 
 
+def _stage_all_reduce_through_host():
+    """--same-device only: gloo's own handling of device tensors stalls on the 32 MB gradient buckets when both ranks share one GPU
+    (both ranks stuck in work.wait(), round 6 session E; the 3 MB buckets of tests/test_ddp_fullmodel.py pass).  The rehearsal
+    stages every all-reduce through host memory instead: device -> host, gloo on the host tensor, host -> device, synchronously.
+    Slower, and nothing overlaps -- it is a rehearsal of the code path and of the line's fields, not of the timing."""
+    import torch.distributed as dist
+    orig = dist.all_reduce
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def all_reduce(tensor, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        if not tensor.is_cuda:
+            return orig(tensor, op=op, group=group, async_op=async_op)
+        host = tensor.detach().cpu()
+        orig(host, op=op, group=group)
+        tensor.copy_(host)
+        return _Done() if async_op else None
+
+    dist.all_reduce = all_reduce
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -759,6 +782,10 @@ def main():
     relaunch = self_launch_command(args, sys.argv[1:])
     if relaunch is not None:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL needs dmabuf IPC on this host driver
+        if args.same_device and "GPU_MAX_HW_QUEUES" not in os.environ.get("SAE_BENCH_KEEP_ENV", ""):
+            # N processes x 8 hardware queues on ONE GPU oversubscribe the device's queues and the driver time-slices them
+            # (HISTORY.md section 6, round 4: a two-rank one-GPU test took 14 minutes instead of 45 s): 4 per process here
+            os.environ["GPU_MAX_HW_QUEUES"] = "4"
         os.execv(relaunch[0], relaunch)                              # never returns
     import torch
     import torch.distributed as dist
@@ -789,6 +816,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.same_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+            if os.environ.get("SAE_BENCH_SAME_DEVICE_STAGE", "1") != "0":
+                _stage_all_reduce_through_host()
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus
@@ -876,10 +905,10 @@ def main():
     allreduce_fields = None
     alt_streams = None
     if world > 1:
-        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
-        every_rank = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(every_rank, mine)
-        dt_by_rank = [float(t.item()) for t in every_rank]
+        every_rank = torch.zeros(world, device=dev, dtype=torch.float64)      # (a sum of one-hot vectors: all_reduce only)
+        every_rank[rank] = dt
+        dist.all_reduce(every_rank, op=dist.ReduceOp.SUM)
+        dt_by_rank = [float(v) for v in every_rank.tolist()]
         dt = max(dt_by_rank)
     if world > 1 or args.force_allreduce:
         allreduce_fields = {"D": optimizer.reducer_D.summary(records_before[0]), "G": optimizer.reducer_G.summary(records_before[1])}

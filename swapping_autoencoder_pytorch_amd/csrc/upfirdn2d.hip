@@ -312,6 +312,216 @@ __global__ __launch_bounds__(kBlock) void blur_tail_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Streaming blur (round 6): the up = down = 1 FIR of <= 4 x 4 taps on planes at least 32 floats wide, WITHOUT the LDS strip.
+//
+// blur_strip moves one dword per lane and instruction (a wave = one 256-byte run) and re-reads 3 of every 11 staged rows; the
+// big planes of the step ran it at 3.3 - 4.5 TB/s where the elementwise kernels, which move 16 bytes per lane, reach 5.5.  Here
+// a thread owns FOUR consecutive output columns of a vertical strip of `rb` output rows (32 or so: 3 halo rows re-read per
+// strip) and walks down the strip with the last KH input rows' contributions in registers:
+//   * per input row two 16-byte buffer loads fetch the 8 floats [4 j - pad_x0, 4 j - pad_x0 + 8) its four outputs draw on (only
+//     4-byte aligned -- rows are 2^k or 2^k + 1 floats -- which gfx950's vector memory takes); neighbouring lanes overlap by
+//     4 floats, which the L1 absorbs; the loads of the NEXT four rows are in flight while four rows are consumed;
+//   * the descriptor starts at the wave's first plane, the per-lane offset is relative to it, and the range check returns zeros
+//     before the tensor's first and after its last float; window columns left or right of the ROW (the zero padding of
+//     upfirdn2d_kernel.cu:98-104, which the check cannot see: they are the neighbouring row's data) are zeroed by a
+//     loop-invariant per-lane mask, rows above / below the plane by an out-of-range offset;
+//   * four accumulator rows (a ring over output rows): input row i feeds outputs i - ky through tap row ky, in exactly the
+//     order blur_strip uses (tap rows outer, tap columns inner, one fp32 fma chain per output): BIT-IDENTICAL results;
+//   * the forward epilogue of StyledConv's upsampling form (noise, bias, leaky ReLU: K1Epilogue::fwd_act) on the way out;
+//     each finished row leaves as one 16-byte store per lane.
+struct StreamParams {
+    int64_t planes, slots;     // slots = planes * strips
+    int in_h, in_w, out_h, out_w;
+    int pad_x0, pad_y0;
+    int kh, kw;
+    int lpr;                   // lanes per output row = ceil(out_w / 4)
+    int rb, strips;            // output rows per strip (a multiple of 4), strips per plane
+};
+
+typedef float f32x4a4 __attribute__((ext_vector_type(4), aligned(4)));
+
+template <bool FWD_ACT>
+__global__ __launch_bounds__(kBlock) void blur_stream_kernel(const float* __restrict__ x, const float* __restrict__ k,
+                                                             float* __restrict__ y, const StreamParams p, const K1Epilogue e) {
+    const int64_t gt = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t slot_raw = gt / p.lpr;
+    const int j = (int)(gt - slot_raw * p.lpr);
+    const bool live = slot_raw < p.slots;
+    const int64_t slot = live ? slot_raw : p.slots - 1;
+    const int64_t plane = slot / p.strips;
+    const int oy0 = (int)(slot - plane * p.strips) * p.rb;
+    const int ox0 = 4 * j;
+
+    // flipped taps, zero beyond the actual counts (upfirdn2d_kernel.cu:71-81); uniform -> scalar registers
+    float tap[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const bool has = a < p.kh && b < p.kw;
+            const float t = k[has ? (p.kh - 1 - a) * p.kw + (p.kw - 1 - b) : 0];
+            tap[a][b] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, has ? t : 0.0f)));
+        }
+
+    // descriptor: from the first plane any lane of this wave touches to the end of the tensor (at most 2 GiB - 1)
+    const int64_t hw = (int64_t)p.in_h * p.in_w;
+    const int64_t plane0 = __builtin_amdgcn_readfirstlane((int)plane);
+    int64_t span = (p.planes - plane0) * hw * 4;
+    if (span > 0x7fffffff) span = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + plane0 * hw), 0, (unsigned)span, 0x00020000);
+    // The 8-float window of the lane starts at column c0 = ox0 - pad_x0; the lanes at the left border (c0 < 0) fetch theirs from
+    // column 0 instead and move it into place (`shift` columns) -- an offset left of the tensor's first float would have to rely
+    // on how the hardware wraps a negative offset.  Every offset below is >= 0 for a row inside the plane.
+    const int c0 = ox0 - p.pad_x0;
+    const int shift = c0 < 0 ? -c0 : 0;                       // 0 ... 3 (pad_x0 <= kw - 1 <= 3)
+    // per-row offset = this + i * row_bytes (i = 0: input row oy0 - pad_y0, possibly above the plane: masked below)
+    const int64_t rel = ((plane - plane0) * p.in_h + (oy0 - p.pad_y0)) * (int64_t)p.in_w + c0 + shift;
+    const int rel_bytes = (int)(rel * 4);
+    const int row_bytes = p.in_w * 4;
+    bool colok[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) colok[q] = c0 + q >= 0 && c0 + q < p.in_w;
+
+    auto load_row = [&](int i, f32x4& lo, f32x4& hi) {        // input row oy0 - pad_y0 + i
+        const int iy = oy0 - p.pad_y0 + i;
+        const bool ok = live && iy >= 0 && iy < p.in_h && i < p.rb + 3;
+        const unsigned v = ok ? (unsigned)(rel_bytes + i * row_bytes) : 0x80000000u;
+        lo = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, v, 0, 0));
+        hi = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, v + 16u, 0, 0));
+    };
+
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
+
+    [[maybe_unused]] float fwd_nw = 0.0f, fwd_b = 0.0f;
+    [[maybe_unused]] const float* zp = nullptr;
+    if constexpr (FWD_ACT) {
+        if (e.fwd_noise) {
+            fwd_nw = e.fwd_noise_w[0];
+            zp = e.fwd_noise + (plane / e.channels) * (int64_t)p.out_h * p.out_w;
+        }
+        if (e.fwd_bias) fwd_b = e.fwd_bias[plane % e.channels];
+    }
+    float* yp = y + plane * (int64_t)p.out_h * p.out_w;
+    const bool full = ox0 + 3 < p.out_w;          // all four columns exist: one 16-byte store
+
+    f32x4 nlo[4], nhi[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) load_row(s4, nlo[s4], nhi[s4]);
+    for (int i0 = 0; i0 < p.rb + 3; i0 += 4) {
+        float v[4][8];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float w[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) w[q] = q < 4 ? nlo[s4][q] : nhi[s4][q - 4];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                // window element q is fetched element q - shift
+                float t = w[q];
+                if (q >= 1) t = shift == 1 ? w[q - 1] : t;
+                if (q >= 2) t = shift == 2 ? w[q - 2] : t;
+                if (q >= 3) t = shift == 3 ? w[q - 3] : t;
+                v[s4][q] = colok[q] ? t : 0.0f;
+            }
+        }
+        if (i0 + 4 < p.rb + 3) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) load_row(i0 + 4 + s4, nlo[s4], nhi[s4]);
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            // input row i = i0 + s4 feeds output row i - ky through tap row ky; ring slot of output row o is o & 3
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky) {
+                const int rs = (s4 - ky + 4) & 3;
+#pragma unroll
+                for (int xo = 0; xo < 4; ++xo)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[rs][xo] = fmaf(v[s4][xo + c], tap[ky][c], acc[rs][xo]);
+            }
+            // output row o = i - 3 is complete (its last contribution came through tap row 3)
+            const int o = i0 + s4 - 3;
+            const int rs = (s4 + 1) & 3;            // = (s4 - 3 + 4) & 3
+            const int oy = oy0 + o;
+            if (live && o >= 0 && o < p.rb && oy < p.out_h) {
+                float t[4];
+#pragma unroll
+                for (int xo = 0; xo < 4; ++xo) t[xo] = acc[rs][xo];
+                if constexpr (FWD_ACT) {
+                    float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (zp) {
+                        const float* zr = zp + (int64_t)oy * p.out_w + ox0;
+                        if (full) {
+                            const f32x4a4 zq = *reinterpret_cast<const f32x4a4*>(zr);
+#pragma unroll
+                            for (int xo = 0; xo < 4; ++xo) z[xo] = zq[xo];
+                        } else {
+#pragma unroll
+                            for (int xo = 0; xo < 4; ++xo)
+                                if (ox0 + xo < p.out_w) z[xo] = zr[xo];
+                        }
+                    }
+#pragma unroll
+                    for (int xo = 0; xo < 4; ++xo) {
+                        float u = t[xo];
+                        if (zp) u = u + fwd_nw * z[xo];             // (image + weight * noise) + bias, stylegan2_layers.py:340-351
+                        u = u + fwd_b;
+                        t[xo] = ((u > 0.0f) ? u : u * e.slope) * e.scale;
+                    }
+                }
+                float* yr = yp + (int64_t)oy * p.out_w + ox0;
+                if (full) {
+                    *reinterpret_cast<f32x4a4*>(yr) = f32x4a4{t[0], t[1], t[2], t[3]};
+                } else {
+#pragma unroll
+                    for (int xo = 0; xo < 4; ++xo)
+                        if (ox0 + xo < p.out_w) yr[xo] = t[xo];
+                }
+            }
+#pragma unroll
+            for (int xo = 0; xo < 4; ++xo) acc[rs][xo] = 0.0f;
+        }
+    }
+}
+
+// The planes the streaming kernel takes -- where the same-box A/B says it wins (tools/ab_k1_stream.py ->
+// profiles/r6_ab_k1_stream.txt, TB/s of algorithmic bytes, strip kernel -> streaming kernel):
+//   blur + noise + bias + leaky-ReLU forward (2^k + 1 -> 2^k wide): 257: 3.4 -> 4.4, 129: 3.5 -> 4.4 / 3.9 -> 4.5, 513: 3.5 -> 4.3;
+//     65: 3.9 -> 4.1 (even), 33: 2.9 -> 2.6 (loses)                                             => output rows of 96 floats and up
+//   plain 4 x 4 blur (2^k -> 2^k + 1 wide): 32: 2.6 -> 3.2 / 2.9 -> 4.2; 64 ... 1024: 4.0 - 4.5 -> 3.9 - 4.2 (loses 2 - 9 %: its
+//     16-byte stores start on 4-byte boundaries of the 2^k + 1 wide rows)                          => the 32-wide planes only
+//   3-tap blurs: 4.8 - 5.7 -> 4.2 (the strip kernel stages 10 rows for 8 there)                    => never
+// SAE_K1_STREAM (tuning builds): 0 = never, 1 = this rule, 2 = every plane the kernel can take (the bit-identity tests)
+inline bool blur_streams(const BlurParams& p, bool fwd_act) {
+    const int knob = tuning_knob("SAE_K1_STREAM", 1);
+    const bool can = p.kh <= 4 && p.kw <= 4 && p.kh >= 2 && p.in_w >= 32 && p.out_w >= 32 && p.out_h >= 16;
+    if (knob == 0 || !can) return false;
+    if (knob == 2) return true;
+    if (p.kh != 4 || p.kw != 4) return false;
+    return fwd_act ? p.out_w >= 96 : (p.in_w == 32 && p.in_h == 32);
+}
+
+template <bool FWD_ACT>
+void launch_blur_stream(const float* x, const float* k, float* y, const BlurParams& b, hipStream_t s, const K1Epilogue& e) {
+    StreamParams p{};
+    p.planes = b.planes;
+    p.in_h = b.in_h; p.in_w = b.in_w; p.out_h = b.out_h; p.out_w = b.out_w;
+    p.pad_x0 = b.pad_x0; p.pad_y0 = b.pad_y0; p.kh = b.kh; p.kw = b.kw;
+    p.lpr = ceil_div(b.out_w, 4);
+    // about 32 output rows per strip, strips of equal height (a 257-row plane: 8 strips of 36 / 5 rows, not 8 x 32 + 1)
+    const int nstrips = b.out_h >= 48 ? (b.out_h + 16) / 32 : 1;
+    p.rb = ceil_div(ceil_div(b.out_h, nstrips), 4) * 4;
+    p.strips = ceil_div(b.out_h, p.rb);
+    p.slots = p.planes * p.strips;
+    const int64_t blocks = ceil_div64(p.slots * p.lpr, kBlock);
+    hipLaunchKernelGGL((blur_stream_kernel<FWD_ACT>), dim3((unsigned)blocks), dim3(kBlock), 0, s, x, k, y, p, e);
+}
+
 struct GenericParams {
     int64_t major, minor;
     int in_h, in_w, out_h, out_w;
@@ -620,7 +830,8 @@ extern "C" int sae_upfirdn2d_f32(const float* x, const float* k, float* y, int64
         p.planes = major;
         p.in_h = (int)in_h; p.in_w = (int)in_w; p.out_h = (int)out_h; p.out_w = (int)out_w;
         p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
-        if (kh == 1 && kw == 1) dispatch_blur<1, 1>(x, k, y, p, s);
+        if (blur_streams(p, false)) launch_blur_stream<false>(x, k, y, p, s, K1Epilogue{});
+        else if (kh == 1 && kw == 1) dispatch_blur<1, 1>(x, k, y, p, s);
         else if (kh <= 3 && kw <= 3) dispatch_blur<3, 3>(x, k, y, p, s);
         else dispatch_blur<4, 4>(x, k, y, p, s);
         return check_launch("sae_upfirdn2d_f32(blur)");
@@ -737,6 +948,7 @@ extern "C" int sae_upfirdn2d_noise_bias_act_f32(const float* x, const float* k, 
     p.planes = major;
     p.in_h = (int)in_h; p.in_w = (int)in_w; p.out_h = (int)out_h; p.out_w = (int)out_w;
     p.pad_x0 = pad_x0; p.pad_y0 = pad_y0; p.kh = kh; p.kw = kw;
-    dispatch_blur44<true>(x, k, y, p, (hipStream_t)stream, e);
+    if (blur_streams(p, true)) launch_blur_stream<true>(x, k, y, p, (hipStream_t)stream, e);
+    else dispatch_blur44<true>(x, k, y, p, (hipStream_t)stream, e);
     return check_launch(who);
 }

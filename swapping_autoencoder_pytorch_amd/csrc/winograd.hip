@@ -15,7 +15,7 @@
 // with U[xi][m][c] = alpha (G g G^T)[xi] from sae_wino_weights_f32 (flip = 1: the filter of the data gradient, taps reversed;
 // the caller swaps the roles of the two channel strides).  The matrix work falls by 2.25; the price is moving 4x the
 // activation through HBM twice, so it pays where a layer's FLOP per activation byte are high: 256 channels and up on maps up
-// to 64 wide (estimate from the per-shape ledger: DESIGN.md 4.0f).  Exact-fp32 arithmetic throughout; the result differs from
+// to 64 wide (estimate from the per-shape ledger: HISTORY.md 4.0f).  Exact-fp32 arithmetic throughout; the result differs from
 // the direct kernels' by rounding (different association), ~1e-6 relative -- inside the per-op tolerance of 1e-4
 // (BASELINE.json) and of the kernel tests (2e-5), but NOT bit-identical to them.
 //
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void wino_wgrad_output_kernel(const float* 
 }
 
 // ---- four tiles per thread (tiles_w a multiple of 4, 16-byte aligned rows): the same arithmetic per tile, 16-byte accesses.
-// A wave64 vector-memory instruction costs the CU's address path ~28 cycles whatever its width: one tile per
+// A wave64 vector-memory instruction costs the CU's address path ~28 cycles whatever its width (HISTORY.md 4.0b): one tile per
 // thread is 32 - 34 such instructions per 64 tiles (320 B of HBM traffic each) and bound by their issue near 3.5 TB/s; four
 // tiles per thread need 8 per 64 tiles.
 

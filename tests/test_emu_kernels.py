@@ -23,6 +23,47 @@ def test_upfirdn2d(emu_lib, oracle_lib, case):
     assert H.rel_err(a, o) < TOL
 
 
+# planes the streaming blur takes (csrc/upfirdn2d.hip: blur_streams -- at least 32 wide, 16 output rows, 2 ... 4 taps): 2^k and
+# 2^k + 1 wide rows, the left-border window shift for every pad_x0, strips of unequal height, several planes per wave
+K1_STREAM = [((3, 67, 70, 1), (4, 4), (2, 2, 2, 2)), ((3, 33, 33, 1), (4, 4), (1, 1, 1, 1)), ((2, 64, 64, 1), (4, 4), (2, 2, 2, 2)),
+             ((2, 65, 65, 1), (4, 4), (1, 1, 1, 1)), ((5, 40, 32, 1), (3, 3), (0, 0, 0, 0)), ((1, 300, 64, 1), (4, 4), (2, 2, 1, 1)),
+             ((7, 16, 36, 1), (4, 4), (3, 0, 3, 0)), ((2, 129, 129, 1), (4, 4), (1, 1, 1, 1)), ((3, 48, 35, 1), (2, 2), (1, 0, 1, 0))]
+
+
+def k1_stream_case(lib, oracle_lib, case, monkeypatch, device=None):
+    """blur_stream_kernel against the oracle and -- bit for bit -- against the LDS-strip kernels it replaces on these planes (the
+    dispatch knob SAE_K1_STREAM exists in tuning builds: the emulator, tests/tuning)."""
+    xs, ks, pad = case
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(xs).astype(np.float32)
+    k = rng.standard_normal(ks).astype(np.float32)
+    monkeypatch.setenv("SAE_K1_STREAM", "2")
+    a = H.upfirdn2d(lib, x, k, (1, 1), (1, 1), pad, device=device)
+    monkeypatch.setenv("SAE_K1_STREAM", "0")
+    b = H.upfirdn2d(lib, x, k, (1, 1), (1, 1), pad, device=device)
+    o = H.upfirdn2d(oracle_lib, x, k, (1, 1), (1, 1), pad)
+    assert not np.isnan(a).any() and H.rel_err(a, o) < 2e-6
+    assert np.array_equal(a, b), float(np.abs(a - b).max())
+    # ... and with the forward epilogue of StyledConv's upsampling form
+    ch = 1 if xs[0] % 2 else 2
+    outer = xs[0] // ch
+    oh, ow = a.shape[1], a.shape[2]
+    nz = rng.standard_normal((outer, oh, ow)).astype(np.float32)
+    nw = np.array([0.7], np.float32)
+    bias = rng.standard_normal(ch).astype(np.float32)
+    monkeypatch.setenv("SAE_K1_STREAM", "2")
+    ya = H.upfirdn2d_noise_bias_act(lib, x[..., 0], k, pad, nz, nw, bias, ch, device=device)
+    monkeypatch.setenv("SAE_K1_STREAM", "0")
+    yb = H.upfirdn2d_noise_bias_act(lib, x[..., 0], k, pad, nz, nw, bias, ch, device=device)
+    yo = H.upfirdn2d_noise_bias_act(oracle_lib, x[..., 0], k, pad, nz, nw, bias, ch)
+    assert H.rel_err(ya, yo) < 2e-6 and np.array_equal(ya, yb)
+
+
+@pytest.mark.parametrize("case", K1_STREAM, ids=lambda c: "x".join(map(str, c[0])) + "_k%dx%d" % c[1])
+def test_streaming_blur_is_the_strip_blur_bit_for_bit(emu_lib, oracle_lib, case, monkeypatch):
+    k1_stream_case(emu_lib, oracle_lib, case, monkeypatch)
+
+
 def k1_epilogue_case(lib, oracle_lib, case, device=None):
     """Every epilogue combination of sae_upfirdn2d_epilogue_f32 against (a) the oracle's restatement and (b) the SAME
     library's separate calls (upfirdn2d, then the add, then the K2 backward): the fused value must be bit-identical to the

@@ -321,3 +321,27 @@ def test_reflect_pad(hip_lib, oracle_lib, case):
     gy = rng.standard_normal(o.shape).astype(np.float32)
     assert np.allclose(H.reflect_pad_adj(hip_lib, gy, pads, device=DEV), H.reflect_pad_adj(oracle_lib, gy, pads),
                        rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", [((512, 256, 256, 1), (4, 4), (2, 2, 2, 2)), ((256, 257, 257, 1), (4, 4), (1, 1, 1, 1)),
+                                  ((1024, 64, 64, 1), (4, 4), (2, 2, 2, 2)), ((64, 129, 129, 1), (4, 4), (1, 1, 1, 1)),
+                                  ((96, 259, 259, 1), (3, 3), (0, 0, 0, 0)), ((3, 67, 70, 1), (4, 4), (2, 2, 2, 2))],
+                         ids=lambda c: "x".join(map(str, c[0])) + "_k%dx%d" % c[1])
+def test_streaming_blur_is_the_strip_blur_bit_for_bit(oracle_lib, case, monkeypatch):
+    """blur_stream_kernel (csrc/upfirdn2d.hip) at the step's plane sizes: same bits as the LDS-strip kernels (the tuning build of
+    the same sources has the dispatch knob), oracle parity on a slice of planes.  upfirdn2d_kernel.cu:52-137 of the reference."""
+    from swapping_autoencoder_pytorch_amd.hip_lib import SaeLibrary
+    from tuning import build_tuning
+    from test_emu_kernels import k1_stream_case
+    lib = SaeLibrary(build_tuning.build())
+    xs, ks, pad = case
+    small = ((min(xs[0], 4),) + xs[1:], ks, pad)        # the oracle walks a few planes; bit-identity is checked on all of them below
+    k1_stream_case(lib, oracle_lib, small, monkeypatch, device=DEV)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(xs).astype(np.float32)
+    k = rng.standard_normal(ks).astype(np.float32)
+    monkeypatch.setenv("SAE_K1_STREAM", "2")
+    a = H.upfirdn2d(lib, x, k, (1, 1), (1, 1), pad, device=DEV)
+    monkeypatch.setenv("SAE_K1_STREAM", "0")
+    b = H.upfirdn2d(lib, x, k, (1, 1), (1, 1), pad, device=DEV)
+    assert not np.isnan(a).any() and np.array_equal(a, b)

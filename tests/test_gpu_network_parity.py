@@ -116,7 +116,7 @@ def _grads_and_errors(ref64, ref32, ours, inputs, run_ref, run_ours, loss_weight
 
 # relative L2 of every gradient tensor against the double run under this package's own sign patterns: the north-star tolerance,
 # for both arithmetics (measured r5, profiles/r5_network_parity_tensors.jsonl: f32 worst tensor 2.4e-6; the opt-in bf16x6 arithmetic
-# -- six bf16 products per fp32 product, DESIGN.md 4.1 -- 4.8e-5; with the Winograd route on 2.2e-6)
+# -- six bf16 products per fp32 product, DESIGN.md section 4 (bf16x6) -- 4.8e-5; with the Winograd route on 2.2e-6)
 GRAD_TOL = {"f32": 1e-4, "bf16x6": 1e-4}
 
 

@@ -1,4 +1,4 @@
-"""The quad-staged gather / weight-gradient kernels and the LDS-transposed epilogue (csrc/conv2d.hip) change
+"""The quad-staged gather / weight-gradient kernels and the LDS-transposed epilogue (csrc/conv2d.hip, HISTORY.md 4.0b) change
 how operands reach LDS and how results leave the registers, not the arithmetic or its order: their results must be
 BIT-identical to the dword-staged kernels.  The same holds for the second-generation transposed gather
 (conv_igemm_tr2_kernel: quad staging, 16- or 8-channel chunks, LDS-transposed row stores) against conv_igemm_tr_kernel.  Two subprocesses (the knobs are read once per process), on the emulator and on

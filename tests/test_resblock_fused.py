@@ -36,7 +36,7 @@ def _run(blk, x, fused, mode):
         params = list(blk.parameters())
         if mode == "first":
             torch.manual_seed(3)
-            g = torch.randn_like(out)
+            g = torch.randn(out.shape).to(out.device)        # (drawn on the CPU: the same output gradient on every device)
             grads = torch.autograd.grad(out, [x] + params, g)
             return [out.detach()] + [t.detach() for t in grads]
         if mode == "input_only":            # generator step: D's parameters are frozen

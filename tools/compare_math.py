@@ -1,5 +1,5 @@
 """Train the same model from the same seed on the same synthetic batches under both conv arithmetics and report
-how far the loss trajectories drift apart (evidence for DESIGN.md section 4.1).
+how far the loss trajectories drift apart (evidence for DESIGN.md section 4, bf16x6).
 python tools/compare_math.py [preset] [batch] [iters]"""
 import json
 import os

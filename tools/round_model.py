@@ -1,4 +1,4 @@
-"""Rounds-of-workgroups model of the step's 3x3 forward / data-gradient launches: work items per launch from
+"""Rounds-of-workgroups model of the step's 3x3 forward / data-gradient launches (HISTORY.md section 8): work items per launch from
 the plans of csrc/conv2d.hip (tile shapes restated here), 512 slots (two workgroups per CU), and the share of each launch's measured
 time that a partly filled last round can account for AT MOST (a workgroup alone on its CU runs ~1.7x faster, and in the step another
 stream fills idle CUs).  Input: profiles/r4_roofline_by_shape_church256.txt.   python tools/round_model.py"""

@@ -1,4 +1,4 @@
-"""Per-layer A/B of the Winograd F(2x2,3x3) route against the direct MFMA kernels: every 3x3 stride-1 geometry one
+"""Per-layer A/B of the Winograd F(2x2,3x3) route against the direct MFMA kernels (HISTORY.md 4.0f): every 3x3 stride-1 geometry one
 training iteration of a preset launches (forward, data gradient, weight gradient, with their call counts), timed on both routes
 with HIP events, and the per-iteration saving of an eligibility rule read off the table.
     python tools/wino_ab.py --preset church256 > gpurun_out/wino_ab_church256.json"""
