@@ -25,10 +25,16 @@
 namespace sae {
 namespace {
 
-// The input transform works on packed pairs -- v_pk_add_f32 with op_sel / neg modifiers (sae_common.h: pk_sub / pk_c01 / pk_c23), 56
-// instead of 84 vector-ALU instructions per thread and chunk -- with V kept in LDS as pairs of POINTS and the MFMA loop walking the
-// points two at a time (+1.3 % on the 128 / 256-channel layers; the scalar form and the packed form of the weight gradient's x
-// side, which measured 4 - 7 % SLOWER, are recorded in profiles/r5_ab_wino_fused_pk.txt and tools/archive/variants/).
+// SAE_WF_PK (default 1; 0 = the scalar form, kept for tools/build_wf_variant.sh A/B): the input transform on packed pairs --
+// v_pk_add_f32 with op_sel / neg modifiers (sae_common.h: pk_sub / pk_c01 / pk_c23), 56 instead of 84 vector-ALU instructions per
+// thread and chunk -- with V kept in LDS as pairs of POINTS and the MFMA loop walking the points two at a time (two alternating
+// accumulation chains).  +1.3 % on the 128 / 256-channel layers (profiles/r5_ab_wino_fused_pk.txt).
+#ifndef SAE_WF_PK
+#define SAE_WF_PK 1
+#endif
+#ifndef SAE_WF_PK_WGRAD      // the same for the x side of the weight gradient (its V operand): measured 4 - 7 % SLOWER
+#define SAE_WF_PK_WGRAD 0    // (profiles/r5_ab_wino_fused_pk.txt), kept for the record behind this switch
+#endif
 
 constexpr int kWfM = 64;       // output channels per workgroup
 constexpr int kWfT = 64;       // 2x2 output tiles per workgroup
@@ -245,6 +251,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
             vreg[4 * a + 3][c2] = e[a][1] - e[a][3];
         }
     };
+#if SAE_WF_PK
     // packed form: pv[c2][a][bp] = (V[4 a + 2 bp], V[4 a + 2 bp + 1]) of channel c2; LDS: Vs[a][bp][half][s][t] pairs, channel
     // 2 wid + c2 = (half = wid >> 1, s = 2 (wid & 1) + c2)
     f32x2 pv[2][4][2];
@@ -303,6 +310,14 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) vd[pp * 512 + c2 * 64] = pv[c2][pp >> 1][pp & 1];
     };
+#else
+    // channel 2 wid + c2 of the chunk = (half = wid >> 1, s = 2 (wid & 1) + c2): both channels share one 8-byte slot
+    auto write_v = [&](int buf, int lo) {                      // 8 LDS 8-byte writes
+        f32x2* vd = reinterpret_cast<f32x2*>(Vs[buf]) + (((wid >> 1) * 2 + (wid & 1)) * 64 + lane);
+#pragma unroll
+        for (int xi = lo; xi < lo + 8; ++xi) vd[xi * 256] = vreg[xi];
+    };
+#endif
     auto write_u = [&](int buf, int lo) {                      // 4 LDS 16-byte writes
         f32x4* ud = reinterpret_cast<f32x4*>(Us[buf]) + tid;
 #pragma unroll
@@ -319,6 +334,48 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
     // read while the MFMAs of point xi run, and with STAGE the pieces of the next chunk's staging ride in the groups' shadows --
     // x first (transformed by groups 8, 9), the weights last (written by groups 14, 15).  sched_barrier keeps the pieces in
     // their groups; inside a group the scheduler is free.
+#if !SAE_WF_PK
+    auto pass = [&](auto stage_tag, auto mode_tag, int cur, int chunk) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        const f32x4* ua = reinterpret_cast<const f32x4*>(Us[cur]) + (half * 64 + wm * 32 + l31);
+        const f32x2* vb = reinterpret_cast<const f32x2*>(Vs[cur]) + (half * 128 + wt * 32 + l31);
+        f32x4 a = ua[0];
+        f32x2 b01 = vb[0], b23 = vb[64];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            f32x4 an = a;
+            f32x2 b01n = b01, b23n = b23;
+            if (xi < 15) {
+                an = ua[(xi + 1) * 128];
+                b01n = vb[(xi + 1) * 256];
+                b23n = vb[(xi + 1) * 256 + 64];
+            }
+            if (STAGE) {
+                if (xi == 0) load_x(chunk + 1, 0);
+                if (xi == 1) load_x(chunk + 1, 1);
+                if (xi == 2) load_u(chunk + 1, 0);
+                if (xi == 3) load_u(chunk + 1, 4);
+            }
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b01[0], acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b01[1], acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b23[0], acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b23[1], acc[xi], 0, 0, 0);
+            if (STAGE) {
+                if (xi == 8) transform(mode_tag, 0);
+                if (xi == 9) transform(mode_tag, 1);
+                if (xi == 12) write_v(cur ^ 1, 0);
+                if (xi == 13) write_v(cur ^ 1, 8);
+                if (xi == 14) write_u(cur ^ 1, 0);
+                if (xi == 15) write_u(cur ^ 1, 4);
+            }
+            a = an;
+            b01 = b01n;
+            b23 = b23n;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+#else
     // packed form: eight groups of eight MFMAs, one PAIR of points (4 a + 2 bp, + 1) each: the pair's V values share 8-byte LDS
     // words, so four 8-byte reads serve both points; the two accumulation chains alternate
     auto pass = [&](auto stage_tag, auto mode_tag, int cur, int chunk) {
@@ -360,6 +417,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+#endif
 
     auto run = [&](auto mode_tag) {
         // prologue: chunk 0
@@ -367,8 +425,13 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
         load_x(0, 1);
         load_u(0, 0);
         load_u(0, 4);
+#if SAE_WF_PK
         transform_pk(mode_tag, 0);
         transform_pk(mode_tag, 1);
+#else
+        transform(mode_tag, 0);
+        transform(mode_tag, 1);
+#endif
         write_v(0, 0);
         write_v(0, 8);
         write_u(0, 0);
@@ -632,11 +695,59 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
 #pragma unroll
         for (int xi = lo; xi < lo + 8; ++xi) d[xi * 256] = ev[xi];
     };
+#if SAE_WF_PK_WGRAD
+    // packed form (see wino_fused_kernel): pw[a][bp] = (tile 0: V[4 a + 2 bp], V[.. + 1]; tile 1: the same two points) -- one
+    // 16-byte word of Vs[a][bp][half][c][s] pairs, s = the thread's two tiles
+    f32x4 pw[4][2];
+    auto transform_v_pk = [&]() {
+        f32x2 e[4][3];         // B^T d on the column pairs (0, 1), (2, 3), (4, 5) of the 4 x 6 window
+        f32x2 d[4][3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            d[r][0] = f32x2{xr4[r][0], xr4[r][1]};
+            d[r][1] = f32x2{xr4[r][2], xr4[r][3]};
+            d[r][2] = xr2[r];
+            if (MOD) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) d[r][j] *= sx;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            e[0][j] = pk_sub(d[0][j], d[2][j]);
+            e[1][j] = d[1][j] + d[2][j];
+            e[2][j] = pk_sub(d[2][j], d[1][j]);
+            e[3][j] = pk_sub(d[1][j], d[3][j]);
+        }
+        if (edge) {                        // (uniform branch: chunks at the left / right border of the map only)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float l0 = e[a][0][0], l1 = e[a][0][1], l2 = e[a][1][0], l3 = e[a][1][1], l4 = e[a][2][0], l5 = e[a][2][1];
+                e[a][0] = f32x2{zl ? 0.0f : l0, zl ? l0 : l1};
+                e[a][1] = f32x2{zl ? l1 : l2, zl ? l2 : l3};
+                e[a][2] = f32x2{zl ? l3 : l4, zl ? l4 : (zr ? 0.0f : l5)};
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x2 t0a = pk_c01(e[a][0], e[a][1]), t0b = pk_c23(e[a][0], e[a][1]);      // tile 0: columns 0 .. 3
+            const f32x2 t1a = pk_c01(e[a][1], e[a][2]), t1b = pk_c23(e[a][1], e[a][2]);      // tile 1: columns 2 .. 5
+            pw[a][0] = f32x4{t0a[0], t0a[1], t1a[0], t1a[1]};
+            pw[a][1] = f32x4{t0b[0], t0b[1], t1b[0], t1b[1]};
+        }
+    };
+    auto write_v = [&](int buf, int lo) {                      // 4 LDS 16-byte writes
+        f32x4* d = reinterpret_cast<f32x4*>(Vs[buf]) + ((hf * 64 + ch) * 2 + q1);
+#pragma unroll
+        for (int pp = lo / 2; pp < lo / 2 + 4; ++pp) d[pp * 256] = pw[pp >> 1][pp & 1];
+    };
+#else
     auto write_v = [&](int buf, int lo) {
         f32x2* d = reinterpret_cast<f32x2*>(Vs[buf]) + ((hf * 64 + ch) * 2 + q1);
 #pragma unroll
         for (int xi = lo; xi < lo + 8; ++xi) d[xi * 256] = vv[xi];
     };
+#endif
 
     f32x16 acc[16];
 #pragma unroll
@@ -644,6 +755,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[xi][r] = 0.0f;
 
+#if !SAE_WF_PK_WGRAD
     auto pass = [&](int cur, bool more) {
         const f32x4* ea = reinterpret_cast<const f32x4*>(Es[cur]) + (half * 64 + wm * 32 + l31);
         const f32x4* vb = reinterpret_cast<const f32x4*>(Vs[cur]) + (half * 64 + wt * 32 + l31);
@@ -675,13 +787,58 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
         }
     };
 
+#else
+    // packed form: eight groups of eight MFMAs, one pair of points each; a lane's V values of the pair are 32 contiguous bytes
+    auto pass = [&](int cur, bool more) {
+        const f32x4* ea = reinterpret_cast<const f32x4*>(Es[cur]) + (half * 64 + wm * 32 + l31);
+        const f32x4* vb = reinterpret_cast<const f32x4*>(Vs[cur]) + (half * 64 + wt * 32 + l31) * 2;
+        f32x4 a0 = ea[0], a1 = ea[128], b0 = vb[0], b1 = vb[1];
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            f32x4 a0n = a0, a1n = a1, b0n = b0, b1n = b1;
+            if (pp < 7) {
+                a0n = ea[(2 * pp + 2) * 128];
+                a1n = ea[(2 * pp + 3) * 128];
+                b0n = vb[(pp + 1) * 256];
+                b1n = vb[(pp + 1) * 256 + 1];
+            }
+            if (pp == 0) { load_gy(); load_x(0); }
+            if (pp == 1) {
+                load_x(2);
+                if (more) advance();       // (the last chunk of the slice stages itself again into the buffer nobody reads)
+            }
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[0], b0[0], acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0], b0[1], acc[2 * pp + 1], 0, 0, 0);
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[1], b0[2], acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1], b0[3], acc[2 * pp + 1], 0, 0, 0);
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2], b1[0], acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2], b1[1], acc[2 * pp + 1], 0, 0, 0);
+            acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[3], b1[2], acc[2 * pp], 0, 0, 0);
+            acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[3], b1[3], acc[2 * pp + 1], 0, 0, 0);
+            if (pp == 3) transform_e();
+            if (pp == 4) transform_v_pk();
+            if (pp == 5) write_e(cur ^ 1, 0);
+            if (pp == 6) { write_e(cur ^ 1, 8); write_v(cur ^ 1, 0); }
+            if (pp == 7) write_v(cur ^ 1, 8);
+            a0 = a0n;
+            a1 = a1n;
+            b0 = b0n;
+            b1 = b1n;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+#endif
 
     if (ch_begin < ch_end) {
         load_gy();
         load_x(0);
         load_x(2);
         transform_e();
+#if SAE_WF_PK_WGRAD
+        transform_v_pk();
+#else
         transform_v();
+#endif
         write_e(0, 0);
         write_e(0, 8);
         write_v(0, 0);
