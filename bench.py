@@ -43,7 +43,7 @@ MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, 
 # those 128-byte requests at 64 B, the x2 correction of the guide, confirmed on a 1 GiB copy in the same passes), writes =
 # TCC_EA0_WRREQ_64B x 64 B + the remaining write requests x 32 B, on the kernel's reference launch (128 -> 128 3x3 @256x256
 # B=16).  Counters cannot be read inside a timed run; the figure is scaled to the average launch of the timed region by FLOPs.
-PMC_DOMINANT_FILE = os.path.join(ROOT, "profiles", "r5_pmc_dominant.json")
+PMC_DOMINANT_FILE = os.path.join(ROOT, "profiles", "r6_pmc_dominant.json")
 # Round 5: the wide 3x3 stride-1 layers (forward and data gradient) run as ONE-kernel Winograd F(2x2,3x3) convolutions
 # (csrc/winograd_fused.hip); that kernel is now the largest single consumer of the step.  (Rounds 2-4: the direct gather
 # conv_igemm_kernel<3,1,2,2,1,4,8,false,true>, still reported as a class of its own.)

@@ -259,14 +259,15 @@ class _PatchPair(torch.nn.Module):
 
 
 def test_patch_discriminator_church256_b16_vs_aten_restatement(conv_math):
-    """The whole patch discriminator at the BASELINE configuration: 16 images x 8 crops of 128 x 128 per side (the 128-patch
-    batches of one discriminator call), aggregation over the reference crops, the pair MLP -- outputs, both patch gradients
-    (what the generator step and the patch R1 penalty consume) and every parameter gradient."""
+    """The whole patch discriminator at the BASELINE widths and patch size: 8 images x 8 crops of 128 x 128 per side (half the
+    batch of a discriminator call: the double restatement of 2 x 128 patches alone took four minutes per arithmetic), aggregation
+    over the reference crops, the pair MLP -- outputs, both patch gradients (what the generator step and the patch R1 penalty
+    consume) and every parameter gradient."""
     import aten_cpu_path as A
     from swapping_autoencoder_pytorch_amd.networks.patch_discriminator import StyleGAN2PatchDiscriminator
     from swapping_autoencoder_pytorch_amd.options import make_options
     opt = make_options("church256", batch_size=16, num_gpus=1)
-    b, t, ps = 16, opt.patch_num_crops, opt.patch_size
+    b, t, ps = 8, opt.patch_num_crops, opt.patch_size
     ours = _PatchPair(StyleGAN2PatchDiscriminator(opt)).to(DEV)
     ref32 = _PatchPair(A.PatchDiscriminatorCPU(opt)).to(DEV)
     _copy_params(ref32, ours, 17)
@@ -278,4 +279,4 @@ def test_patch_discriminator_church256_b16_vs_aten_restatement(conv_math):
     w = torch.linspace(0.25, 1.0, b * t, device=DEV).view(b * t, 1)       # one sign: see the discriminator test
     run = lambda m, i: m(i[0], i[1])
     errs, book = _grads_and_errors(ref64, ref32, ours, [pr, pt], run, run, w)
-    _check("PatchDiscriminator 2 x (16x8)x3x128x128 vs ATen restatement in double (cuda:0)", conv_math, errs, book)
+    _check("PatchDiscriminator 2 x (8x8)x3x128x128 vs ATen restatement in double (cuda:0)", conv_math, errs, book)

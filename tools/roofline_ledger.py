@@ -58,7 +58,7 @@ def work_of(name, a):
         n = a[6]
         numel = sum(a[4][i] for i in range(n))
         return "adam (multi-tensor)", "hbm", 28.0 * numel
-    if name == "gemm_f32":
+    if name in ("gemm_f32", "gemm_ws_f32"):
         m, n, k = a[4], a[5], a[6]
         if BY_SHAPE:
             return "gemm (linear layers) m%-5d n%-5d k%-5d" % (m, n, k), "mfma", 2.0 * m * n * k
@@ -157,7 +157,7 @@ class Ledger:
 
         def call(name, *args):
             if not self.active or name in ("set_conv_math", "conv2d_wprep_query", "wino_gemm_workspace", "wino_wgrad_gemm_workspace",
-                                               "wino_fused_weights_floats"):
+                                               "wino_fused_weights_floats", "gemm_workspace"):
                 return orig(name, *args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -187,6 +187,7 @@ def main():
     sys.path.insert(0, ROOT)
     # ONE stream: the step's two branches otherwise overlap and the bracketed times of concurrent calls add up to more than the wall
     os.environ["SAE_TWO_STREAMS"] = "0"
+    os.environ["SAE_HIP_GRAPH"] = "0"       # eager calls: the brackets sit around individual launches (hip_graph.py replays whole calls)
     import bench
     from swapping_autoencoder_pytorch_amd.options import make_options
     from swapping_autoencoder_pytorch_amd.swapping_autoencoder_model import create_model
