@@ -67,6 +67,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0        # same table, dense bf16 matrix; the bf16x
                                       # (20/3 with the zero-padded ninth tap) per fp32 product
 FLOPS_PER_IMAGE = {"church256": 1.815e12, "bedroom256": 1.815e12, "ffhq512": 3.91e12, "ffhq1024": 6.08e12}
 DEFAULT_BATCH = {"church256": 16, "bedroom256": 16, "ffhq512": 8, "ffhq1024": 4, "tiny32": 4}
+ALT_STREAMS_WATCHDOG_S = 180          # multi-rank runs: the extra leg in the other stream mode may take this long at most
 CPU_BASELINE_BATCH = 2                # images of the measured whole CPU iteration of the default run (cpu_baseline)
 
 
@@ -903,7 +904,6 @@ def main():
     dt = time.perf_counter() - t0
     dt_by_rank = None
     allreduce_fields = None
-    alt_streams = None
     if world > 1:
         every_rank = torch.zeros(world, device=dev, dtype=torch.float64)      # (a sum of one-hot vectors: all_reduce only)
         every_rank[rank] = dt
@@ -921,34 +921,6 @@ def main():
                                     "bucket's launch to the last bucket's completion, and the time the waiting stream stood idle for "
                                     "collectives (exposed = not overlapped with backward / Adam)")
     done = skew + args.warmup + args.steps
-    if world > 1 and args.alt_streams_steps > 0:
-        # the OTHER stream mode on the same ranks, same batches: decides streams.enabled()'s multi-rank default on hardware
-        from swapping_autoencoder_pytorch_amd import streams as _streams
-        was = os.environ.get("SAE_TWO_STREAMS")
-        other_two = not _streams.enabled()
-        os.environ["SAE_TWO_STREAMS"] = "1" if other_two else "0"
-        try:
-            for i in range(2):
-                iteration(done + i)
-            fence()
-            t0 = time.perf_counter()
-            for i in range(args.alt_streams_steps):
-                iteration(done + 2 + i)
-            fence()
-            sdt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-            dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
-            sdt = float(sdt.item())
-        finally:
-            if was is None:
-                os.environ.pop("SAE_TWO_STREAMS", None)
-            else:
-                os.environ["SAE_TWO_STREAMS"] = was
-        done += 2 + args.alt_streams_steps
-        alt_streams = {"streams": "two" if other_two else "one", "steps": args.alt_streams_steps,
-                       "value": round(world * batch * args.alt_streams_steps / sdt, 3), "unit": "images/s",
-                       "ms_per_step": round(sdt / args.alt_streams_steps * 1e3, 3),
-                       "note": "no lazy-R1 iteration in this window unless it spans a multiple of 16"}
-
     # kernel pass (not `value`): the same iterations with everything on ONE stream and an event bracket around every launch
     # of the tracked kernels.  The timed region above runs the step's independent branches on two streams: two kernels then
     # share the CUs and the duration of either says how the chip was shared, not how good the kernel is.
@@ -1048,8 +1020,6 @@ def main():
             line["ms_per_step_by_rank"] = [round(t / args.steps * 1e3, 3) for t in dt_by_rank]
         if allreduce_fields is not None:
             line["allreduce"] = allreduce_fields
-        if alt_streams is not None:
-            line["alt_streams"] = alt_streams
         if args.same_device and world > 1:
             line["config"]["same_device"] = ("REHEARSAL: all %d ranks on cuda:0 over gloo -- the ranks share one GPU, nothing here is a "
                                              "scaling number" % world)
@@ -1109,6 +1079,51 @@ def main():
             line["other_presets"] = other_presets_leg(args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.preset, size, batch, full=args.full_cpu_baseline)
+    else:
+        line = None
+    # Multi-rank runs, LAST of all legs: a few steps in the OTHER stream mode on the same ranks and batches (decides
+    # streams.enabled()'s multi-rank default on hardware).  Guarded: this combination (two streams + a multi-rank RCCL communicator)
+    # has never run on more than one GPU; should it stall, a watchdog on every rank lets rank 0 print the line without it and
+    # ends the process, so the run's headline figures are never lost to the extra leg.
+    if world > 1 and args.alt_streams_steps > 0:
+        import threading
+        from swapping_autoencoder_pytorch_amd import streams as _streams
+
+        def _give_up():
+            if rank == 0:
+                line["alt_streams"] = {"error": "the leg did not finish within %d s: left out" % ALT_STREAMS_WATCHDOG_S}
+                print(json.dumps(line), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(ALT_STREAMS_WATCHDOG_S, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        was = os.environ.get("SAE_TWO_STREAMS")
+        other_two = not _streams.enabled()
+        os.environ["SAE_TWO_STREAMS"] = "1" if other_two else "0"
+        try:
+            for i in range(2):
+                iteration(done + i)
+            fence()
+            t0 = time.perf_counter()
+            for i in range(args.alt_streams_steps):
+                iteration(done + 2 + i)
+            fence()
+            sdt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(sdt, op=dist.ReduceOp.MAX)
+            sdt = float(sdt.item())
+        finally:
+            if was is None:
+                os.environ.pop("SAE_TWO_STREAMS", None)
+            else:
+                os.environ["SAE_TWO_STREAMS"] = was
+        watchdog.cancel()
+        if rank == 0:
+            line["alt_streams"] = {"streams": "two" if other_two else "one", "steps": args.alt_streams_steps,
+                                   "value": round(world * batch * args.alt_streams_steps / sdt, 3), "unit": "images/s",
+                                   "ms_per_step": round(sdt / args.alt_streams_steps * 1e3, 3),
+                                   "note": "no lazy-R1 iteration in this window unless it spans a multiple of 16"}
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if launched:
         dist.destroy_process_group()

@@ -243,6 +243,10 @@ inline int gemm_slices(int64_t m, int64_t n, int64_t k) {
     const int64_t tiles64 = ceil_div64(m, 64) * ceil_div64(n, 64);
     if (!(tiles64 < 128 && k >= 256)) return 0;                 // sae_gemm_f32's own rule for the 32 x 32 split-K kernel
     const int64_t tiles32 = ceil_div64(m, 32) * ceil_div64(n, 32);
+    // from 192 tiles on the one-launch kernel already fills the chip and the slices + reduction only add traffic (measured in the
+    // step, round 6: [128 x 2048] x [2048 x 2048] 35 -> 45 us with three slices; the deep-K shapes under that count gain:
+    // [24 x 8192] x [8192 x 512] 142 -> 40 us, [16 x 4376] x [4376 x 2048] 84 -> 37)
+    if (tiles32 >= 192) return 0;
     const int64_t nchunks = ceil_div64(k, kKc);
     int64_t s = ceil_div64(768, tiles32);                       // ~3 workgroups per CU
     const int64_t most = nchunks / 4 > 0 ? nchunks / 4 : 1;     // at least one chunk per wave and slice

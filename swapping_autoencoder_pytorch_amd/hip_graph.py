@@ -62,9 +62,21 @@ class _Captured:
         self.static_in = images.detach().clone()
         weight_prep.invalidate()
         self.graph = torch.cuda.CUDAGraph()
-        # thread_local: a data-loading thread may go on allocating and copying while this thread captures
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.out = body(self.static_in)
+        # capture_begin / capture_end by hand instead of the `torch.cuda.graph` context manager, which empties the caching
+        # allocator first: the eager passes that remain (the lazy-R1 call, every 16th discriminator iteration) would then rebuild
+        # their gigabytes of blocks from hipMalloc at their first call after the capture -- 100 - 340 ms on the ffhq512 preset
+        # (profiles/r6_ffhq512_lazy_r1_graph_vs_eager.txt).  thread_local: a data-loading thread may go on allocating and copying
+        # while this thread captures.
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.graph.capture_begin(capture_error_mode="thread_local")
+            try:
+                self.out = body(self.static_in)
+            finally:
+                self.graph.capture_end()
+        torch.cuda.current_stream().wait_stream(side)
         # nothing has RUN yet: whatever the capture "prepared" holds no data until the first replay
         weight_prep.invalidate()
 

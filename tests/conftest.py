@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# The whole-network parity tests run stock ATen / MIOpen convolutions as their fp32 control: MIOpen's default "find" benchmarks
+# every solver for every new conv geometry (a minute or two per network at full size).  The immediate mode is enough for a control.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -20,7 +25,7 @@ def pytest_configure(config):
 # alphabetical place in between.
 _FIRST = ["test_gpu_kernels", "test_gpu_parity", "test_modconv", "test_adam", "test_weight_prep", "test_resblock_fused",
           "test_styled_fused", "test_quad_paths", "test_winograd", "test_ws_gather", "test_glue", "test_f8_gather"]
-_LAST = ["test_gpu_fullsize_oracle", "test_gpu_fullsize_properties", "test_gpu_network_parity"]
+_LAST = ["test_gpu_fullsize_oracle", "test_gpu_fullsize_properties", "test_gpu_step_parity", "test_gpu_network_parity"]
 
 
 def pytest_collection_modifyitems(session, config, items):
