@@ -60,7 +60,7 @@
 extern "C" {
 #endif
 
-#define SAE_ABI_VERSION 11  /* 11: sae_gemm_ws_f32 (K split across workgroups);  10: sae_adam_multi_dev_f32 (step counts in device memory: hipGraph replays);  9: sae_wino_fused_wgrad_*;  8: sae_wino_fused_* (one-kernel Winograd convolution);  7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
+#define SAE_ABI_VERSION 12  /* 12: sae_s2wino_* (stride-2 3x3 family on the polyphase minimal-filtering form);  11: sae_gemm_ws_f32 (K split across workgroups);  10: sae_adam_multi_dev_f32 (step counts in device memory: hipGraph replays);  9: sae_wino_fused_wgrad_*;  8: sae_wino_fused_* (one-kernel Winograd convolution);  7: sae_wino_* (Winograd F(2x2,3x3) transforms);  6: prepared weights (sae_conv2d_desc::prepped*, sae_conv2d_wprep_*);  2: modconv / adam / glue entry points (round 2), 3: sae_upfirdn2d_epilogue_f32, 4: sae_conv2d_fwd_residual_f32, 5: sae_weight_demod_*, sae_modconv2d_fwd_noise_bias_act_f32, sae_upfirdn2d_noise_bias_act_f32, sae_plane_scale_dot_act_f32 */
 
 #define SAE_OK 0
 #define SAE_EINVAL (-1)    /* bad argument (null pointer, non-positive size, unsupported mode) */
@@ -488,6 +488,26 @@ int64_t sae_wino_fused_wgrad_workspace(int64_t n, int64_t c, int64_t m, int64_t 
 int sae_wino_fused_wgrad_f32(const float* x, const float* x_scale, const float* gy, const float* y_scale, float* gw, int64_t n,
                              int64_t c, int64_t m, int64_t h, int64_t w, int32_t pad, int64_t w_stride_m, int64_t w_stride_c,
                              float alpha, float* workspace, int64_t workspace_floats, sae_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The 3x3 STRIDE-2 family on its polyphase minimal-filtering form (csrc/s2wino.hip): the reference's
+ * F.conv_transpose2d(stride 2) of ModulatedConv2d(upsample=True) (models/networks/stylegan2_layers.py:296-309) and the data
+ * gradient autograd forms for F.conv2d(stride 2) of ConvLayer(downsample=True) (:136,627-648).  Along an axis the even positions
+ * of the (2h+1)-long side meet the 2-tap filter (w0, w2) -- F(2,2): 3 products per 2 outputs -- and the odd positions the 1-tap
+ * filter w1: 25 instead of 36 multiplications per 2x2 of small-side positions, transforms in registers, one kernel.
+ *   sae_s2wino_weights_floats(cout, cin)  floats of the prepared weights (opaque layout; both point sets of the kernel)
+ *   sae_s2wino_weights_f32    w[co * w_stride_out + ci * w_stride_in + tap] (co: the channel the PRODUCT writes, ci: the one it
+ *                             contracts), times alpha, row_scale[co], col_scale[ci] if given; flip = 1: the taps reversed (the
+ *                             data gradient / transposed convolution meets the reversed filter).  uf 16-byte aligned.
+ *   sae_s2wino_dgrad_f32      g [n][cin][h][w] (h, w even, w >= 4) times g_scale[n * cin + ci] if given ->
+ *                             dx [n][cout][2h+1][2w+1], dx[2 oy + ky][2 ox + kx] += w[ky][kx] g[oy][ox] (uf prepared with
+ *                             flip = 1), times out_scale[n * cout + co] if given.  No workspace.
+ */
+int64_t sae_s2wino_weights_floats(int64_t cout, int64_t cin);
+int sae_s2wino_weights_f32(const float* w, const float* row_scale, const float* col_scale, float* uf, int64_t cout, int64_t cin,
+                           int64_t w_stride_out, int64_t w_stride_in, int32_t flip, float alpha, sae_stream_t stream);
+int sae_s2wino_dgrad_f32(const float* g, const float* g_scale, const float* uf, const float* out_scale, float* dx, int64_t n,
+                         int64_t cin, int64_t cout, int64_t h, int64_t w, sae_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,7 @@ typedef struct sae_conv2d_desc {
 
 static __thread char g_err[256];
 
-int oracle_abi_version(void) { return 11; }
+int oracle_abi_version(void) { return 12; }
 const char* oracle_last_error(void) { return g_err; }
 
 /* include/sae_hip.h: the mode only selects GPU arithmetic; the oracle always accumulates in double */
@@ -1367,6 +1367,101 @@ int oracle_wino_fused_wgrad_f32(const float* x, const float* x_scale, const floa
                         for (int b = 0; b < 4; ++b) acc += WINO_G[a][i] * gU[4 * a + b] * WINO_G[b][j];
                     gw[mi * w_stride_m + ci * w_stride_c + 3 * i + j] = (float)((double)alpha * acc);
                 }
+        }
+    return SAE_OK;
+}
+
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * sae_s2wino_* (csrc/s2wino.hip): the stride-2 3x3 family on its polyphase minimal-filtering form, restated in double from the
+ * identities themselves.  Along an axis, with the taps t0 t1 t2 as the product sees them (flip = 1: reversed), a tile takes
+ * the inputs (a, b, c) = g[2t-1], g[2t], g[2t+1] to the outputs
+ *     dx[4t]   = (a - b) t0 + b (t0 + t2)          dx[4t+2] = b (t0 + t2) + (c - b) t2         (F(2,2) on the 2-tap even filter)
+ *     dx[4t+1] = b t1                              dx[4t+3] = c t1                             (the 1-tap odd filter)
+ * i.e. five products P = {(a-b) t0, b (t0+t2), (c-b) t2, b t1, c t1}; in the plane the 25 products of a tile are the tensor
+ * product of the two axes.  The prepared weights here are the oracle's own layout: uf[(p * cout + co) * cin + ci], p = 5 py + px.
+ * Reference: F.conv_transpose2d(stride 2) (models/networks/stylegan2_layers.py:306) / autograd's data gradient of
+ * F.conv2d(stride 2) (:136). */
+static const double S2W_IN[5][3] = {{1, -1, 0}, {0, 1, 0}, {0, -1, 1}, {0, 1, 0}, {0, 0, 1}};      /* point <- (a, b, c) */
+static const double S2W_WT[5][3] = {{1, 0, 0}, {1, 0, 1}, {0, 0, 1}, {0, 1, 0}, {0, 1, 0}};       /* point <- (t0, t1, t2) */
+static const double S2W_OUT[4][5] = {{1, 1, 0, 0, 0}, {0, 0, 0, 1, 0}, {0, 1, 1, 0, 0}, {0, 0, 0, 0, 1}};   /* dx[4t + o] <- points */
+
+int64_t oracle_s2wino_weights_floats(int64_t cout, int64_t cin) {
+    if (cout < 1 || cin < 1) return 0;
+    return 25 * cout * cin;
+}
+
+int oracle_s2wino_weights_f32(const float* w, const float* row_scale, const float* col_scale, float* uf, int64_t cout, int64_t cin,
+                              int64_t w_stride_out, int64_t w_stride_in, int32_t flip, float alpha, sae_stream_t stream) {
+    (void)stream;
+    if (cout < 1 || cin < 1 || !w || !uf) return set_err("oracle_s2wino_weights_f32: bad argument");
+    for (int64_t co = 0; co < cout; ++co)
+        for (int64_t ci = 0; ci < cin; ++ci) {
+            const float* wp = w + co * w_stride_out + ci * w_stride_in;
+            double t[3][3];
+            for (int k = 0; k < 9; ++k)
+                t[k / 3][k % 3] = (double)alpha * (double)wp[flip ? 8 - k : k] * (row_scale ? (double)row_scale[co] : 1.0) *
+                                  (col_scale ? (double)col_scale[ci] : 1.0);
+            for (int py = 0; py < 5; ++py)
+                for (int px = 0; px < 5; ++px) {
+                    double acc = 0.0;
+                    for (int i = 0; i < 3; ++i)
+                        for (int j = 0; j < 3; ++j) acc += S2W_WT[py][i] * t[i][j] * S2W_WT[px][j];
+                    uf[((5 * py + px) * cout + co) * cin + ci] = (float)acc;
+                }
+        }
+    return SAE_OK;
+}
+
+int oracle_s2wino_dgrad_f32(const float* g, const float* g_scale, const float* uf, const float* out_scale, float* dx, int64_t n,
+                            int64_t cin, int64_t cout, int64_t h, int64_t w, sae_stream_t stream) {
+    (void)stream;
+    if (n < 0 || cin < 1 || cout < 1 || h < 2 || w < 4 || (h & 1) || (w & 1))
+        return set_err("oracle_s2wino_dgrad_f32: the small side must have even sides and rows of at least 4 floats");
+    if (n == 0) return SAE_OK;
+    if (!g || !uf || !dx) return set_err("oracle_s2wino_dgrad_f32: null tensor");
+    const int64_t oh = 2 * h + 1, ow = 2 * w + 1, th = h / 2 + 1, tw = w / 2 + 1;
+    #pragma omp parallel for collapse(2)
+    for (int64_t ni = 0; ni < n; ++ni)
+        for (int64_t ty = 0; ty < th; ++ty) {
+            double* V = (double*)malloc(sizeof(double) * (size_t)(25 * cin));
+            for (int64_t tx = 0; tx < tw; ++tx) {
+                for (int64_t ci = 0; ci < cin; ++ci) {
+                    double d[3][3];
+                    const float* gp = g + (ni * cin + ci) * h * w;
+                    for (int r = 0; r < 3; ++r)
+                        for (int q = 0; q < 3; ++q) {
+                            const int64_t iy = 2 * ty - 1 + r, ix = 2 * tx - 1 + q;
+                            const int in = iy >= 0 && iy < h && ix >= 0 && ix < w;
+                            d[r][q] = in ? (double)(g_scale ? gp[iy * w + ix] * g_scale[ni * cin + ci] : gp[iy * w + ix]) : 0.0;
+                        }
+                    for (int py = 0; py < 5; ++py)
+                        for (int px = 0; px < 5; ++px) {
+                            double acc = 0.0;
+                            for (int i = 0; i < 3; ++i)
+                                for (int j = 0; j < 3; ++j) acc += S2W_IN[py][i] * d[i][j] * S2W_IN[px][j];
+                            V[(5 * py + px) * cin + ci] = acc;
+                        }
+                }
+                for (int64_t co = 0; co < cout; ++co) {
+                    double M[25];
+                    for (int pt = 0; pt < 25; ++pt) {
+                        double acc = 0.0;
+                        for (int64_t ci = 0; ci < cin; ++ci) acc += (double)uf[(pt * cout + co) * cin + ci] * V[pt * cin + ci];
+                        M[pt] = acc;
+                    }
+                    for (int a = 0; a < 4; ++a)
+                        for (int b = 0; b < 4; ++b) {
+                            const int64_t oy = 4 * ty + a, ox = 4 * tx + b;
+                            if (oy >= oh || ox >= ow) continue;
+                            double acc = 0.0;
+                            for (int i = 0; i < 5; ++i)
+                                for (int j = 0; j < 5; ++j) acc += S2W_OUT[a][i] * M[5 * i + j] * S2W_OUT[b][j];
+                            dx[((ni * cout + co) * oh + oy) * ow + ox] = out_scale ? (float)acc * out_scale[ni * cout + co] : (float)acc;
+                        }
+                }
+            }
+            free(V);
         }
     return SAE_OK;
 }

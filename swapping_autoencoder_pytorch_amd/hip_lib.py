@@ -43,7 +43,7 @@ class ConvMod(C.Structure):
     _fields_ = [("x_scale", C.c_void_p), ("y_scale", C.c_void_p), ("wm_scale", C.c_void_p), ("wc_scale", C.c_void_p)]
 
 
-ABI_VERSION = 11     # include/sae_hip.h: SAE_ABI_VERSION
+ABI_VERSION = 12     # include/sae_hip.h: SAE_ABI_VERSION
 
 _SIGNATURES = {
     "abi_version": (C.c_int, []),
@@ -121,6 +121,9 @@ _SIGNATURES = {
     "wino_fused_wgrad_workspace": (_i64, [_i64, _i64, _i64, _i64, _i64, _i32]),
     "wino_fused_wgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _i32, _i64, _i64, _f32,
                                        _f32p, _i64, _stream]),
+    "s2wino_weights_floats": (_i64, [_i64, _i64]),
+    "s2wino_weights_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i32, _f32, _stream]),
+    "s2wino_dgrad_f32": (C.c_int, [_f32p, _f32p, _f32p, _f32p, _f32p, _i64, _i64, _i64, _i64, _i64, _stream]),
 }
 
 EXPORTED_SYMBOLS = tuple("sae_" + name for name in _SIGNATURES)

@@ -527,3 +527,25 @@ def wino_fused_wgrad(lib, x, gy, alpha=1.0, cm_layout=False, x_scale=None, y_sca
     lib.call("wino_fused_wgrad_f32", bx.ptr, bxs.ptr if bxs else None, bg.ptr, bys.ptr if bys else None, bw.ptr, n, c, m, ih, iw, pad,
              sm, sc, alpha, ws.ptr, n_ws, _stream(device))
     return bw.numpy()
+
+
+def s2wino_dgrad(lib, gy, wt, alpha=1.0, cm_layout=False, g_scale=None, row_scale=None, col_scale=None, out_scale=None, device=None):
+    """The data gradient / transposed convolution of a 3x3 stride-2 pad-0 layer through sae_s2wino_weights_f32 (flip = 1) +
+    sae_s2wino_dgrad_f32: gy [n][m][h][w] -> dx [n][c][2h+1][2w+1]; wt is the layer's weight, [m][c][3][3] or ([C, M] layout)
+    [c][m][3][3]; row_scale [c] / col_scale [m] follow the product's output / contraction axes."""
+    n, m, h, w = gy.shape
+    if cm_layout:
+        c, m2 = wt.shape[0], wt.shape[1]
+        s_out, s_in = m2 * 9, 9
+    else:
+        m2, c = wt.shape[0], wt.shape[1]
+        s_out, s_in = 9, c * 9
+    assert m2 == m
+    floats = lib.query("s2wino_weights_floats", c, m)
+    bw, bu = _Buf(wt, device), _out((floats,), device)
+    opt = [None if t is None else _Buf(np.asarray(t, np.float32).reshape(-1), device) for t in (row_scale, col_scale, g_scale, out_scale)]
+    prs, pcs, pgs, pos = [b.ptr if b is not None else None for b in opt]
+    lib.call("s2wino_weights_f32", bw.ptr, prs, pcs, bu.ptr, c, m, s_out, s_in, 1, alpha, _stream(device))
+    bg, bo = _Buf(gy, device), _out((n, c, 2 * h + 1, 2 * w + 1), device)
+    lib.call("s2wino_dgrad_f32", bg.ptr, pgs, bu.ptr, pos, bo.ptr, n, m, c, h, w, _stream(device))
+    return bo.numpy()

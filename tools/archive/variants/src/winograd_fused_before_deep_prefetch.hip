@@ -14,11 +14,7 @@
 // Four waves = 2 (halves of the 64 channels) x 2 (halves of the 64 tiles); each wave keeps 16 points x 16 registers = 256
 // accumulators (the AGPR half of the 512-entry file: one wave per SIMD) and per chunk of 8 input channels issues 64 MFMAs against
 // 48 LDS reads (U as one 16-byte read per point, V as two 8-byte reads), 16 LDS writes and 16 global 16-byte loads.
-// LDS: two stages x (U 32 KB + V 32 KB) = 128 KB; one barrier per chunk.  The patches of a chunk are loaded TWO chunks ahead
-// (they sit in registers for a whole pass before their transform: the loads miss the L2 for every first channel block that
-// touches them) and no MFMA group carries more than two loads per wave: the four waves' loads queue up in the CU's one
-// texture addresser, and a wave that cannot issue its load cannot issue the MFMAs behind it either (round 6: +5 - 8 % on the
-// 128 / 256-channel layers, profiles/r6_ab_wino_deep_prefetch.txt).
+// LDS: two stages x (U 32 KB + V 32 KB) = 128 KB; one barrier per chunk.
 //
 // Data gradient of the same layers: the same kernel on the output gradient with the flipped / transposed filter (flip = 1 in the
 // weight preparation) and padding 2 - pad.
@@ -319,22 +315,14 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[xi][r] = 0.0f;
 
-    auto load_x_rows = [&](int chunk, int c2, int r0) {
-        int ch = chunk * kWfCK + 2 * wid + c2;
-        if (ch > p.C - 1) ch = p.C - 1;
-        const unsigned soff = (unsigned)ch * plane_bytes;
-#pragma unroll
-        for (int r = r0; r < r0 + 2; ++r) dreg[c2][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, rowv[r], soff, 0));
-        if (XS && r0 == 0) xsc[c2] = p.x_scale[(int64_t)(s_valid ? s_n : 0) * p.C + ch];
-    };
-    auto load_u2 = [&](int chunk, int j0) {
-#pragma unroll
-        for (int j = j0; j < j0 + 2; ++j)
-            ureg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uoff, (unsigned)(chunk * kWfStage * 4 + j * 4096), 0));
-    };
-    // the patches of chunk c1 were loaded during the PREVIOUS pass (a whole pass of latency cover); every group carries at most
-    // two loads per wave (the four waves' loads of a group queue up in the one texture addresser of the CU)
-    auto pass = [&](auto mode_tag, int cur, int c1, int c2n) {
+    // One pass over the staged chunk `cur`: sixteen groups of four MFMAs (one point each); the operands of point xi + 1 are
+    // read while the MFMAs of point xi run, and with STAGE the pieces of the next chunk's staging ride in the groups' shadows --
+    // x first (transformed by groups 8, 9), the weights last (written by groups 14, 15).  sched_barrier keeps the pieces in
+    // their groups; inside a group the scheduler is free.
+    // packed form: eight groups of eight MFMAs, one PAIR of points (4 a + 2 bp, + 1) each: the pair's V values share 8-byte LDS
+    // words, so four 8-byte reads serve both points; the two accumulation chains alternate
+    auto pass = [&](auto stage_tag, auto mode_tag, int cur, int chunk) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
         const f32x4* ua = reinterpret_cast<const f32x4*>(Us[cur]) + (half * 64 + wm * 32 + l31);
         const f32x2* vb = reinterpret_cast<const f32x2*>(Vs[cur]) + (half * 256 + wt * 32 + l31);
         f32x4 a0 = ua[0], a1 = ua[128];
@@ -349,20 +337,22 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) bn[s4] = vb[(pp + 1) * 512 + s4 * 64];
             }
-            if (pp < 4) load_u2(c1, 2 * pp);
+            if (STAGE) {
+                if (pp == 0) { load_x(chunk + 1, 0); load_x(chunk + 1, 1); }
+                if (pp == 1) { load_u(chunk + 1, 0); load_u(chunk + 1, 4); }
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s4], b[s4][0], acc[2 * pp], 0, 0, 0);
                 acc[2 * pp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s4], b[s4][1], acc[2 * pp + 1], 0, 0, 0);
             }
-            if (pp == 0) transform_pk(mode_tag, 0);
-            if (pp == 1) transform_pk(mode_tag, 1);
-            if (pp == 2) { write_v(cur ^ 1, 0); load_x_rows(c2n, 0, 0); }
-            if (pp == 3) { write_v(cur ^ 1, 8); load_x_rows(c2n, 0, 2); }
-            if (pp == 4) load_x_rows(c2n, 1, 0);
-            if (pp == 5) load_x_rows(c2n, 1, 2);
-            if (pp == 6) write_u(cur ^ 1, 0);
-            if (pp == 7) write_u(cur ^ 1, 4);
+            if (STAGE) {
+                if (pp == 3) transform_pk(mode_tag, 0);
+                if (pp == 4) transform_pk(mode_tag, 1);
+                if (pp == 5) write_v(cur ^ 1, 0);
+                if (pp == 6) { write_v(cur ^ 1, 8); write_u(cur ^ 1, 0); }
+                if (pp == 7) write_u(cur ^ 1, 4);
+            }
             a0 = a0n;
             a1 = a1n;
 #pragma unroll
@@ -370,24 +360,25 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+
     auto run = [&](auto mode_tag) {
-        const int last = p.chunks - 1;
+        // prologue: chunk 0
         load_x(0, 0);
         load_x(0, 1);
         load_u(0, 0);
         load_u(0, 4);
         transform_pk(mode_tag, 0);
         transform_pk(mode_tag, 1);
-        load_x(last < 1 ? last : 1, 0);
-        load_x(last < 1 ? last : 1, 1);
         write_v(0, 0);
         write_v(0, 8);
         write_u(0, 0);
         write_u(0, 4);
         __syncthreads();
+        // (ONE instantiation of the pass: the last chunk stages itself again into the buffer nobody reads -- a second, staging-free
+        // copy of the pass costs 300 accumulator moves between the two register assignments)
         int cur = 0;
         for (int chunk = 0; chunk < p.chunks; ++chunk) {
-            pass(mode_tag, cur, chunk + 1 < last ? chunk + 1 : last, chunk + 2 < last ? chunk + 2 : last);
+            pass(std::true_type{}, mode_tag, cur, chunk + 1 < p.chunks ? chunk : chunk - 1);
             __syncthreads();
             cur ^= 1;
         }
@@ -653,8 +644,6 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[xi][r] = 0.0f;
 
-    // the operands of chunk + 1 were loaded during the PREVIOUS pass; they are transformed first, and the loads of chunk + 2
-    // follow as soon as their registers are free
     auto pass = [&](int cur, bool more) {
         const f32x4* ea = reinterpret_cast<const f32x4*>(Es[cur]) + (half * 64 + wm * 32 + l31);
         const f32x4* vb = reinterpret_cast<const f32x4*>(Vs[cur]) + (half * 64 + wt * 32 + l31);
@@ -666,25 +655,27 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
                 an = ea[(xi + 1) * 128];
                 bn = vb[(xi + 1) * 128];
             }
+            if (xi == 0) load_gy();
+            if (xi == 1) load_x(0);
+            if (xi == 2) {
+                load_x(2);
+                if (more) advance();       // (the last chunk of the slice stages itself again into the buffer nobody reads)
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], acc[xi], 0, 0, 0);
-            if (xi == 0) transform_e();
-            if (xi == 1) transform_v();
-            if (xi == 2) load_gy();          // (after BOTH transforms: it also fetches the two style factors of the chunk it loads)
-            if (xi == 3) load_x(0);
-            if (xi == 4) {
-                load_x(2);
-                if (more) advance();
-            }
-            if (xi == 6) write_e(cur ^ 1, 0);
-            if (xi == 7) write_e(cur ^ 1, 8);
-            if (xi == 8) write_v(cur ^ 1, 0);
-            if (xi == 9) write_v(cur ^ 1, 8);
+            if (xi == 7) transform_e();
+            if (xi == 9) transform_v();
+            if (xi == 12) write_e(cur ^ 1, 0);
+            if (xi == 13) write_e(cur ^ 1, 8);
+            if (xi == 14) write_v(cur ^ 1, 0);
+            if (xi == 15) write_v(cur ^ 1, 8);
             a = an;
             b = bn;
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+
+
     if (ch_begin < ch_end) {
         load_gy();
         load_x(0);
@@ -696,14 +687,10 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
         write_v(0, 0);
         write_v(0, 8);
         if (ch_begin + 1 < ch_end) advance();
-        load_gy();
-        load_x(0);
-        load_x(2);
-        if (ch_begin + 2 < ch_end) advance();
         __syncthreads();
         int cur = 0;
         for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
-            pass(cur, chunk + 3 < ch_end);
+            pass(cur, chunk + 2 < ch_end);
             __syncthreads();
             cur ^= 1;
         }
