@@ -173,11 +173,14 @@ KERNEL_CLASSES = {
     "s1_gather_256": ("conv 3x3 s1 direct gather on maps >= 128 wide: 64 x 256 tile, quad staging", "conv_igemm_kernel<3,1,2,2,1,4,8,false,true>"),
     "s1_gather_128": ("conv 3x3 s1 direct gather on smaller maps: 128 x 128 tile, quad staging", "conv_igemm_kernel<3,1,2,2,2,2,8,false,true>"),
     "s2_dgrad": ("conv 3x3 s2 data gradient / transposed conv (plain + modulated)", "conv_igemm_tr2_kernel<2,16,*> / conv_igemm_tr_kernel"),
+    "s2_dgrad_poly": ("conv 3x3 s2 data gradient / transposed conv on the polyphase minimal-filtering form (2^k + 1 maps up to 65 wide, "
+                      ">= 256 contraction channels; 25 of the direct form's 36 multiplications)", "s2w_dgrad_kernel<*>"),
     "s2_fwd": ("conv 3x3 s2 forward gather (plain + modulated)", "conv_igemm_kernel<3,2,*>"),
     "s1_wgrad": ("conv 3x3 s1 weight gradient, direct (plain + modulated)", "conv_wgrad16_kernel<1> (fallback conv_wgrad_kernel<3,1,*>)"),
     "s2_wgrad": ("conv 3x3 s2 weight gradient (plain + modulated)", "conv_wgrad_kernel<3,2,*> (<= 64 gradient channels: conv_wgrad16_kernel<2>)"),
 }
 WINO_CLASSES = ("dominant", "wino_wgrad", "wino_unfused")
+EXECUTED_NOTE = {"s2_dgrad_poly": "achieved = executed FLOPs (algorithmic x 25 / 36); *_algorithmic = the direct convolution's"}
 
 
 class DominantKernelTimer:
@@ -209,6 +212,8 @@ class DominantKernelTimer:
             elif op == cg.SAE_CONV_DGRAD:
                 tile = _quad_gather_tile(geom.c, geom.ow, geom.h, geom.w, 2 - geom.pad)
             return {"64x256": "s1_gather_256", "128x128": "s1_gather_128"}.get(tile)
+        if op == cg.SAE_CONV_DGRAD and wino.route(geom, wino.DGRAD) is not None:
+            return None                 # (the polyphase form: bracketed in winograd.conv)
         return {cg.SAE_CONV_FWD: "s2_fwd", cg.SAE_CONV_DGRAD: "s2_dgrad", cg.SAE_CONV_WGRAD: "s2_wgrad"}.get(op)
 
     def install(self):
@@ -255,8 +260,8 @@ class DominantKernelTimer:
 
         def wino_conv(x, w, geom, transpose=False, **kw):
             kind = kw.get("kind") or wino.route(geom, wino.DGRAD if transpose else wino.FWD) or "unfused"
-            key = ("dominant" if kind == "fused" else "wino_unfused") if timer.active else None
-            return bracket(key, geom, lambda: orig_conv(x, w, geom, transpose=transpose, **kw), 4.0 / 9.0)
+            key = {"fused": "dominant", "s2poly": "s2_dgrad_poly"}.get(kind, "wino_unfused") if timer.active else None
+            return bracket(key, geom, lambda: orig_conv(x, w, geom, transpose=transpose, **kw), 25.0 / 36.0 if kind == "s2poly" else 4.0 / 9.0)
 
         def wino_wgrad(x, gy, geom, **kw):
             kind = kw.get("kind") or wino.route(geom, wino.WGRAD) or "unfused"
@@ -310,10 +315,10 @@ class DominantKernelTimer:
                    "launches": len(rec), "ms_per_step": round(kms / steps, 3),
                    "achieved": round(kfx / (kms * 1e-3) / 1e12, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                    "frac": round(kfx / (kms * 1e-3) / 1e12 / peak, 4)}
-            if key in WINO_CLASSES:
+            if key in WINO_CLASSES or key in EXECUTED_NOTE:
                 row["achieved_algorithmic"] = round(kfl / (kms * 1e-3) / 1e12, 2)
                 row["frac_algorithmic"] = round(kfl / (kms * 1e-3) / 1e12 / peak, 4)
-                row["flops"] = "achieved = executed FLOPs (algorithmic / 2.25); *_algorithmic = the direct convolution's"
+                row["flops"] = EXECUTED_NOTE.get(key, "achieved = executed FLOPs (algorithmic / 2.25); *_algorithmic = the direct convolution's")
             by_kernel.append(row)
         return roof, (by_kernel or None)
 

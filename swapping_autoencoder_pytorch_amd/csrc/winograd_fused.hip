@@ -539,6 +539,8 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
     auto load_gy = [&]() {
         greg[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, g_lane, g_soff, 0));
         greg[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, g_lane + ow_bytes, g_soff, 0));
+    };
+    auto load_scales = [&]() {             // the two style factors of the chunk being loaded (its image)
         if (MOD) {
             sx = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sxr, (unsigned)(c_ch * 4), (unsigned)(ld_n * p.C * 4), 0));
             sy = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(syr, (unsigned)(m_ch * 4), (unsigned)(ld_n * p.M * 4), 0));
@@ -668,18 +670,23 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], acc[xi], 0, 0, 0);
+            // (this order is measured: profiles/r6_ab_wino_deep_prefetch.txt -- with the gy loads between the two transforms the
+            // kernel is 5 - 6 % faster than with both transforms first)
             if (xi == 0) transform_e();
-            if (xi == 1) transform_v();
-            if (xi == 2) load_gy();          // (after BOTH transforms: it also fetches the two style factors of the chunk it loads)
-            if (xi == 3) load_x(0);
+            if (xi == 1) load_gy();
+            if (xi == 3) transform_v();
             if (xi == 4) {
+                load_scales();               // (after BOTH transforms: they use the factors of the chunk loaded a pass ago)
+                load_x(0);
+            }
+            if (xi == 5) {
                 load_x(2);
                 if (more) advance();
             }
-            if (xi == 6) write_e(cur ^ 1, 0);
-            if (xi == 7) write_e(cur ^ 1, 8);
-            if (xi == 8) write_v(cur ^ 1, 0);
-            if (xi == 9) write_v(cur ^ 1, 8);
+            if (xi == 8) write_e(cur ^ 1, 0);
+            if (xi == 9) write_e(cur ^ 1, 8);
+            if (xi == 10) write_v(cur ^ 1, 0);
+            if (xi == 11) write_v(cur ^ 1, 8);
             a = an;
             b = bn;
             __builtin_amdgcn_sched_barrier(0);
@@ -687,6 +694,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
     };
     if (ch_begin < ch_end) {
         load_gy();
+        load_scales();
         load_x(0);
         load_x(2);
         transform_e();
@@ -697,6 +705,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_wgrad_kernel(const float
         write_v(0, 8);
         if (ch_begin + 1 < ch_end) advance();
         load_gy();
+        load_scales();
         load_x(0);
         load_x(2);
         if (ch_begin + 2 < ch_end) advance();

@@ -99,6 +99,8 @@ def _route_of(geom, op):
                 4M): 0.62 / 0.66 / 0.78 of the direct estimate at >= 512 / 384 / 256 channels (measured 0.60 - 0.80)
       fused     rounds of 256 workgroups (one per CU: 256 accumulators per lane) x (0.162 ms x C / 512 + 6 us) per round --
                 within 5 % of every measured row; forward and data gradient only"""
+    if geom.k == 3 and geom.stride == 2:
+        return _route_of_stride2(geom, op)
     if geom.k != 3 or geom.stride != 1 or geom.pad not in (0, 1) or (geom.h & 1) or (geom.w & 1):
         return None
     cmin = min(geom.c, geom.m)
@@ -140,6 +142,23 @@ def _route_of(geom, op):
     return best
 
 
+def _route_of_stride2(geom, op):
+    """None or "s2poly": the data gradient / transposed convolution of a 3x3 stride-2 pad-0 layer between a (2h+1) x (2w+1) map and
+    an h x w map on its polyphase minimal-filtering form (csrc/s2wino.hip: 25 instead of 36 multiplications per 2x2 of small-side
+    positions).  Same-box A/B of the step's launches (tools/ab_s2wino.py -> profiles/r6_ab_s2wino_dgrad.txt): 1.1 - 1.2x the direct
+    kernel on the small-side maps of 8 .. 32 with >= 256 contraction channels (the direct kernel's tiles quantise badly on the
+    17 / 33 / 65-wide grids), behind it on the 64 / 128 maps -- which stay on the direct kernel."""
+    if op != DGRAD or geom.pad != 0 or geom.h != 2 * geom.oh + 1 or geom.w != 2 * geom.ow + 1:
+        return None
+    if (geom.oh & 1) or (geom.ow & 1) or geom.ow < 4 or geom.n * geom.m * geom.oh * geom.ow * 4 >= (1 << 31):
+        return None
+    if _CFG.min_c is not None:                        # explicit threshold (tests): everything at least that wide
+        return "s2poly" if min(geom.c, geom.m) >= _CFG.min_c else None
+    if geom.m >= 256 and geom.c >= 128 and 8 <= geom.oh <= 32 and 8 <= geom.ow <= 32 and geom.n * geom.oh * geom.ow >= 4096:
+        return "s2poly"
+    return None
+
+
 def route(geom, op=FWD):
     if not _CFG.enabled:
         return None
@@ -160,6 +179,11 @@ def _weights(lib, w, kind, cout, cin, sm, sc, flip, alpha, row_scale, col_scale,
     """Transform-domain weights of `w`, kept per parameter version (weight_prep.cached) when the factors are a function of the
     parameter alone (tag: () = no factors, a hashable description, or None = unknown -> rebuilt per call)."""
     def build():
+        if kind == "s2poly":
+            u = torch.empty(lib.query("s2wino_weights_floats", cout, cin), dtype=torch.float32, device=w.device)
+            lib.call("s2wino_weights_f32", w.data_ptr(), hip_lib.ptr(row_scale), hip_lib.ptr(col_scale), u.data_ptr(), cout, cin,
+                     sm, sc, flip, alpha, lib.stream(w))
+            return u
         if kind == "fused":
             u = torch.empty(lib.query("wino_fused_weights_floats", cout, cin), dtype=torch.float32, device=w.device)
             lib.call("wino_fused_weights_f32", w.data_ptr(), hip_lib.ptr(row_scale), hip_lib.ptr(col_scale), u.data_ptr(), cout, cin,
@@ -204,6 +228,17 @@ def conv(x, w, geom, transpose=False, bias=None, act=None, x_scale=None, row_sca
         kind = route(geom, DGRAD if transpose else FWD) or "unfused"
     stream = lib.stream(x)
     dev = x.device
+    if kind == "s2poly":        # stride-2 data gradient: x is the small side [n, m, oh, ow], the result the (2 oh + 1) x (2 ow + 1) side
+        if not transpose or act is not None or noise is not None or bias is not None:
+            raise hip_lib.SaeError("winograd conv: the polyphase stride-2 form covers the data gradient / transposed convolution only")
+        if tuple(x.shape) != (geom.n, geom.m, geom.oh, geom.ow):
+            raise hip_lib.SaeError("polyphase stride-2 data gradient: input %s, expected (%d, %d, %d, %d)" % (
+                tuple(x.shape), geom.n, geom.m, geom.oh, geom.ow))
+        u = _weights(lib, w, kind, geom.c, geom.m, d.w_stride_c, d.w_stride_m, 1, geom.alpha, row_scale, col_scale, factor_tag)
+        y = torch.empty((geom.n, geom.c, geom.h, geom.w), dtype=torch.float32, device=dev)
+        lib.call("s2wino_dgrad_f32", x.data_ptr(), hip_lib.ptr(x_scale), u.data_ptr(), hip_lib.ptr(out_scale), y.data_ptr(), geom.n,
+                 geom.m, geom.c, geom.oh, geom.ow, stream)
+        return y
     u = _weights(lib, w, kind, cout, cin, sm, sc, flip, geom.alpha, row_scale, col_scale, factor_tag)
     y = torch.empty((n, cout, h, wd), dtype=torch.float32, device=dev)
     slope, scale = act if act is not None else (0.0, 1.0)

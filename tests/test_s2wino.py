@@ -63,3 +63,38 @@ def test_polyphase_data_gradient_on_the_gpu(oracle_lib):
         d = H.conv_desc(n, c, 2 * side + 1, 2 * side + 1, m, 3, 2, 0)
         direct = H.conv(lib, 1, d, gy, wt, (n, c, 2 * side + 1, 2 * side + 1), alpha=0.01, device="cuda:0")
         assert H.rel_err(H.s2wino_dgrad(lib, gy, wt, alpha=0.01, device="cuda:0"), direct) < TOL
+
+
+def test_python_route_polyphase_data_gradient(oracle_lib, monkeypatch):
+    """The route of stylegan2_op/winograd.py: the data gradient of a stride-2 ConvLayer's conv and the forward of the stride-2
+    transposed (modulated, demodulated) conv on the polyphase form, against the direct kernels -- forward values and every
+    gradient the autograd nodes produce (the weight gradient and the forward stay direct)."""
+    import torch
+    from swapping_autoencoder_pytorch_amd import hip_lib
+    from swapping_autoencoder_pytorch_amd.stylegan2_op import conv2d_gemm as G, winograd
+    monkeypatch.setattr(hip_lib, "_LIB", oracle_lib)
+    torch.manual_seed(11)
+    x = torch.randn(2, 12, 17, 17, requires_grad=True)          # ConvLayer(downsample): blur output 17 x 17 -> 8 x 8
+    w = torch.randn(16, 12, 3, 3, requires_grad=True)
+    b = torch.randn(16, requires_grad=True)
+    z = torch.randn(2, 16, 8, 8, requires_grad=True)            # ModulatedConv2d(upsample): 8 x 8 -> 17 x 17
+    wu = torch.randn(12, 16, 3, 3, requires_grad=True)
+    s = (1 + 0.3 * torch.randn(2, 16)).requires_grad_(True)
+    geom = G._Geom(2, 12, 17, 17, 16, 3, 2, 0, False, 0.25)
+
+    def run():
+        y = G.conv2d_bias_act(x, w, b, stride=2, padding=0, alpha=0.25)
+        up = G.modulated_conv2d(z, s, wu, alpha=0.1, transposed=True, demod_eps=1e-8)
+        return (y.detach(), up.detach()) + torch.autograd.grad((y * y).sum() + (up * up).sum(), (x, w, b, z, wu, s))
+
+    with winograd.override(enabled=False):
+        direct = run()
+    with winograd.override(enabled=True, min_c=8):
+        assert [winograd.route(geom, op) for op in (winograd.FWD, winograd.DGRAD, winograd.WGRAD)] == [None, "s2poly", None]
+        routed = run()
+    for a, o in zip(routed, direct):
+        assert float((a - o).abs().max() / o.abs().max()) < TOL
+    with winograd.override(enabled=True):      # the measured rule: small-side maps of 8 .. 32 with >= 256 contraction channels
+        assert winograd.route(G._Geom(40, 512, 65, 65, 512, 3, 2, 0, False, 1.0), winograd.DGRAD) == "s2poly"
+        assert winograd.route(G._Geom(40, 128, 257, 257, 256, 3, 2, 0, False, 1.0), winograd.DGRAD) is None
+        assert winograd.route(G._Geom(40, 512, 64, 64, 512, 3, 2, 0, False, 1.0), winograd.DGRAD) is None      # not a 2^k + 1 map

@@ -14,20 +14,15 @@
 // the large-side row / column: EE 3x3 = 9 points, EO 3x2 = 6, OE 2x3 = 6, OO 2x2 = 4.
 //
 // Data gradient (s2w_dgrad_kernel): the four classes write DISJOINT outputs (the parity classes of dx), so a workgroup takes
-// one half of the points -- type A = EE + OO (13 points), type B = EO + OE (12) -- for 64 output channels x 64 tiles; a tile is
-// the 3x3 patch g[2ty-1 .. 2ty+1][2tx-1 .. 2tx+1] -> the 4x4 block dx[4ty .. 4ty+3][4tx .. 4tx+3].  The pipeline is
-// winograd_fused.hip's: per chunk of 8 contraction channels a wave issues 4 MFMAs (32x32x2 fp32) per point against operands
-// staged through two LDS stages with ONE barrier per chunk; the patches are loaded two chunks ahead and transformed at the
-// start of the pass that follows, and no MFMA group carries more than two loads per wave.  The (2H+1)-th row / column of dx
-// (tiles ty = H/2 or tx = W/2: one extra tile row and column whose patches are mostly padding) is a linear list of STRIP tiles
-// after the main H/2 x W/2 region, so the main region keeps power-of-two tile blocks.
-//
-// Measured (profiles/r6_ab_s2wino_dgrad.txt): 1.15 - 1.25x the direct kernel on the 2^k + 1 grids up to 65 wide with >= 512
-// contraction channels (the direct kernel's tiles quantise badly there), parity or behind on the 129 / 257-wide maps: the
-// 1.44x fewer MFMAs are paid for with 13 / 12 points per staged patch instead of the 16 of F(2x2,3x3) and a checkerboard of
-// 4-byte stores.  The split by ROW parity (15 / 10 points, whole 16-byte runs per lane) fixed the stores and lost as much to
-// the short passes of its 10-point type (tools/archive/variants/src/s2wino_row_parity_split_with_experiment_switches.hip).  The
-// route (stylegan2_op/winograd.py) takes this kernel only where it wins.
+// the points of one ROW parity -- type 0 = even rows = EE + EO (15 points), type 1 = odd rows = OE + OO (10) -- for 64 output
+// channels x 64 tiles, and a lane ends up with whole 4-float runs of two output rows (16-byte stores); a tile is the 3x3 patch
+// g[2ty-1 .. 2ty+1][2tx-1 .. 2tx+1] -> the 4x4 block dx[4ty .. 4ty+3][4tx .. 4tx+3].  The pipeline is winograd_fused.hip's:
+// per chunk of 8 contraction channels a wave issues 4 MFMAs (32x32x2 fp32) per point against operands staged through two LDS
+// stages with ONE barrier per chunk, the next chunk's transform / LDS writes pinned into the MFMA groups of the current one --
+// with the patch loads issued one chunk further ahead (the patches come from HBM: a whole pass of latency cover instead of
+// two groups was worth 20 % here).  The (2H+1)-th row / column of dx (tiles ty = H/2 or tx = W/2: one extra tile row and
+// column whose patches are mostly padding) is a linear list of STRIP tiles after the main H/2 x W/2 region, so the main
+// region keeps power-of-two tile blocks.
 #include "sae_common.h"
 
 #include <type_traits>
@@ -41,12 +36,14 @@ constexpr int kS2CK = 8;        // contraction channels per chunk
 
 template <int TYPE>
 struct S2wPoints {
-    static constexpr int NP = TYPE == 0 ? 13 : 12;      // points of the type
-    static constexpr int NPAIR = TYPE == 0 ? 7 : 6;     // pairs of points (the LDS words of V hold two points)
+    static constexpr int NP = TYPE == 0 ? 15 : 10;      // points of the type
+    static constexpr int NPAIR = TYPE == 0 ? 8 : 5;     // pairs of points (the LDS words of V hold two points)
     static constexpr int NPS = 2 * NPAIR;               // point slots of a weight stage
 };
-constexpr int kS2Slots0 = 14, kS2Slots1 = 12;
+constexpr int kS2Slots0 = 16, kS2Slots1 = 10;
 constexpr int kS2SlotsAll = kS2Slots0 + kS2Slots1;
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte aligned 16-byte global access
 
 struct S2wParams {
     int N, K, H, W;            // small side  [N][K][H][W], H and W even
@@ -91,12 +88,12 @@ __device__ __forceinline__ bool s2w_tile(const S2wParams& p, int b, int idx, int
     return n < p.N;
 }
 
-// Uf: type A (EE + OO) then type B (EO + OE); within a type [qb][chunk][slot][half][ql][s] = U[slot][q = 64 qb + ql][k = 8 chunk +
-// 4 half + s], zero beyond Q / K and in type A's fourteenth slot: one chunk of one channel block is contiguous in the order the
-// kernel keeps it in LDS.  g[ky][kx] are the taps as the PRODUCT sees them (flip = 1: the data gradient meets the reversed
-// filter); along an axis the even class multiplies by (g0, g0 + g2, g2) and the odd class by g1.
-//   type A: EE point 3 i + j, OO point 9 + 2 i' + j'     (i, j: even-class row / column factor; i', j': odd row / column)
-//   type B: EO point 2 i + j', OE point 6 + 3 i' + j
+// Uf: type 0 (even rows: EE + EO) then type 1 (odd rows: OE + OO); within a type [qb][chunk][slot][half][ql][s] = U[slot][q = 64 qb +
+// ql][k = 8 chunk + 4 half + s], zero beyond Q / K and in type 0's sixteenth slot: one chunk of one channel block is contiguous
+// in the order the kernel keeps it in LDS.  g[ky][kx] are the taps as the PRODUCT sees them (flip = 1: the data gradient meets
+// the reversed filter); along an axis the even class multiplies by (g0, g0 + g2, g2) and the odd class by g1.
+//   type 0: EE point 3 i + j, EO point 9 + 2 i + j'      (i: even-class row factor, j: even-class column factor, j': odd column)
+//   type 1: OE point 3 i' + j, OO point 6 + 2 i' + j'    (i': odd row)
 __global__ __launch_bounds__(kBlock) void s2w_wprep_kernel(const float* __restrict__ w, float* __restrict__ Uf, int Q, int K, int chunks,
                                                            int64_t sq, int64_t sk, int flip, float alpha,
                                                            const float* __restrict__ rs_q, const float* __restrict__ rs_k) {
@@ -137,16 +134,16 @@ __global__ __launch_bounds__(kBlock) void s2w_wprep_kernel(const float* __restri
             ua[3 * a + 0] = r[a][0];                    // EE
             ua[3 * a + 1] = r[a][0] + r[a][2];
             ua[3 * a + 2] = r[a][2];
-            ub[2 * a + 0] = r[a][1];                    // EO
-            ub[2 * a + 1] = r[a][1];
+            ua[9 + 2 * a + 0] = r[a][1];                // EO
+            ua[9 + 2 * a + 1] = r[a][1];
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) ua[9 + t] = g[1][1];      // OO
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {                   // OE
-            ub[6 + 3 * a + 0] = g[1][0];
-            ub[6 + 3 * a + 1] = g[1][0] + g[1][2];
-            ub[6 + 3 * a + 2] = g[1][2];
+        for (int a = 0; a < 2; ++a) {
+            ub[3 * a + 0] = g[1][0];                    // OE
+            ub[3 * a + 1] = g[1][0] + g[1][2];
+            ub[3 * a + 2] = g[1][2];
+            ub[6 + 2 * a + 0] = g[1][1];                // OO
+            ub[6 + 2 * a + 1] = g[1][1];
         }
     }
     const int64_t within = (hf * 64 + ql) * 4 + s;
@@ -167,6 +164,7 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
     constexpr int kUStage = NPS * 512;         // floats of a weight stage: [slot][half][q][s]
     constexpr int kVStage = NPAIR * 1024;      // floats of an input stage: [pair][half][s][t][2]
     constexpr int UQ = NPS / 2;                // 16-byte quads of the weight stage per thread
+    constexpr int R0 = TYPE == 0 ? 0 : 1;      // first patch row the type reads (the odd rows do not see row a)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -212,24 +210,37 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
     f32x2 pv[2][NPAIR];
     float xsc[2] = {1.0f, 1.0f};
 
-    auto load_x_row = [&](int chunk, int c2, int r) {          // one buffer load, no vector ALU
+    auto load_x = [&](int chunk, int c2) {
         int ch = chunk * kS2CK + 2 * wid + c2;
-        if (ch > p.K - 1) ch = p.K - 1;                        // (a channel beyond K meets zero weights)
+        if (ch > p.K - 1) ch = p.K - 1;                 // (a channel beyond K meets zero weights)
+        const unsigned soff = (unsigned)ch * plane_bytes;
+#pragma unroll
+        for (int r = R0; r < 3; ++r) dreg[c2][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, rowv[r], soff, 0));
+        if (XS) xsc[c2] = p.in_scale[(int64_t)(s_valid ? s_n : 0) * p.K + ch];
+    };
+    auto load_x_row = [&](int chunk, int c2, int r) {
+        int ch = chunk * kS2CK + 2 * wid + c2;
+        if (ch > p.K - 1) ch = p.K - 1;
         const unsigned soff = (unsigned)ch * plane_bytes;
         dreg[c2][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, rowv[r], soff, 0));
-        if (XS && r == 0) xsc[c2] = p.in_scale[(int64_t)(s_valid ? s_n : 0) * p.K + ch];
+        if (XS && r == R0) xsc[c2] = p.in_scale[(int64_t)(s_valid ? s_n : 0) * p.K + ch];
     };
     auto load_u1 = [&](int chunk, int j) {
         ureg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uoff, (unsigned)(chunk * kUStage * 4 + j * 4096), 0));
+    };
+    auto load_u = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < UQ; ++j)
+            ureg[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(urs, uoff, (unsigned)(chunk * kUStage * 4 + j * 4096), 0));
     };
     auto transform = [&](auto mode_tag, int c2) {
         constexpr int MODE = decltype(mode_tag)::value;        // 0: all columns inside, 1: zero the outside columns, 2: shifted windows
         f32x4 d[3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) d[r] = XS ? dreg[c2][r] * xsc[c2] : dreg[c2][r];
+        for (int r = R0; r < 3; ++r) d[r] = XS ? dreg[c2][r] * xsc[c2] : dreg[c2][r];
         if (MODE == 2) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int r = R0; r < 3; ++r) {
                 const f32x4 l = d[r];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -243,28 +254,28 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
         }
         if (MODE == 1) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int r = R0; r < 3; ++r)
 #pragma unroll
                 for (int q = 0; q < 3; ++q) d[r][q] = colok[q] ? d[r][q] : 0.0f;
         }
-        const f32x4 e0 = d[0] - d[1], e2 = d[2] - d[1];       // even class along the rows: (a - b, b, c - b)
         if (TYPE == 0) {
-            // EE: point 3 i + j = (row factor i) x (column factor j);  OO: 9 + 2 i' + j' = g[1 + i'][1 + j']
+            // even rows: the row factors (a - b, b, c - b); EE: point 3 i + j, the column factor applied; EO: 9 + 2 i + j' = columns 1, 2
+            const f32x4 e0 = d[0] - d[1], e2 = d[2] - d[1];
             pv[c2][0] = f32x2{e0[0] - e0[1], e0[1]};
             pv[c2][1] = f32x2{e0[2] - e0[1], d[1][0] - d[1][1]};
             pv[c2][2] = f32x2{d[1][1], d[1][2] - d[1][1]};
             pv[c2][3] = f32x2{e2[0] - e2[1], e2[1]};
-            pv[c2][4] = f32x2{e2[2] - e2[1], d[1][1]};
-            pv[c2][5] = f32x2{d[1][2], d[2][1]};
-            pv[c2][6 < NPAIR ? 6 : 0] = f32x2{d[2][2], 0.0f};
+            pv[c2][4] = f32x2{e2[2] - e2[1], e0[1]};
+            pv[c2][5] = f32x2{e0[2], d[1][1]};
+            pv[c2][6] = f32x2{d[1][2], e2[1]};
+            pv[c2][7 < NPAIR ? 7 : 0] = f32x2{e2[2], 0.0f};
         } else {
-            // EO: point 2 i + j' = (row factor i) x column 1 + j';  OE: 6 + 3 i' + j = row 1 + i' x (column factor j)
-            pv[c2][0] = f32x2{e0[1], e0[2]};
-            pv[c2][1] = f32x2{d[1][1], d[1][2]};
-            pv[c2][2] = f32x2{e2[1], e2[2]};
-            pv[c2][3] = f32x2{d[1][0] - d[1][1], d[1][1]};
-            pv[c2][4] = f32x2{d[1][2] - d[1][1], d[2][0] - d[2][1]};
-            pv[c2][5] = f32x2{d[2][1], d[2][2] - d[2][1]};
+            // odd rows b, c; OE: point 3 i' + j, the column factor applied; OO: 6 + 2 i' + j' = columns 1, 2
+            pv[c2][0] = f32x2{d[1][0] - d[1][1], d[1][1]};
+            pv[c2][1] = f32x2{d[1][2] - d[1][1], d[2][0] - d[2][1]};
+            pv[c2][2] = f32x2{d[2][1], d[2][2] - d[2][1]};
+            pv[c2][3] = f32x2{d[1][1], d[1][2]};
+            pv[c2][4] = f32x2{d[2][1], d[2][2]};
         }
     };
     auto write_v = [&](int buf, int lo, int hi) {
@@ -274,10 +285,10 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
 #pragma unroll
             for (int c2 = 0; c2 < 2; ++c2) vd[pp * 512 + c2 * 64] = pv[c2][pp];
     };
-    auto write_u = [&](int buf) {
+    auto write_u = [&](int buf, int lo, int hi) {
         f32x4* ud = reinterpret_cast<f32x4*>(UsBase + buf * kUStage) + tid;
 #pragma unroll
-        for (int j = 0; j < UQ; ++j) ud[j * kBlock] = ureg[j];
+        for (int j = lo; j < hi; ++j) ud[j * kBlock] = ureg[j];
     };
 
     f32x16 acc[NP];
@@ -286,10 +297,10 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[xi][r] = 0.0f;
 
-    // One pass over the staged chunk `cur`: NPAIR groups of eight MFMAs (a pair of points each; type A's last group holds one
-    // point), the operands of the next group read while this one runs.  Riding in the groups: the weights of chunk c1 (two quads
-    // per group from group 0 on, written to LDS in the last one), the transform of chunk c1's patches (groups 0 / 1: they were
-    // loaded during the PREVIOUS pass) and their LDS writes, and the six patch-row loads of chunk c2n = c1 + 1, one per group.
+    // One pass over the staged chunk `cur`: NPAIR groups of eight MFMAs (a pair of points each; type 0's last group holds one
+    // point), the operands of the next group read while this one runs.  Riding in the groups: the weights of chunk c1 (loaded in
+    // group 0, written to LDS in the last one), the transform of chunk c1's patches (groups 0 / 1: they were loaded during the
+    // PREVIOUS pass) and their LDS writes, and the patch loads of chunk c2 = c1 + 1 as soon as the registers are free.
     auto pass = [&](auto mode_tag, int cur, int c1, int c2n) {
         const f32x4* ua = reinterpret_cast<const f32x4*>(UsBase + cur * kUStage) + (half * 64 + wm * 32 + l31);
         const f32x2* vb = reinterpret_cast<const f32x2*>(VsBase + cur * kVStage) + (half * 256 + wt * 32 + l31);
@@ -306,22 +317,62 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) bn[s4] = vb[(pp + 1) * 512 + s4 * 64];
             }
+#if !defined(S2W_EXP_NOSTAGE) && !defined(S2W_EXP_NOLOADU)
+#ifdef S2W_EXP_SPREADU
+            {
+                constexpr int PER = (UQ + NPAIR - 2) / (NPAIR - 1);      // quads per group over groups 0 .. NPAIR - 2
 #pragma unroll
-            for (int j = 2 * pp; j < 2 * pp + 2; ++j)
-                if (j < UQ) load_u1(c1, j);
+                for (int j = pp * PER; j < (pp + 1) * PER && j < UQ; ++j) load_u1(c1, j);
+            }
+#else
+            if (pp == 0) load_u(c1);
+#endif
+#endif
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 acc[2 * pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s4], bq[s4][0], acc[2 * pp], 0, 0, 0);
                 if (two) acc[2 * pp + (two ? 1 : 0)] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s4], bq[s4][1], acc[2 * pp + (two ? 1 : 0)], 0, 0, 0);
             }
+#ifndef S2W_EXP_NOSTAGE
             if (pp == 0) transform(mode_tag, 0);
-            if (pp == 1) transform(mode_tag, 1);
+#ifdef S2W_EXP_NOLOADX
+            if (pp == 1) {
+                transform(mode_tag, 1);
+#ifdef S2W_EXP_KEEPXFORM
 #pragma unroll
-            for (int li = 0; li < 6; ++li)                    // row load li rides in group 1 + li (type B: the last two share group 5)
-                if (1 + (li < NPAIR - 1 ? li : NPAIR - 2) == pp) load_x_row(c2n, li / 3, li % 3);
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int r = R0; r < 3; ++r) asm volatile("" : "+v"(dreg[c2][r]));
+#endif
+            }
+#else
+#ifdef S2W_EXP_SPREAD
+            if (pp == 1) transform(mode_tag, 1);
+            {
+                constexpr int NR = 3 - R0;
+                const int li = pp - 1;                        // the li-th of the 2 NR row loads rides in group 1 + li
+#ifdef S2W_EXP_SAMEX
+                if (li >= 0 && li < 2 * NR) load_x_row(0, li / NR, R0 + li % NR);
+#else
+                if (li >= 0 && li < 2 * NR) load_x_row(c2n, li / NR, R0 + li % NR);
+#endif
+            }
+#else
+#ifdef S2W_EXP_SAMEX
+            if (pp == 1) { transform(mode_tag, 1); load_x(0, 0); load_x(0, 1); }
+#else
+            if (pp == 1) { transform(mode_tag, 1); load_x(c2n, 0); load_x(c2n, 1); }
+#endif
+#endif
+#endif
+#ifndef S2W_EXP_NOWRITEV
             if (pp == 2) write_v(cur ^ 1, 0, NPAIR / 2);
             if (pp == 3) write_v(cur ^ 1, NPAIR / 2, NPAIR);
-            if (pp == NPAIR - 1) write_u(cur ^ 1);
+#endif
+#ifndef S2W_EXP_NOWRITEU
+            if (pp == NPAIR - 1) write_u(cur ^ 1, 0, UQ);
+#endif
+#endif
             a0 = a0n;
             a1 = a1n;
 #pragma unroll
@@ -331,16 +382,15 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
     };
 
     auto run = [&](auto mode_tag) {
-#pragma unroll
-        for (int li = 0; li < 6; ++li) load_x_row(0, li / 3, li % 3);
-#pragma unroll
-        for (int j = 0; j < UQ; ++j) load_u1(0, j);
+        load_x(0, 0);
+        load_x(0, 1);
+        load_u(0);
         transform(mode_tag, 0);
         transform(mode_tag, 1);
-#pragma unroll
-        for (int li = 0; li < 6; ++li) load_x_row(last < 1 ? last : 1, li / 3, li % 3);
+        load_x(last < 1 ? last : 1, 0);
+        load_x(last < 1 ? last : 1, 1);
         write_v(0, 0, NPAIR);
-        write_u(0);
+        write_u(0, 0, UQ);
         __syncthreads();
         int cur = 0;
         for (int chunk = 0; chunk < p.chunks; ++chunk) {
@@ -357,69 +407,73 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
     else
         run(std::integral_constant<int, 1>{});
 
-    // ---- output transform, lane-local: acc[point][r] of (q = ... r ..., tile = wt * 32 + l31) -> this type's eight elements of the
-    // tile's 4x4 block: v[k] at (row, column) = (RO[k], CO[k])
+    // ---- output transform, lane-local: acc[point][r] of (q = ... r ..., tile = wt * 32 + l31) -> two rows of four floats
     int o_n, o_ty, o_tx;
     if (!s2w_tile(p, b, wt * 32 + l31, o_n, o_ty, o_tx)) return;
     const int64_t OHW = (int64_t)p.OH * p.OW;
-    const int oy = 4 * o_ty, ox = 4 * o_tx;
+    const int oy = 4 * o_ty + TYPE, ox = 4 * o_tx;          // this type's rows: oy, oy + 2
     float* ybase = dx + (int64_t)o_n * p.Q * OHW + (int64_t)oy * p.OW + ox;
     const float* osc = p.out_scale ? p.out_scale + (int64_t)o_n * p.Q : nullptr;
-    constexpr int ROA[8] = {0, 0, 2, 2, 1, 1, 3, 3}, COA[8] = {0, 2, 0, 2, 1, 3, 1, 3};
-    constexpr int ROB[8] = {0, 0, 2, 2, 1, 1, 3, 3}, COB[8] = {1, 3, 1, 3, 0, 2, 0, 2};
-    auto values_of = [&](int r, float (&v)[8]) {
+    auto rows_of = [&](int r, f32x4& v0, f32x4& v1) {
         if (TYPE == 0) {
-            float t0[3], t1[3];
+            float t[2][3], u[2][2];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                t0[j] = acc[j][r] + acc[3 + j][r];
-                t1[j] = acc[3 + j][r] + acc[6 + j][r];
+            for (int R = 0; R < 2; ++R) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) t[R][j] = acc[3 * R + j][r] + acc[3 * R + 3 + j][r];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) u[R][j] = acc[9 + 2 * R + j][r] + acc[11 + 2 * R + j][r];
             }
-            v[0] = t0[0] + t0[1]; v[1] = t0[1] + t0[2]; v[2] = t1[0] + t1[1]; v[3] = t1[1] + t1[2];
-            v[4] = acc[9][r]; v[5] = acc[10][r]; v[6] = acc[11][r]; v[7] = acc[12][r];
+            v0 = f32x4{t[0][0] + t[0][1], u[0][0], t[0][1] + t[0][2], u[0][1]};
+            v1 = f32x4{t[1][0] + t[1][1], u[1][0], t[1][1] + t[1][2], u[1][1]};
         } else {
-            v[0] = acc[0][r] + acc[2][r]; v[1] = acc[1][r] + acc[3][r];
-            v[2] = acc[2][r] + acc[4][r]; v[3] = acc[3][r] + acc[5][r];
-            v[4] = acc[6][r] + acc[7][r]; v[5] = acc[7][r] + acc[8][r];
-            v[6] = acc[9][r] + acc[10][r]; v[7] = acc[10][r] + acc[11][r];
+            v0 = f32x4{acc[0][r] + acc[1][r], acc[6][r], acc[1][r] + acc[2][r], acc[7][r]};
+            v1 = f32x4{acc[3][r] + acc[4][r], acc[8][r], acc[4][r] + acc[5][r], acc[9][r]};
         }
     };
     // uniform: every tile of the block has its whole 4x4 inside dx and every channel of the block exists
     const bool whole = b < p.main_blocks && (qb + 1) * kS2Q <= p.Q;
     if (whole) {
-        int off[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) off[k] = (TYPE == 0 ? ROA[k] : ROB[k]) * p.OW + (TYPE == 0 ? COA[k] : COB[k]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = qb * kS2Q + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v[8];
-            values_of(r, v);
-            const float ps = osc ? osc[q] : 1.0f;
+            f32x4 v0, v1;
+            rows_of(r, v0, v1);
+            if (osc) {
+                const float ps = osc[q];
+                v0 *= ps;
+                v1 *= ps;
+            }
             float* yp = ybase + (int64_t)q * OHW;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) yp[off[k]] = osc ? v[k] * ps : v[k];
+#ifdef S2W_EXP_NOSTORE
+            if (p.N < 0)
+#endif
+            {
+                *reinterpret_cast<f32x4u*>(yp) = v0;
+                *reinterpret_cast<f32x4u*>(yp + 2 * (int64_t)p.OW) = v1;
+            }
         }
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = qb * kS2Q + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v[8];
-            values_of(r, v);
+            f32x4 v0, v1;
+            rows_of(r, v0, v1);
             const float ps = (osc && q < p.Q) ? osc[q] : 1.0f;
             float* yp = ybase + (int64_t)q * OHW;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int ro = TYPE == 0 ? ROA[k] : ROB[k], co = TYPE == 0 ? COA[k] : COB[k];
-                if (q < p.Q && oy + ro < p.OH && ox + co < p.OW) yp[(int64_t)ro * p.OW + co] = v[k] * ps;
+            for (int c = 0; c < 4; ++c) {
+                if (q < p.Q && ox + c < p.OW) {
+                    if (oy < p.OH) yp[c] = v0[c] * ps;
+                    if (oy + 2 < p.OH) yp[2 * (int64_t)p.OW + c] = v1[c] * ps;
+                }
             }
         }
     }
 }
 
 // Workgroup order: ids go round the 8 XCDs (id % 8), each with its own L2.  An XCD walks a contiguous eighth of the tile blocks,
-// type A and type B of a tile block back to back (they read the same patches and write the two halves of the same output
-// lines), all XCDs on the same channel block at a time (its prepared weights stay in every L2).
+// the two types of a tile block back to back (they read the same patches and write alternate rows of the same 4x4 blocks), all XCDs on the same channel block at a time (its prepared weights stay in every L2).
 template <bool XS>
 __global__ __launch_bounds__(kBlock, 1) void s2w_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ Uf,
                                                               float* __restrict__ dx, const S2wParams p) {

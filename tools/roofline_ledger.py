@@ -134,6 +134,14 @@ def work_of(name, a):
         if BY_SHAPE:
             return "winograd fused wgrad n%-3d %4d->%-4d %3dx%-3d tiles" % (n, c, m, th, tw), "mfma", 32.0 * n * c * m * th * tw
         return "winograd fused weight gradient (one kernel + slice reduction; executed FLOPs = direct / 2.25)", "mfma", 32.0 * n * c * m * th * tw
+    if name == "s2wino_dgrad_f32":
+        # the polyphase stride-2 data gradient, counted with the FLOPs it EXECUTES: 25 multiply-adds per 2x2 of small-side positions
+        n, cin, cout, h, w = a[5], a[6], a[7], a[8], a[9]
+        if BY_SHAPE:
+            return "conv 3x3 s2 dgrad polyphase n%-3d %4d->%-4d %3dx%-3d" % (n, cin, cout, 2 * h + 1, 2 * w + 1), "mfma", 2.0 * 25 / 4 * n * cin * cout * h * w
+        return "conv 3x3 s2 dgrad on the polyphase form (executed FLOPs = direct x 25 / 36)", "mfma", 2.0 * 25 / 4 * n * cin * cout * h * w
+    if name == "s2wino_weights_f32":
+        return "winograd weight transform", "hbm", 140.0 * a[4] * a[5]
     if name == "wino_fused_weights_f32":
         return "winograd weight transform", "hbm", 100.0 * a[4] * a[5]
     if name in ("wino_input_f32", "wino_gy_f32"):
@@ -157,7 +165,7 @@ class Ledger:
 
         def call(name, *args):
             if not self.active or name in ("set_conv_math", "conv2d_wprep_query", "wino_gemm_workspace", "wino_wgrad_gemm_workspace",
-                                               "wino_fused_weights_floats", "gemm_workspace"):
+                                               "wino_fused_weights_floats", "s2wino_weights_floats", "gemm_workspace"):
                 return orig(name, *args)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
