@@ -407,7 +407,9 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
     if (!(o_tx < p.TW && o_ty < p.TH && o_n < p.N)) return;
     const int64_t OHW = (int64_t)p.OH * p.OW;
     const int64_t pix = (int64_t)(2 * o_ty) * p.OW + 2 * o_tx;
-    float nz[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+    // (the identities of the epilogue's optional factors -- out_scale 1, noise -0 -- leave every value as it is, signed zeros
+    // included: the loop below applies them unconditionally instead of selecting per output)
+    float nz[2][2] = {{-0.0f, -0.0f}, {-0.0f, -0.0f}};
     if (ACT && p.noise) {
         const float nw = p.noise_w[0];
         const float* zp = p.noise + (int64_t)o_n * OHW + pix;
@@ -417,32 +419,66 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
             nz[a][1] = nw * zp[(int64_t)a * p.OW + 1];
         }
     }
+    // The per-channel factors of the lane's sixteen rows are fetched in ONE go and the loop below is straight-line code (rows
+    // beyond M are computed and not stored): with the loads and the `m < M` branch inside it every row waited for its own two
+    // loads -- and, vmcnt counting stores as well, for the previous row's stores -- sixteen round trips per workgroup with nobody
+    // else on the SIMD to fill them (round 6: profiles/r6_ab_wino_epilogue.txt)
+    const int m_lane = mb * kWfM + wm * 32 + 4 * half;
+    float psv[16], bvv[16];
+    if (p.out_scale) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_lane + (r & 3) + 8 * (r >> 2);
+            psv[r] = p.out_scale[(int64_t)o_n * p.M + (m < p.M ? m : p.M - 1)];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) psv[r] = 1.0f;
+    }
+    if (ACT && p.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m_lane + (r & 3) + 8 * (r >> 2);
+            bvv[r] = p.bias[m < p.M ? m : p.M - 1];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bvv[r] = 0.0f;
+    }
+    // all of them have landed before the first store is issued: the compiler's counter bookkeeping across the sixteen conditional
+    // store blocks would otherwise make every row wait for (nearly) all stores issued before it
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
+    float* yp = y + ((int64_t)o_n * p.M + m_lane) * OHW + pix;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = mb * kWfM + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m >= p.M) continue;
+        const int mo = (r & 3) + 8 * (r >> 2);
         float t[2][4];      // A^T acc
 #pragma unroll
         for (int bq = 0; bq < 4; ++bq) {
             t[0][bq] = (acc[bq][r] + acc[4 + bq][r]) + acc[8 + bq][r];
             t[1][bq] = (acc[4 + bq][r] - acc[8 + bq][r]) - acc[12 + bq][r];
         }
-        const float ps = p.out_scale ? p.out_scale[(int64_t)o_n * p.M + m] : 1.0f;
-        const float bv = (ACT && p.bias) ? p.bias[m] : 0.0f;
-        float* yp = y + ((int64_t)o_n * p.M + m) * OHW + pix;
+        const float ps = psv[r];
+        const float bv = bvv[r];
+        f32x2 o[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            float o0 = (t[a][0] + t[a][1]) + t[a][2];
-            float o1 = (t[a][1] - t[a][2]) - t[a][3];
-            if (p.out_scale) { o0 *= ps; o1 *= ps; }
+#pragma clang fp contract(off)      // product, sum, sum as the reference's separate ops round them (no fma across the factors)
+            float o0 = ((t[a][0] + t[a][1]) + t[a][2]) * ps;
+            float o1 = ((t[a][1] - t[a][2]) - t[a][3]) * ps;
             if (ACT) {
-                if (p.noise) { o0 = o0 + nz[a][0]; o1 = o1 + nz[a][1]; }       // (image + weight * noise) + bias
-                o0 += bv; o1 += bv;
+                o0 = (o0 + nz[a][0]) + bv;                                      // (image + weight * noise) + bias
+                o1 = (o1 + nz[a][1]) + bv;
                 o0 = ((o0 > 0.0f) ? o0 : o0 * p.slope) * p.act_scale;
                 o1 = ((o1 > 0.0f) ? o1 : o1 * p.slope) * p.act_scale;
             }
-            *reinterpret_cast<f32x2*>(yp + (int64_t)a * p.OW) = f32x2{o0, o1};      // 2 tx and OW are even: 8-byte aligned
+            o[a] = f32x2{o0, o1};
         }
+        if (m_lane + mo < p.M) {
+            *reinterpret_cast<f32x2*>(yp) = o[0];                              // 2 tx and OW are even: 8-byte aligned
+            *reinterpret_cast<f32x2*>(yp + p.OW) = o[1];
+        }
+        yp += ((r & 3) == 3 ? 5 : 1) * OHW;
     }
 }
 

@@ -1,3 +1,4 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r6l
-timeout 900 python tools/ab_conv.py wg_spread2 ig_spread1 ig_spread2 ig_spread3 --op=fwd "--s2 " "--Dp s2" "--Dp3 s2" 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6l/ig_spread.txt
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r6p
+timeout 600 python tools/wf_variants.py wf_head product 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6p/wf_epilogue2.txt
+timeout 900 python -m pytest tests/test_winograd.py tests/test_gpu_fullsize_oracle.py -m gpu -x -q -k "wino or Wino" 2>&1 | tail -5 | tee gpurun_out/r6p/wino_tests2.txt

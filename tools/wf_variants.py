@@ -38,10 +38,20 @@ def main():
                 gy = torch.randn(n, c, side, side, device="cuda")
                 w = torch.nn.Parameter(torch.randn(c, c, 3, 3, device="cuda"))
                 ex = 32.0 * n * c * c * (side // 2) ** 2
+                bias = torch.randn(c, device="cuda")
+                xs = torch.rand(n, c, device="cuda") + 0.5
+                os_ = torch.rand(n, c, device="cuda") + 0.5
+                nz = torch.randn(n, 1, side, side, device="cuda")
+                nw = torch.full((1,), 0.1, device="cuda")
                 tf = timed(lambda: winograd.conv(x, w, g, kind="fused"))
+                ta = timed(lambda: winograd.conv(x, w, g, bias=bias, act=(0.2, 2 ** 0.5), kind="fused"))
+                tm = timed(lambda: winograd.conv(x, w, g, bias=bias, act=(0.2, 2 ** 0.5), x_scale=xs, out_scale=os_, noise=nz,
+                                                 noise_weight=nw, kind="fused"))
                 tw = timed(lambda: winograd.wgrad(x, gy, g, kind="fused"))
-                out.append("%dch@%d n%d: conv %.3f ms (%.3f) wgrad %.3f ms (%.3f)" % (c, side, n, tf, ex / tf / 1e9 / 157.3, tw, ex / tw / 1e9 / 157.3))
-            print("%-12s %s" % (name, " | ".join(out)), flush=True)
+                fr = lambda t: ex / t / 1e9 / 157.3
+                out.append("%dch@%d n%d: conv %.3f ms (%.3f) +bias+act %.3f (%.3f) modulated+noise %.3f (%.3f) wgrad %.3f ms (%.3f)"
+                           % (c, side, n, tf, fr(tf), ta, fr(ta), tm, fr(tm), tw, fr(tw)))
+            print("%-12s %s" % (name, "\n             ".join(out)), flush=True)
 
 
 if __name__ == "__main__":
