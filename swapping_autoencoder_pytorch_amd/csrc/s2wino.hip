@@ -386,6 +386,20 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
     };
     // uniform: every tile of the block has its whole 4x4 inside dx and every channel of the block exists
     const bool whole = b < p.main_blocks && (qb + 1) * kS2Q <= p.Q;
+    // the lane's sixteen out_scale factors in one go, landed before the first store (inside the store loops every row waited for
+    // its own load and -- vmcnt counts stores too -- for the previous row's stores: csrc/winograd_fused.hip's epilogue)
+    float psv[16];
+    if (osc) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = qb * kS2Q + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            psv[r] = osc[q < p.Q ? q : p.Q - 1];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) psv[r] = 1.0f;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0)
     if (whole) {
         int off[8];
 #pragma unroll
@@ -395,10 +409,10 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
             const int q = qb * kS2Q + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             float v[8];
             values_of(r, v);
-            const float ps = osc ? osc[q] : 1.0f;
+            const float ps = psv[r];
             float* yp = ybase + (int64_t)q * OHW;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) yp[off[k]] = osc ? v[k] * ps : v[k];
+            for (int k = 0; k < 8; ++k) yp[off[k]] = v[k] * ps;
         }
     } else {
 #pragma unroll
@@ -406,7 +420,7 @@ __device__ __forceinline__ void s2w_dgrad_body(const float* __restrict__ g, cons
             const int q = qb * kS2Q + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             float v[8];
             values_of(r, v);
-            const float ps = (osc && q < p.Q) ? osc[q] : 1.0f;
+            const float ps = psv[r];
             float* yp = ybase + (int64_t)q * OHW;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {

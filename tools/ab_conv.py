@@ -141,8 +141,13 @@ def main():
         wt = torch.randn(m, c, k, k, device=dev)
         gy = torch.randn(n, m, d.oh, d.ow, device=dev)
         flops = 2.0 * n * m * d.oh * d.ow * c * k * k
-        for op, oname in [(0, "fwd"), (1, "dgrad"), (2, "wgrad")]:
-            if want_ops and oname not in want_ops:
+        bias = torch.randn(m, device=dev)
+        res = torch.randn(n, m, d.oh, d.ow, device=dev)
+        # fwdact / fwdres (only with --op=): the forward with its fused epilogues (bias + leaky ReLU; residual merge, 1x1 only)
+        for op, oname in [(0, "fwd"), (1, "dgrad"), (2, "wgrad"), (0, "fwdact"), (0, "fwdres")]:
+            if (want_ops and oname not in want_ops) or (not want_ops and oname in ("fwdact", "fwdres")):
+                continue
+            if oname == "fwdres" and k != 1:
                 continue
             a, b = [(x, wt), (gy, wt), (x, gy)][op]
             shape = [(n, m, d.oh, d.ow), (n, c, h, w), (m, c, k, k)][op]
@@ -153,8 +158,15 @@ def main():
                     o = torch.empty(shape, device=dev)
                     nws = lib.query("conv2d_workspace", C.byref(d), op)
                     ws = torch.empty(max(nws, 1), device=dev)
-                    fn = lambda: lib.call(H.OPS[op], a.data_ptr(), b.data_ptr(), o.data_ptr(), C.byref(d), 1.0,
-                                          ws.data_ptr(), nws, stream())
+                    if oname == "fwdact":
+                        fn = lambda: lib.call("conv2d_fwd_bias_act_f32", a.data_ptr(), b.data_ptr(), bias.data_ptr(), o.data_ptr(),
+                                              C.byref(d), 1.0, 0.2, 2 ** 0.5, ws.data_ptr(), nws, stream())
+                    elif oname == "fwdres":
+                        fn = lambda: lib.call("conv2d_fwd_residual_f32", a.data_ptr(), b.data_ptr(), res.data_ptr(), o.data_ptr(),
+                                              C.byref(d), 1.0, 2 ** -0.5, ws.data_ptr(), nws, stream())
+                    else:
+                        fn = lambda: lib.call(H.OPS[op], a.data_ptr(), b.data_ptr(), o.data_ptr(), C.byref(d), 1.0,
+                                              ws.data_ptr(), nws, stream())
                     best[i] = min(best[i], timeit(fn, 5 if flops > 5e10 else 10))
                     if rnd == 0:
                         outs.append(o)

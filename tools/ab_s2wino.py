@@ -61,6 +61,9 @@ def main():
             i = argv.index(flag)
             opts[flag] = argv[i + 1]
             del argv[i:i + 2]
+    mod = "--mod" in argv          # the modulated form: g_scale [n, m] and out_scale [n, c] on the polyphase side (timing only)
+    if mod:
+        argv.remove("--mod")
     ops = argv or ["dgrad"]
     out_json = opts.get("--json")
     lib = L.get()
@@ -98,8 +101,11 @@ def main():
                 def direct():
                     lib.call("conv2d_dgrad_f32", gy.data_ptr(), wt.data_ptr(), out_a.data_ptr(), C.byref(d), 1.0, ws.data_ptr(), n_ws, st)
 
+                gs = torch.rand(n, m, device=dev) + 0.5 if mod else None
+                osc = torch.rand(n, c, device=dev) + 0.5 if mod else None
+
                 def poly():
-                    plib.call("s2wino_dgrad_f32", gy.data_ptr(), None, uf.data_ptr(), None, out_b.data_ptr(), n, m, c, s, s, st)
+                    plib.call("s2wino_dgrad_f32", gy.data_ptr(), L.ptr(gs), uf.data_ptr(), L.ptr(osc), out_b.data_ptr(), n, m, c, s, s, st)
             else:
                 raise SystemExit("unknown op " + op)
             iters = max(3, min(30, int(0.05 / (flops / 100e12))))
