@@ -87,6 +87,11 @@ __device__ __forceinline__ void k1_epilogue(const K1Epilogue& e, const K1Operand
         if (e.fwd_noise) fwd_nw = e.fwd_noise_w[0];
         if (e.fwd_bias) fwd_b = e.fwd_bias[plane % e.channels];
     }
+    // The prefetched operands (k1_prefetch) have landed before the first row is stored: the compiler cannot carry its vmcnt
+    // bookkeeping across the RB skippable row blocks below and put `s_waitcnt vmcnt(0)` into every one of them -- and vmcnt counts
+    // stores, so every row waited for the previous row's store to reach the L2: one store in flight per wave (round 6, read off
+    // the ISA; profiles/r6_ab_k1_epilogue_wait.txt)
+    __builtin_amdgcn_s_waitcnt(0x0F70);         // vmcnt(0), once
     if (col_ok) {
 #pragma unroll
         for (int o = 0; o < RB; ++o) {
