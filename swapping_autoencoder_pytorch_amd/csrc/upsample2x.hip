@@ -55,14 +55,18 @@ __global__ __launch_bounds__(kBlock) void upsample2x_add_kernel(const float* __r
                 out[r][c] = hl0 * (wl0 * a + wl1 * b) + hl1 * (wl0 * cc + wl1 * d);
             }
         }
+        // both rows' residual pairs are fetched before the first row is stored: fetched row by row, the second row's load waited
+        // for the first row's store to reach the L2 as well (vmcnt counts stores)
+        float2 q[2] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
+        if (res) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) q[r] = *reinterpret_cast<const float2*>(res + obase + (int64_t)(2 * i + r) * (2 * p.w) + 2 * j);
+        }
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
             const int64_t o = obase + (int64_t)(2 * i + r) * (2 * p.w) + 2 * j;
             float2 v = make_float2(out[r][0], out[r][1]);
-            if (res) {
-                const float2 q = *reinterpret_cast<const float2*>(res + o);
-                v.x += q.x; v.y += q.y;
-            }
+            if (res) { v.x += q[r].x; v.y += q[r].y; }
             v.x *= p.alpha; v.y *= p.alpha;
             *reinterpret_cast<float2*>(y + o) = v;
         }
