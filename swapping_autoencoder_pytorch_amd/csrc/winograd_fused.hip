@@ -110,7 +110,10 @@ __global__ __launch_bounds__(kBlock) void wino_fused_wprep_kernel(const float* _
     for (int xi = 0; xi < 16; ++xi) dst[xi * 512] = u[xi];
 }
 
-template <bool ACT, bool PAD2, bool XS>
+// XS: 0 = no input scale, 1 = x_scale[n, c] fetched per lane, 2 = every tile of a block lies in ONE image (BN == 1: the maps with
+// at least 64 tiles -- every modulated layer of the generator): the factor is wave-uniform and comes through a scalar load (two
+// vector loads and their address arithmetic less per chunk)
+template <bool ACT, bool PAD2, int XS>
 __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __restrict__ x, const float* __restrict__ Uf,
                                                                float* __restrict__ y, const WinoFusedParams p) {
     __shared__ float Us[2][kWfStage];      // [xi][half][m][s]: channel 4 half + s of the chunk
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
     const int s_ty = by * BH + ((lane >> p.bw_log2) & (BH - 1));
     const int s_n = bn * BN + (lane >> bshift);
     const bool s_valid = s_tx < p.TW && s_ty < p.TH && s_n < p.N;
+    [[maybe_unused]] const int n_u = __builtin_amdgcn_readfirstlane(bn * BN);        // XS == 2 (BN == 1): the block's image
     const int iy0 = 2 * s_ty - p.pad, ix0 = 2 * s_tx - p.pad;
     const int64_t HW = (int64_t)p.H * p.W;
     // The block that holds the tensor's first row (block 0) cannot start a window one float left of it: an offset of -4 wraps to
@@ -199,7 +203,8 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
         // right-border window in the tensor's last row cannot reach past x for any channel)
 #pragma unroll
         for (int r = 0; r < 4; ++r) dreg[c2][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, rowv[r], soff, 0));
-        if (XS) xsc[c2] = p.x_scale[(int64_t)(s_valid ? s_n : 0) * p.C + ch];
+        if (XS == 2) xsc[c2] = p.x_scale[(int64_t)n_u * p.C + ch];
+        else if (XS) xsc[c2] = p.x_scale[(int64_t)(s_valid ? s_n : 0) * p.C + ch];
     };
     auto load_u = [&](int chunk, int lo) {                     // 4 buffer loads, no vector ALU
 #pragma unroll
@@ -323,7 +328,8 @@ __global__ __launch_bounds__(kBlock, 1) void wino_fused_kernel(const float* __re
         const unsigned soff = (unsigned)ch * plane_bytes;
 #pragma unroll
         for (int r = r0; r < r0 + 2; ++r) dreg[c2][r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, rowv[r], soff, 0));
-        if (XS && r0 == 0) xsc[c2] = p.x_scale[(int64_t)(s_valid ? s_n : 0) * p.C + ch];
+        if (XS == 2 && r0 == 0) xsc[c2] = p.x_scale[(int64_t)n_u * p.C + ch];
+        else if (XS && r0 == 0) xsc[c2] = p.x_scale[(int64_t)(s_valid ? s_n : 0) * p.C + ch];
     };
     auto load_u2 = [&](int chunk, int j0) {
 #pragma unroll
@@ -887,16 +893,21 @@ extern "C" int sae_wino_fused_conv_f32(const float* x, const float* x_scale, con
     const dim3 grid((unsigned)blocks, (unsigned)ceil_div64(m, kWfM));
     const hipStream_t st = (hipStream_t)stream;
 #define SAE_WF_LAUNCH(A, P2, X) hipLaunchKernelGGL((wino_fused_kernel<A, P2, X>), grid, dim3(kBlock), 0, st, x, uf, y, p)
-    const int variant = (act ? 4 : 0) | (pad == 2 ? 2 : 0) | (x_scale ? 1 : 0);
+    const int xs = x_scale ? (BN == 1 ? 2 : 1) : 0;
+    const int variant = (act ? 6 : 0) + (pad == 2 ? 3 : 0) + xs;
     switch (variant) {
-        case 0: SAE_WF_LAUNCH(false, false, false); break;
-        case 1: SAE_WF_LAUNCH(false, false, true); break;
-        case 2: SAE_WF_LAUNCH(false, true, false); break;
-        case 3: SAE_WF_LAUNCH(false, true, true); break;
-        case 4: SAE_WF_LAUNCH(true, false, false); break;
-        case 5: SAE_WF_LAUNCH(true, false, true); break;
-        case 6: SAE_WF_LAUNCH(true, true, false); break;
-        default: SAE_WF_LAUNCH(true, true, true); break;
+        case 0: SAE_WF_LAUNCH(false, false, 0); break;
+        case 1: SAE_WF_LAUNCH(false, false, 1); break;
+        case 2: SAE_WF_LAUNCH(false, false, 2); break;
+        case 3: SAE_WF_LAUNCH(false, true, 0); break;
+        case 4: SAE_WF_LAUNCH(false, true, 1); break;
+        case 5: SAE_WF_LAUNCH(false, true, 2); break;
+        case 6: SAE_WF_LAUNCH(true, false, 0); break;
+        case 7: SAE_WF_LAUNCH(true, false, 1); break;
+        case 8: SAE_WF_LAUNCH(true, false, 2); break;
+        case 9: SAE_WF_LAUNCH(true, true, 0); break;
+        case 10: SAE_WF_LAUNCH(true, true, 1); break;
+        default: SAE_WF_LAUNCH(true, true, 2); break;
     }
 #undef SAE_WF_LAUNCH
     return check_launch("sae_wino_fused_conv_f32");
