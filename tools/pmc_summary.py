@@ -17,7 +17,7 @@ def short(n):
 # Round 5: the dominant kernel is the one-kernel Winograd convolution; tools/pmc_wino_fused.py's reference launch of it is
 # 512 -> 512 3x3 @64x64, B = 16 (grid 2048 workgroups).  gflop = the FLOPs it EXECUTES (16 multiply-adds per 2x2 tile and channel
 # pair); algorithmic bytes = x and y once + the prepared weights once.
-DOMINANT = "wino_fused_kernel<false,false,false>"
+DOMINANT = "wino_fused_kernel<false,false,0>"      # (third argument: 0 = no input scale; before round 6's last session a bool)
 DOMINANT_REF = {"gflop": 32.0 * 16 * 512 * 512 * 32 * 32 / 1e9,
                 "algorithmic_bytes": 2.0 * 16 * 512 * 64 * 64 * 4 + 16.0 * 512 * 512 * 4,
                 "launch": "512 -> 512 3x3 stride 1 @64x64, B = 16, forward (tools/pmc_wino_fused.py)"}
