@@ -1,4 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r6p
-timeout 600 python tools/wf_variants.py wf_xs product 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6p/wf_early_barrier_wgrad.txt
-timeout 900 python -m pytest tests/test_winograd.py tests/test_gpu_fullsize_oracle.py -m gpu -x -q -k "wino or Wino" 2>&1 | tail -3 | tee gpurun_out/r6p/wino_tests6.txt
+timeout 600 python tools/kb_k1.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6p/kb_k1.txt
