@@ -413,6 +413,26 @@ __global__ __launch_bounds__(kBlock) void blur_stream_kernel(const float* __rest
     }
     float* yp = y + plane * (int64_t)p.out_h * p.out_w;
     const bool full = ox0 + 3 < p.out_w;          // all four columns exist: one 16-byte store
+    // The noise quads of an iteration's four output rows are requested together at the top of the iteration, BEFORE the next rows
+    // of x, as range-checked buffer loads over the whole noise tensor (a row outside the strip reads zeros; a quad at a row's end
+    // reaches into the next row or past the tensor: values nobody uses) -- fetched inside each row's store block they were the
+    // NEWEST load in flight, and waiting for the newest load drains everything before it: the eight prefetched rows of x and the
+    // previous row's store, four times per iteration (round 6, read off the ISA)
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t zrs = xrs;
+    [[maybe_unused]] int zrel = 0;
+    if constexpr (FWD_ACT) {
+        if (zp) {
+            int64_t zbytes = (p.planes / e.channels) * (int64_t)p.out_h * p.out_w * 4;
+            if (zbytes > 0x7fffffff) zbytes = 0x7fffffff;
+            zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.fwd_noise), 0, (unsigned)zbytes, 0x00020000);
+            zrel = (int)((((plane / e.channels) * p.out_h + oy0) * (int64_t)p.out_w + ox0) * 4);
+        }
+    }
+    [[maybe_unused]] auto load_z = [&](int o) {                // the quad of output row oy0 + o
+        const bool ok = live && o >= 0 && o < p.rb && oy0 + o < p.out_h;
+        const unsigned v = ok ? (unsigned)(zrel + o * p.out_w * 4) : 0x80000000u;
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zrs, v, 0, 0));
+    };
 
     f32x4 nlo[4], nhi[4];
 #pragma unroll
@@ -434,9 +454,21 @@ __global__ __launch_bounds__(kBlock) void blur_stream_kernel(const float* __rest
                 v[s4][q] = colok[q] ? t : 0.0f;
             }
         }
-        if (i0 + 4 < p.rb + 3) {
+        [[maybe_unused]] f32x4 zq[4];
+        if constexpr (FWD_ACT) {
+            if (zp) {
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) load_row(i0 + 4 + s4, nlo[s4], nhi[s4]);
+                for (int s4 = 0; s4 < 4; ++s4) zq[s4] = load_z(i0 + s4 - 3);
+            }
+        }
+        // (always issued: beyond the strip's last row load_row masks the offset and the load reads zeros -- an `if` around the
+        // prefetch would hide from the compiler how many loads are in flight behind the noise quads)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) load_row(i0 + 4 + s4, nlo[s4], nhi[s4]);
+        if constexpr (FWD_ACT) {
+            // the quads have landed (the compiler waits for exactly them in front of this empty asm: the x rows behind them stay
+            // in flight) -- the skippable store blocks below then need no wait of their own
+            if (zp) asm volatile("" : "+v"(zq[0]), "+v"(zq[1]), "+v"(zq[2]), "+v"(zq[3]));
         }
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
@@ -460,16 +492,8 @@ __global__ __launch_bounds__(kBlock) void blur_stream_kernel(const float* __rest
                 if constexpr (FWD_ACT) {
                     float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (zp) {
-                        const float* zr = zp + (int64_t)oy * p.out_w + ox0;
-                        if (full) {
-                            const f32x4a4 zq = *reinterpret_cast<const f32x4a4*>(zr);
 #pragma unroll
-                            for (int xo = 0; xo < 4; ++xo) z[xo] = zq[xo];
-                        } else {
-#pragma unroll
-                            for (int xo = 0; xo < 4; ++xo)
-                                if (ox0 + xo < p.out_w) z[xo] = zr[xo];
-                        }
+                        for (int xo = 0; xo < 4; ++xo) z[xo] = zq[s4][xo];
                     }
 #pragma unroll
                     for (int xo = 0; xo < 4; ++xo) {

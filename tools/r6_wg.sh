@@ -1,3 +1,3 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r6p
-timeout 600 python tools/kb_k1.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6p/kb_k1.txt
+timeout 1200 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fullsize_oracle.py tests/test_styled_fused.py tests/test_gpu_fullsize_properties.py -m gpu -x -q 2>&1 | tail -3 | tee gpurun_out/r6p/k1_tests2.txt
