@@ -70,7 +70,7 @@ __device__ __forceinline__ void k1_prefetch(const K1Epilogue& e, K1Operands<RB, 
     for (int o = 0; o < RB; ++o) {
         const int oy = oy0 + o;
         const bool ok = col_ok && oy < out_h;
-        const int64_t idx = ok ? (int64_t)oy * out_w + ox : 0;       // branch-free (see blur_kernel): element 0 otherwise
+        const int idx = ok ? oy * out_w + ox : 0;       // branch-free (see blur_kernel): element 0 otherwise; a plane has < 2^31 elements
         if constexpr (ACC) q.old[o] = e.accumulate ? yp[idx] : 0.0f;
         q.ref[o] = want_ref ? rp[idx] : 1.0f;
     }
@@ -109,7 +109,7 @@ __device__ __forceinline__ void k1_epilogue(const K1Epilogue& e, const K1Operand
                     t = t + fwd_b;
                     t = ((t > 0.0f) ? t : t * e.slope) * e.scale;
                 }
-                yp[(int64_t)oy * out_w + ox] = t;
+                yp[oy * out_w + ox] = t;          // (32-bit index: a plane has < 2^31 elements)
             }
         }
     }
@@ -128,9 +128,11 @@ __device__ __forceinline__ void k1_epilogue(const K1Epilogue& e, const K1Operand
 // straddle the 64-column tile boundaries of the 2^k + 1 wide rows, so in launch order every XCD fetched its own copy: 1102 MB
 // read from HBM for 537 MB of input (blur 256^2 -> 257^2, profiles/r3_pmc_f32.txt), i.e. the kernel sat at the HBM roof with
 // 1.6x its algorithmic traffic.  XCD k now takes the k-th contiguous eighth of the workgroup list.
-__device__ __forceinline__ int64_t k1_block_id() {
-    const int64_t per = gridDim.x >> 3;          // the host rounds the grid up to a multiple of 8
-    return (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+// (32-bit throughout: the id is below gridDim.x, and the row-group / plane indices derived from it are below 2^31 -- checked on
+// the host, k1_groups_fit -- so that none of the divisions below is a 64-bit one: ~60 instructions each in front of 128 FMAs)
+__device__ __forceinline__ unsigned k1_block_id() {
+    const unsigned per = gridDim.x >> 3;         // the host rounds the grid up to a multiple of 8
+    return (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
 }
 
 struct BlurParams {
@@ -149,18 +151,30 @@ struct BlurParams {
 // through the thread row's LDS strip `sp`.  `xt` is the strip's x-tile index in the epilogue's partial-sum layout.
 template <int KH, int KW, int TW, int RB, bool EPI, bool ACC = true>
 __device__ __forceinline__ void blur_strip(const float* __restrict__ x, float* __restrict__ y, const BlurParams& p,
-                                           const K1Epilogue& e, float* sp, const float* taps, const int tx, const int64_t g,
+                                           const K1Epilogue& e, float* sp, const float* taps, const int tx, const unsigned g,
                                            const int xt, const int ox0) {
     constexpr int SR = RB + KH - 1;          // staged rows per strip
     constexpr int SW = TW + KW - 1;          // staged columns per strip
     constexpr int SWP = SW | 1;              // odd row stride
-    const bool live = g < p.groups;
-    const int64_t plane = live ? g / p.groups_per_plane : 0;
-    const int oy0 = live ? (int)(g - plane * p.groups_per_plane) * RB : 0;
+    const bool live = g < (unsigned)p.groups;
+    const unsigned plane_u = live ? g / (unsigned)p.groups_per_plane : 0u;
+    const int64_t plane = plane_u;
+    const int oy0 = live ? (int)(g - plane_u * (unsigned)p.groups_per_plane) * RB : 0;
     const int iy0 = oy0 - p.pad_y0;  // input row of staged row 0
     const int ix0 = ox0 - p.pad_x0;  // input column of staged column 0
 
-    const float* xp = x + plane * (int64_t)p.in_h * p.in_w;
+    // The strip is fetched through range-checked buffer loads with 32-bit per-lane offsets relative to the first plane the wave
+    // touches: an element outside the image carries an out-of-range offset and reads as zero (no select), and the address of a
+    // row is one 32-bit add.  With 64-bit indexing (a v_mad_u64_u32 and a 64-bit add per load and store, selects for the zero
+    // padding) the kernel issued ~7 instructions per FMA and was bound by instruction issue, not by HBM: the form with an
+    // epilogue moved 50 % more bytes in the same time (round 6, HISTORY 4.0i)
+    const int64_t hw_in = (int64_t)p.in_h * p.in_w;
+    const int64_t plane0 = __builtin_amdgcn_readfirstlane((int)plane);
+    int64_t span = (p.planes - plane0) * hw_in * 4;
+    if (span > 0x7fffffff) span = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + plane0 * hw_in), 0, (unsigned)span,
+                                                                       0x00020000);
+    const int rel = (int)((plane - plane0) * hw_in) + iy0 * p.in_w + ix0;       // element offset of staged (row 0, column 0)
     // all global loads of the strip are issued back to back into registers, then written to LDS: one load in flight
     // per wave would leave HBM latency fully exposed.  The strip is fetched ROW-wise: lane tx takes column tx of each of
     // the SR rows (one contiguous TW * 4-byte run per instruction, no per-element index division — the generic
@@ -178,8 +192,8 @@ __device__ __forceinline__ void blur_strip(const float* __restrict__ x, float* _
         // branch-free: a load inside a divergent branch makes hipcc drain vmcnt at the join, which left two
         // loads in flight per wave; out-of-image elements read element 0 of the plane and are zeroed
         const bool ok = col_ok && iy >= 0 && iy < p.in_h;
-        const float v = xp[ok ? (int64_t)iy * p.in_w + ixb : 0];
-        body[r] = ok ? v : 0.0f;
+        const unsigned off = ok ? (unsigned)((rel + r * p.in_w + tx) * 4) : 0x80000000u;
+        body[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -187,8 +201,8 @@ __device__ __forceinline__ void blur_strip(const float* __restrict__ x, float* _
         const int r = e / (XW > 0 ? XW : 1), c = TW + e - r * XW;
         const int iy = iy0 + r, ix = ix0 + c;
         const bool ok = live && e < XW * SR && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-        const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
-        halo[i] = ok ? v : 0.0f;
+        const unsigned off = ok ? (unsigned)((rel + r * p.in_w + c) * 4) : 0x80000000u;
+        halo[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
     }
     [[maybe_unused]] K1Operands<EPI ? RB : 1, ACC> eq;
     if constexpr (EPI)
@@ -236,18 +250,16 @@ __device__ __forceinline__ void blur_strip(const float* __restrict__ x, float* _
 
     const int ox = ox0 + tx;
     if constexpr (EPI) {
-        const int gi = (int)(g - plane * p.groups_per_plane);
+        const int gi = (int)(g - plane_u * (unsigned)p.groups_per_plane);
         k1_epilogue<TW, RB, ACC>(e, eq, acc, y + plane * (int64_t)p.out_h * p.out_w, live && ox < p.out_w, oy0, p.out_h, p.out_w, ox,
                             plane, gi * p.x_tiles + xt, p.groups_per_plane * p.x_tiles, live, tx);
         return;
     }
     if (live && ox < p.out_w) {
-        float* yp = y + plane * (int64_t)p.out_h * p.out_w;
+        float* yb = y + (plane * (int64_t)p.out_h + oy0) * p.out_w + ox;       // one 64-bit address; rows are 32-bit steps from it
 #pragma unroll
-        for (int o = 0; o < RB; ++o) {
-            const int oy = oy0 + o;
-            if (oy < p.out_h) yp[(int64_t)oy * p.out_w + ox] = acc[o];
-        }
+        for (int o = 0; o < RB; ++o)
+            if (oy0 + o < p.out_h) yb[o * p.out_w] = acc[o];
     }
 }
 
@@ -272,10 +284,11 @@ __global__ __launch_bounds__(kBlock) void blur_kernel(const float* __restrict__ 
         taps[threadIdx.x] = v;
     }
 
-    const int64_t bid = k1_block_id();
-    if (bid >= p.blocks) return;                    // (whole workgroup: the grid's padding to a multiple of 8)
-    const int xt = (int)(bid % p.x_tiles);
-    const int64_t g = (bid / p.x_tiles) * NR + tr;  // strip (row group) handled by this thread row
+    const unsigned bid = k1_block_id();
+    if (bid >= (unsigned)p.blocks) return;          // (whole workgroup: the grid's padding to a multiple of 8)
+    const unsigned bq = bid / (unsigned)p.x_tiles;
+    const int xt = (int)(bid - bq * (unsigned)p.x_tiles);
+    const unsigned g = bq * NR + tr;                // strip (row group) handled by this thread row
     blur_strip<KH, KW, TW, RB, EPI, ACC>(x, y, p, e, strip[tr], taps, tx, g, xt, xt * TW);
 }
 
@@ -300,15 +313,16 @@ __global__ __launch_bounds__(kBlock) void blur_tail_kernel(const float* __restri
         if (ky < p.kh && kx < p.kw) v = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
         taps[threadIdx.x] = v;
     }
-    const int64_t bid = k1_block_id();
-    if (bid >= p.blocks) return;
-    const int64_t unit = bid / (p.main_per_unit + 1);
-    const int r = (int)(bid - unit * (p.main_per_unit + 1));
+    const unsigned bid = k1_block_id();
+    if (bid >= (unsigned)p.blocks) return;
+    const unsigned unit = bid / (unsigned)(p.main_per_unit + 1);
+    const int r = (int)(bid - unit * (unsigned)(p.main_per_unit + 1));
     if (r < p.main_per_unit) {
         const int xm = p.x_tiles - 1;
-        const int xt = r % xm;
+        const int rq = r / xm;
+        const int xt = r - rq * xm;
         const int tr = threadIdx.x / 64;
-        const int64_t g = (unit * 8 + r / xm) * 4 + tr;
+        const unsigned g = (unit * 8 + rq) * 4 + tr;
         blur_strip<KH, KW, 64, RB, EPI, ACC>(x, y, p, e, strips + tr * SR * SWP_M, taps, threadIdx.x % 64, g, xt, xt * 64);
     } else {
         const int tr = threadIdx.x / 8;
@@ -625,20 +639,30 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
         if (ky < p.kh && kx < p.kw) v = k[(p.kh - 1 - ky) * p.kw + (p.kw - 1 - kx)];
         taps[threadIdx.x] = v;
     }
-    const int64_t bid = k1_block_id();
-    if (bid >= p.blocks) return;
-    const int xt = (int)(bid % p.x_tiles);
-    const int64_t g = (bid / p.x_tiles) * NR + tr;
-    const bool live = g < p.groups;
-    const int64_t plane = live ? g / p.groups_per_plane : 0;
-    const int oy0 = live ? (int)(g - plane * p.groups_per_plane) * RB : 0;
+    const unsigned bid = k1_block_id();
+    if (bid >= (unsigned)p.blocks) return;
+    const unsigned bq = bid / (unsigned)p.x_tiles;
+    const int xt = (int)(bid - bq * (unsigned)p.x_tiles);
+    const unsigned g = bq * NR + tr;
+    const bool live = g < (unsigned)p.groups;
+    const unsigned plane_u = live ? g / (unsigned)p.groups_per_plane : 0u;
+    const int64_t plane = plane_u;
+    const int oy0 = live ? (int)(g - plane_u * (unsigned)p.groups_per_plane) * RB : 0;
     const int ox0 = xt * TW;
     const int tile_mid_y = oy0 * DOWN + UP - 1 - p.pad_y0;
     const int tile_mid_x = ox0 * DOWN + UP - 1 - p.pad_x0;
     const int tile_in_y = floor_div_i(tile_mid_y, UP);
     const int tile_in_x = floor_div_i(tile_mid_x, UP);
 
-    const float* xp = x + plane * (int64_t)p.in_h * p.in_w;
+    // (range-checked buffer loads with 32-bit offsets relative to the wave's first plane, as in blur_strip)
+    const int64_t hw_in = (int64_t)p.in_h * p.in_w;
+    const int64_t plane0 = __builtin_amdgcn_readfirstlane((int)plane);
+    int64_t span = (p.planes - plane0) * hw_in * 4;
+    if (span > 0x7fffffff) span = 0x7fffffff;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + plane0 * hw_in), 0, (unsigned)span,
+                                                                       0x00020000);
+    [[maybe_unused]] const int rel = (int)((plane - plane0) * hw_in) + tile_in_y * p.in_w + tile_in_x;   // element offset of staged (0, 0)
+    [[maybe_unused]] const float* xg = x + plane * hw_in;
     float* sp = strip[tr];
     // row-wise staging as in blur_kernel: CB full TW-wide column blocks per row (lane tx takes column tx + b * TW),
     // the SW - CB * TW remaining columns of all rows gathered by NX more loads; no per-element index division
@@ -655,8 +679,13 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
         for (int b = 0; b < CB; ++b) {
             const int ix = tile_in_x + tx + b * TW;
             const bool ok = row_ok && ix >= 0 && ix < p.in_w;   // branch-free, see blur_kernel
-            const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
-            body[r][b] = ok ? v : 0.0f;
+            if constexpr (DOWN == 1) {
+                const unsigned off = ok ? (unsigned)((rel + r * p.in_w + tx + b * TW) * 4) : 0x80000000u;
+                body[r][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
+            } else {       // (the decimating form measured 2 % slower on buffer loads: 5.78 -> 5.66 TB/s)
+                const float v = xg[ok ? (int64_t)iy * p.in_w + ix : 0];
+                body[r][b] = ok ? v : 0.0f;
+            }
         }
     }
 #pragma unroll
@@ -665,8 +694,13 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
         const int r = e / (XW > 0 ? XW : 1), c = CB * TW + e - r * XW;
         const int iy = tile_in_y + r, ix = tile_in_x + c;
         const bool ok = live && e < XW * SR && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-        const float v = xp[ok ? (int64_t)iy * p.in_w + ix : 0];
-        halo[i] = ok ? v : 0.0f;
+        if constexpr (DOWN == 1) {
+            const unsigned off = ok ? (unsigned)((rel + r * p.in_w + c) * 4) : 0x80000000u;
+            halo[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
+        } else {
+            const float v = xg[ok ? (int64_t)iy * p.in_w + ix : 0];
+            halo[i] = ok ? v : 0.0f;
+        }
     }
     [[maybe_unused]] K1Operands<EPI ? RB : 1> eq;
     if constexpr (EPI)
@@ -710,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
         else if (live && ox < p.out_w && oy < p.out_h) yp[(int64_t)oy * p.out_w + ox] = v;
     }
     if constexpr (EPI) {
-        const int gi = (int)(g - plane * p.groups_per_plane);
+        const int gi = (int)(g - plane_u * (unsigned)p.groups_per_plane);
         k1_epilogue<TW, RB>(e, eq, vo, yp, live && ox < p.out_w, oy0, p.out_h, p.out_w, ox, plane, gi * p.x_tiles + xt,
                             p.groups_per_plane * p.x_tiles, live, tx);
     }
@@ -747,6 +781,14 @@ void launch_blur_tail(const float* x, const float* k, float* y, BlurParams p, hi
     p.blocks = ceil_div64(p.groups, 32) * (p.main_per_unit + 1);
     hipLaunchKernelGGL((blur_tail_kernel<KH, KW, RB, EPI, ACC>), dim3((unsigned)((p.blocks + 7) / 8 * 8)), dim3(kBlock), 0, s, x, k, y,
                        p, e);
+}
+
+// the planes kernels index row groups in 32 bits (k1_block_id): planes x ceil(out_h / 4) row groups at most
+inline bool k1_groups_fit(int64_t planes, int64_t out_h) { return planes * ((out_h + 3) / 4) < ((int64_t)1 << 31); }
+// ... and elements inside a plane, and the byte offsets of a wave's buffer loads (relative to the first of the at most 8 planes a
+// wave of 8-column thread rows touches), in 32 bits
+inline bool k1_plane_fits(int64_t in_h, int64_t in_w, int64_t out_h, int64_t out_w) {
+    return in_h * in_w <= ((int64_t)1 << 24) && out_h * out_w <= ((int64_t)1 << 28);
 }
 
 // 64-column tiles with a remainder of 1 ... 8 columns
@@ -853,7 +895,9 @@ extern "C" int sae_upfirdn2d_f32(const float* x, const float* k, float* y, int64
     if (!x || !k || !y) return fail(SAE_EINVAL, "sae_upfirdn2d_f32: null tensor");
     hipStream_t s = (hipStream_t)stream;
 
-    const bool is_blur = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && minor == 1 && kh <= 4 && kw <= 4;
+    // (planes beyond the 32-bit indexing of the planes kernels -- 4096 x 4096 inputs -- take the generic kernel)
+    const bool planes_ok = minor == 1 && k1_groups_fit(major, out_h) && k1_plane_fits(in_h, in_w, out_h, out_w);
+    const bool is_blur = planes_ok && up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh <= 4 && kw <= 4;
     if (is_blur) {
         BlurParams p{};
         p.planes = major;
@@ -865,7 +909,7 @@ extern "C" int sae_upfirdn2d_f32(const float* x, const float* k, float* y, int64
         else dispatch_blur<4, 4>(x, k, y, p, s);
         return check_launch("sae_upfirdn2d_f32(blur)");
     }
-    const bool is_x2 = minor == 1 && kh <= 4 && kw <= 4 && up_x == up_y && down_x == down_y &&
+    const bool is_x2 = planes_ok && kh <= 4 && kw <= 4 && up_x == up_y && down_x == down_y &&
                        ((up_x == 1 && down_x == 2) || (up_x == 2 && down_x == 1));
     if (is_x2) {
         UpDownParams p{};
@@ -924,6 +968,8 @@ extern "C" int sae_upfirdn2d_epilogue_f32(const float* x, const float* k, float*
     }
     if (major == 0) return SAE_OK;
     if (!x || !k || !y) return fail(SAE_EINVAL, "sae_upfirdn2d_epilogue_f32: null tensor");
+    if (!k1_groups_fit(major, out_h) || !k1_plane_fits(in_h, in_w, out_h, out_w))
+        return fail(SAE_EINVAL, "sae_upfirdn2d_epilogue_f32: more than 2^31 row groups, or a plane beyond 4096 x 4096");
     K1Epilogue e{};
     e.act_ref = act_ref; e.slope = slope; e.scale = scale; e.accumulate = accumulate ? 1 : 0;
     e.channels = act_ref ? (int)channels : 1;
@@ -970,6 +1016,8 @@ extern "C" int sae_upfirdn2d_noise_bias_act_f32(const float* x, const float* k, 
     if (out_h < 1 || out_w < 1) return fail(SAE_EINVAL, "%s: empty output (%lld x %lld)", who, (long long)out_h, (long long)out_w);
     if (major == 0) return SAE_OK;
     if (!x || !k || !y || (noise && !noise_weight)) return fail(SAE_EINVAL, "%s: null tensor", who);
+    if (!k1_groups_fit(major, out_h) || !k1_plane_fits(in_h, in_w, out_h, out_w))
+        return fail(SAE_EINVAL, "%s: more than 2^31 row groups, or a plane beyond 4096 x 4096", who);
     K1Epilogue e{};
     e.slope = slope; e.scale = scale; e.channels = (int)channels;
     e.fwd_act = 1; e.fwd_noise = noise; e.fwd_noise_w = noise_weight; e.fwd_bias = bias;

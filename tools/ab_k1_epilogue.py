@@ -70,6 +70,27 @@ def main():
                 best[i] = min(best[i], timeit(fn))
         same = [bool(torch.equal(o[0], outs[0][0]) and (not act or torch.equal(o[1], outs[0][1]))) for o in outs]
         print("%-40s " % tag + " ".join("%9.2f%s" % (gbytes / t, " " if ok else "*") for t, ok in zip(best, same)), flush=True)
+    # plain decimate x2 / zero-insert x2 (sae_upfirdn2d_f32, 4 x 4 taps): the ResBlock skip path and its gradient
+    for planes, h, down, tag in [(5120, 257, 2, "decimate x2 257^2 n40"), (10240, 129, 2, "decimate x2 129^2 n40"),
+                                 (12288, 129, 2, "decimate x2 129^2 Dp"), (5120, 128, 1, "zero-insert x2 128^2 n40 (plain)")]:
+        up = 2 if down == 1 else 1
+        p0, p1 = (2, 1) if up == 2 else (1, 1)
+        oh = (h * up + p0 + p1 - 4 + down) // down
+        x = torch.randn(planes, h, h, device=dev)
+        kk = torch.rand(4, 4, device=dev)
+        gbytes = 4.0 * (x.numel() + planes * oh * oh) / 1e9
+        best, outs = [1e9] * len(libs), []
+        for rnd in range(2):
+            for i, lib in enumerate(libs):
+                y = torch.empty(planes, oh, oh, device=dev)
+                fn = lambda: lib.call("upfirdn2d_f32", x.data_ptr(), kk.data_ptr(), y.data_ptr(), planes, h, h, 1, 4, 4, up, up, down, down,
+                                      p0, p1, p0, p1, st)
+                if rnd == 0:
+                    fn()
+                    outs.append(y.clone())
+                best[i] = min(best[i], timeit(fn))
+        same = [bool(torch.equal(o, outs[0])) for o in outs]
+        print("%-40s " % tag + " ".join("%9.2f%s" % (gbytes / t, " " if ok else "*") for t, ok in zip(best, same)), flush=True)
     for planes, h, w, ch, tag in FWD:
         oh, ow = h - 1, w - 1
         x = torch.randn(planes, h, w, device=dev)
