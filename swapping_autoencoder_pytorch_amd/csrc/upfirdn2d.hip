@@ -151,11 +151,14 @@ struct BlurParams {
 // through the thread row's LDS strip `sp`.  `xt` is the strip's x-tile index in the epilogue's partial-sum layout.
 template <int KH, int KW, int TW, int RB, bool EPI, bool ACC = true>
 __device__ __forceinline__ void blur_strip(const float* __restrict__ x, float* __restrict__ y, const BlurParams& p,
-                                           const K1Epilogue& e, float* sp, const float* taps, const int tx, const unsigned g,
+                                           const K1Epilogue& e, float* sp, const float* taps, const int tx, const unsigned g_in,
                                            const int xt, const int ox0) {
     constexpr int SR = RB + KH - 1;          // staged rows per strip
     constexpr int SW = TW + KW - 1;          // staged columns per strip
     constexpr int SWP = SW | 1;              // odd row stride
+    // With 64-column strips a wave IS one thread row: the row group, and with it the plane, the strip's rows and their validity,
+    // are wave-uniform -- said so, all of that arithmetic runs on the scalar unit and the row of a load rides in its scalar offset
+    const unsigned g = TW == 64 ? (unsigned)__builtin_amdgcn_readfirstlane((int)g_in) : g_in;
     const bool live = g < (unsigned)p.groups;
     const unsigned plane_u = live ? g / (unsigned)p.groups_per_plane : 0u;
     const int64_t plane = plane_u;
@@ -186,14 +189,21 @@ __device__ __forceinline__ void blur_strip(const float* __restrict__ x, float* _
     float halo[NX > 0 ? NX : 1];
     const int ixb = ix0 + tx;
     const bool col_ok = live && ixb >= 0 && ixb < p.in_w;
+    [[maybe_unused]] const unsigned vcol = col_ok ? (unsigned)(ixb * 4) : 0x80000000u;   // TW == 64: the lane's column, once
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
         const int iy = iy0 + r;
         // branch-free: a load inside a divergent branch makes hipcc drain vmcnt at the join, which left two
-        // loads in flight per wave; out-of-image elements read element 0 of the plane and are zeroed
-        const bool ok = col_ok && iy >= 0 && iy < p.in_h;
-        const unsigned off = ok ? (unsigned)((rel + r * p.in_w + tx) * 4) : 0x80000000u;
-        body[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
+        // loads in flight per wave; out-of-image elements carry an out-of-range offset and read as zero
+        if constexpr (TW == 64) {
+            const bool row_ok = iy >= 0 && iy < p.in_h;                                  // scalar
+            const unsigned soff = row_ok ? (unsigned)(((int)((plane - plane0) * hw_in) + iy * p.in_w) * 4) : 0u;
+            body[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, row_ok ? vcol : 0x80000000u, soff, 0));
+        } else {
+            const bool ok = col_ok && iy >= 0 && iy < p.in_h;
+            const unsigned off = ok ? (unsigned)((rel + r * p.in_w + tx) * 4) : 0x80000000u;
+            body[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, off, 0, 0));
+        }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
