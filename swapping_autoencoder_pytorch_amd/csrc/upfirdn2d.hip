@@ -735,6 +735,38 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
     const int ox = ox0 + tx;
     float* yp = y + plane * (int64_t)p.out_h * p.out_w;
     [[maybe_unused]] float vo[RB];
+    if constexpr (UP == 2 && DOWN == 1 && KH == 4 && KW == 4) {
+        // Zero-insert x2 with compile-time tap phases.  Output row oy0 + o reads staged rows (o + q) >> 1 + yy through tap rows
+        // 1 - ((o + q) & 1) + 2 yy, q = tile_mid_y & 1 (uniform per thread row); the same along x with the lane's own parity.
+        // The lane's eight taps (its column phase, all four rows) are read from LDS once, the two row phases are told apart by ONE
+        // select per tap on q, and every LDS address is a per-thread base + a compile-time offset: the generic loop below spends
+        // ~100 vector instructions per output on run-time tap indices and predicates (870 for 54 FMAs in the epilogue form), and
+        // these kernels are bound by what they issue.  Same taps, same order (tap rows outer, columns inner): bit-identical.
+        const int q = tile_mid_y & 1;
+        const float* tp = taps + kx0;
+        float te[2][2], to[2][2];                    // taps of the even / odd output rows of the strip: [yy][xx]
+#pragma unroll
+        for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+            for (int xx = 0; xx < 2; ++xx) {
+                const float t1 = tp[(1 + 2 * yy) * KW + 2 * xx], t0 = tp[(2 * yy) * KW + 2 * xx];   // tap rows 1 + 2 yy / 2 yy
+                te[yy][xx] = q ? t0 : t1;            // even o: tap row 1 - (q & 1) + 2 yy
+                to[yy][xx] = q ? t1 : t0;
+            }
+        const float* se = sp + rel_x;                // even o: staged row o / 2 + yy
+        const float* so = sp + rel_x + q * SWP;      // odd o: staged row (o - 1) / 2 + q + yy
+#pragma unroll
+        for (int o = 0; o < RB; ++o) {
+            const float* sr = (o & 1) ? so + (o >> 1) * SWP : se + (o >> 1) * SWP;
+            float v = 0.0f;
+#pragma unroll
+            for (int yy = 0; yy < 2; ++yy)
+#pragma unroll
+                for (int xx = 0; xx < 2; ++xx) v = fmaf(sr[yy * SWP + xx], (o & 1) ? to[yy][xx] : te[yy][xx], v);
+            if constexpr (EPI) vo[o] = v;
+            else if (live && ox < p.out_w && oy0 + o < p.out_h) yp[(int64_t)(oy0 + o) * p.out_w + ox] = v;
+        }
+    } else {
 #pragma unroll
     for (int o = 0; o < RB; ++o) {
         const int mid_y = tile_mid_y + o * DOWN;
@@ -752,6 +784,7 @@ __global__ __launch_bounds__(kBlock) void updown_kernel(const float* __restrict_
         const int oy = oy0 + o;
         if constexpr (EPI) vo[o] = v;
         else if (live && ox < p.out_w && oy < p.out_h) yp[(int64_t)oy * p.out_w + ox] = v;
+    }
     }
     if constexpr (EPI) {
         const int gi = (int)(g - plane_u * (unsigned)p.groups_per_plane);
